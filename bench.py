@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- transducer loss+grad throughput on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one synthetic batch resident in HBM:
+    compute_rnnt_loss_fwd  (log-softmax denominators + alpha/beta sweeps -> costs)
+  + compute_rnnt_loss_bwd  (gradient w.r.t. the logits, scaled by 1/global_batch, run_rnnt.py:278)
+called through the C ABI of libwarprnnt.so with all buffers pre-allocated.
+Workload at N=1: BASELINE.json configs[1]  B=32 T=600 U=150 V=28, acts ~ N(0,1), full lengths.
+N>1: utterances shard across ranks (weak scaling: every rank owns a full B=32 batch); the op-level
+path has no exchange step, so no collective is issued inside the timed region.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline`, `cpu_baseline` (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured copy ceiling)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--shape", type=str, default="32,600,150,28", help="B,T,U,V per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(B, T, U, V, reps):
+    """The C restatement of the reference CPU path (oracle/cpu_rnnt.c; kind = "port"), wrapped by
+    PyTorch CPU log_softmax forward/backward exactly as utils/loss.py:29-30 does on non-CUDA builds.
+    Timed on the host cores on the FULL headline batch, `reps` times (a few seconds in total)."""
+    from oracle import cpu_oracle
+
+    cpu_oracle.build()
+    ncpu = os.cpu_count() or 1
+    g = torch.Generator().manual_seed(1234)
+    acts = torch.randn(B, T, U, V, generator=g, dtype=torch.float32)
+    labels = torch.randint(1, V, (B, U - 1), generator=g, dtype=torch.int32).numpy()
+    il = np.full(B, T, np.int32)
+    ll = np.full(B, U - 1, np.int32)
+    times = []
+    for r in range(reps + 1):
+        t0 = time.perf_counter()
+        x = acts.clone().requires_grad_(True)
+        lp = torch.log_softmax(x, dim=-1)
+        costs, glp = cpu_oracle.rnnt_cpu(lp.detach().numpy(), labels, il, ll, num_threads=ncpu)
+        lp.backward(torch.from_numpy(glp) / B)
+        dt = time.perf_counter() - t0
+        if r > 0:
+            times.append(dt)
+    med = float(np.median(times))
+    return {
+        "value": B * T * U / med, "unit": "cells/s", "cores": min(ncpu, B), "host_cores": ncpu, "kind": "port",
+        "seconds_per_step": med,
+        "sample": f"full headline batch B={B} T={T} U={U} V={V}, median of {reps} runs after 1 warm-up; "
+                  "OpenMP over utterances only (like the reference), torch CPU log_softmax fwd+bwd around it",
+    }
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import rnnt_speech_recognition_amd as pkg
+    from rnnt_speech_recognition_amd import _lib
+
+    pkg.build()
+    lib = _lib.load()
+
+    B, T, U, V = (int(v) for v in a.shape.split(","))
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    acts = torch.randn(B, T, U, V, generator=g, dtype=torch.float32).to(dev)
+    labels = torch.randint(1, V, (B, U - 1), generator=g, dtype=torch.int32).to(dev)
+    il = torch.full((B,), T, dtype=torch.int32, device=dev)
+    ll = torch.full((B,), U - 1, dtype=torch.int32, device=dev)
+    scale = torch.full((B,), 1.0 / (B * world), dtype=torch.float32, device=dev)
+    costs = torch.empty(B, dtype=torch.float32, device=dev)
+    grads = torch.empty_like(acts)
+    ws = torch.empty(_lib.workspace_bytes(T, U, B), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream()
+    opts = _lib.make_options(stream.cuda_stream, 0, T, U)
+
+    def fwd():
+        _lib.check(lib.compute_rnnt_loss_fwd(acts.data_ptr(), labels.data_ptr(), ll.data_ptr(), il.data_ptr(),
+                                             V, B, costs.data_ptr(), ws.data_ptr(), opts), "fwd")
+
+    def bwd():
+        _lib.check(lib.compute_rnnt_loss_bwd(acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), ll.data_ptr(),
+                                             il.data_ptr(), scale.data_ptr(), V, B, ws.data_ptr(), opts), "bwd")
+
+    def step():
+        fwd()
+        bwd()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    cells = B * T * U
+    value = world * cells * a.steps / dt
+
+    # ---- per-stage durations, HIP events on the launch stream (the kernels run on `stream`) ----
+    roof = None
+    if rank == 0:
+        n_ev = max(10, min(a.steps, 50))
+        ef = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+               torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+        for e0, e1, e2 in ef:
+            e0.record(stream)
+            fwd()
+            e1.record(stream)
+            bwd()
+            e2.record(stream)
+        torch.cuda.synchronize()
+        t_f = float(np.mean([e0.elapsed_time(e1) for e0, e1, _ in ef])) * 1e-3
+        t_b = float(np.mean([e1.elapsed_time(e2) for _, e1, e2 in ef])) * 1e-3
+        alg = 8.0 * V * cells  # read each f32 logit once + write each f32 gradient once
+        ach_grad = alg / t_b / 1e9
+        ach_op = alg / (t_f + t_b) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("grad_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {
+            "bound": "hbm",
+            "kernel": "gradient pass (cell_small_kernel<GRAD=true>): reads V logits + writes V grads per cell",
+            "achieved": ach_grad, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_grad / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg,
+            "kernel_avg_ms": t_b * 1e3,
+            "whole_op": {"note": "same algorithmic bytes over ALL kernels of one step (memset+lsm+sweeps+grad)",
+                         "achieved": ach_op, "frac": ach_op / HBM_PEAK_GBS,
+                         "fwd_ms": t_f * 1e3, "bwd_ms": t_b * 1e3},
+        }
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(B, T, U, V, a.cpu_reps)
+
+    if rank == 0:
+        out = {
+            "metric": "rnnt_loss_grad_lattice_cells_per_sec", "value": value, "unit": "cells/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"transducer loss+grad on given logits (warp-transducer op contract), "
+                                   f"B={B} T={T} U={U} V={V} per GPU, full lengths, acts~N(0,1)",
+                       "global_batch": B * world, "parallelism": f"utterance-sharded x{world}, no data-path collective"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if cpu:
+            out["gpu_over_cpu"] = value / cpu["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,142 @@
+/*
+ * include/rnnt.h -- C ABI of libwarprnnt.so, the MI355X-native (gfx950) transducer-loss engine.
+ *
+ * This is the drop-in boundary for the reference's native op.  The reference
+ * (noahchalifour/rnnt-speech-recognition) reaches its loss through
+ *     utils/loss.py:6        from warprnnt_tensorflow import rnnt_loss
+ *     utils/loss.py:34-35    rnnt_loss(y_pred, y_true, spec_lengths, label_lengths)
+ * and builds the library behind it with scripts/build_rnnt.sh:1-13, which compiles the
+ * warp-transducer submodule into `libwarprnnt.so` (cmake/warp-rnnt-cmakelist.txt:99,119) and
+ * installs this header's namesake (cmake/warp-rnnt-cmakelist.txt:137: include/rnnt.h).  The
+ * submodule source is absent from the reference tree, so the entry points below restate the
+ * library's published C interface; each one names the reference-side
+ * interface it replaces.
+ *
+ * Ownership: the caller owns every buffer.  The library allocates no device memory and never
+ * synchronises the host; all work is enqueued on the caller's HIP stream.
+ * Location: this library is device-only.  `loc == RNNT_CPU` is rejected with
+ * RNNT_STATUS_INVALID_VALUE -- there is deliberately no CPU fallback inside the product.
+ */
+#ifndef MI355X_RNNT_H
+#define MI355X_RNNT_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Opaque stand-in for hipStream_t so that C callers need no HIP headers.
+ * Replaces the `CUstream stream` member of upstream's rnntOptions. */
+typedef struct ihipStream_t *rnntStream_t;
+
+/* Replaces upstream rnntStatus_t (include/rnnt.h of warp-transducer; installed by
+ * cmake/warp-rnnt-cmakelist.txt:137).  Values keep upstream's order. */
+typedef enum {
+    RNNT_STATUS_SUCCESS = 0,
+    RNNT_STATUS_MEMOPS_FAILED = 1,
+    RNNT_STATUS_INVALID_VALUE = 2,
+    RNNT_STATUS_EXECUTION_FAILED = 3,
+    RNNT_STATUS_UNKNOWN_ERROR = 4
+} rnntStatus_t;
+
+/* Replaces upstream rnntComputeLocation. */
+typedef enum { RNNT_CPU = 0, RNNT_GPU = 1 } rnntComputeLocation;
+
+/* Replaces upstream rnntOptions (passed by value). */
+typedef struct rnntOptions {
+    rnntComputeLocation loc; /* must be RNNT_GPU */
+    union {
+        unsigned int num_threads; /* ignored (CPU location is not provided) */
+        rnntStream_t stream;      /* HIP stream all kernels are enqueued on */
+    };
+    int blank_label; /* reference never passes it -> op default 0 (utils/vocabulary.py:3-6) */
+    int maxT;        /* acts.shape[1] */
+    int maxU;        /* acts.shape[2] = L_max + 1 (utils/preprocessing.py:177-183) */
+    int batch_first; /* must be non-zero: acts is [B, maxT, maxU, V] row-major */
+} rnntOptions;
+
+/* Replaces upstream get_warprnnt_version(). */
+int get_warprnnt_version(void);
+
+/* Replaces upstream rnntGetStatusString(). */
+const char *rnntGetStatusString(rnntStatus_t status);
+
+/* Replaces upstream get_workspace_size(maxT, maxU, minibatch, gpu, &size_bytes).
+ * `gpu` must be non-zero.  The size depends on (maxT, maxU, minibatch) only. */
+rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, int gpu, size_t *size_bytes);
+
+/* Replaces upstream compute_rnnt_loss(...): the body of the WarpRNNT TensorFlow op that
+ * utils/loss.py:34-35 calls.
+ *
+ *   acts           device f32 [minibatch, maxT, maxU, alphabet_size]  RAW LOGITS (the log-softmax
+ *                  is fused, as in upstream's GPU path; utils/loss.py:29-30 skips it on CUDA builds)
+ *   grads          device f32, same shape, or NULL for score-only.  Receives d cost_b / d acts;
+ *                  padded cells (t >= T_b or u > L_b) are written as exact zeros, so the caller
+ *                  need not pre-zero it.
+ *   flat_labels    device i32 [minibatch, maxU-1] (padded rows, as run_rnnt.py:262-263 passes them)
+ *   label_lengths  device i32 [minibatch]   L_b
+ *   input_lengths  device i32 [minibatch]   T_b (already divided by the time-reduction factor,
+ *                  utils/loss.py:31-33)
+ *   costs          device f32 [minibatch]   -ln P(y_b | x_b)
+ *   workspace      device, >= get_workspace_size() bytes, 256-byte aligned
+ *
+ * Returns immediately after enqueueing; errors detected at enqueue time are returned, device
+ * faults surface on the caller's next stream synchronisation. */
+rnntStatus_t compute_rnnt_loss(const float *acts, float *grads, const int *flat_labels,
+                               const int *label_lengths, const int *input_lengths,
+                               int alphabet_size, int minibatch, float *costs, void *workspace,
+                               rnntOptions options);
+
+/* Build-only split of compute_rnnt_loss (no upstream counterpart).  The reference multiplies the
+ * op's gradient by the upstream gradient afterwards (the TF binding's registered gradient;
+ * run_rnnt.py:278 makes that factor 1/global_batch).  Splitting the call lets an autograd host
+ * run the gradient pass only when backward is requested and fold that factor in for free:
+ *   compute_rnnt_loss_fwd  = costs + lattice state in `workspace` (reads acts once)
+ *   compute_rnnt_loss_bwd  = grads[b] = cost_scale[b] * d cost_b / d acts  (cost_scale NULL = 1),
+ *                            from the SAME acts and the workspace left by _fwd.
+ * compute_rnnt_loss(acts, grads, ...) == _fwd followed by _bwd(cost_scale = NULL). */
+rnntStatus_t compute_rnnt_loss_fwd(const float *acts, const int *flat_labels,
+                                   const int *label_lengths, const int *input_lengths,
+                                   int alphabet_size, int minibatch, float *costs, void *workspace,
+                                   rnntOptions options);
+
+rnntStatus_t compute_rnnt_loss_bwd(const float *acts, float *grads, const int *flat_labels,
+                                   const int *label_lengths, const int *input_lengths,
+                                   const float *cost_scale, int alphabet_size, int minibatch,
+                                   void *workspace, rnntOptions options);
+
+/* ------------------------------------------------------------------------------------------
+ * Build-only extension (no upstream counterpart): the joint network fused with the loss, so the
+ * [B,T,U,J] and [B,T,U,V] tensors of model.py:158-166 are never materialised.
+ *
+ * The first Dense layer is factored exactly:  W1^T(e_t + p_u) + b1 = (W1^T e_t + b1) + W1^T p_u,
+ * so the caller passes the two small projections
+ *   enc_proj   device f32 [B, maxT, J]   = enc  @ W1 + b1   (model.py:162-163, bias folded here)
+ *   pred_proj  device f32 [B, maxU, J]   = pred @ W1
+ * and the kernels evaluate  logits[b,t,u,:] = tanh(enc_proj[b,t,:] + pred_proj[b,u,:]) @ W2 + b2
+ * (model.py:162-166) tile by tile on the matrix cores.
+ *
+ *   W2 [J, V], b2 [V]            device f32 (model.py:165-166)
+ *   cost_scale                   device f32 [B] or NULL (=1): upstream gradient of each cost, e.g.
+ *                                1/global_batch (run_rnnt.py:278)
+ *   d_enc_proj [B,maxT,J], d_pred_proj [B,maxU,J], dW2 [J,V], db2 [V]
+ *                                device f32 outputs: gradients of sum_b cost_scale[b]*cost_b.
+ *                                Fully overwritten.  May all be NULL for score-only.
+ *   joint_dtype                  0 = f32 MFMA (exact f32), 1 = f16-input MFMA with f32 accumulate
+ */
+rnntStatus_t get_joint_workspace_size(int maxT, int maxU, int minibatch, int joint_size,
+                                      int alphabet_size, size_t *size_bytes);
+
+rnntStatus_t compute_rnnt_joint_loss(const float *enc_proj, const float *pred_proj,
+                                     const float *W2, const float *b2, const int *flat_labels,
+                                     const int *label_lengths, const int *input_lengths,
+                                     const float *cost_scale, int joint_size, int alphabet_size,
+                                     int minibatch, float *costs, float *d_enc_proj,
+                                     float *d_pred_proj, float *dW2, float *db2, int joint_dtype,
+                                     void *workspace, rnntOptions options);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355X_RNNT_H */

@@ -1,0 +1,51 @@
+"""Build driver for libwarprnnt.so (the MI355X counterpart of the reference's
+scripts/build_rnnt.sh:1-13, which runs cmake+make on warp-transducer and installs the binding).
+
+hipcc cross-compiles for gfx950 without a GPU.  The library is built IN-TREE
+(`rnnt-speech-recognition_amd/lib/libwarprnnt.so`) so that it travels with the source snapshot."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libwarprnnt.so")
+SOURCES = ["rnnt_kernels.hip", "joint_kernels.hip", "rnnt_entrypoint.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+
+
+def _deps():
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "rnnt.h"))
+    return files
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(f) > t for f in _deps())
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source into lib/libwarprnnt.so; returns the path."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libwarprnnt.so (ROCm toolchain required)")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    tmp = LIB_PATH + ".tmp"
+    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

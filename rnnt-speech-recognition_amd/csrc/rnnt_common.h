@@ -1,0 +1,110 @@
+// rnnt_common.h -- shared device/host definitions for the gfx950 transducer-loss kernels.
+//
+// Data layout in HBM (see DESIGN.md "Data layout"):
+//   acts / grads   f32 [B][T][U][V]            caller-owned, row-major (batch_first)
+//   lse            f32 [B*T*U]                 natural-log softmax denominator per lattice cell
+//   W              f32 [B][Nr][2][Up]          edge weights in LOG2 domain, DIAGONAL-MAJOR (skewed):
+//                                              W[b][n][0][u] = log2 p(blank | t=n-u, u)
+//                                              W[b][n][1][u] = log2 p(y_{u+1} | t=n-u, u)
+//   A, Bt          f32 [B][Nr][Up]             alpha~/beta~ lattices, log2 domain, skewed,
+//                                              stored relative to a per-16-diagonal offset
+//   offA, offB     f64 [B][NC]                 the offsets (one per block of kRebase diagonals)
+//   ll             f64 [B][2]                  log2-likelihood from the alpha side / beta side
+// with N = T+U-1 diagonals, Nr = N rounded up to 16, Up = 64*K (K = lattice columns per sweep lane).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rnnt {
+
+constexpr float kNeg = -1.0e30f;      // "log zero" that survives additions without inf-inf
+constexpr float kNegTest = -1.0e29f;  // anything below this is "log zero"
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr int kRebase = 16;  // diagonals per precision block (alpha~/beta~ are re-based each block)
+
+// Unsigned division by a launch-constant for n < 2^31 (Granlund-Montgomery, add-shift form).
+struct FastDiv {
+    uint32_t d, m, s;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    f.s = s;
+    f.m = (uint32_t)((((1ull << s) - d) << 32) / d) + 1u;
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv f) {
+    return (__umulhi(n, f.m) + n) >> f.s;
+}
+
+struct LossParams {
+    const float *acts;
+    float *grads;
+    const int *labels;
+    const int *label_lengths;
+    const int *input_lengths;
+    const float *cost_scale;  // nullable
+    float *costs;
+    float *lse;
+    float *W;
+    float *A;
+    float *Bt;
+    double *offA;
+    double *offB;
+    double *ll;
+    int B, T, U, V, blank;
+    int N, Nr, Up, NC;
+    uint32_t cells;  // B*T*U
+    FastDiv divU, divT, divV;
+};
+
+struct WsLayout {
+    size_t lse, W, A, Bt, offA, offB, ll, total;
+    int N, Nr, Up, NC;
+};
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Lattice columns per lane in the sweeps (one of the instantiated widths); 0 = unsupported (U > 1024).
+inline int sweep_K(int U) {
+    const int k = (U + 63) / 64;
+    const int avail[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    for (int a : avail)
+        if (k <= a) return a;
+    return 0;
+}
+// Byte every W word is pre-filled with: 0xF1F1F1F1 = -2.39e30f, a finite "log zero".
+constexpr int kFillByte = 0xF1;
+
+inline WsLayout make_layout(int T, int U, int B) {
+    WsLayout w;
+    w.N = T + U - 1;
+    w.Nr = (int)align_up((size_t)w.N, kRebase);
+    w.Up = 64 * sweep_K(U);  // row stride of the skewed arrays = 64 lanes x K columns
+    w.NC = w.Nr / kRebase + 1;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = align_up(off + bytes, 256);
+        return o;
+    };
+    w.lse = take((size_t)B * T * U * sizeof(float));
+    w.W = take((size_t)B * w.Nr * 2 * w.Up * sizeof(float));
+    w.A = take((size_t)B * w.Nr * w.Up * sizeof(float));
+    w.Bt = take((size_t)B * w.Nr * w.Up * sizeof(float));
+    w.offA = take((size_t)B * w.NC * sizeof(double));
+    w.offB = take((size_t)B * w.NC * sizeof(double));
+    w.ll = take((size_t)B * 2 * sizeof(double));
+    w.total = off;
+    return w;
+}
+
+// kernel launchers (rnnt_kernels.hip); return hipError_t from the launch
+hipError_t launch_lsm(const LossParams &p, hipStream_t s);
+hipError_t launch_sweeps(const LossParams &p, hipStream_t s);
+hipError_t launch_grad(const LossParams &p, hipStream_t s);
+
+}  // namespace rnnt

@@ -1,0 +1,166 @@
+// rnnt_entrypoint.hip -- the extern "C" boundary of libwarprnnt.so (declared in include/rnnt.h).
+//
+// Replaces the reference's native entry points (warp-transducer `src/rnnt_entrypoint.cu`, named at
+// cmake/warp-rnnt-cmakelist.txt:99; reached from utils/loss.py:34-35).  Argument validation follows
+// the published contract: null pointers / non-positive sizes ->
+// RNNT_STATUS_INVALID_VALUE; nothing is allocated; everything is enqueued on the caller's stream.
+#include "../../include/rnnt.h"
+#include "rnnt_common.h"
+
+using namespace rnnt;
+
+namespace rnnt {
+// joint_kernels.hip
+hipError_t joint_workspace_bytes(int T, int U, int B, int J, int V, size_t *bytes);
+hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2,
+                             const int *labels, const int *label_lengths, const int *input_lengths,
+                             const float *cost_scale, int J, int V, int B, int T, int U, int blank, float *costs,
+                             float *d_enc_proj, float *d_pred_proj, float *dW2, float *db2, int joint_dtype,
+                             void *workspace, hipStream_t s);
+}  // namespace rnnt
+
+static rnntStatus_t check_options(const rnntOptions &o) {
+    if (o.loc != RNNT_GPU) return RNNT_STATUS_INVALID_VALUE;  // device-only library: no CPU fallback
+    if (!o.batch_first) return RNNT_STATUS_INVALID_VALUE;
+    if (o.maxT <= 0 || o.maxU <= 0 || o.blank_label < 0) return RNNT_STATUS_INVALID_VALUE;
+    if (o.maxU > 1024) return RNNT_STATUS_INVALID_VALUE;  // register-resident sweep limit
+    return RNNT_STATUS_SUCCESS;
+}
+
+static bool fill_params(LossParams &p, const float *acts, float *grads, const int *labels,
+                        const int *label_lengths, const int *input_lengths, const float *cost_scale, int V,
+                        int B, float *costs, void *workspace, const rnntOptions &o) {
+    const long long cells = (long long)B * o.maxT * o.maxU;
+    if (cells <= 0 || cells >= (1ll << 31)) return false;
+    if (((uintptr_t)workspace & 255) != 0) return false;
+    const WsLayout w = make_layout(o.maxT, o.maxU, B);
+    char *ws = (char *)workspace;
+    p.acts = acts;
+    p.grads = grads;
+    p.labels = labels;
+    p.label_lengths = label_lengths;
+    p.input_lengths = input_lengths;
+    p.cost_scale = cost_scale;
+    p.costs = costs;
+    p.lse = (float *)(ws + w.lse);
+    p.W = (float *)(ws + w.W);
+    p.A = (float *)(ws + w.A);
+    p.Bt = (float *)(ws + w.Bt);
+    p.offA = (double *)(ws + w.offA);
+    p.offB = (double *)(ws + w.offB);
+    p.ll = (double *)(ws + w.ll);
+    p.B = B, p.T = o.maxT, p.U = o.maxU, p.V = V, p.blank = o.blank_label;
+    p.N = w.N, p.Nr = w.Nr, p.Up = w.Up, p.NC = w.NC;
+    p.cells = (uint32_t)cells;
+    p.divU = make_fastdiv((uint32_t)o.maxU);
+    p.divT = make_fastdiv((uint32_t)o.maxT);
+    p.divV = make_fastdiv((uint32_t)V);
+    return true;
+}
+
+static rnntStatus_t from_hip(hipError_t e) {
+    if (e == hipSuccess) return RNNT_STATUS_SUCCESS;
+    if (e == hipErrorInvalidValue) return RNNT_STATUS_INVALID_VALUE;
+    return RNNT_STATUS_EXECUTION_FAILED;
+}
+
+extern "C" {
+
+int get_warprnnt_version(void) { return 1; }
+
+const char *rnntGetStatusString(rnntStatus_t status) {
+    switch (status) {
+        case RNNT_STATUS_SUCCESS: return "no error";
+        case RNNT_STATUS_MEMOPS_FAILED: return "hip memcpy or memset failed";
+        case RNNT_STATUS_INVALID_VALUE: return "invalid value";
+        case RNNT_STATUS_EXECUTION_FAILED: return "execution failed";
+        case RNNT_STATUS_UNKNOWN_ERROR:
+        default: return "unknown error";
+    }
+}
+
+rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, int gpu, size_t *size_bytes) {
+    if (!size_bytes || maxT <= 0 || maxU <= 0 || minibatch <= 0 || !gpu) return RNNT_STATUS_INVALID_VALUE;
+    *size_bytes = make_layout(maxT, maxU, minibatch).total;
+    return RNNT_STATUS_SUCCESS;
+}
+
+// Build-only split of compute_rnnt_loss so that an autograd caller can delay the gradient pass
+// until the upstream gradient (run_rnnt.py:278: 1/global_batch) is known, and fold it in for free.
+rnntStatus_t compute_rnnt_loss_fwd(const float *acts, const int *flat_labels, const int *label_lengths,
+                                   const int *input_lengths, int alphabet_size, int minibatch, float *costs,
+                                   void *workspace, rnntOptions options) {
+    if (!acts || !flat_labels || !label_lengths || !input_lengths || !costs || !workspace)
+        return RNNT_STATUS_INVALID_VALUE;
+    if (alphabet_size <= 0 || minibatch <= 0) return RNNT_STATUS_INVALID_VALUE;
+    rnntStatus_t st = check_options(options);
+    if (st != RNNT_STATUS_SUCCESS) return st;
+    if (options.blank_label >= alphabet_size) return RNNT_STATUS_INVALID_VALUE;
+    LossParams p;
+    if (!fill_params(p, acts, nullptr, flat_labels, label_lengths, input_lengths, nullptr, alphabet_size,
+                     minibatch, costs, workspace, options))
+        return RNNT_STATUS_INVALID_VALUE;
+    hipStream_t s = (hipStream_t)options.stream;
+    // every edge weight starts as log zero; the lsm pass overwrites the real lattice cells
+    const WsLayout w = make_layout(options.maxT, options.maxU, minibatch);
+    if (hipMemsetAsync(p.W, kFillByte, w.A - w.W, s) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
+    hipError_t e = launch_lsm(p, s);
+    if (e != hipSuccess) return from_hip(e);
+    return from_hip(launch_sweeps(p, s));
+}
+
+rnntStatus_t compute_rnnt_loss_bwd(const float *acts, float *grads, const int *flat_labels,
+                                   const int *label_lengths, const int *input_lengths, const float *cost_scale,
+                                   int alphabet_size, int minibatch, void *workspace, rnntOptions options) {
+    if (!acts || !grads || !flat_labels || !label_lengths || !input_lengths || !workspace)
+        return RNNT_STATUS_INVALID_VALUE;
+    if (alphabet_size <= 0 || minibatch <= 0) return RNNT_STATUS_INVALID_VALUE;
+    rnntStatus_t st = check_options(options);
+    if (st != RNNT_STATUS_SUCCESS) return st;
+    if (options.blank_label >= alphabet_size) return RNNT_STATUS_INVALID_VALUE;
+    LossParams p;
+    if (!fill_params(p, acts, grads, flat_labels, label_lengths, input_lengths, cost_scale, alphabet_size,
+                     minibatch, nullptr, workspace, options))
+        return RNNT_STATUS_INVALID_VALUE;
+    return from_hip(launch_grad(p, (hipStream_t)options.stream));
+}
+
+rnntStatus_t compute_rnnt_loss(const float *acts, float *grads, const int *flat_labels,
+                               const int *label_lengths, const int *input_lengths, int alphabet_size,
+                               int minibatch, float *costs, void *workspace, rnntOptions options) {
+    rnntStatus_t st = compute_rnnt_loss_fwd(acts, flat_labels, label_lengths, input_lengths, alphabet_size,
+                                            minibatch, costs, workspace, options);
+    if (st != RNNT_STATUS_SUCCESS || !grads) return st;
+    return compute_rnnt_loss_bwd(acts, grads, flat_labels, label_lengths, input_lengths, nullptr, alphabet_size,
+                                 minibatch, workspace, options);
+}
+
+rnntStatus_t get_joint_workspace_size(int maxT, int maxU, int minibatch, int joint_size, int alphabet_size,
+                                      size_t *size_bytes) {
+    if (!size_bytes || maxT <= 0 || maxU <= 0 || minibatch <= 0 || joint_size <= 0 || alphabet_size <= 0)
+        return RNNT_STATUS_INVALID_VALUE;
+    return from_hip(joint_workspace_bytes(maxT, maxU, minibatch, joint_size, alphabet_size, size_bytes));
+}
+
+rnntStatus_t compute_rnnt_joint_loss(const float *enc_proj, const float *pred_proj, const float *W2,
+                                     const float *b2, const int *flat_labels, const int *label_lengths,
+                                     const int *input_lengths, const float *cost_scale, int joint_size,
+                                     int alphabet_size, int minibatch, float *costs, float *d_enc_proj,
+                                     float *d_pred_proj, float *dW2, float *db2, int joint_dtype, void *workspace,
+                                     rnntOptions options) {
+    if (!enc_proj || !pred_proj || !W2 || !b2 || !flat_labels || !label_lengths || !input_lengths || !costs ||
+        !workspace)
+        return RNNT_STATUS_INVALID_VALUE;
+    if (joint_size <= 0 || alphabet_size <= 0 || minibatch <= 0) return RNNT_STATUS_INVALID_VALUE;
+    rnntStatus_t st = check_options(options);
+    if (st != RNNT_STATUS_SUCCESS) return st;
+    if (options.blank_label >= alphabet_size) return RNNT_STATUS_INVALID_VALUE;
+    const bool any_grad = d_enc_proj || d_pred_proj || dW2 || db2;
+    if (any_grad && !(d_enc_proj && d_pred_proj && dW2 && db2)) return RNNT_STATUS_INVALID_VALUE;
+    return from_hip(launch_joint_loss(enc_proj, pred_proj, W2, b2, flat_labels, label_lengths, input_lengths,
+                                      cost_scale, joint_size, alphabet_size, minibatch, options.maxT, options.maxU,
+                                      options.blank_label, costs, d_enc_proj, d_pred_proj, dW2, db2, joint_dtype,
+                                      workspace, (hipStream_t)options.stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,674 @@
+// rnnt_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the transducer loss.
+//
+// Replaces the three GPU stages of the reference's native op:
+//   a-6  log-softmax denominator            -> cell_*_kernel<GRAD=false>   ("lsm" pass)
+//   a-7/a-8 alpha / beta lattice recurrences -> sweep_kernel
+//   a-9  fused-softmax gradient              -> cell_*_kernel<GRAD=true>    ("grad" pass)
+// Call site in the reference: utils/loss.py:34-35 (rnnt_loss) via run_rnnt.py:272.
+//
+// Design (DESIGN.md has the full account):
+//  * lsm pass reads every logit once (coalesced 16-B LDS-DMA), reduces each lattice cell's
+//    V logits inside ONE lane (no cross-lane traffic for small V), and emits 3 scalars per
+//    cell: lse, and the two lattice edge weights in log2 domain, written DIAGONAL-MAJOR so
+//    that the sweeps' per-step loads are contiguous.
+//  * the sweeps run one wave64 per (utterance, direction): the live anti-diagonal stays in
+//    VGPRs (K consecutive u per lane), the only cross-lane traffic per step is ONE DPP
+//    wave-shift, no LDS exchange and no s_barrier; edge weights stream HBM -> LDS by
+//    LDS-DMA in double-buffered chunks of G diagonals.  alpha~/beta~ are re-based every 16
+//    diagonals (f64 offsets kept aside) so f32 log-space values stay O(100) instead of O(T+U).
+//  * grad pass re-reads the logits once, forms all V gradients of a cell in one lane from
+//    alpha~, beta~, lse, applies the blank/label corrections, and stores through LDS so the
+//    HBM writes are full 16-B coalesced lines.
+#include "rnnt_common.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+
+namespace rnnt {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+struct Cell {
+    int b, t, u, Tb, Ub;
+    bool valid;
+};
+
+__device__ __forceinline__ Cell decode(const LossParams &p, uint32_t c) {
+    Cell r;
+    r.b = r.t = r.u = r.Tb = r.Ub = 0;
+    r.valid = false;
+    if (c < p.cells) {
+        const uint32_t row = fdiv(c, p.divU);
+        r.u = (int)(c - row * (uint32_t)p.U);
+        const uint32_t b = fdiv(row, p.divT);
+        r.t = (int)(row - b * (uint32_t)p.T);
+        r.b = (int)b;
+        r.Tb = p.input_lengths[b];
+        r.Ub = p.label_lengths[b] + 1;
+        r.valid = (r.t < r.Tb) && (r.u < r.Ub);
+    }
+    return r;
+}
+
+__device__ __forceinline__ int clamp_label(int lab, int V) { return min(max(lab, 0), V - 1); }
+
+// What one valid cell needs from the lattice to form its gradient (all log2 domain).
+struct CellGrad {
+    float c0;     // alpha + beta - ll - lse*log2e  (add x*log2e -> log2 of softmax*occupancy)
+    float nl;     // -lse*log2e
+    float cb;     // alpha + beta(t+1,u) - ll   (blank correction exponent base) or terminal
+    float cl;     // alpha + beta(t,u+1) - ll   (label correction exponent base)
+    bool has_blank_corr, has_label;
+    int lab;
+    float scale;
+};
+
+__device__ __forceinline__ CellGrad cell_grad_setup(const LossParams &p, const Cell &cl, uint32_t c) {
+    CellGrad g;
+    const int n = cl.t + cl.u;
+    const size_t sk = ((size_t)cl.b * p.Nr + n) * p.Up + cl.u;
+    const float a = p.A[sk];
+    const float bt = p.Bt[sk];
+    const int kc = n >> 4, kc1 = (n + 1) >> 4;
+    const double oa = p.offA[(size_t)cl.b * p.NC + kc];
+    const double ll2 = p.ll[2 * cl.b];
+    const float E0 = (float)(oa + p.offB[(size_t)cl.b * p.NC + kc] - ll2);
+    const float E1 = (float)(oa + p.offB[(size_t)cl.b * p.NC + kc1] - ll2);
+    g.scale = p.cost_scale ? p.cost_scale[cl.b] : 1.0f;
+    g.nl = -p.lse[c] * kLog2e;
+    g.c0 = (a + bt) + E0 + g.nl;
+    g.has_blank_corr = true;
+    if (cl.t < cl.Tb - 1)
+        g.cb = a + p.Bt[sk + p.Up] + E1;
+    else if (cl.u == cl.Ub - 1)
+        g.cb = a + (float)(oa - ll2);
+    else {
+        g.cb = 0.f;
+        g.has_blank_corr = false;
+    }
+    g.has_label = cl.u < cl.Ub - 1;
+    g.lab = 0;
+    g.cl = 0.f;
+    if (g.has_label) {
+        g.lab = clamp_label(p.labels[(size_t)cl.b * (p.U - 1) + cl.u], p.V);
+        g.cl = a + p.Bt[sk + p.Up + 1] + E1;
+    }
+    return g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small-vocabulary path (V <= VP <= 64): one lattice cell per LANE.
+// A 256-thread workgroup owns 256 consecutive cells = one contiguous 1024*V-byte span of acts.
+// ---------------------------------------------------------------------------------------------
+template <int VP, bool V4, bool GRAD>
+__global__ __launch_bounds__(256) void cell_small_kernel(const LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int V = p.V;
+    const uint32_t c0 = blockIdx.x * 256u;
+    const uint32_t c = c0 + (uint32_t)tid;
+    const Cell cl = decode(p, c);
+
+    unsigned long long *bm = (unsigned long long *)(lds + 256 * V);
+    const unsigned long long msk = __ballot(cl.valid);
+    if ((tid & 63) == 0) bm[tid >> 6] = msk;
+    __syncthreads();
+    const bool any = (bm[0] | bm[1] | bm[2] | bm[3]) != 0ull;
+
+    const uint32_t nchunk = 64u * (uint32_t)V;  // 16-byte chunks in this block's span
+    const size_t fbase = (size_t)c0 * V;
+    const size_t total = (size_t)p.cells * V;
+
+    if (!any) {
+        if (GRAD) {  // an all-padding span: exact zeros, no reads
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (uint32_t k = tid; k < nchunk; k += 256)
+                if (fbase + (size_t)k * 4 < total) *(float4 *)(p.grads + fbase + (size_t)k * 4) = z;
+        }
+        return;
+    }
+
+    // ---- stage this span's logits HBM -> LDS with 16-byte LDS-DMA (lane-linear destination) ----
+    const float *gsrc = p.acts + fbase;
+    for (uint32_t k0 = 0; k0 < nchunk; k0 += 256) {
+        const uint32_t k = k0 + (uint32_t)tid;
+        if (k < nchunk) {
+            const uint32_t f0 = k * 4u;
+            const uint32_t ca = fdiv(f0, p.divV);
+            const uint32_t cb = V4 ? ca : min(fdiv(f0 + 3u, p.divV), 255u);
+            const bool need = (((bm[ca >> 6] >> (ca & 63)) | (bm[cb >> 6] >> (cb & 63))) & 1ull) != 0ull;
+            if (need)
+                __builtin_amdgcn_global_load_lds((glb_void *)(gsrc + f0),
+                                                 (lds_void *)(lds + (k0 + ((uint32_t)tid & ~63u)) * 4u), 16, 0, 0);
+        }
+    }
+    wait_vm0();
+    __syncthreads();
+
+    float *xs = lds + tid * V;
+    if (cl.valid) {
+        float x[VP];
+        if (V4) {
+#pragma unroll
+            for (int i = 0; i < VP / 4; ++i) {
+                if (i * 4 < V) {
+                    const float4 q = ((const float4 *)xs)[i];
+                    x[4 * i] = q.x, x[4 * i + 1] = q.y, x[4 * i + 2] = q.z, x[4 * i + 3] = q.w;
+                } else {
+                    x[4 * i] = x[4 * i + 1] = x[4 * i + 2] = x[4 * i + 3] = -INFINITY;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < VP; ++i) x[i] = (i < V) ? xs[i] : -INFINITY;
+        }
+
+        if (!GRAD) {
+            float m = x[0];
+#pragma unroll
+            for (int i = 1; i < VP; ++i) m = fmaxf(m, x[i]);
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < VP; ++i) s += ex2((x[i] - m) * kLog2e);
+            const float lse = m + kLn2 * lg2(s);
+            // a blank from the last frame leaves the lattice unless it is THE terminal transition
+            const bool blank_stays = (cl.t < cl.Tb - 1) || (cl.u == cl.Ub - 1);
+            const float ob = blank_stays ? (xs[p.blank] - lse) * kLog2e : kNeg;
+            float ol = kNeg;
+            if (cl.u < cl.Ub - 1) {
+                const int lab = clamp_label(p.labels[(size_t)cl.b * (p.U - 1) + cl.u], V);
+                ol = (xs[lab] - lse) * kLog2e;
+            }
+            p.lse[c] = lse;
+            const size_t wi = ((size_t)cl.b * p.Nr + (cl.t + cl.u)) * 2 * p.Up + cl.u;
+            p.W[wi] = ob;
+            p.W[wi + p.Up] = ol;
+        } else {
+            const CellGrad g = cell_grad_setup(p, cl, c);
+            const float xb = xs[p.blank];
+            const float xl = g.has_label ? xs[g.lab] : 0.f;
+            if (V4) {
+#pragma unroll
+                for (int i = 0; i < VP / 4; ++i)
+                    if (i * 4 < V) {
+                        float4 q;
+                        q.x = g.scale * ex2(fmaf(x[4 * i], kLog2e, g.c0));
+                        q.y = g.scale * ex2(fmaf(x[4 * i + 1], kLog2e, g.c0));
+                        q.z = g.scale * ex2(fmaf(x[4 * i + 2], kLog2e, g.c0));
+                        q.w = g.scale * ex2(fmaf(x[4 * i + 3], kLog2e, g.c0));
+                        ((float4 *)xs)[i] = q;
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < VP; ++i)
+                    if (i < V) xs[i] = g.scale * ex2(fmaf(x[i], kLog2e, g.c0));
+            }
+            if (g.has_blank_corr) xs[p.blank] -= g.scale * ex2(fmaf(xb, kLog2e, g.nl) + g.cb);
+            if (g.has_label) xs[g.lab] -= g.scale * ex2(fmaf(xl, kLog2e, g.nl) + g.cl);
+        }
+    } else if (GRAD) {
+        for (int i = 0; i < V; ++i) xs[i] = 0.f;
+    }
+
+    if (GRAD) {
+        __syncthreads();
+        float *gdst = p.grads + fbase;
+        for (uint32_t k = tid; k < nchunk; k += 256)
+            if (fbase + (size_t)k * 4 < total) *(float4 *)(gdst + (size_t)k * 4) = ((const float4 *)lds)[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// General path (any V, any alignment): one lattice cell per WAVE, lanes stride over V.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void online_upd(float &m, float &s, float xv) {
+    const float mn = fmaxf(m, xv);
+    s = s * ex2((m - mn) * kLog2e) + ex2((xv - mn) * kLog2e);
+    m = mn;
+}
+
+template <bool V4, bool GRAD>
+__global__ __launch_bounds__(256) void cell_wave_kernel(const LossParams p) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t w0 = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t nw = gridDim.x * 4u;
+    const int V = p.V;
+    for (uint32_t c = w0; c < p.cells; c += nw) {
+        const Cell cl = decode(p, c);
+        const float *x = p.acts + (size_t)c * V;
+        if (!GRAD) {
+            if (!cl.valid) continue;
+            float m = -FLT_MAX, s = 0.f;
+            if (V4) {
+                for (int i = lane * 4; i < V; i += 256) {
+                    const float4 q = *(const float4 *)(x + i);
+                    online_upd(m, s, q.x), online_upd(m, s, q.y), online_upd(m, s, q.z), online_upd(m, s, q.w);
+                }
+            } else {
+                for (int i = lane; i < V; i += 64) online_upd(m, s, x[i]);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float mo = __shfl_xor(m, off), so = __shfl_xor(s, off);
+                const float M = fmaxf(m, mo);
+                s = s * ex2((m - M) * kLog2e) + so * ex2((mo - M) * kLog2e);
+                m = M;
+            }
+            if (lane == 0) {
+                const float lse = m + kLn2 * lg2(s);
+                const bool blank_stays = (cl.t < cl.Tb - 1) || (cl.u == cl.Ub - 1);
+                const float ob = blank_stays ? (x[p.blank] - lse) * kLog2e : kNeg;
+                float ol = kNeg;
+                if (cl.u < cl.Ub - 1) {
+                    const int lab = clamp_label(p.labels[(size_t)cl.b * (p.U - 1) + cl.u], V);
+                    ol = (x[lab] - lse) * kLog2e;
+                }
+                p.lse[c] = lse;
+                const size_t wi = ((size_t)cl.b * p.Nr + (cl.t + cl.u)) * 2 * p.Up + cl.u;
+                p.W[wi] = ob;
+                p.W[wi + p.Up] = ol;
+            }
+        } else {
+            float *gd = p.grads + (size_t)c * V;
+            if (!cl.valid) {
+                if (V4) {
+                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int i = lane * 4; i < V; i += 256) *(float4 *)(gd + i) = z;
+                } else {
+                    for (int i = lane; i < V; i += 64) gd[i] = 0.f;
+                }
+                continue;
+            }
+            const CellGrad g = cell_grad_setup(p, cl, c);
+            const float corr_b = g.has_blank_corr ? g.scale * ex2(fmaf(x[p.blank], kLog2e, g.nl) + g.cb) : 0.f;
+            const float corr_l = g.has_label ? g.scale * ex2(fmaf(x[g.lab], kLog2e, g.nl) + g.cl) : 0.f;
+            const int lab = g.has_label ? g.lab : -1;
+            if (V4) {
+                for (int i = lane * 4; i < V; i += 256) {
+                    const float4 q = *(const float4 *)(x + i);
+                    float r[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float gv = g.scale * ex2(fmaf(r[k], kLog2e, g.c0));
+                        if (i + k == p.blank) gv -= corr_b;
+                        if (i + k == lab) gv -= corr_l;
+                        r[k] = gv;
+                    }
+                    *(float4 *)(gd + i) = make_float4(r[0], r[1], r[2], r[3]);
+                }
+            } else {
+                for (int i = lane; i < V; i += 64) {
+                    float gv = g.scale * ex2(fmaf(x[i], kLog2e, g.c0));
+                    if (i == p.blank) gv -= corr_b;
+                    if (i == lab) gv -= corr_l;
+                    gd[i] = gv;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// alpha / beta anti-diagonal sweeps: one wave64 per (utterance, direction).
+//
+// Lane l owns the K consecutive lattice columns u = l*K .. l*K+K-1 (row stride Up = 64*K, so every
+// lane is always inside its row).  There are NO validity masks in the step: "log zero" is carried
+// by the data.  The W workspace is pre-filled with a finite log-zero bit pattern, the lsm pass
+// overwrites only real lattice cells and writes log-zero for edges that leave the lattice, hence
+// any node outside [0,T_b) x [0,U_b) stays at log zero by construction.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_from_lower_lane(float x, float fill) {  // lane i <- lane i-1
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x138 /*wave_shr:1*/,
+                                                      0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_upper_lane(float x, float fill) {  // lane i <- lane i+1
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x130 /*wave_shl:1*/,
+                                                      0xf, 0xf, false));
+}
+#define RNNT_DPP_MAX(x, ctrl, rmask)                                                                          \
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), ctrl, rmask, \
+                                                            0xf, false)))
+__device__ __forceinline__ float wave_max(float x) {
+    RNNT_DPP_MAX(x, 0x111, 0xf);  // row_shr:1
+    RNNT_DPP_MAX(x, 0x112, 0xf);  // row_shr:2
+    RNNT_DPP_MAX(x, 0x114, 0xf);  // row_shr:4
+    RNNT_DPP_MAX(x, 0x118, 0xf);  // row_shr:8   -> lane 15 of every row holds the row max
+    RNNT_DPP_MAX(x, 0x142, 0xa);  // row_bcast:15 into rows 1,3
+    RNNT_DPP_MAX(x, 0x143, 0xc);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave max
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
+// log2(2^a + 2^b); log zero is any value <= kNeg (finite), so this never forms inf-inf.
+__device__ __forceinline__ float lse2(float a, float b) {
+    const float d = a - b;
+    return fmaxf(a, b) + lg2(1.0f + ex2(-fabsf(d)));
+}
+
+// Stream `n16` 16-byte units global -> LDS (destination lane-linear, as LDS-DMA requires).
+__device__ __forceinline__ void dma_rows(const float *g, float *l, int n16, int lane) {
+    for (int i0 = 0; i0 < n16; i0 += 64) {
+        const int k = i0 + lane;
+        if (k < n16) __builtin_amdgcn_global_load_lds((glb_void *)(g + (size_t)k * 4), (lds_void *)(l + i0 * 4), 16, 0, 0);
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void rebase(float (&v)[K], double &off) {
+    float m = v[0];
+#pragma unroll
+    for (int j = 1; j < K; ++j) m = fmaxf(m, v[j]);
+    m = wave_max(m);
+    if (m > kNegTest) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) v[j] -= m;  // log zeros stay log zeros: |m| << 1e30
+        off += (double)m;
+    }
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// number of store instructions store_diag<K, true> issues (pieces of 4, 2, 1 dwords)
+constexpr int store_pieces(int K) { return K / 4 + (K % 4) / 2 + (K % 2); }
+
+// Write one diagonal's K values of this lane.  COUNTED: explicit instructions so that the number of
+// VMEM operations per step is known exactly (for the counted s_waitcnt at chunk boundaries).
+template <int K, bool COUNTED>
+__device__ __forceinline__ void store_diag(float *dst, const float (&v)[K]) {
+    if (!COUNTED) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) dst[j] = v[j];
+    } else {
+        int j = 0;
+#pragma unroll
+        for (; j + 4 <= K; j += 4) {
+            const f32x4 q = {v[j], v[j + 1], v[j + 2], v[j + 3]};
+            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst + j), "v"(q));
+        }
+        if (K % 4 >= 2) {
+            const f32x2 q = {v[j], v[j + 1]};
+            asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(dst + j), "v"(q));
+            j += 2;
+        }
+        if (K % 2) asm volatile("global_store_dword %0, %1, off\n\ts_nop 1" ::"v"(dst + j), "v"(v[j]));
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm_counted() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Edge weights of one diagonal for this lane: w[0..K) blank edges, w[K..2K) label edges.
+template <int K>
+__device__ __forceinline__ void load_w(float (&w)[2 * K], const float *wrow) {
+    constexpr int Up = 64 * K;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        w[j] = wrow[j];
+        w[K + j] = wrow[Up + j];
+    }
+}
+
+// One alpha step: diagonal r -> r+1 using the outgoing edge weights `w` of diagonal r.
+template <int K>
+__device__ __forceinline__ void alpha_step(float (&a)[K], const float (&w)[2 * K]) {
+    float d[K], e[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        d[j] = a[j] + w[j];      // blank:  (t-1,u) -> (t,u)
+        e[j] = a[j] + w[K + j];  // label:  (t,u-1) -> (t,u)
+    }
+    const float from_left = dpp_from_lower_lane(e[K - 1], kNeg);
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = lse2(d[j], (j == 0) ? from_left : e[j - 1]);
+}
+
+// One beta step: diagonal n+1 -> n using the outgoing edge weights `w` of diagonal n.
+template <int K>
+__device__ __forceinline__ void beta_step(float (&bv)[K], const float (&w)[2 * K]) {
+    const float from_right = dpp_from_upper_lane(bv[0], kNeg);
+    float nv[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const float right = (j == K - 1) ? from_right : bv[j + 1];
+        nv[j] = lse2(bv[j] + w[j], right + w[K + j]);
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) bv[j] = nv[j];
+}
+
+template <int K, int G, bool COUNTED>
+__device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const int lane) {
+    constexpr int Up = 64 * K;
+    constexpr int chunkf = G * 2 * Up, n16 = chunkf / 4;
+    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int Nb = Tb + Ub - 1;
+    const float *Wb = p.W + (size_t)b * p.Nr * 2 * Up;
+    float *out = p.A + (size_t)b * p.Nr * Up + lane * K;
+    double *offp = p.offA + (size_t)b * p.NC;
+    const int u0 = lane * K;
+    float *buf0 = lds, *buf1 = lds + chunkf;
+
+    float a[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = (u0 + j == 0) ? 0.f : kNeg;
+    store_diag<K, false>(out, a);
+    if (lane == 0) offp[0] = 0.0;
+    double off = 0.0;
+    const int last_row = Nb - 1;  // rows 0..Nb-2 feed the steps, row Nb-1 the final likelihood
+    const int nchunks = last_row / G + 1;
+
+    dma_rows(Wb, buf0, n16, lane);
+    bool prev_full = false;
+    for (int ck = 0; ck < nchunks; ++ck) {
+        if (COUNTED && prev_full)
+            wait_vm_counted<G * store_pieces(K)>();
+        else
+            wait_vm0();
+        const float *cur = ((ck & 1) ? buf1 : buf0) + u0;
+        if (ck + 1 < nchunks) dma_rows(Wb + (size_t)(ck + 1) * chunkf, (ck & 1) ? buf0 : buf1, n16, lane);
+        const int r0 = ck * G;
+        if (r0 + G <= last_row) {  // every row of this chunk feeds a step: straight-line code
+            float wc[2 * K], wn[2 * K];
+            load_w<K>(wc, cur);
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int n = r0 + i + 1;
+                if (i + 1 < G) load_w<K>(wn, cur + (i + 1) * 2 * Up);  // next step's weights: hides LDS latency
+                alpha_step<K>(a, wc);
+                if ((n & (kRebase - 1)) == 0) {
+                    rebase<K>(a, off);
+                    if (lane == 0) offp[n / kRebase] = off;
+                }
+                store_diag<K, COUNTED>(out + (size_t)n * Up, a);
+#pragma unroll
+                for (int q = 0; q < 2 * K; ++q) wc[q] = wn[q];
+            }
+            prev_full = true;
+        } else {
+            for (int i = 0; i < G; ++i) {
+                const int n = r0 + i + 1;
+                if (n > last_row) break;
+                float wc[2 * K];
+                load_w<K>(wc, cur + i * 2 * Up);
+                alpha_step<K>(a, wc);
+                if ((n & (kRebase - 1)) == 0) {
+                    rebase<K>(a, off);
+                    if (lane == 0) offp[n / kRebase] = off;
+                }
+                store_diag<K, false>(out + (size_t)n * Up, a);
+            }
+            prev_full = false;
+        }
+    }
+    {
+        const float *wrow = (((nchunks - 1) & 1) ? buf1 : buf0) + (last_row % G) * 2 * Up + u0;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (u0 + j == Ub - 1) {
+                const double ll2 = off + (double)a[j] + (double)wrow[j];
+                p.ll[2 * b] = ll2;
+                p.costs[b] = (float)(-ll2 * 0.6931471805599453);
+            }
+    }
+}
+
+template <int K, int G, bool COUNTED>
+__device__ void beta_sweep(const LossParams &p, float *lds, const int b, const int lane) {
+    constexpr int Up = 64 * K;
+    constexpr int chunkf = G * 2 * Up, n16 = chunkf / 4;
+    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int Nb = Tb + Ub - 1;
+    const float *Wb = p.W + (size_t)b * p.Nr * 2 * Up;
+    float *out = p.Bt + (size_t)b * p.Nr * Up + lane * K;
+    double *offp = p.offB + (size_t)b * p.NC;
+    const int u0 = lane * K;
+    float *buf0 = lds, *buf1 = lds + chunkf;
+
+    float bv[K];  // beta on the diagonal below; starts as the virtual terminal node (Tb, Ub-1) = 0
+#pragma unroll
+    for (int j = 0; j < K; ++j) bv[j] = (u0 + j == Ub - 1) ? 0.f : kNeg;
+    double off = 0.0;
+    const int last = Nb - 1;
+    const int ckl = last / G;
+
+    dma_rows(Wb + (size_t)ckl * chunkf, (ckl & 1) ? buf1 : buf0, n16, lane);
+    bool prev_full = false;
+    for (int ck = ckl; ck >= 0; --ck) {
+        if (COUNTED && prev_full)
+            wait_vm_counted<G * store_pieces(K)>();
+        else
+            wait_vm0();
+        const float *cur = ((ck & 1) ? buf1 : buf0) + u0;
+        if (ck > 0) dma_rows(Wb + (size_t)(ck - 1) * chunkf, (ck & 1) ? buf0 : buf1, n16, lane);
+        const int r0 = ck * G;
+        if (r0 + G - 1 < last) {  // whole chunk strictly below the first (terminal) diagonal
+            float wc[2 * K], wn[2 * K];
+            load_w<K>(wc, cur + (G - 1) * 2 * Up);
+#pragma unroll
+            for (int ii = 0; ii < G; ++ii) {
+                const int i = G - 1 - ii;
+                const int n = r0 + i;
+                if (i > 0) load_w<K>(wn, cur + (i - 1) * 2 * Up);  // next step's weights: hides LDS latency
+                beta_step<K>(bv, wc);
+                if ((n & (kRebase - 1)) == kRebase - 1) {
+                    rebase<K>(bv, off);
+                    if (lane == 0) offp[n / kRebase] = off;
+                }
+                store_diag<K, COUNTED>(out + (size_t)n * Up, bv);
+#pragma unroll
+                for (int q = 0; q < 2 * K; ++q) wc[q] = wn[q];
+            }
+            prev_full = true;
+        } else {
+            for (int ii = 0; ii < G; ++ii) {
+                const int i = G - 1 - ii;
+                const int n = r0 + i;
+                if (n > last) continue;
+                float wc[2 * K];
+                load_w<K>(wc, cur + i * 2 * Up);
+                beta_step<K>(bv, wc);
+                if (((n & (kRebase - 1)) == kRebase - 1) || n == last) {
+                    rebase<K>(bv, off);
+                    if (lane == 0) offp[n / kRebase] = off;
+                }
+                store_diag<K, false>(out + (size_t)n * Up, bv);
+            }
+            prev_full = false;
+        }
+    }
+    if (lane == 0) p.ll[2 * b + 1] = off + (double)bv[0];
+}
+
+template <int K, int G, bool COUNTED>
+__global__ __launch_bounds__(64) void sweep_kernel(const LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x >> 1;
+    const int lane = threadIdx.x;
+    if (blockIdx.x & 1)
+        beta_sweep<K, G, COUNTED>(p, lds, b, lane);
+    else
+        alpha_sweep<K, G, COUNTED>(p, lds, b, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+static bool small_path_ok(const LossParams &p, bool grad) {
+    if (p.V > 60) return false;  // 256*V*4 B of LDS must stay under the 64 KiB dynamic limit
+    const size_t total = (size_t)p.cells * p.V;
+    if (total % 4 != 0 || total >= (1ull << 31)) return false;
+    if (((uintptr_t)p.acts & 15) != 0) return false;
+    if (grad && ((uintptr_t)p.grads & 15) != 0) return false;
+    return true;
+}
+
+template <bool GRAD>
+static hipError_t launch_cell(const LossParams &p, hipStream_t s) {
+    if (small_path_ok(p, GRAD)) {
+        const unsigned blocks = (p.cells + 255u) / 256u;
+        const size_t shm = (size_t)256 * p.V * sizeof(float) + 64;
+        const bool v4 = (p.V % 4) == 0;
+        if (p.V <= 32) {
+            if (v4)
+                hipLaunchKernelGGL((cell_small_kernel<32, true, GRAD>), dim3(blocks), dim3(256), shm, s, p);
+            else
+                hipLaunchKernelGGL((cell_small_kernel<32, false, GRAD>), dim3(blocks), dim3(256), shm, s, p);
+        } else {
+            if (v4)
+                hipLaunchKernelGGL((cell_small_kernel<64, true, GRAD>), dim3(blocks), dim3(256), shm, s, p);
+            else
+                hipLaunchKernelGGL((cell_small_kernel<64, false, GRAD>), dim3(blocks), dim3(256), shm, s, p);
+        }
+    } else {
+        const bool v4 = (p.V % 4) == 0 && ((uintptr_t)p.acts & 15) == 0 && (!GRAD || ((uintptr_t)p.grads & 15) == 0);
+        unsigned blocks = (p.cells + 3u) / 4u;
+        if (blocks > 256u * 16u) blocks = 256u * 16u;
+        if (v4)
+            hipLaunchKernelGGL((cell_wave_kernel<true, GRAD>), dim3(blocks), dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((cell_wave_kernel<false, GRAD>), dim3(blocks), dim3(256), 0, s, p);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_lsm(const LossParams &p, hipStream_t s) { return launch_cell<false>(p, s); }
+hipError_t launch_grad(const LossParams &p, hipStream_t s) { return launch_cell<true>(p, s); }
+
+static int sweep_mode() {  // 1 (default) = counted s_waitcnt at chunk boundaries, 0 = plain stores + vmcnt(0)
+    const char *e = getenv("RNNT_SWEEP_MODE");
+    return (e && e[0] == '0') ? 0 : 1;
+}
+
+template <int K, int G>
+static hipError_t launch_sweep_kg(const LossParams &p, hipStream_t s) {
+    const size_t shm = (size_t)2 * G * 2 * 64 * K * sizeof(float);
+    if (sweep_mode() == 1)
+        hipLaunchKernelGGL((sweep_kernel<K, G, true>), dim3(2 * p.B), dim3(64), shm, s, p);
+    else
+        hipLaunchKernelGGL((sweep_kernel<K, G, false>), dim3(2 * p.B), dim3(64), shm, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_sweeps(const LossParams &p, hipStream_t s) {
+    switch (sweep_K(p.U)) {
+        case 1: return launch_sweep_kg<1, 16>(p, s);
+        case 2: return launch_sweep_kg<2, 16>(p, s);
+        case 3: return launch_sweep_kg<3, 8>(p, s);
+        case 4: return launch_sweep_kg<4, 8>(p, s);
+        case 6: return launch_sweep_kg<6, 4>(p, s);
+        case 8: return launch_sweep_kg<8, 4>(p, s);
+        case 12: return launch_sweep_kg<12, 2>(p, s);
+        case 16: return launch_sweep_kg<16, 2>(p, s);
+        default: return hipErrorInvalidValue;  // maxU > 1024 is outside the register-resident sweep
+    }
+}
+
+}  // namespace rnnt

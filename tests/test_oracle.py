@@ -1,0 +1,161 @@
+"""CPU tests of the oracles themselves (no GPU): the float64 NumPy oracle is pinned by the upstream
+known-answer vector, finite differences and the alpha/beta likelihood identity; the C restatement of
+the reference CPU path is checked against it; committed goldens are regression-checked."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cpu_oracle, rnnt_oracle as orc
+
+
+def _kat(golden_dir):
+    with open(os.path.join(golden_dir, "kat_small.json")) as f:
+        return json.load(f)
+
+
+def test_kat_cost_and_grad(golden_dir):
+    k = _kat(golden_dir)
+    costs, grads = orc.rnnt_loss_and_grad(
+        np.array(k["logits"]), np.array(k["labels"]), k["input_lengths"], k["label_lengths"], blank=k["blank"])
+    assert abs(costs[0] - k["cost_f64"]) < 1e-12
+    assert abs(costs[0] - k["cost"]) < 1e-6
+    np.testing.assert_allclose(grads, np.array(k["grads_wrt_logits"]), atol=2e-7, rtol=0)
+
+
+def test_kat_c_restatement(golden_dir):
+    """The C restatement takes log-probs and returns log-prob gradients (CPU-op convention);
+    chaining the log-softmax backward must reproduce the KAT's logits-gradient."""
+    k = _kat(golden_dir)
+    x = np.array(k["logits"], dtype=np.float64)
+    lp = orc.log_softmax(x)
+    costs, glp = cpu_oracle.rnnt_cpu(lp, k["labels"], k["input_lengths"], k["label_lengths"], blank=k["blank"])
+    assert abs(costs[0] - k["cost"]) < 2e-6
+    g = glp - np.exp(lp) * glp.sum(-1, keepdims=True)
+    np.testing.assert_allclose(g, np.array(k["grads_wrt_logits"]), atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_finite_differences(fused):
+    rng = np.random.default_rng(7)
+    B, T, U, V = 2, 5, 4, 6
+    x = rng.normal(size=(B, T, U, V))
+    if not fused:
+        x = orc.log_softmax(x)  # treat entries as free variables anyway
+    lab = rng.integers(1, V, size=(B, U - 1))
+    il, ll = np.array([5, 3]), np.array([3, 2])
+    _, g = orc.rnnt_loss_and_grad(x, lab, il, ll, fused_softmax=fused)
+    eps = 1e-6
+    fd = np.zeros_like(x)
+    for idx in np.ndindex(*x.shape):
+        xp, xm = x.copy(), x.copy()
+        xp[idx] += eps
+        xm[idx] -= eps
+        cp, _ = orc.rnnt_loss_and_grad(xp, lab, il, ll, fused_softmax=fused)
+        cm, _ = orc.rnnt_loss_and_grad(xm, lab, il, ll, fused_softmax=fused)
+        fd[idx] = (cp.sum() - cm.sum()) / (2 * eps)
+    np.testing.assert_allclose(g, fd, atol=1e-7, rtol=0)
+    # padded cells carry exactly zero gradient
+    assert np.all(g[1, 3:, :, :] == 0) and np.all(g[1, :, 3:, :] == 0)
+
+
+def test_alpha_beta_likelihood_identity_and_cell_sums():
+    rng = np.random.default_rng(3)
+    T, U, V = 17, 6, 9
+    x = rng.normal(size=(T, U, V))
+    lab = rng.integers(1, V, size=U - 1)
+    cost, g, a, b, ll_b = orc.utterance_cost_and_grad(x, lab)
+    assert abs(-cost - ll_b) < 1e-10
+    # occupancy sums to one on every anti-diagonal
+    occ = np.exp(a + b + cost)
+    for n in range(T + U - 1):
+        s = sum(occ[n - u, u] for u in range(U) if 0 <= n - u < T)
+        assert abs(s - 1) < 1e-10
+    # fused-softmax gradient of every cell sums to zero over the vocabulary
+    assert np.abs(g.sum(-1)).max() < 1e-12
+
+
+@pytest.mark.parametrize("T,U", [(1, 1), (1, 4), (6, 1), (2, 2)])
+def test_edge_shapes(T, U):
+    rng = np.random.default_rng(T * 10 + U)
+    V = 5
+    x = rng.normal(size=(1, T, U, V))
+    lab = rng.integers(1, V, size=(1, max(U - 1, 0)))
+    costs, g = orc.rnnt_loss_and_grad(x, lab, [T], [U - 1])
+    lp = orc.log_softmax(x[0])
+    if U == 1:  # only blanks
+        assert abs(costs[0] + lp[:, 0, 0].sum()) < 1e-12
+    if T == 1:  # all labels in the single frame, then the terminal blank
+        ref = -(sum(lp[0, u, lab[0, u]] for u in range(U - 1)) + lp[0, U - 1, 0])
+        assert abs(costs[0] - ref) < 1e-12
+    assert np.isfinite(g).all()
+
+
+def test_c_restatement_matches_numpy_oracle_ragged():
+    rng = np.random.default_rng(11)
+    B, T, U, V = 6, 40, 13, 28
+    x = rng.normal(size=(B, T, U, V)).astype(np.float32)
+    lab = rng.integers(1, V, size=(B, U - 1)).astype(np.int32)
+    il = np.array([40, 31, 1, 25, 40, 7])
+    ll = np.array([12, 0, 5, 12, 3, 9])
+    lp = orc.log_softmax(x)
+    c64, g64 = orc.rnnt_loss_and_grad(lp, lab, il, ll, fused_softmax=False)
+    for nt in (1, 0):
+        c32, g32 = cpu_oracle.rnnt_cpu(lp, lab, il, ll, num_threads=nt)
+        np.testing.assert_allclose(c32, c64, rtol=2e-6, atol=1e-5)
+        np.testing.assert_allclose(g32, g64, atol=5e-5, rtol=0)
+    # score-only mode
+    c_only, none = cpu_oracle.rnnt_cpu(lp, lab, il, ll, want_grad=False)
+    assert none is None
+    np.testing.assert_allclose(c_only, c64, rtol=2e-6, atol=1e-5)
+
+
+def test_c_restatement_rejects_bad_lengths():
+    lp = np.zeros((1, 3, 2, 4), np.float32)
+    with pytest.raises(RuntimeError):
+        cpu_oracle.rnnt_cpu(lp, [[1]], [4], [1])
+    with pytest.raises(RuntimeError):
+        cpu_oracle.rnnt_cpu(lp, [[1]], [3], [2])
+
+
+def test_goldens_regression(golden_dir):
+    files = sorted(glob.glob(os.path.join(golden_dir, "*.npz")))
+    assert len(files) >= 5
+    for f in files:
+        d = np.load(f)
+        costs, grads = orc.rnnt_loss_and_grad(
+            d["acts"], d["labels"], d["input_lengths"], d["label_lengths"], blank=int(d["blank"]))
+        np.testing.assert_allclose(costs, d["costs"], rtol=1e-12)
+        np.testing.assert_allclose(grads, d["grads"], atol=1e-7)
+
+
+def test_joint_oracle_backward_fd():
+    rng = np.random.default_rng(5)
+    B, T, U, H, J, V = 2, 4, 3, 5, 6, 7
+    enc, pred = rng.normal(size=(B, T, H)), rng.normal(size=(B, U, H))
+    W1, b1 = rng.normal(size=(H, J)) * 0.5, rng.normal(size=J) * 0.1
+    W2, b2 = rng.normal(size=(J, V)) * 0.5, rng.normal(size=V) * 0.1
+    lab = rng.integers(1, V, size=(B, U - 1))
+    il, ll = np.array([4, 3]), np.array([2, 1])
+    scale = np.array([0.5, 0.25])
+
+    def total(**kw):
+        args = dict(enc=enc, pred=pred, W1=W1, b1=b1, W2=W2, b2=b2)
+        args.update(kw)
+        out = orc.joint_loss_and_grads(args["enc"], args["pred"], args["W1"], args["b1"], args["W2"], args["b2"],
+                                       lab, il, ll, cost_scale=scale)
+        return (out["costs"] * scale).sum(), out
+
+    _, out = total()
+    eps = 1e-6
+    for name, arr, key in [("enc", enc, "d_enc"), ("pred", pred, "d_pred"), ("W1", W1, "dW1"), ("b1", b1, "db1"),
+                           ("W2", W2, "dW2"), ("b2", b2, "db2")]:
+        fd = np.zeros_like(arr)
+        for idx in np.ndindex(*arr.shape):
+            ap, am = arr.copy(), arr.copy()
+            ap[idx] += eps
+            am[idx] -= eps
+            fd[idx] = (total(**{name: ap})[0] - total(**{name: am})[0]) / (2 * eps)
+        np.testing.assert_allclose(out[key], fd, atol=2e-7, err_msg=name)
