@@ -7,10 +7,10 @@
 //                                              W[b][n][0][u] = log2 p(blank | t=n-u, u)
 //                                              W[b][n][1][u] = log2 p(y_{u+1} | t=n-u, u)
 //   A, Bt          f32 [B][Nr][Up]             alpha~/beta~ lattices, log2 domain, skewed,
-//                                              stored relative to a per-16-diagonal offset
+//                                              stored relative to a per-block offset (kRebase diagonals)
 //   offA, offB     f64 [B][NC]                 the offsets (one per block of kRebase diagonals)
 //   ll             f64 [B][2]                  log2-likelihood from the alpha side / beta side
-// with N = T+U-1 diagonals, Nr = N rounded up to 16, Up = 64*K (K = lattice columns per sweep lane).
+// with N = T+U-1 diagonals, Nr = N rounded up to 16 (a multiple of every chunk length), Up = 64*K (K = lattice columns per sweep lane).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,7 +21,7 @@ constexpr float kNeg = -1.0e30f;      // "log zero" that survives additions with
 constexpr float kNegTest = -1.0e29f;  // anything below this is "log zero"
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
-constexpr int kRebase = 16;  // diagonals per precision block (alpha~/beta~ are re-based each block)
+constexpr int kRebase = 4;  // diagonals per precision block (alpha~/beta~ are re-based each block)
 
 // Unsigned division by a launch-constant for n < 2^31 (Granlund-Montgomery, add-shift form).
 struct FastDiv {
@@ -82,7 +82,7 @@ constexpr int kFillByte = 0xF1;
 inline WsLayout make_layout(int T, int U, int B) {
     WsLayout w;
     w.N = T + U - 1;
-    w.Nr = (int)align_up((size_t)w.N, kRebase);
+    w.Nr = (int)align_up((size_t)w.N, 16);  // multiple of every sweep chunk length G
     w.Up = 64 * sweep_K(U);  // row stride of the skewed arrays = 64 lanes x K columns
     w.NC = w.Nr / kRebase + 1;
     size_t off = 0;
