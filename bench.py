@@ -1,10 +1,10 @@
 #!/usr/bin/env python
 """bench.py -- transducer loss+grad throughput on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one synthetic batch resident in HBM:
-    compute_rnnt_loss_fwd  (log-softmax denominators + alpha/beta sweeps -> costs)
-  + compute_rnnt_loss_bwd  (gradient w.r.t. the logits, scaled by 1/global_batch, run_rnnt.py:278)
-called through the C ABI of libwarprnnt.so with all buffers pre-allocated.
+One "step" = one pass of the hot path over one synthetic batch resident in HBM: ONE call of
+compute_rnnt_loss_ex through the C ABI of libwarprnnt.so (log-softmax denominators + alpha/beta
+sweeps -> costs, then the gradient w.r.t. the logits scaled by 1/global_batch, run_rnnt.py:278),
+all buffers pre-allocated.
 Workload at N=1: BASELINE.json configs[1]  B=32 T=600 U=150 V=28, acts ~ N(0,1), full lengths.
 N>1: utterances shard across ranks (weak scaling: every rank owns a full B=32 batch); the op-level
 path has no exchange step, so no collective is issued inside the timed region.
@@ -111,8 +111,11 @@ def main():
                                              il.data_ptr(), scale.data_ptr(), V, B, ws.data_ptr(), opts), "bwd")
 
     def step():
-        fwd()
-        bwd()
+        # ONE call = the reference op's contract (costs + grads) with the 1/global_batch factor folded in;
+        # inside, utterance groups are pipelined across the library's side streams.
+        _lib.check(lib.compute_rnnt_loss_ex(acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), ll.data_ptr(),
+                                            il.data_ptr(), scale.data_ptr(), V, B, costs.data_ptr(), ws.data_ptr(),
+                                            opts), "compute_rnnt_loss_ex")
 
     def sync():
         torch.cuda.synchronize()
@@ -153,7 +156,6 @@ def main():
         t_b = float(np.mean([e1.elapsed_time(e2) for _, e1, e2 in ef])) * 1e-3
         alg = 8.0 * V * cells  # read each f32 logit once + write each f32 gradient once
         ach_grad = alg / t_b / 1e9
-        ach_op = alg / (t_f + t_b) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
@@ -168,9 +170,9 @@ def main():
             "traffic": traffic,
             "algorithmic_bytes_per_launch": alg,
             "kernel_avg_ms": t_b * 1e3,
-            "whole_op": {"note": "same algorithmic bytes over ALL kernels of one step (memset+lsm+sweeps+grad)",
-                         "achieved": ach_op, "frac": ach_op / HBM_PEAK_GBS,
-                         "fwd_ms": t_f * 1e3, "bwd_ms": t_b * 1e3},
+            "whole_op": {"note": "same algorithmic bytes over the whole timed step (memset+lsm+sweeps+grad, pipelined)",
+                         "achieved": alg / (dt / a.steps) / 1e9, "frac": alg / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
+                         "unpipelined_fwd_ms": t_f * 1e3, "unpipelined_bwd_ms": t_b * 1e3},
         }
 
     cpu = None

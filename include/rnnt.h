@@ -95,7 +95,10 @@ rnntStatus_t compute_rnnt_loss(const float *acts, float *grads, const int *flat_
  *   compute_rnnt_loss_fwd  = costs + lattice state in `workspace` (reads acts once)
  *   compute_rnnt_loss_bwd  = grads[b] = cost_scale[b] * d cost_b / d acts  (cost_scale NULL = 1),
  *                            from the SAME acts and the workspace left by _fwd.
- * compute_rnnt_loss(acts, grads, ...) == _fwd followed by _bwd(cost_scale = NULL). */
+ * compute_rnnt_loss(acts, grads, ...) == _fwd followed by _bwd(cost_scale = NULL).
+ *   compute_rnnt_loss_ex   = compute_rnnt_loss with cost_scale folded into grads, in ONE call; this
+ *                            form pipelines utterance groups across internal streams (the gradient
+ *                            pass of one group overlaps the alpha/beta sweeps of the next). */
 rnntStatus_t compute_rnnt_loss_fwd(const float *acts, const int *flat_labels,
                                    const int *label_lengths, const int *input_lengths,
                                    int alphabet_size, int minibatch, float *costs, void *workspace,
@@ -105,6 +108,11 @@ rnntStatus_t compute_rnnt_loss_bwd(const float *acts, float *grads, const int *f
                                    const int *label_lengths, const int *input_lengths,
                                    const float *cost_scale, int alphabet_size, int minibatch,
                                    void *workspace, rnntOptions options);
+
+rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, const int *flat_labels,
+                                  const int *label_lengths, const int *input_lengths,
+                                  const float *cost_scale, int alphabet_size, int minibatch,
+                                  float *costs, void *workspace, rnntOptions options);
 
 /* ------------------------------------------------------------------------------------------
  * Build-only extension (no upstream counterpart): the joint network fused with the loss, so the

@@ -19,6 +19,7 @@ SYMBOLS = [
     "compute_rnnt_loss",
     "compute_rnnt_loss_fwd",
     "compute_rnnt_loss_bwd",
+    "compute_rnnt_loss_ex",
     "get_joint_workspace_size",
     "compute_rnnt_joint_loss",
 ]
@@ -73,6 +74,8 @@ def load():
     lib.compute_rnnt_loss_fwd.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, rnntOptions]
     lib.compute_rnnt_loss_bwd.restype = ci
     lib.compute_rnnt_loss_bwd.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, vp, rnntOptions]
+    lib.compute_rnnt_loss_ex.restype = ci
+    lib.compute_rnnt_loss_ex.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, rnntOptions]
     lib.get_joint_workspace_size.restype = ci
     lib.get_joint_workspace_size.argtypes = [ci, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_size_t)]
     lib.compute_rnnt_joint_loss.restype = ci

@@ -40,6 +40,12 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv f) {
     return (__umulhi(n, f.m) + n) >> f.s;
 }
 
+// Patch geometry of the small-vocabulary tile kernels (TT*UU <= 256 lattice cells per workgroup).
+struct TileGeom {
+    int TT, UU, tiles_t, tiles_u, cpr;  // cpr = 16-byte chunks per patch row = UU*V/4
+    FastDiv div_tu, div_tt, divUU, div_cpr;
+};
+
 struct LossParams {
     const float *acts;
     float *grads;
@@ -56,9 +62,11 @@ struct LossParams {
     double *offB;
     double *ll;
     int B, T, U, V, blank;
+    int b0, nb;  // this launch covers utterances [b0, b0+nb)  (group pipelining)
     int N, Nr, Up, NC;
     uint32_t cells;  // B*T*U
     FastDiv divU, divT, divV;
+    TileGeom tile;
 };
 
 struct WsLayout {
@@ -102,7 +110,24 @@ inline WsLayout make_layout(int T, int U, int B) {
     return w;
 }
 
+inline TileGeom make_tile(int T, int U, int V) {
+    TileGeom g;
+    const int nu = (U + 15) / 16;
+    g.UU = (U + nu - 1) / nu;  // <= 16, splits U evenly
+    g.TT = 256 / g.UU;
+    if (g.TT > T) g.TT = T;
+    g.tiles_u = (U + g.UU - 1) / g.UU;
+    g.tiles_t = (T + g.TT - 1) / g.TT;
+    g.cpr = g.UU * V / 4;
+    g.div_tu = make_fastdiv((uint32_t)g.tiles_u);
+    g.div_tt = make_fastdiv((uint32_t)g.tiles_t);
+    g.divUU = make_fastdiv((uint32_t)g.UU);
+    g.div_cpr = make_fastdiv((uint32_t)(g.cpr > 0 ? g.cpr : 1));
+    return g;
+}
+
 // kernel launchers (rnnt_kernels.hip); return hipError_t from the launch
+bool tile_path_ok(const LossParams &p, bool grad);
 hipError_t launch_lsm(const LossParams &p, hipStream_t s);
 hipError_t launch_sweeps(const LossParams &p, hipStream_t s);
 hipError_t launch_grad(const LossParams &p, hipStream_t s);

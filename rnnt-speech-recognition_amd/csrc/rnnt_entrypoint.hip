@@ -7,6 +7,8 @@
 #include "../../include/rnnt.h"
 #include "rnnt_common.h"
 
+#include <stdlib.h>
+
 using namespace rnnt;
 
 namespace rnnt {
@@ -50,6 +52,8 @@ static bool fill_params(LossParams &p, const float *acts, float *grads, const in
     p.offB = (double *)(ws + w.offB);
     p.ll = (double *)(ws + w.ll);
     p.B = B, p.T = o.maxT, p.U = o.maxU, p.V = V, p.blank = o.blank_label;
+    p.b0 = 0, p.nb = B;
+    p.tile = make_tile(o.maxT, o.maxU, V);
     p.N = w.N, p.Nr = w.Nr, p.Up = w.Up, p.NC = w.NC;
     p.cells = (uint32_t)cells;
     p.divU = make_fastdiv((uint32_t)o.maxU);
@@ -85,39 +89,123 @@ rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, int gpu, size
     return RNNT_STATUS_SUCCESS;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Utterance-group pipelining.  The sweeps are latency-bound (T+U-1 dependent steps, one wave per
+// utterance and direction) and use a fraction of the CUs, while the lsm / gradient passes are
+// HBM-bound.  Splitting the batch into groups lets group g's sweeps run on a side stream while the
+// caller's stream streams the next group's logits:
+//     main :  memset  lsm(0) lsm(1) ... lsm(G-1)          [wait s(0)] grad(0) [wait s(1)] grad(1) ...
+//     side g:          [wait lsm(g)] sweeps(g)
+// Side streams and events are created once per device and owned by the library (no device memory
+// is allocated); every fork is joined back into the caller's stream before the call returns, so the
+// caller still sees ordinary stream-ordered semantics.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int kMaxGroups = 8;
+constexpr int kMaxDevices = 16;
+struct Pipe {
+    bool ready = false;
+    hipStream_t side[kMaxGroups];
+    hipEvent_t lsm_done[kMaxGroups], sweep_done[kMaxGroups];
+};
+Pipe g_pipes[kMaxDevices];
+
+Pipe *get_pipe() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    Pipe &pp = g_pipes[dev];
+    if (!pp.ready) {
+        for (int i = 0; i < kMaxGroups; ++i) {
+            if (hipStreamCreateWithFlags(&pp.side[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+            if (hipEventCreateWithFlags(&pp.lsm_done[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+            if (hipEventCreateWithFlags(&pp.sweep_done[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        }
+        pp.ready = true;
+    }
+    return &pp;
+}
+
+int choose_groups(const LossParams &p, bool grad) {
+    int g = 4;
+    if (const char *e = getenv("RNNT_GROUPS")) g = atoi(e);
+    if (g > kMaxGroups) g = kMaxGroups;
+    if (g > p.B) g = p.B;
+    if (g < 1) g = 1;
+    if (!tile_path_ok(p, grad)) g = 1;  // only the patch kernels take an utterance range
+    return g;
+}
+
+// lsm + sweeps for all groups; on return (status success) the caller's stream has either been
+// joined with every sweep (join_all) or `ngroups`/`pipe` tell the caller which events to wait for.
+rnntStatus_t run_forward(LossParams &p, const WsLayout &w, hipStream_t s, bool grad_follows, int &ngroups,
+                         Pipe *&pipe) {
+    if (hipMemsetAsync(p.W, kFillByte, w.A - w.W, s) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
+    ngroups = choose_groups(p, grad_follows);
+    pipe = (ngroups > 1) ? get_pipe() : nullptr;
+    if (!pipe) ngroups = 1;
+    if (ngroups == 1) {
+        hipError_t e = launch_lsm(p, s);
+        if (e != hipSuccess) return from_hip(e);
+        return from_hip(launch_sweeps(p, s));
+    }
+    const int B = p.B;
+    for (int g = 0; g < ngroups; ++g) {
+        LossParams q = p;
+        q.b0 = (int)((long long)B * g / ngroups);
+        q.nb = (int)((long long)B * (g + 1) / ngroups) - q.b0;
+        hipError_t e = launch_lsm(q, s);
+        if (e != hipSuccess) return from_hip(e);
+        if (hipEventRecord(pipe->lsm_done[g], s) != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
+        if (hipStreamWaitEvent(pipe->side[g], pipe->lsm_done[g], 0) != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
+        e = launch_sweeps(q, pipe->side[g]);
+        if (e != hipSuccess) return from_hip(e);
+        if (hipEventRecord(pipe->sweep_done[g], pipe->side[g]) != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
+    }
+    return RNNT_STATUS_SUCCESS;
+}
+
+rnntStatus_t validate(const void *acts, const void *labels, const void *ll, const void *il, const void *ws,
+                      int V, int B, const rnntOptions &o) {
+    if (!acts || !labels || !ll || !il || !ws) return RNNT_STATUS_INVALID_VALUE;
+    if (V <= 0 || B <= 0) return RNNT_STATUS_INVALID_VALUE;
+    rnntStatus_t st = check_options(o);
+    if (st != RNNT_STATUS_SUCCESS) return st;
+    if (o.blank_label >= V) return RNNT_STATUS_INVALID_VALUE;
+    return RNNT_STATUS_SUCCESS;
+}
+}  // namespace
+
 // Build-only split of compute_rnnt_loss so that an autograd caller can delay the gradient pass
 // until the upstream gradient (run_rnnt.py:278: 1/global_batch) is known, and fold it in for free.
 rnntStatus_t compute_rnnt_loss_fwd(const float *acts, const int *flat_labels, const int *label_lengths,
                                    const int *input_lengths, int alphabet_size, int minibatch, float *costs,
                                    void *workspace, rnntOptions options) {
-    if (!acts || !flat_labels || !label_lengths || !input_lengths || !costs || !workspace)
-        return RNNT_STATUS_INVALID_VALUE;
-    if (alphabet_size <= 0 || minibatch <= 0) return RNNT_STATUS_INVALID_VALUE;
-    rnntStatus_t st = check_options(options);
+    if (!costs) return RNNT_STATUS_INVALID_VALUE;
+    rnntStatus_t st = validate(acts, flat_labels, label_lengths, input_lengths, workspace, alphabet_size, minibatch,
+                               options);
     if (st != RNNT_STATUS_SUCCESS) return st;
-    if (options.blank_label >= alphabet_size) return RNNT_STATUS_INVALID_VALUE;
     LossParams p;
     if (!fill_params(p, acts, nullptr, flat_labels, label_lengths, input_lengths, nullptr, alphabet_size,
                      minibatch, costs, workspace, options))
         return RNNT_STATUS_INVALID_VALUE;
     hipStream_t s = (hipStream_t)options.stream;
-    // every edge weight starts as log zero; the lsm pass overwrites the real lattice cells
     const WsLayout w = make_layout(options.maxT, options.maxU, minibatch);
-    if (hipMemsetAsync(p.W, kFillByte, w.A - w.W, s) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
-    hipError_t e = launch_lsm(p, s);
-    if (e != hipSuccess) return from_hip(e);
-    return from_hip(launch_sweeps(p, s));
+    int ng = 1;
+    Pipe *pipe = nullptr;
+    st = run_forward(p, w, s, false, ng, pipe);
+    if (st != RNNT_STATUS_SUCCESS) return st;
+    for (int g = 0; g < ng && pipe; ++g)
+        if (hipStreamWaitEvent(s, pipe->sweep_done[g], 0) != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
+    return RNNT_STATUS_SUCCESS;
 }
 
 rnntStatus_t compute_rnnt_loss_bwd(const float *acts, float *grads, const int *flat_labels,
                                    const int *label_lengths, const int *input_lengths, const float *cost_scale,
                                    int alphabet_size, int minibatch, void *workspace, rnntOptions options) {
-    if (!acts || !grads || !flat_labels || !label_lengths || !input_lengths || !workspace)
-        return RNNT_STATUS_INVALID_VALUE;
-    if (alphabet_size <= 0 || minibatch <= 0) return RNNT_STATUS_INVALID_VALUE;
-    rnntStatus_t st = check_options(options);
+    if (!grads) return RNNT_STATUS_INVALID_VALUE;
+    rnntStatus_t st = validate(acts, flat_labels, label_lengths, input_lengths, workspace, alphabet_size, minibatch,
+                               options);
     if (st != RNNT_STATUS_SUCCESS) return st;
-    if (options.blank_label >= alphabet_size) return RNNT_STATUS_INVALID_VALUE;
     LossParams p;
     if (!fill_params(p, acts, grads, flat_labels, label_lengths, input_lengths, cost_scale, alphabet_size,
                      minibatch, nullptr, workspace, options))
@@ -125,14 +213,45 @@ rnntStatus_t compute_rnnt_loss_bwd(const float *acts, float *grads, const int *f
     return from_hip(launch_grad(p, (hipStream_t)options.stream));
 }
 
+// compute_rnnt_loss with the upstream gradient folded in (cost_scale NULL = 1): the pipelined form.
+rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, const int *flat_labels,
+                                  const int *label_lengths, const int *input_lengths, const float *cost_scale,
+                                  int alphabet_size, int minibatch, float *costs, void *workspace,
+                                  rnntOptions options) {
+    if (!grads)
+        return compute_rnnt_loss_fwd(acts, flat_labels, label_lengths, input_lengths, alphabet_size, minibatch,
+                                     costs, workspace, options);
+    if (!costs) return RNNT_STATUS_INVALID_VALUE;
+    rnntStatus_t st = validate(acts, flat_labels, label_lengths, input_lengths, workspace, alphabet_size, minibatch,
+                               options);
+    if (st != RNNT_STATUS_SUCCESS) return st;
+    LossParams p;
+    if (!fill_params(p, acts, grads, flat_labels, label_lengths, input_lengths, cost_scale, alphabet_size,
+                     minibatch, costs, workspace, options))
+        return RNNT_STATUS_INVALID_VALUE;
+    hipStream_t s = (hipStream_t)options.stream;
+    const WsLayout w = make_layout(options.maxT, options.maxU, minibatch);
+    int ng = 1;
+    Pipe *pipe = nullptr;
+    st = run_forward(p, w, s, true, ng, pipe);
+    if (st != RNNT_STATUS_SUCCESS) return st;
+    if (ng == 1 || !pipe) return from_hip(launch_grad(p, s));
+    for (int g = 0; g < ng; ++g) {
+        LossParams q = p;
+        q.b0 = (int)((long long)p.B * g / ng);
+        q.nb = (int)((long long)p.B * (g + 1) / ng) - q.b0;
+        if (hipStreamWaitEvent(s, pipe->sweep_done[g], 0) != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
+        hipError_t e = launch_grad(q, s);
+        if (e != hipSuccess) return from_hip(e);
+    }
+    return RNNT_STATUS_SUCCESS;
+}
+
 rnntStatus_t compute_rnnt_loss(const float *acts, float *grads, const int *flat_labels,
                                const int *label_lengths, const int *input_lengths, int alphabet_size,
                                int minibatch, float *costs, void *workspace, rnntOptions options) {
-    rnntStatus_t st = compute_rnnt_loss_fwd(acts, flat_labels, label_lengths, input_lengths, alphabet_size,
-                                            minibatch, costs, workspace, options);
-    if (st != RNNT_STATUS_SUCCESS || !grads) return st;
-    return compute_rnnt_loss_bwd(acts, grads, flat_labels, label_lengths, input_lengths, nullptr, alphabet_size,
-                                 minibatch, workspace, options);
+    return compute_rnnt_loss_ex(acts, grads, flat_labels, label_lengths, input_lengths, nullptr, alphabet_size,
+                                minibatch, costs, workspace, options);
 }
 
 rnntStatus_t get_joint_workspace_size(int maxT, int maxU, int minibatch, int joint_size, int alphabet_size,

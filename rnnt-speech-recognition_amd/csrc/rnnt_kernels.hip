@@ -102,56 +102,12 @@ __device__ __forceinline__ CellGrad cell_grad_setup(const LossParams &p, const C
     return g;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Small-vocabulary path (V <= VP <= 64): one lattice cell per LANE.
-// A 256-thread workgroup owns 256 consecutive cells = one contiguous 1024*V-byte span of acts.
-// ---------------------------------------------------------------------------------------------
+// Everything one lane does for its lattice cell once the cell's V logits sit in LDS at `xs`:
+// GRAD=false: softmax denominator + the two lattice edge weights;  GRAD=true: the V gradients
+// (written back into `xs`, zeros for padded cells).
 template <int VP, bool V4, bool GRAD>
-__global__ __launch_bounds__(256) void cell_small_kernel(const LossParams p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x;
+__device__ __forceinline__ void cell_body(const LossParams &p, const Cell &cl, const uint32_t c, float *xs) {
     const int V = p.V;
-    const uint32_t c0 = blockIdx.x * 256u;
-    const uint32_t c = c0 + (uint32_t)tid;
-    const Cell cl = decode(p, c);
-
-    unsigned long long *bm = (unsigned long long *)(lds + 256 * V);
-    const unsigned long long msk = __ballot(cl.valid);
-    if ((tid & 63) == 0) bm[tid >> 6] = msk;
-    __syncthreads();
-    const bool any = (bm[0] | bm[1] | bm[2] | bm[3]) != 0ull;
-
-    const uint32_t nchunk = 64u * (uint32_t)V;  // 16-byte chunks in this block's span
-    const size_t fbase = (size_t)c0 * V;
-    const size_t total = (size_t)p.cells * V;
-
-    if (!any) {
-        if (GRAD) {  // an all-padding span: exact zeros, no reads
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (uint32_t k = tid; k < nchunk; k += 256)
-                if (fbase + (size_t)k * 4 < total) *(float4 *)(p.grads + fbase + (size_t)k * 4) = z;
-        }
-        return;
-    }
-
-    // ---- stage this span's logits HBM -> LDS with 16-byte LDS-DMA (lane-linear destination) ----
-    const float *gsrc = p.acts + fbase;
-    for (uint32_t k0 = 0; k0 < nchunk; k0 += 256) {
-        const uint32_t k = k0 + (uint32_t)tid;
-        if (k < nchunk) {
-            const uint32_t f0 = k * 4u;
-            const uint32_t ca = fdiv(f0, p.divV);
-            const uint32_t cb = V4 ? ca : min(fdiv(f0 + 3u, p.divV), 255u);
-            const bool need = (((bm[ca >> 6] >> (ca & 63)) | (bm[cb >> 6] >> (cb & 63))) & 1ull) != 0ull;
-            if (need)
-                __builtin_amdgcn_global_load_lds((glb_void *)(gsrc + f0),
-                                                 (lds_void *)(lds + (k0 + ((uint32_t)tid & ~63u)) * 4u), 16, 0, 0);
-        }
-    }
-    wait_vm0();
-    __syncthreads();
-
-    float *xs = lds + tid * V;
     if (cl.valid) {
         float x[VP];
         if (V4) {
@@ -216,11 +172,150 @@ __global__ __launch_bounds__(256) void cell_small_kernel(const LossParams p) {
         for (int i = 0; i < V; ++i) xs[i] = 0.f;
     }
 
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small-vocabulary path (V <= VP <= 64): one lattice cell per LANE.
+// A 256-thread workgroup owns 256 consecutive cells = one contiguous 1024*V-byte span of acts.
+// ---------------------------------------------------------------------------------------------
+template <int VP, bool V4, bool GRAD>
+__global__ __launch_bounds__(256) void cell_small_kernel(const LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int V = p.V;
+    const uint32_t c0 = blockIdx.x * 256u;
+    const uint32_t c = c0 + (uint32_t)tid;
+    const Cell cl = decode(p, c);
+
+    unsigned long long *bm = (unsigned long long *)(lds + 256 * V);
+    const unsigned long long msk = __ballot(cl.valid);
+    if ((tid & 63) == 0) bm[tid >> 6] = msk;
+    __syncthreads();
+    const bool any = (bm[0] | bm[1] | bm[2] | bm[3]) != 0ull;
+
+    const uint32_t nchunk = 64u * (uint32_t)V;  // 16-byte chunks in this block's span
+    const size_t fbase = (size_t)c0 * V;
+    const size_t total = (size_t)p.cells * V;
+
+    if (!any) {
+        if (GRAD) {  // an all-padding span: exact zeros, no reads
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (uint32_t k = tid; k < nchunk; k += 256)
+                if (fbase + (size_t)k * 4 < total) *(float4 *)(p.grads + fbase + (size_t)k * 4) = z;
+        }
+        return;
+    }
+
+    // ---- stage this span's logits HBM -> LDS with 16-byte LDS-DMA (lane-linear destination) ----
+    const float *gsrc = p.acts + fbase;
+    for (uint32_t k0 = 0; k0 < nchunk; k0 += 256) {
+        const uint32_t k = k0 + (uint32_t)tid;
+        if (k < nchunk) {
+            const uint32_t f0 = k * 4u;
+            const uint32_t ca = fdiv(f0, p.divV);
+            const uint32_t cb = V4 ? ca : min(fdiv(f0 + 3u, p.divV), 255u);
+            const bool need = (((bm[ca >> 6] >> (ca & 63)) | (bm[cb >> 6] >> (cb & 63))) & 1ull) != 0ull;
+            if (need)
+                __builtin_amdgcn_global_load_lds((glb_void *)(gsrc + f0),
+                                                 (lds_void *)(lds + (k0 + ((uint32_t)tid & ~63u)) * 4u), 16, 0, 0);
+        }
+    }
+    wait_vm0();
+    __syncthreads();
+
+    cell_body<VP, V4, GRAD>(p, cl, c, lds + tid * V);
+
     if (GRAD) {
         __syncthreads();
         float *gdst = p.grads + fbase;
         for (uint32_t k = tid; k < nchunk; k += 256)
             if (fbase + (size_t)k * 4 < total) *(float4 *)(gdst + (size_t)k * 4) = ((const float4 *)lds)[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small-vocabulary TILE path (V % 4 == 0): a workgroup owns a TT x UU patch of one utterance's
+// lattice instead of 256 consecutive cells.  HBM reads are TT row segments of UU*V*4 contiguous
+// bytes; the diagonal-major (skewed) W / alpha~ / beta~ accesses of a patch fall into runs of up to
+// min(TT,UU) consecutive words per diagonal, all issued from ONE CU (one XCD L2), so lines are
+// merged on chip instead of being touched by 16 different workgroups on 8 different L2s.
+// ---------------------------------------------------------------------------------------------
+template <int VP, bool GRAD>
+__global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int V = p.V;
+    const TileGeom &tg = p.tile;
+    // XCD-aware remap: hand each XCD (blockIdx % 8) a contiguous range of patches (bijective form)
+    uint32_t bid;
+    {
+        const uint32_t nwg = gridDim.x, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+        const uint32_t q = nwg >> 3, r = nwg & 7u;
+        bid = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
+    }
+    const uint32_t q1 = fdiv(bid, tg.div_tu);
+    const uint32_t tu = bid - q1 * (uint32_t)tg.tiles_u;
+    const uint32_t bb = fdiv(q1, tg.div_tt);
+    const uint32_t tt = q1 - bb * (uint32_t)tg.tiles_t;
+    const int b = p.b0 + (int)bb;
+    const int t0 = (int)tt * tg.TT, u0 = (int)tu * tg.UU;
+
+    const uint32_t r = fdiv((uint32_t)tid, tg.divUU);
+    const int cu = tid - (int)r * tg.UU;
+    Cell cl;
+    cl.b = b, cl.t = t0 + (int)r, cl.u = u0 + cu;
+    cl.Tb = p.input_lengths[b];
+    cl.Ub = p.label_lengths[b] + 1;
+    cl.valid = ((int)r < tg.TT) && (cl.t < cl.Tb) && (cl.u < cl.Ub);
+    const uint32_t c = ((uint32_t)(b * p.T + cl.t)) * (uint32_t)p.U + (uint32_t)cl.u;
+
+    unsigned long long *bm = (unsigned long long *)(lds + 256 * V);
+    const unsigned long long msk = __ballot(cl.valid);
+    if ((tid & 63) == 0) bm[tid >> 6] = msk;
+    __syncthreads();
+    const bool any = (bm[0] | bm[1] | bm[2] | bm[3]) != 0ull;
+
+    const uint32_t cpr = (uint32_t)tg.cpr;             // 16-byte chunks per patch row
+    const uint32_t nchunk = (uint32_t)tg.TT * cpr;
+    const size_t row_f = (size_t)p.U * V;              // floats per lattice row
+    const size_t patch0 = ((size_t)(b * p.T + t0) * p.U + u0) * V;
+
+    if (!any) {
+        if (GRAD) {  // an all-padding patch: exact zeros, no reads
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (uint32_t k = tid; k < nchunk; k += 256) {
+                const uint32_t rr = fdiv(k, tg.div_cpr), qq = k - rr * cpr;
+                const uint32_t ccu = fdiv(qq * 4u, p.divV);
+                if (t0 + (int)rr < p.T && u0 + (int)ccu < p.U)
+                    *(float4 *)(p.grads + patch0 + rr * row_f + qq * 4u) = z;
+            }
+        }
+        return;
+    }
+
+    for (uint32_t k0 = 0; k0 < nchunk; k0 += 256) {
+        const uint32_t k = k0 + (uint32_t)tid;
+        if (k < nchunk) {
+            const uint32_t rr = fdiv(k, tg.div_cpr), qq = k - rr * cpr;
+            const uint32_t lc = rr * (uint32_t)tg.UU + fdiv(qq * 4u, p.divV);  // patch-local cell of this chunk
+            if ((bm[lc >> 6] >> (lc & 63)) & 1ull)
+                __builtin_amdgcn_global_load_lds((glb_void *)(p.acts + patch0 + rr * row_f + qq * 4u),
+                                                 (lds_void *)(lds + (k0 + ((uint32_t)tid & ~63u)) * 4u), 16, 0, 0);
+        }
+    }
+    wait_vm0();
+    __syncthreads();
+
+    cell_body<VP, true, GRAD>(p, cl, c, lds + tid * V);
+
+    if (GRAD) {
+        __syncthreads();
+        for (uint32_t k = tid; k < nchunk; k += 256) {
+            const uint32_t rr = fdiv(k, tg.div_cpr), qq = k - rr * cpr;
+            const uint32_t ccu = fdiv(qq * 4u, p.divV);
+            if (t0 + (int)rr < p.T && u0 + (int)ccu < p.U)
+                *(float4 *)(p.grads + patch0 + rr * row_f + qq * 4u) = ((const float4 *)lds)[k];
+        }
     }
 }
 
@@ -597,7 +692,7 @@ __device__ void beta_sweep(const LossParams &p, float *lds, const int b, const i
 template <int K, int G, bool COUNTED>
 __global__ __launch_bounds__(64) void sweep_kernel(const LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int b = blockIdx.x >> 1;
+    const int b = p.b0 + (int)(blockIdx.x >> 1);
     const int lane = threadIdx.x;
     if (blockIdx.x & 1)
         beta_sweep<K, G, COUNTED>(p, lds, b, lane);
@@ -617,9 +712,25 @@ static bool small_path_ok(const LossParams &p, bool grad) {
     return true;
 }
 
+bool tile_path_ok(const LossParams &p, bool grad) {
+    if (p.V > 60 || (p.V % 4) != 0) return false;
+    if (((uintptr_t)p.acts & 15) != 0) return false;
+    if (grad && ((uintptr_t)p.grads & 15) != 0) return false;
+    const char *e = getenv("RNNT_CELL_PATH");  // "flat" forces the 256-consecutive-cells kernels
+    if (e && e[0] == 'f') return false;
+    return true;
+}
+
 template <bool GRAD>
 static hipError_t launch_cell(const LossParams &p, hipStream_t s) {
-    if (small_path_ok(p, GRAD)) {
+    if (tile_path_ok(p, GRAD)) {
+        const unsigned blocks = (unsigned)p.nb * p.tile.tiles_t * p.tile.tiles_u;
+        const size_t shm = (size_t)256 * p.V * sizeof(float) + 64;
+        if (p.V <= 32)
+            hipLaunchKernelGGL((cell_tile_kernel<32, GRAD>), dim3(blocks), dim3(256), shm, s, p);
+        else
+            hipLaunchKernelGGL((cell_tile_kernel<64, GRAD>), dim3(blocks), dim3(256), shm, s, p);
+    } else if (small_path_ok(p, GRAD)) {
         const unsigned blocks = (p.cells + 255u) / 256u;
         const size_t shm = (size_t)256 * p.V * sizeof(float) + 64;
         const bool v4 = (p.V % 4) == 0;
@@ -658,9 +769,9 @@ template <int K, int G>
 static hipError_t launch_sweep_kg(const LossParams &p, hipStream_t s) {
     const size_t shm = (size_t)2 * G * 2 * 64 * K * sizeof(float);
     if (sweep_mode() == 1)
-        hipLaunchKernelGGL((sweep_kernel<K, G, true>), dim3(2 * p.B), dim3(64), shm, s, p);
+        hipLaunchKernelGGL((sweep_kernel<K, G, true>), dim3(2 * p.nb), dim3(64), shm, s, p);
     else
-        hipLaunchKernelGGL((sweep_kernel<K, G, false>), dim3(2 * p.B), dim3(64), shm, s, p);
+        hipLaunchKernelGGL((sweep_kernel<K, G, false>), dim3(2 * p.nb), dim3(64), shm, s, p);
     return hipGetLastError();
 }
 

@@ -194,6 +194,32 @@ def test_sweep_variants_agree(monkeypatch, mode):
     check(acts, labels, il, ll)
 
 
+@pytest.mark.parametrize("groups", ["1", "2", "3", "8"])
+@pytest.mark.parametrize("path", ["tile", "flat"])
+def test_group_pipelining_and_cell_paths(monkeypatch, groups, path):
+    """compute_rnnt_loss pipelines utterance groups over side streams (RNNT_GROUPS) and picks the
+    patch ("tile") or the 256-consecutive-cells ("flat") kernels; every combination must agree."""
+    monkeypatch.setenv("RNNT_GROUPS", groups)
+    monkeypatch.setenv("RNNT_CELL_PATH", path)
+    acts, labels, il, ll = make_case(7, 61, 37, 28, True, seed=int(groups) * 7 + len(path))
+    check(acts, labels, il, ll)
+
+
+def test_back_to_back_calls_share_side_streams():
+    """Several pipelined calls in flight on one stream, different workspaces/inputs: joins must hold."""
+    dev = torch.device("cuda:0")
+    cases = [make_case(5, 80, 33, 28, True, seed=100 + i) for i in range(4)]
+    outs = []
+    for acts, labels, il, ll in cases:  # enqueue everything before any synchronisation
+        outs.append(pkg.rnnt_loss_and_grad(torch.tensor(acts, device=dev), torch.tensor(labels, device=dev),
+                                           torch.tensor(il, device=dev), torch.tensor(ll, device=dev)))
+    torch.cuda.synchronize()
+    for (acts, labels, il, ll), (c, g) in zip(cases, outs):
+        c_ref, g_ref = orc.rnnt_loss_and_grad(acts, labels, il, ll)
+        np.testing.assert_allclose(c.cpu().numpy(), c_ref, rtol=CTOL)
+        assert np.abs(g.cpu().numpy() - g_ref).max() <= GTOL
+
+
 def test_autograd_folds_upstream_gradient():
     """run_rnnt.py:278: loss = sum(costs) / global_batch; gradient reaches the logits scaled."""
     acts, labels, il, ll = make_case(4, 30, 12, 28, True, seed=61)
