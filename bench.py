@@ -165,7 +165,7 @@ def main():
                 traffic = None
         roof = {
             "bound": "hbm",
-            "kernel": "gradient pass (cell_small_kernel<GRAD=true>): reads V logits + writes V grads per cell",
+            "kernel": "gradient pass rnnt::cell_tile_kernel<32, true>: reads V logits + writes V grads per cell",
             "achieved": ach_grad, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_grad / HBM_PEAK_GBS,
             "traffic": traffic,
             "algorithmic_bytes_per_launch": alg,

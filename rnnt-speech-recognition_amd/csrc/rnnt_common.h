@@ -3,9 +3,9 @@
 // Data layout in HBM (see DESIGN.md "Data layout"):
 //   acts / grads   f32 [B][T][U][V]            caller-owned, row-major (batch_first)
 //   lse            f32 [B*T*U]                 natural-log softmax denominator per lattice cell
-//   W              f32 [B][Nr][2][Up]          edge weights in LOG2 domain, DIAGONAL-MAJOR (skewed):
-//                                              W[b][n][0][u] = log2 p(blank | t=n-u, u)
-//                                              W[b][n][1][u] = log2 p(y_{u+1} | t=n-u, u)
+//   W              f32 [B][Nr][Up][2]          edge weights in LOG2 domain, DIAGONAL-MAJOR (skewed):
+//                                              W[b][n][u][0] = log2 p(blank | t=n-u, u)
+//                                              W[b][n][u][1] = log2 p(y_{u+1} | t=n-u, u)
 //   A, Bt          f32 [B][Nr][Up]             alpha~/beta~ lattices, log2 domain, skewed,
 //                                              stored relative to a per-block offset (kRebase diagonals)
 //   offA, offB     f64 [B][NC]                 the offsets (one per block of kRebase diagonals)

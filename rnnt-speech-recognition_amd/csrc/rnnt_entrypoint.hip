@@ -126,7 +126,9 @@ Pipe *get_pipe() {
 }
 
 int choose_groups(const LossParams &p, bool grad) {
-    int g = 4;
+    // Measured on MI355X (profiles/r01_notes.md): with 4 HW queues and ~10 us per cross-stream event hop,
+    // kernel-level group pipelining LOSES to one group (0.465 ms vs 0.334 ms at C2), so it is opt-in.
+    int g = 1;
     if (const char *e = getenv("RNNT_GROUPS")) g = atoi(e);
     if (g > kMaxGroups) g = kMaxGroups;
     if (g > p.B) g = p.B;

@@ -130,8 +130,9 @@ __device__ __forceinline__ void cell_body(const LossParams &p, const Cell &cl, c
 #pragma unroll
             for (int i = 1; i < VP; ++i) m = fmaxf(m, x[i]);
             float s = 0.f;
+            const float nml = -m * kLog2e;
 #pragma unroll
-            for (int i = 0; i < VP; ++i) s += ex2((x[i] - m) * kLog2e);
+            for (int i = 0; i < VP; ++i) s += ex2(fmaf(x[i], kLog2e, nml));
             const float lse = m + kLn2 * lg2(s);
             // a blank from the last frame leaves the lattice unless it is THE terminal transition
             const bool blank_stays = (cl.t < cl.Tb - 1) || (cl.u == cl.Ub - 1);
@@ -142,9 +143,8 @@ __device__ __forceinline__ void cell_body(const LossParams &p, const Cell &cl, c
                 ol = (xs[lab] - lse) * kLog2e;
             }
             p.lse[c] = lse;
-            const size_t wi = ((size_t)cl.b * p.Nr + (cl.t + cl.u)) * 2 * p.Up + cl.u;
-            p.W[wi] = ob;
-            p.W[wi + p.Up] = ol;
+            const size_t wi = ((size_t)cl.b * p.Nr + (cl.t + cl.u)) * p.Up + cl.u;
+            ((float2 *)p.W)[wi] = make_float2(ob, ol);
         } else {
             const CellGrad g = cell_grad_setup(p, cl, c);
             const float xb = xs[p.blank];
@@ -244,6 +244,8 @@ template <int VP, bool GRAD>
 __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int V = p.V;
     const TileGeom &tg = p.tile;
     // XCD-aware remap: hand each XCD (blockIdx % 8) a contiguous range of patches (bijective form)
@@ -259,62 +261,55 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
     const uint32_t tt = q1 - bb * (uint32_t)tg.tiles_t;
     const int b = p.b0 + (int)bb;
     const int t0 = (int)tt * tg.TT, u0 = (int)tu * tg.UU;
+    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
 
-    const uint32_t r = fdiv((uint32_t)tid, tg.divUU);
-    const int cu = tid - (int)r * tg.UU;
-    Cell cl;
-    cl.b = b, cl.t = t0 + (int)r, cl.u = u0 + cu;
-    cl.Tb = p.input_lengths[b];
-    cl.Ub = p.label_lengths[b] + 1;
-    cl.valid = ((int)r < tg.TT) && (cl.t < cl.Tb) && (cl.u < cl.Ub);
-    const uint32_t c = ((uint32_t)(b * p.T + cl.t)) * (uint32_t)p.U + (uint32_t)cl.u;
-
-    unsigned long long *bm = (unsigned long long *)(lds + 256 * V);
-    const unsigned long long msk = __ballot(cl.valid);
-    if ((tid & 63) == 0) bm[tid >> 6] = msk;
-    __syncthreads();
-    const bool any = (bm[0] | bm[1] | bm[2] | bm[3]) != 0ull;
-
-    const uint32_t cpr = (uint32_t)tg.cpr;             // 16-byte chunks per patch row
-    const uint32_t nchunk = (uint32_t)tg.TT * cpr;
-    const size_t row_f = (size_t)p.U * V;              // floats per lattice row
+    // The valid part of a patch is a rectangle known to the whole workgroup: no per-cell bookkeeping.
+    const int rows_valid = max(0, min(tg.TT, Tb - t0));         // lattice rows with t < T_b
+    const int cols_valid = max(0, min(tg.UU, Ub - u0));         // lattice columns with u < U_b
+    const int rows_in = max(0, min(tg.TT, p.T - t0));           // rows that exist in the tensor
+    const int cols_in = max(0, min(tg.UU, p.U - u0));
+    const int q_valid = cols_valid * V / 4;                     // 16-byte chunks per row that carry valid cells
+    const int q_in = cols_in * V / 4;
+    const int row_lds = tg.UU * V;                              // floats per patch row in LDS
+    const size_t row_f = (size_t)p.U * V;                       // floats per lattice row in HBM
     const size_t patch0 = ((size_t)(b * p.T + t0) * p.U + u0) * V;
 
-    if (!any) {
+    if (rows_valid == 0 || cols_valid == 0) {
         if (GRAD) {  // an all-padding patch: exact zeros, no reads
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (uint32_t k = tid; k < nchunk; k += 256) {
-                const uint32_t rr = fdiv(k, tg.div_cpr), qq = k - rr * cpr;
-                const uint32_t ccu = fdiv(qq * 4u, p.divV);
-                if (t0 + (int)rr < p.T && u0 + (int)ccu < p.U)
-                    *(float4 *)(p.grads + patch0 + rr * row_f + qq * 4u) = z;
-            }
+            for (int r = wave; r < rows_in; r += 4)
+                for (int q = lane; q < q_in; q += 64) *(float4 *)(p.grads + patch0 + r * row_f + q * 4) = z;
         }
         return;
     }
 
-    for (uint32_t k0 = 0; k0 < nchunk; k0 += 256) {
-        const uint32_t k = k0 + (uint32_t)tid;
-        if (k < nchunk) {
-            const uint32_t rr = fdiv(k, tg.div_cpr), qq = k - rr * cpr;
-            const uint32_t lc = rr * (uint32_t)tg.UU + fdiv(qq * 4u, p.divV);  // patch-local cell of this chunk
-            if ((bm[lc >> 6] >> (lc & 63)) & 1ull)
-                __builtin_amdgcn_global_load_lds((glb_void *)(p.acts + patch0 + rr * row_f + qq * 4u),
-                                                 (lds_void *)(lds + (k0 + ((uint32_t)tid & ~63u)) * 4u), 16, 0, 0);
+    // ---- stage: each wave streams whole row segments HBM -> LDS with 16-byte LDS-DMA ----
+    for (int r = wave; r < rows_valid; r += 4) {
+        const float *src = p.acts + patch0 + r * row_f;
+        float *dst = lds + r * row_lds;
+        for (int q0 = 0; q0 < q_valid; q0 += 64) {
+            const int q = q0 + lane;
+            if (q < q_valid)
+                __builtin_amdgcn_global_load_lds((glb_void *)(src + q * 4), (lds_void *)(dst + q0 * 4), 16, 0, 0);
         }
     }
     wait_vm0();
     __syncthreads();
 
-    cell_body<VP, true, GRAD>(p, cl, c, lds + tid * V);
+    const uint32_t r = fdiv((uint32_t)tid, tg.divUU);
+    const int cu = tid - (int)r * tg.UU;
+    Cell cl;
+    cl.b = b, cl.t = t0 + (int)r, cl.u = u0 + cu, cl.Tb = Tb, cl.Ub = Ub;
+    cl.valid = ((int)r < rows_valid) && (cu < cols_valid);
+    const uint32_t c = ((uint32_t)(b * p.T + cl.t)) * (uint32_t)p.U + (uint32_t)cl.u;
+    if (GRAD || cl.valid) cell_body<VP, true, GRAD>(p, cl, c, lds + tid * V);
 
     if (GRAD) {
         __syncthreads();
-        for (uint32_t k = tid; k < nchunk; k += 256) {
-            const uint32_t rr = fdiv(k, tg.div_cpr), qq = k - rr * cpr;
-            const uint32_t ccu = fdiv(qq * 4u, p.divV);
-            if (t0 + (int)rr < p.T && u0 + (int)ccu < p.U)
-                *(float4 *)(p.grads + patch0 + rr * row_f + qq * 4u) = ((const float4 *)lds)[k];
+        for (int rr = wave; rr < rows_in; rr += 4) {
+            const float4 *srcl = (const float4 *)(lds + rr * row_lds);
+            float *dstg = p.grads + patch0 + rr * row_f;
+            for (int q = lane; q < q_in; q += 64) *(float4 *)(dstg + q * 4) = srcl[q];
         }
     }
 }
@@ -365,9 +360,8 @@ __global__ __launch_bounds__(256) void cell_wave_kernel(const LossParams p) {
                     ol = (x[lab] - lse) * kLog2e;
                 }
                 p.lse[c] = lse;
-                const size_t wi = ((size_t)cl.b * p.Nr + (cl.t + cl.u)) * 2 * p.Up + cl.u;
-                p.W[wi] = ob;
-                p.W[wi + p.Up] = ol;
+                const size_t wi = ((size_t)cl.b * p.Nr + (cl.t + cl.u)) * p.Up + cl.u;
+                ((float2 *)p.W)[wi] = make_float2(ob, ol);
             }
         } else {
             float *gd = p.grads + (size_t)c * V;
@@ -477,11 +471,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // number of store instructions store_diag<K, true> issues (pieces of 4, 2, 1 dwords)
 constexpr int store_pieces(int K) { return K / 4 + (K % 4) / 2 + (K % 2); }
 
-// Write one diagonal's K values of this lane.  COUNTED: explicit instructions so that the number of
-// VMEM operations per step is known exactly (for the counted s_waitcnt at chunk boundaries).
+// Write one diagonal's K values of this lane: `row` is the wave-uniform row base (SGPR pair), `voff`
+// the lane's byte offset.  COUNTED: explicit instructions so that the number of VMEM operations per
+// step is known exactly (for the counted s_waitcnt at chunk boundaries).
 template <int K, bool COUNTED>
-__device__ __forceinline__ void store_diag(float *dst, const float (&v)[K]) {
+__device__ __forceinline__ void store_diag(float *row, const int voff, const int lane, const float (&v)[K]) {
     if (!COUNTED) {
+        float *dst = row + lane * K;
 #pragma unroll
         for (int j = 0; j < K; ++j) dst[j] = v[j];
     } else {
@@ -489,14 +485,15 @@ __device__ __forceinline__ void store_diag(float *dst, const float (&v)[K]) {
 #pragma unroll
         for (; j + 4 <= K; j += 4) {
             const f32x4 q = {v[j], v[j + 1], v[j + 2], v[j + 3]};
-            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst + j), "v"(q));
+            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff), "v"(q), "s"(row), "n"(j * 4));
         }
         if (K % 4 >= 2) {
             const f32x2 q = {v[j], v[j + 1]};
-            asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(dst + j), "v"(q));
+            asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff), "v"(q), "s"(row), "n"(j * 4));
             j += 2;
         }
-        if (K % 2) asm volatile("global_store_dword %0, %1, off\n\ts_nop 1" ::"v"(dst + j), "v"(v[j]));
+        if (K % 2)
+            asm volatile("global_store_dword %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff), "v"(v[j]), "s"(row), "n"(j * 4));
     }
 }
 
@@ -506,13 +503,38 @@ __device__ __forceinline__ void wait_vm_counted() {
 }
 
 // Edge weights of one diagonal for this lane: w[0..K) blank edges, w[K..2K) label edges.
+// LDS row layout = HBM row layout = [Up][2] (blank, label interleaved per column): K 8-byte reads.
 template <int K>
 __device__ __forceinline__ void load_w(float (&w)[2 * K], const float *wrow) {
-    constexpr int Up = 64 * K;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        w[j] = wrow[j];
-        w[K + j] = wrow[Up + j];
+        const float2 q = ((const float2 *)wrow)[j];
+        w[j] = q.x;
+        w[K + j] = q.y;
+    }
+}
+
+// Explicitly scheduled variant of load_w for the counted sweep: K ds_read_b64 whose completion the
+// compiler does NOT track -- the caller waits with lds_wait<N>() (LDS returns in order, so waiting
+// for "<= N outstanding" retires everything older than the newest N reads).  `addr` is the lane's
+// LDS byte address of row 0 of the chunk buffer; the row/column offsets are immediates.
+template <int K, int ROW>
+__device__ __forceinline__ void lds_issue_row(f32x2 (&q)[K], const uint32_t addr) {
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(q[j]) : "v"(addr), "n"(ROW * 2 * 64 * K * 4 + j * 8));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);  // nothing that consumes the rows may be hoisted above the wait
+}
+template <int K>
+__device__ __forceinline__ void unpack_w(float (&w)[2 * K], const f32x2 (&q)[K]) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        w[j] = q[j][0];
+        w[K + j] = q[j][1];
     }
 }
 
@@ -544,6 +566,59 @@ __device__ __forceinline__ void beta_step(float (&bv)[K], const float (&w)[2 * K
     for (int j = 0; j < K; ++j) bv[j] = nv[j];
 }
 
+// Fully unrolled, explicitly pipelined steps of one chunk (compile-time recursion over the step index
+// II so that every LDS offset is an immediate and the two weight register sets ping-pong by name).
+template <int K, int G, int II>
+__device__ __forceinline__ void alpha_fast_steps(const LossParams &p, float (&a)[K], f32x2 (&wq)[2][K],
+                                                 const uint32_t abase, double &off, double *offp, float *out,
+                                                 const int voff, const int lane, const int r0, const RidgeLine &ridge) {
+    if constexpr (II < G) {
+        constexpr int cur = II & 1, nxt = cur ^ 1;
+        if constexpr (II + 1 < G) {
+            lds_issue_row<K, II + 1>(wq[nxt], abase);
+            lds_wait<K>();  // row II has landed, row II+1 stays in flight
+        } else {
+            lds_wait<0>();
+        }
+        float w[2 * K];
+        unpack_w<K>(w, wq[cur]);
+        const int n = r0 + II + 1;
+        alpha_step<K>(a, w);
+        if ((n & (kRebase - 1)) == 0) {
+            rebase<K>(a, off, ridge.u_at(n));
+            if (lane == 0) offp[n / kRebase] = off;
+        }
+        store_diag<K, true>(out + (size_t)n * (64 * K), voff, lane, a);
+        alpha_fast_steps<K, G, II + 1>(p, a, wq, abase, off, offp, out, voff, lane, r0, ridge);
+    }
+}
+
+template <int K, int G, int II>
+__device__ __forceinline__ void beta_fast_steps(const LossParams &p, float (&bv)[K], f32x2 (&wq)[2][K],
+                                                const uint32_t abase, double &off, double *offp, float *out,
+                                                const int voff, const int lane, const int r0, const RidgeLine &ridge) {
+    if constexpr (II < G) {
+        constexpr int cur = II & 1, nxt = cur ^ 1;
+        constexpr int i = G - 1 - II;  // row inside the chunk (descending)
+        if constexpr (i > 0) {
+            lds_issue_row<K, i - 1>(wq[nxt], abase);
+            lds_wait<K>();
+        } else {
+            lds_wait<0>();
+        }
+        float w[2 * K];
+        unpack_w<K>(w, wq[cur]);
+        const int n = r0 + i;
+        beta_step<K>(bv, w);
+        if ((n & (kRebase - 1)) == kRebase - 1) {
+            rebase<K>(bv, off, ridge.u_at(n));
+            if (lane == 0) offp[n / kRebase] = off;
+        }
+        store_diag<K, true>(out + (size_t)n * (64 * K), voff, lane, bv);
+        beta_fast_steps<K, G, II + 1>(p, bv, wq, abase, off, offp, out, voff, lane, r0, ridge);
+    }
+}
+
 template <int K, int G, bool COUNTED>
 __device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const int lane) {
     constexpr int Up = 64 * K;
@@ -552,7 +627,8 @@ __device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const 
     const int Nb = Tb + Ub - 1;
     const RidgeLine ridge = make_ridge(Ub, Nb);
     const float *Wb = p.W + (size_t)b * p.Nr * 2 * Up;
-    float *out = p.A + (size_t)b * p.Nr * Up + lane * K;
+    float *out = p.A + (size_t)b * p.Nr * Up;  // wave-uniform; the lane offset is added at the store
+    const int voff = lane * K * 4;
     double *offp = p.offA + (size_t)b * p.NC;
     const int u0 = lane * K;
     float *buf0 = lds, *buf1 = lds + chunkf;
@@ -560,7 +636,7 @@ __device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const 
     float a[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) a[j] = (u0 + j == 0) ? 0.f : kNeg;
-    store_diag<K, false>(out, a);
+    store_diag<K, false>(out, voff, lane, a);
     if (lane == 0) offp[0] = 0.0;
     double off = 0.0;
     const int last_row = Nb - 1;  // rows 0..Nb-2 feed the steps, row Nb-1 the final likelihood
@@ -573,24 +649,33 @@ __device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const 
             wait_vm_counted<G * store_pieces(K)>();
         else
             wait_vm0();
-        const float *cur = ((ck & 1) ? buf1 : buf0) + u0;
+        const float *cur = ((ck & 1) ? buf1 : buf0) + 2 * u0;
         if (ck + 1 < nchunks) dma_rows(Wb + (size_t)(ck + 1) * chunkf, (ck & 1) ? buf0 : buf1, n16, lane);
         const int r0 = ck * G;
         if (r0 + G <= last_row) {  // every row of this chunk feeds a step: straight-line code
-            float wc[2 * K], wn[2 * K];
-            load_w<K>(wc, cur);
+            if (COUNTED && K <= 15) {
+                // explicit software pipeline: row i+1's LDS reads are in flight under step i
+                const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
+                f32x2 wq[2][K];
+                lds_issue_row<K, 0>(wq[0], abase);
+                alpha_fast_steps<K, G, 0>(p, a, wq, abase, off, offp, out, voff, lane, r0, ridge);
+            } else {
+                float wc[2 * K], wn[2 * K];
+                load_w<K>(wc, cur);
 #pragma unroll
-            for (int i = 0; i < G; ++i) {
-                const int n = r0 + i + 1;
-                if (i + 1 < G) load_w<K>(wn, cur + (i + 1) * 2 * Up);  // next step's weights: hides LDS latency
-                alpha_step<K>(a, wc);
-                if ((n & (kRebase - 1)) == 0) {
-                    rebase<K>(a, off, ridge.u_at(n));
-                    if (lane == 0) offp[n / kRebase] = off;
+                for (int i = 0; i < G; ++i) {
+                    const int n = r0 + i + 1;
+                    if (i + 1 < G) load_w<K>(wn, cur + (i + 1) * 2 * Up);  // next step's weights
+                    __builtin_amdgcn_sched_barrier(0);
+                    alpha_step<K>(a, wc);
+                    if ((n & (kRebase - 1)) == 0) {
+                        rebase<K>(a, off, ridge.u_at(n));
+                        if (lane == 0) offp[n / kRebase] = off;
+                    }
+                    store_diag<K, COUNTED>(out + (size_t)n * Up, voff, lane, a);
+#pragma unroll
+                    for (int q = 0; q < 2 * K; ++q) wc[q] = wn[q];
                 }
-                store_diag<K, COUNTED>(out + (size_t)n * Up, a);
-#pragma unroll
-                for (int q = 0; q < 2 * K; ++q) wc[q] = wn[q];
             }
             prev_full = true;
         } else {
@@ -604,17 +689,17 @@ __device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const 
                     rebase<K>(a, off, ridge.u_at(n));
                     if (lane == 0) offp[n / kRebase] = off;
                 }
-                store_diag<K, false>(out + (size_t)n * Up, a);
+                store_diag<K, false>(out + (size_t)n * Up, voff, lane, a);
             }
             prev_full = false;
         }
     }
     {
-        const float *wrow = (((nchunks - 1) & 1) ? buf1 : buf0) + (last_row % G) * 2 * Up + u0;
+        const float *wrow = (((nchunks - 1) & 1) ? buf1 : buf0) + (last_row % G) * 2 * Up + 2 * u0;
 #pragma unroll
         for (int j = 0; j < K; ++j)
             if (u0 + j == Ub - 1) {
-                const double ll2 = off + (double)a[j] + (double)wrow[j];
+                const double ll2 = off + (double)a[j] + (double)wrow[2 * j];
                 p.ll[2 * b] = ll2;
                 p.costs[b] = (float)(-ll2 * 0.6931471805599453);
             }
@@ -629,7 +714,8 @@ __device__ void beta_sweep(const LossParams &p, float *lds, const int b, const i
     const int Nb = Tb + Ub - 1;
     const RidgeLine ridge = make_ridge(Ub, Nb);
     const float *Wb = p.W + (size_t)b * p.Nr * 2 * Up;
-    float *out = p.Bt + (size_t)b * p.Nr * Up + lane * K;
+    float *out = p.Bt + (size_t)b * p.Nr * Up;  // wave-uniform; the lane offset is added at the store
+    const int voff = lane * K * 4;
     double *offp = p.offB + (size_t)b * p.NC;
     const int u0 = lane * K;
     float *buf0 = lds, *buf1 = lds + chunkf;
@@ -648,25 +734,33 @@ __device__ void beta_sweep(const LossParams &p, float *lds, const int b, const i
             wait_vm_counted<G * store_pieces(K)>();
         else
             wait_vm0();
-        const float *cur = ((ck & 1) ? buf1 : buf0) + u0;
+        const float *cur = ((ck & 1) ? buf1 : buf0) + 2 * u0;
         if (ck > 0) dma_rows(Wb + (size_t)(ck - 1) * chunkf, (ck & 1) ? buf0 : buf1, n16, lane);
         const int r0 = ck * G;
         if (r0 + G - 1 < last) {  // whole chunk strictly below the first (terminal) diagonal
-            float wc[2 * K], wn[2 * K];
-            load_w<K>(wc, cur + (G - 1) * 2 * Up);
+            if (COUNTED && K <= 15) {
+                const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
+                f32x2 wq[2][K];
+                lds_issue_row<K, G - 1>(wq[0], abase);
+                beta_fast_steps<K, G, 0>(p, bv, wq, abase, off, offp, out, voff, lane, r0, ridge);
+            } else {
+                float wc[2 * K], wn[2 * K];
+                load_w<K>(wc, cur + (G - 1) * 2 * Up);
 #pragma unroll
-            for (int ii = 0; ii < G; ++ii) {
-                const int i = G - 1 - ii;
-                const int n = r0 + i;
-                if (i > 0) load_w<K>(wn, cur + (i - 1) * 2 * Up);  // next step's weights: hides LDS latency
-                beta_step<K>(bv, wc);
-                if ((n & (kRebase - 1)) == kRebase - 1) {
-                    rebase<K>(bv, off, ridge.u_at(n));
-                    if (lane == 0) offp[n / kRebase] = off;
+                for (int ii = 0; ii < G; ++ii) {
+                    const int i = G - 1 - ii;
+                    const int n = r0 + i;
+                    if (i > 0) load_w<K>(wn, cur + (i - 1) * 2 * Up);  // next step's weights
+                    __builtin_amdgcn_sched_barrier(0);
+                    beta_step<K>(bv, wc);
+                    if ((n & (kRebase - 1)) == kRebase - 1) {
+                        rebase<K>(bv, off, ridge.u_at(n));
+                        if (lane == 0) offp[n / kRebase] = off;
+                    }
+                    store_diag<K, COUNTED>(out + (size_t)n * Up, voff, lane, bv);
+#pragma unroll
+                    for (int q = 0; q < 2 * K; ++q) wc[q] = wn[q];
                 }
-                store_diag<K, COUNTED>(out + (size_t)n * Up, bv);
-#pragma unroll
-                for (int q = 0; q < 2 * K; ++q) wc[q] = wn[q];
             }
             prev_full = true;
         } else {
@@ -681,7 +775,7 @@ __device__ void beta_sweep(const LossParams &p, float *lds, const int b, const i
                     rebase<K>(bv, off, ridge.u_at(n));
                     if (lane == 0) offp[n / kRebase] = off;
                 }
-                store_diag<K, false>(out + (size_t)n * Up, bv);
+                store_diag<K, false>(out + (size_t)n * Up, voff, lane, bv);
             }
             prev_full = false;
         }
