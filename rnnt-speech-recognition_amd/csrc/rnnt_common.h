@@ -8,7 +8,7 @@
 //                                              W[b][n][u][1] = log2 p(y_{u+1} | t=n-u, u)
 //   A, Bt          f32 [B][Nr][Up]             alpha~/beta~ lattices, log2 domain, skewed,
 //                                              stored relative to a per-block offset (kRebase diagonals)
-//   offA, offB     f64 [B][NC]                 the offsets (one per block of kRebase diagonals)
+//   offA, offB     f64 [B][NC][NG]             the offsets (per block of kRebase diagonals and group of 64 columns)
 //   ll             f64 [B][2]                  log2-likelihood from the alpha side / beta side
 // with N = T+U-1 diagonals, Nr = N rounded up to 16 (a multiple of every chunk length), Up = 64*K (K = lattice columns per sweep lane).
 #pragma once
@@ -63,7 +63,7 @@ struct LossParams {
     double *ll;
     int B, T, U, V, blank;
     int b0, nb;  // this launch covers utterances [b0, b0+nb)  (group pipelining)
-    int N, Nr, Up, NC;
+    int N, Nr, Up, NC, NG;  // NG = Up/64 column groups (offset tables are [NC][NG])
     uint32_t cells;  // B*T*U
     FastDiv divU, divT, divV;
     TileGeom tile;
@@ -71,7 +71,7 @@ struct LossParams {
 
 struct WsLayout {
     size_t lse, W, A, Bt, offA, offB, ll, total;
-    int N, Nr, Up, NC;
+    int N, Nr, Up, NC, NG;
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -93,6 +93,7 @@ inline WsLayout make_layout(int T, int U, int B) {
     w.Nr = (int)align_up((size_t)w.N, 16);  // multiple of every sweep chunk length G
     w.Up = 64 * sweep_K(U);  // row stride of the skewed arrays = 64 lanes x K columns
     w.NC = w.Nr / kRebase + 1;
+    w.NG = w.Up / 64;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         size_t o = off;
@@ -103,8 +104,8 @@ inline WsLayout make_layout(int T, int U, int B) {
     w.W = take((size_t)B * w.Nr * 2 * w.Up * sizeof(float));
     w.A = take((size_t)B * w.Nr * w.Up * sizeof(float));
     w.Bt = take((size_t)B * w.Nr * w.Up * sizeof(float));
-    w.offA = take((size_t)B * w.NC * sizeof(double));
-    w.offB = take((size_t)B * w.NC * sizeof(double));
+    w.offA = take((size_t)B * w.NC * w.NG * sizeof(double));
+    w.offB = take((size_t)B * w.NC * w.NG * sizeof(double));
     w.ll = take((size_t)B * 2 * sizeof(double));
     w.total = off;
     return w;

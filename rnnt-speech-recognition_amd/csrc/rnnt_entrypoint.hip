@@ -54,7 +54,7 @@ static bool fill_params(LossParams &p, const float *acts, float *grads, const in
     p.B = B, p.T = o.maxT, p.U = o.maxU, p.V = V, p.blank = o.blank_label;
     p.b0 = 0, p.nb = B;
     p.tile = make_tile(o.maxT, o.maxU, V);
-    p.N = w.N, p.Nr = w.Nr, p.Up = w.Up, p.NC = w.NC;
+    p.N = w.N, p.Nr = w.Nr, p.Up = w.Up, p.NC = w.NC, p.NG = w.NG;
     p.cells = (uint32_t)cells;
     p.divU = make_fastdiv((uint32_t)o.maxU);
     p.divT = make_fastdiv((uint32_t)o.maxT);

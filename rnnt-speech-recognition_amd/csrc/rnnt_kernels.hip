@@ -75,17 +75,19 @@ __device__ __forceinline__ CellGrad cell_grad_setup(const LossParams &p, const C
     const size_t sk = ((size_t)cl.b * p.Nr + n) * p.Up + cl.u;
     const float a = p.A[sk];
     const float bt = p.Bt[sk];
+    // offsets are kept per (block of kRebase diagonals, group of 64 lattice columns)
     const int kc = n / kRebase, kc1 = (n + 1) / kRebase;
-    const double oa = p.offA[(size_t)cl.b * p.NC + kc];
+    const int g0 = cl.u >> 6, g1 = (cl.u + 1) >> 6;
+    const size_t ob = (size_t)cl.b * p.NC * p.NG;
+    const double oa = p.offA[ob + (size_t)kc * p.NG + g0];
     const double ll2 = p.ll[2 * cl.b];
-    const float E0 = (float)(oa + p.offB[(size_t)cl.b * p.NC + kc] - ll2);
-    const float E1 = (float)(oa + p.offB[(size_t)cl.b * p.NC + kc1] - ll2);
+    const float E0 = (float)(oa + p.offB[ob + (size_t)kc * p.NG + g0] - ll2);
     g.scale = p.cost_scale ? p.cost_scale[cl.b] : 1.0f;
     g.nl = -p.lse[c] * kLog2e;
     g.c0 = (a + bt) + E0 + g.nl;
     g.has_blank_corr = true;
     if (cl.t < cl.Tb - 1)
-        g.cb = a + p.Bt[sk + p.Up] + E1;
+        g.cb = a + p.Bt[sk + p.Up] + (float)(oa + p.offB[ob + (size_t)kc1 * p.NG + g0] - ll2);
     else if (cl.u == cl.Ub - 1)
         g.cb = a + (float)(oa - ll2);
     else {
@@ -97,7 +99,7 @@ __device__ __forceinline__ CellGrad cell_grad_setup(const LossParams &p, const C
     g.cl = 0.f;
     if (g.has_label) {
         g.lab = clamp_label(p.labels[(size_t)cl.b * (p.U - 1) + cl.u], p.V);
-        g.cl = a + p.Bt[sk + p.Up + 1] + E1;
+        g.cl = a + p.Bt[sk + p.Up + 1] + (float)(oa + p.offB[ob + (size_t)kc1 * p.NG + g1] - ll2);
     }
     return g;
 }
@@ -586,7 +588,7 @@ __device__ __forceinline__ void alpha_fast_steps(const LossParams &p, float (&a)
         alpha_step<K>(a, w);
         if ((n & (kRebase - 1)) == 0) {
             rebase<K>(a, off, ridge.u_at(n));
-            if (lane == 0) offp[n / kRebase] = off;
+            if (lane < p.NG) offp[(n / kRebase) * p.NG + lane] = off;
         }
         store_diag<K, true>(out + (size_t)n * (64 * K), voff, lane, a);
         alpha_fast_steps<K, G, II + 1>(p, a, wq, abase, off, offp, out, voff, lane, r0, ridge);
@@ -612,7 +614,7 @@ __device__ __forceinline__ void beta_fast_steps(const LossParams &p, float (&bv)
         beta_step<K>(bv, w);
         if ((n & (kRebase - 1)) == kRebase - 1) {
             rebase<K>(bv, off, ridge.u_at(n));
-            if (lane == 0) offp[n / kRebase] = off;
+            if (lane < p.NG) offp[(n / kRebase) * p.NG + lane] = off;
         }
         store_diag<K, true>(out + (size_t)n * (64 * K), voff, lane, bv);
         beta_fast_steps<K, G, II + 1>(p, bv, wq, abase, off, offp, out, voff, lane, r0, ridge);
@@ -629,7 +631,7 @@ __device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const 
     const float *Wb = p.W + (size_t)b * p.Nr * 2 * Up;
     float *out = p.A + (size_t)b * p.Nr * Up;  // wave-uniform; the lane offset is added at the store
     const int voff = lane * K * 4;
-    double *offp = p.offA + (size_t)b * p.NC;
+    double *offp = p.offA + (size_t)b * p.NC * p.NG;
     const int u0 = lane * K;
     float *buf0 = lds, *buf1 = lds + chunkf;
 
@@ -637,7 +639,7 @@ __device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const 
 #pragma unroll
     for (int j = 0; j < K; ++j) a[j] = (u0 + j == 0) ? 0.f : kNeg;
     store_diag<K, false>(out, voff, lane, a);
-    if (lane == 0) offp[0] = 0.0;
+    if (lane < p.NG) offp[lane] = 0.0;
     double off = 0.0;
     const int last_row = Nb - 1;  // rows 0..Nb-2 feed the steps, row Nb-1 the final likelihood
     const int nchunks = last_row / G + 1;
@@ -670,7 +672,7 @@ __device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const 
                     alpha_step<K>(a, wc);
                     if ((n & (kRebase - 1)) == 0) {
                         rebase<K>(a, off, ridge.u_at(n));
-                        if (lane == 0) offp[n / kRebase] = off;
+                        if (lane < p.NG) offp[(n / kRebase) * p.NG + lane] = off;
                     }
                     store_diag<K, COUNTED>(out + (size_t)n * Up, voff, lane, a);
 #pragma unroll
@@ -687,7 +689,7 @@ __device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const 
                 alpha_step<K>(a, wc);
                 if ((n & (kRebase - 1)) == 0) {
                     rebase<K>(a, off, ridge.u_at(n));
-                    if (lane == 0) offp[n / kRebase] = off;
+                    if (lane < p.NG) offp[(n / kRebase) * p.NG + lane] = off;
                 }
                 store_diag<K, false>(out + (size_t)n * Up, voff, lane, a);
             }
@@ -716,7 +718,7 @@ __device__ void beta_sweep(const LossParams &p, float *lds, const int b, const i
     const float *Wb = p.W + (size_t)b * p.Nr * 2 * Up;
     float *out = p.Bt + (size_t)b * p.Nr * Up;  // wave-uniform; the lane offset is added at the store
     const int voff = lane * K * 4;
-    double *offp = p.offB + (size_t)b * p.NC;
+    double *offp = p.offB + (size_t)b * p.NC * p.NG;
     const int u0 = lane * K;
     float *buf0 = lds, *buf1 = lds + chunkf;
 
@@ -755,7 +757,7 @@ __device__ void beta_sweep(const LossParams &p, float *lds, const int b, const i
                     beta_step<K>(bv, wc);
                     if ((n & (kRebase - 1)) == kRebase - 1) {
                         rebase<K>(bv, off, ridge.u_at(n));
-                        if (lane == 0) offp[n / kRebase] = off;
+                        if (lane < p.NG) offp[(n / kRebase) * p.NG + lane] = off;
                     }
                     store_diag<K, COUNTED>(out + (size_t)n * Up, voff, lane, bv);
 #pragma unroll
@@ -773,7 +775,7 @@ __device__ void beta_sweep(const LossParams &p, float *lds, const int b, const i
                 beta_step<K>(bv, wc);
                 if (((n & (kRebase - 1)) == kRebase - 1) || n == last) {
                     rebase<K>(bv, off, ridge.u_at(n));
-                    if (lane == 0) offp[n / kRebase] = off;
+                    if (lane < p.NG) offp[(n / kRebase) * p.NG + lane] = off;
                 }
                 store_diag<K, false>(out + (size_t)n * Up, voff, lane, bv);
             }
@@ -792,6 +794,185 @@ __global__ __launch_bounds__(64) void sweep_kernel(const LossParams p) {
         beta_sweep<K, G, COUNTED>(p, lds, b, lane);
     else
         alpha_sweep<K, G, COUNTED>(p, lds, b, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Skewed multi-wave sweep (maxU <= 512): NW compute waves with ONE lattice column per lane plus one
+// loader wave, per (utterance, direction).
+//   * the workgroup advances in lockstep "intervals" separated by one s_barrier; in interval `it`
+//     compute wave w works on its step it - skew(w).  The only cross-wave dependency (the value that
+//     crosses the 64-column boundary) was therefore produced one interval earlier and already sits in
+//     LDS: no communication latency on the dependent chain, ~1/K of the single-wave instruction count.
+//   * the loader wave streams W rows HBM -> LDS ring by LDS-DMA, PF rows ahead, and is the only wave
+//     that ever waits on vmcnt (counted), so the compute waves' stores stay fire-and-forget.
+//   * precision: every wave re-bases its own 64 columns every kRebase diagonals by an INTEGER amount
+//     (exact in f32); the value handed across a wave boundary is converted with the (exact) offset
+//     difference.  Offsets are recorded per (block, column group) for the gradient pass.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NW>
+struct MwCfg {
+    static constexpr int Up = 64 * NW;
+    static constexpr int IPR = (NW + 1) / 2;                                       // 1-KiB DMA instructions per W row
+    static constexpr int RB = (NW <= 4) ? 64 : 32;                                  // ring slots (power of two)
+    static constexpr int PF = (NW <= 2) ? 40 : (NW <= 4) ? 30 : (NW == 6) ? 16 : 12;  // rows in flight
+    static constexpr int XS = 4;                                                    // boundary-value ring depth
+    static constexpr size_t lds_bytes = (size_t)RB * Up * 2 * sizeof(float) + (size_t)XS * NW * 64 * sizeof(float2);
+    static_assert((PF - 2) * IPR <= 63, "vmcnt budget");
+    static_assert(PF + 2 * NW - 2 <= RB, "ring too small for the skew");
+};
+
+template <int NW, bool BETA>
+__device__ __forceinline__ void sweep_mw_body(const LossParams &p, float *lds, const int b, const int tid) {
+    using C = MwCfg<NW>;
+    constexpr int Up = C::Up, IPR = C::IPR, PF = C::PF, RB = C::RB, XS = C::XS;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int Nb = Tb + Ub - 1, last = Nb - 1;
+    const float *Wb = p.W + (size_t)b * p.Nr * 2 * Up;
+    const int nrows = Nb;                          // W rows 0..Nb-1 are consumed
+    const int nsteps = BETA ? Nb : Nb - 1;
+    const int NI = nsteps + 2 * (NW - 1);          // lockstep intervals (waves are skewed by TWO intervals)
+    float *wring = lds;                            // [RB][Up][2]
+    float2 *xbuf = (float2 *)(wring + RB * Up * 2);  // [XS][NW][64] {boundary value, offset it is relative to}
+    const uint32_t ring_base = (uint32_t)(uintptr_t)((lds_void *)wring);
+    const uint32_t xbuf_base = (uint32_t)(uintptr_t)((lds_void *)xbuf);
+
+    if (wave == NW) {
+        // ------------------------------ loader wave ------------------------------
+        // LDS-DMA through inline asm: hipcc must not see an LDS-DMA in this kernel, otherwise it guards
+        // every LDS read of the compute waves with vmcnt(0) (i.e. stalls them on their own stores).
+        // M0 carries the wave-uniform LDS destination and is saved/restored inside the statement.
+        auto issue = [&](const int j) {
+            const int r = BETA ? last - j : j;
+            const float *src = Wb + (size_t)r * Up * 2;
+            const uint32_t dst = ring_base + (uint32_t)(r & (RB - 1)) * (Up * 8);
+#pragma unroll
+            for (int i = 0; i < IPR; ++i) {
+                const int k = i * 64 + lane;
+                if (k < Up / 2) {
+                    uint32_t keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                                 "s_mov_b32 m0, %0"
+                                 : "=&s"(keep)
+                                 : "v"(src + k * 4), "s"(dst + (uint32_t)i * 1024u)
+                                 : "memory");
+                }
+            }
+        };
+        // Invariant: when interval `it` begins, rows (in consumption order) j <= it+1 have landed, because the
+        // leading compute wave prefetches row it+1 during interval it.
+        int issued = 0;
+        const int npro = min(PF, nrows);
+        for (; issued < npro; ++issued) issue(issued);
+        if (nrows >= PF)
+            wait_vm_counted<(PF - 2) * IPR>();  // rows 0 and 1 have landed
+        else
+            wait_vm0();
+        wg_barrier();
+        for (int it = 0; it < NI; ++it) {
+            if (issued < nrows) {
+                issue(issued);
+                ++issued;
+            }
+            if (issued < nrows)
+                wait_vm_counted<(PF - 2) * IPR>();  // rows <= it+2 have landed
+            else
+                wait_vm0();
+            wg_barrier();
+        }
+        return;
+    }
+
+    // ------------------------------ compute waves ------------------------------
+    const int u = wave * 64 + lane;
+    const RidgeLine ridge = make_ridge(Ub, Nb);
+    float *out = (BETA ? p.Bt : p.A) + (size_t)b * p.Nr * Up;
+    double *offp = (BETA ? p.offB : p.offA) + (size_t)b * p.NC * p.NG + wave;
+    float a = BETA ? ((u == Ub - 1) ? 0.f : kNeg) : ((u == 0) ? 0.f : kNeg);
+    float Ow = 0.f;  // this wave's offset: true value = stored value + Ow (always an integer)
+    if (!BETA) {
+        out[u] = a;
+        if (lane == 0) offp[0] = 0.0;
+    }
+    const int skew = 2 * (BETA ? NW - 1 - wave : wave);
+    const bool has_nb = BETA ? (wave < NW - 1) : (wave > 0);
+    const int nbw = BETA ? wave + 1 : wave - 1;
+    const uint32_t my_col = ring_base + (uint32_t)u * 8u;                                       // + slot * Up*8
+    const uint32_t nb_col = xbuf_base + (uint32_t)((nbw * 64) + (BETA ? 0 : 63)) * 8u;           // + slot * NW*512
+    f32x2 cw = {0.f, 0.f}, cn = {kNeg, 0.f};  // weights / neighbour value of the step about to run
+    f32x2 pw = cw, pn = cn;                   // ... of the step after it (in flight during the interval)
+
+    wg_barrier();
+    for (int it = -1; it < NI; ++it) {
+        const int s = it - skew;
+        const int s1 = s + 1;
+        // (1) prefetch for NEXT interval's step: issued first so that the LDS latency hides under this step
+        const bool pre = (s1 >= 0) && (s1 < nsteps);
+        if (pre) {
+            const int r1 = BETA ? last - s1 : s1;
+            const uint32_t wa = my_col + (uint32_t)(r1 & (RB - 1)) * (Up * 8);
+            asm volatile("ds_read_b64 %0, %1" : "=v"(pw) : "v"(wa));
+            if (has_nb) {
+                const uint32_t na = nb_col + (uint32_t)(s1 & (XS - 1)) * (NW * 512);
+                asm volatile("ds_read_b64 %0, %1" : "=v"(pn) : "v"(na));
+            }
+        }
+        // (2) this interval's step, entirely from registers
+        if (s >= 0 && s < nsteps) {
+            const int r = BETA ? last - s : s;  // W row consumed
+            const int n = BETA ? r : r + 1;     // diagonal produced
+            const float nb = has_nb ? cn[0] + (cn[1] - Ow) : kNeg;  // exact: both offsets are integers
+            float2 *xs = xbuf + ((s & (XS - 1)) * NW + wave) * 64 + lane;
+            if (!BETA) {
+                const float d = a + cw[0], e = a + cw[1];
+                *xs = make_float2(e, Ow);
+                a = lse2(d, dpp_from_lower_lane(e, nb));
+            } else {
+                *xs = make_float2(a, Ow);
+                a = lse2(a + cw[0], dpp_from_upper_lane(a, nb) + cw[1]);
+            }
+            const bool reb = BETA ? (((n & (kRebase - 1)) == kRebase - 1) || n == last) : ((n & (kRebase - 1)) == 0);
+            if (reb) {
+                const int lr = min(max(ridge.u_at(n) - wave * 64, 0), 63);  // own lane nearest the ridge line
+                const float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), lr));
+                if (m > kNegTest) {
+                    const float mi = rintf(m);
+                    a -= mi;
+                    Ow += mi;
+                }
+                if (lane == 0) offp[(size_t)(n / kRebase) * p.NG] = (double)Ow;
+            }
+            out[(size_t)n * Up + u] = a;
+        }
+        // (3) the prefetched registers become valid here (nothing may touch them before this wait)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pw), "+v"(pn));
+        cw = pw;
+        cn = pn;
+        wg_barrier();
+    }
+    if (!BETA) {
+        if (u == Ub - 1) {
+            const float2 wv = ((const float2 *)wring)[(last & (RB - 1)) * Up + u];
+            const double ll2 = (double)Ow + (double)a + (double)wv.x;
+            p.ll[2 * b] = ll2;
+            p.costs[b] = (float)(-ll2 * 0.6931471805599453);
+        }
+    } else if (u == 0) {
+        p.ll[2 * b + 1] = (double)Ow + (double)a;
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__((NW + 1) * 64) void sweep_mw_kernel(const LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = p.b0 + (int)(blockIdx.x >> 1);
+    if (blockIdx.x & 1)
+        sweep_mw_body<NW, true>(p, lds, b, threadIdx.x);
+    else
+        sweep_mw_body<NW, false>(p, lds, b, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -854,22 +1035,54 @@ static hipError_t launch_cell(const LossParams &p, hipStream_t s) {
 hipError_t launch_lsm(const LossParams &p, hipStream_t s) { return launch_cell<false>(p, s); }
 hipError_t launch_grad(const LossParams &p, hipStream_t s) { return launch_cell<true>(p, s); }
 
-static int sweep_mode() {  // 1 (default) = counted s_waitcnt at chunk boundaries, 0 = plain stores + vmcnt(0)
+// 1 (default) = register-resident single wave per (utterance, direction), explicit LDS pipeline + counted waits
+// 0           = same kernel, compiler-scheduled LDS reads, vmcnt(0) at chunk boundaries
+// 2           = skewed multi-wave kernel (one column per lane).  Measured at C2 on MI355X: 164-175 us versus
+//               112 us for mode 1 -- a lone wave issues ~1 instruction per 7 cycles whatever its kind, and the
+//               per-interval barrier/boundary bookkeeping costs more instructions than the K=3 columns it saves.
+static int sweep_mode() {
     const char *e = getenv("RNNT_SWEEP_MODE");
-    return (e && e[0] == '0') ? 0 : 1;
+    if (e && e[0] == '0') return 0;
+    if (e && e[0] == '2') return 2;
+    return 1;
 }
 
 template <int K, int G>
 static hipError_t launch_sweep_kg(const LossParams &p, hipStream_t s) {
     const size_t shm = (size_t)2 * G * 2 * 64 * K * sizeof(float);
-    if (sweep_mode() == 1)
+    if (sweep_mode() != 0)
         hipLaunchKernelGGL((sweep_kernel<K, G, true>), dim3(2 * p.nb), dim3(64), shm, s, p);
     else
         hipLaunchKernelGGL((sweep_kernel<K, G, false>), dim3(2 * p.nb), dim3(64), shm, s, p);
     return hipGetLastError();
 }
 
+template <int NW>
+static hipError_t launch_sweep_mw(const LossParams &p, hipStream_t s) {
+    const size_t shm = MwCfg<NW>::lds_bytes;
+    static bool attr_set = false;
+    if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+        hipError_t e = hipFuncSetAttribute((const void *)sweep_mw_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)shm);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((sweep_mw_kernel<NW>), dim3(2 * p.nb), dim3((NW + 1) * 64), shm, s, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_sweeps(const LossParams &p, hipStream_t s) {
+    if (sweep_mode() == 2) {
+        switch (sweep_K(p.U)) {  // = number of 64-column groups
+            case 1: return launch_sweep_mw<1>(p, s);
+            case 2: return launch_sweep_mw<2>(p, s);
+            case 3: return launch_sweep_mw<3>(p, s);
+            case 4: return launch_sweep_mw<4>(p, s);
+            case 6: return launch_sweep_mw<6>(p, s);
+            case 8: return launch_sweep_mw<8>(p, s);
+            default: break;  // wider lattices: register-resident single-wave sweep below
+        }
+    }
     switch (sweep_K(p.U)) {
         case 1: return launch_sweep_kg<1, 16>(p, s);
         case 2: return launch_sweep_kg<2, 16>(p, s);

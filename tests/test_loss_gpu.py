@@ -185,13 +185,16 @@ def test_bitwise_determinism():
     assert np.array_equal(c1, c2) and np.array_equal(g1, g2)
 
 
-@pytest.mark.parametrize("mode", ["0", "1"])
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
 def test_sweep_variants_agree(monkeypatch, mode):
-    """RNNT_SWEEP_MODE=1 (counted s_waitcnt + explicit store instructions) and 0 (drain every chunk)
-    must both meet the parity bar."""
+    """RNNT_SWEEP_MODE=1 (single wave, explicit LDS pipeline + counted waits; default), 0 (same kernel,
+    compiler-scheduled) and 2 (skewed multi-wave kernel) must all meet the parity bar."""
     monkeypatch.setenv("RNNT_SWEEP_MODE", mode)
     acts, labels, il, ll = make_case(3, 200, 150, 28, True, seed=41)
     check(acts, labels, il, ll)
+    for U in (40, 100, 250, 330, 500):  # 1, 2, 4, 6, 8 column groups
+        acts, labels, il, ll = make_case(2, 30, U, 8, True, seed=U)
+        check(acts, labels, il, ll)
 
 
 @pytest.mark.parametrize("groups", ["1", "2", "3", "8"])
