@@ -131,7 +131,13 @@ rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, const int *fl
  *   d_enc_proj [B,maxT,J], d_pred_proj [B,maxU,J], dW2 [J,V], db2 [V]
  *                                device f32 outputs: gradients of sum_b cost_scale[b]*cost_b.
  *                                Fully overwritten.  May all be NULL for score-only.
- *   joint_dtype                  0 = f32 MFMA (exact f32), 1 = f16-input MFMA with f32 accumulate
+ *   joint_dtype                  0 = f32 MFMA (exact f32).  (1 = f16-input MFMA is reserved; this round
+ *                                returns RNNT_STATUS_INVALID_VALUE for it.)
+ * Limits this round: alphabet_size <= 32, joint_size a multiple of 64 (<= 1024), maxU <= 1024.
+ * compute_rnnt_joint_loss      = costs and all four gradients in one call
+ * compute_rnnt_joint_loss_fwd  = costs only (+ lattice state kept in `workspace`)
+ * compute_rnnt_joint_loss_bwd  = the gradients, from the same inputs and that workspace (autograd split,
+ *                                as compute_rnnt_loss_fwd/_bwd)
  */
 rnntStatus_t get_joint_workspace_size(int maxT, int maxU, int minibatch, int joint_size,
                                       int alphabet_size, size_t *size_bytes);
@@ -143,6 +149,21 @@ rnntStatus_t compute_rnnt_joint_loss(const float *enc_proj, const float *pred_pr
                                      int minibatch, float *costs, float *d_enc_proj,
                                      float *d_pred_proj, float *dW2, float *db2, int joint_dtype,
                                      void *workspace, rnntOptions options);
+
+rnntStatus_t compute_rnnt_joint_loss_fwd(const float *enc_proj, const float *pred_proj,
+                                         const float *W2, const float *b2, const int *flat_labels,
+                                         const int *label_lengths, const int *input_lengths,
+                                         int joint_size, int alphabet_size, int minibatch,
+                                         float *costs, int joint_dtype, void *workspace,
+                                         rnntOptions options);
+
+rnntStatus_t compute_rnnt_joint_loss_bwd(const float *enc_proj, const float *pred_proj,
+                                         const float *W2, const float *b2, const int *flat_labels,
+                                         const int *label_lengths, const int *input_lengths,
+                                         const float *cost_scale, int joint_size, int alphabet_size,
+                                         int minibatch, float *d_enc_proj, float *d_pred_proj,
+                                         float *dW2, float *db2, int joint_dtype, void *workspace,
+                                         rnntOptions options);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,8 @@ SYMBOLS = [
     "compute_rnnt_loss_ex",
     "get_joint_workspace_size",
     "compute_rnnt_joint_loss",
+    "compute_rnnt_joint_loss_fwd",
+    "compute_rnnt_joint_loss_bwd",
 ]
 
 
@@ -80,6 +82,10 @@ def load():
     lib.get_joint_workspace_size.argtypes = [ci, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_size_t)]
     lib.compute_rnnt_joint_loss.restype = ci
     lib.compute_rnnt_joint_loss.argtypes = [vp] * 8 + [ci, ci, ci] + [vp] * 5 + [ci, vp, rnntOptions]
+    lib.compute_rnnt_joint_loss_fwd.restype = ci
+    lib.compute_rnnt_joint_loss_fwd.argtypes = [vp] * 7 + [ci, ci, ci, vp, ci, vp, rnntOptions]
+    lib.compute_rnnt_joint_loss_bwd.restype = ci
+    lib.compute_rnnt_joint_loss_bwd.argtypes = [vp] * 8 + [ci, ci, ci] + [vp] * 4 + [ci, vp, rnntOptions]
     _lib = lib
     return lib
 
@@ -102,6 +108,13 @@ def make_options(stream: int, blank: int, maxT: int, maxU: int, loc: int = RNNT_
     o.maxU = maxU
     o.batch_first = 1
     return o
+
+
+def joint_workspace_bytes(maxT: int, maxU: int, minibatch: int, joint_size: int, alphabet_size: int) -> int:
+    n = ctypes.c_size_t(0)
+    check(load().get_joint_workspace_size(maxT, maxU, minibatch, joint_size, alphabet_size, ctypes.byref(n)),
+          "get_joint_workspace_size")
+    return int(n.value)
 
 
 def workspace_bytes(maxT: int, maxU: int, minibatch: int) -> int:

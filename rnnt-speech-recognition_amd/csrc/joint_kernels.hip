@@ -1,17 +1,476 @@
-// joint_kernels.hip -- fused joint network + transducer loss (placeholder until the MFMA kernels land).
+// joint_kernels.hip -- joint network fused with the transducer loss (gfx950, f32 MFMA).
+//
+// Replaces, for the hot path, the tail of the reference model and everything TF autodiff does
+// behind it:
+//   model.py:158-160  z0 = enc[:,:,None,:] + pred[:,None,:,:]
+//   model.py:162-163  h  = tanh(z0 @ W1 + b1)
+//   model.py:165-166  y  = h @ W2 + b2                         -> logits [B,T,U,V]
+//   run_rnnt.py:284   tape.gradient(...) through those three ops
+// The first Dense layer is factored exactly (W1^T(e+p)+b1 = (W1^T e + b1) + W1^T p), so the kernels
+// take the two small projections  enc_proj [B,T,J], pred_proj [B,U,J]  (library GEMMs on the host
+// side) and never materialise the [B,T,U,J] or [B,T,U,V] tensors:
+//
+//   phase 1  (joint_phase1_kernel)  logits tile = tanh(A_t + C_u) . W2 + b2 on v_mfma_f32_32x32x2_f32
+//            forward  epilogue: softmax denominator + lattice edge weights  (same outputs as the
+//                               lsm pass of rnnt_kernels.hip -> the alpha/beta sweeps run unchanged)
+//            backward epilogue: dlogits of the tile (V <= 32 floats per cell) into the workspace
+//   phase 2  (joint_phase2_kernel)  dh = dl . W2^T,  dz = dh * (1-h^2),  d enc_proj = sum_u dz,
+//            d pred_proj = sum_t dz,  dW2 = h^T . dl   -- the "gradient scatter back through the joint".
+//            h is recomputed in the MFMA C/D register layout, which is at the same time a valid
+//            A-operand layout for dW2 (the K-slot <-> lattice-column assignment of a dot product is
+//            free), so no data moves between the three products.
+//   reductions over u-tiles / row splits / blocks go through partial buffers summed in a fixed
+//   order (deterministic; no floating-point atomics).
+//
+// Limits of this round (checked at the boundary): V <= 32 (one MFMA column tile), J % 64 == 0.
 #include "rnnt_common.h"
+#include "rnnt_cell.h"
+
+#include <math.h>
 
 namespace rnnt {
 
-hipError_t joint_workspace_bytes(int, int, int, int, int, size_t *bytes) {
-    *bytes = 0;
-    return hipErrorNotSupported;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ float jex2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float jlg2(float x) { return __builtin_amdgcn_logf(x); }
+// tanh(x) = 1 - 2/(1+e^{2x}); saturates correctly at +-inf, absolute error ~1e-7
+__device__ __forceinline__ float fast_tanh(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + jex2(x * 2.8853900817779268f));
+}
+// row of the 32x32 MFMA C/D tile held in register `reg` of a lane in half `half` (= lane >> 5)
+__device__ __forceinline__ constexpr int cd_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+struct JointParams {
+    LossParams lp;  // lattice workspace, labels, lengths, costs, cost_scale (acts/grads unused)
+    const float *enc_proj, *pred_proj, *W2, *b2;
+    float *dl;      // [cells][32] dlogits of the backward pass
+    float *dApart;  // [n_ut][B][T][J]
+    float *dCpart;  // [n_ts][B][U][J]
+    float *dWpart;  // [B*n_ut*n_ts][J][32]
+    float *dbpart;  // [B*n_ut*n_tr][32]
+    float *d_enc_proj, *d_pred_proj, *dW2, *db2;
+    int J, n_ut, TR, n_tr, TS, n_ts;
+};
+
+constexpr int kStagePad = 33;  // row stride of the per-wave 32x32 staging tiles (bank-conflict free both ways)
+
+// ---------------------------------------------------------------------------------------------
+// phase 1: one lattice row (32 cells of one u-tile) per wave per iteration.
+// LDS: Ct [J][32] (pred_proj tile, transposed) | W2c [2][32][32] | Arow [4][J] | stage [4][32][33]
+// ---------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ __launch_bounds__(256) void joint_phase1_kernel(const JointParams jp) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const LossParams &p = jp.lp;
+    const int J = jp.J, V = p.V;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *Ct = lds;                       // [J][32]
+    float *W2c = Ct + J * 32;              // [2][32][32]
+    float *Arow = W2c + 2 * 32 * 32;       // [4][J]
+    float *stage = Arow + 4 * J;           // [4][32][kStagePad]
+    float *my_arow = Arow + wave * J;
+    float *my_stage = stage + wave * 32 * kStagePad;
+
+    int bid = blockIdx.x;
+    const int tr = bid % jp.n_tr;
+    bid /= jp.n_tr;
+    const int ut = bid % jp.n_ut;
+    const int b = bid / jp.n_ut;
+    const int u0 = ut * 32;
+    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int t_begin = tr * jp.TR, t_end = min(min(t_begin + jp.TR, p.T), Tb);
+    const bool tile_live = (t_begin < t_end) && (u0 < Ub);
+
+    float dbsum = 0.f;  // BWD: this lane's share of sum_cells dl[cell][v = l31] (rows cd_row(*, half))
+    if (tile_live) {
+        // ---- C^T tile: Ct[j][u] = pred_proj[b][u0+u][j]  (lanes run along u: conflict-free LDS writes)
+        for (int idx = tid; idx < 32 * (J / 4); idx += 256) {
+            const int u = idx & 31, j4 = idx >> 5;
+            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u0 + u < p.U) c4 = *(const float4 *)(jp.pred_proj + ((size_t)b * p.U + u0 + u) * J + j4 * 4);
+            Ct[(j4 * 4 + 0) * 32 + u] = c4.x;
+            Ct[(j4 * 4 + 1) * 32 + u] = c4.y;
+            Ct[(j4 * 4 + 2) * 32 + u] = c4.z;
+            Ct[(j4 * 4 + 3) * 32 + u] = c4.w;
+        }
+    }
+    const int n_iter = tile_live ? (t_end - t_begin + 3) / 4 : 0;
+    for (int it = 0; it < n_iter; ++it) {
+        const int t = t_begin + it * 4 + wave;
+        const bool active = t < t_end;  // wave-uniform
+        if (active)
+            for (int j = lane; j < J; j += 64) my_arow[j] = jp.enc_proj[((size_t)b * p.T + t) * J + j];
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int jc = 0; jc < J / 32; ++jc) {
+            float *wbuf = W2c + (jc & 1) * 1024;
+            // W2 chunk [32 j][32 v], zero-padded beyond V
+            for (int e = tid; e < 1024; e += 256) {
+                const int jj = e >> 5, v = e & 31;
+                wbuf[e] = (v < V) ? jp.W2[(size_t)(jc * 32 + jj) * V + v] : 0.f;
+            }
+            __syncthreads();  // chunk (and, first time round, Ct / Arow) visible; the other buffer is free
+            if (active) {
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    const int jl = 2 * kk + half;
+                    const float h = fast_tanh(my_arow[jc * 32 + jl] + Ct[(jc * 32 + jl) * 32 + l31]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h, wbuf[jl * 32 + l31], acc, 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue: logits tile -> LDS, then one lattice cell per lane (lanes 0..31)
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) my_stage[cd_row(r, half) * kStagePad + l31] = acc[r];
+        }
+        __syncthreads();
+        if (active && lane < 32) {
+            Cell cl;
+            cl.b = b, cl.t = t, cl.u = u0 + lane, cl.Tb = Tb, cl.Ub = Ub;
+            cl.valid = cl.u < Ub;
+            float *xs = my_stage + lane * kStagePad;
+            if (cl.valid) {
+                const uint32_t c = ((uint32_t)(b * p.T + t)) * (uint32_t)p.U + (uint32_t)cl.u;
+                float m = -INFINITY;
+                for (int v = 0; v < V; ++v) {
+                    xs[v] += jp.b2[v];
+                    m = fmaxf(m, xs[v]);
+                }
+                if (!BWD) {
+                    float s = 0.f;
+                    const float nml = -m * kLog2e;
+                    for (int v = 0; v < V; ++v) s += jex2(fmaf(xs[v], kLog2e, nml));
+                    const float lse = m + kLn2 * jlg2(s);
+                    const bool blank_stays = (cl.t < Tb - 1) || (cl.u == Ub - 1);
+                    const float ob = blank_stays ? (xs[p.blank] - lse) * kLog2e : kNeg;
+                    float ol = kNeg;
+                    if (cl.u < Ub - 1) {
+                        const int lab = min(max(p.labels[(size_t)b * (p.U - 1) + cl.u], 0), V - 1);
+                        ol = (xs[lab] - lse) * kLog2e;
+                    }
+                    p.lse[c] = lse;
+                    const size_t wi = ((size_t)b * p.Nr + (cl.t + cl.u)) * p.Up + cl.u;
+                    ((float2 *)p.W)[wi] = make_float2(ob, ol);
+                } else {
+                    const CellGrad g = cell_grad_setup(p, cl, c);
+                    const float xb = xs[p.blank];
+                    const float xl = g.has_label ? xs[g.lab] : 0.f;
+                    for (int v = 0; v < V; ++v) xs[v] = g.scale * jex2(fmaf(xs[v], kLog2e, g.c0));
+                    if (g.has_blank_corr) xs[p.blank] -= g.scale * jex2(fmaf(xb, kLog2e, g.nl) + g.cb);
+                    if (g.has_label) xs[g.lab] -= g.scale * jex2(fmaf(xl, kLog2e, g.nl) + g.cl);
+                    for (int v = V; v < 32; ++v) xs[v] = 0.f;
+                }
+            } else if (BWD) {
+                for (int v = 0; v < 32; ++v) xs[v] = 0.f;
+            }
+        }
+        if (BWD) {
+            __syncthreads();
+            if (active) {
+                // dl tile -> workspace (row-major [cell][32]) and the db2 partial sums
+                for (int e = lane; e < 1024; e += 64) {
+                    const int uu = e >> 5, v = e & 31;
+                    if (u0 + uu < p.U) {
+                        const size_t c = ((size_t)(b * p.T + t)) * p.U + u0 + uu;
+                        jp.dl[c * 32 + v] = my_stage[uu * kStagePad + v];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dbsum += my_stage[cd_row(r, half) * kStagePad + l31];
+            }
+        }
+        __syncthreads();  // staging tiles and Arow are rewritten by the next iteration
+    }
+    if (BWD) {
+        // deterministic in-block reduction of the db2 partials: halves, then waves in fixed order
+        float *red = stage;  // reuse
+        __syncthreads();
+        red[tid] = dbsum;
+        __syncthreads();
+        if (tid < 32) {
+            float s = 0.f;
+            for (int w = 0; w < 4; ++w) s += red[w * 64 + tid] + red[w * 64 + 32 + tid];
+            jp.dbpart[(size_t)blockIdx.x * 32 + tid] = s;
+        }
+    }
 }
 
-hipError_t launch_joint_loss(const float *, const float *, const float *, const float *, const int *, const int *,
-                             const int *, const float *, int, int, int, int, int, int, float *, float *, float *,
-                             float *, float *, int, void *, hipStream_t) {
-    return hipErrorNotSupported;
+// ---------------------------------------------------------------------------------------------
+// phase 2: block = (utterance, u-tile, 64-wide J slab, row split); one lattice row per wave per iteration.
+// LDS: Cs [64 j][36] (32 u + pad) | W2s [64 j][33] | dlr [4][32 u][33] | red [4][32][33]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const LossParams &p = jp.lp;
+    const int J = jp.J, V = p.V;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int kCs = 36;                     // row stride of Cs: 16-byte aligned and conflict-free for b128 reads
+    float *Cs = lds;                            // [64][kCs]
+    float *W2s = Cs + 64 * kCs;                 // [64][kStagePad]
+    float *dlr = W2s + 64 * kStagePad;          // [4][32][kStagePad]
+    float *red = dlr + 4 * 32 * kStagePad;      // [4][32][kStagePad]
+    float *my_dl = dlr + wave * 32 * kStagePad;
+
+    int bid = blockIdx.x;
+    const int ts = bid % jp.n_ts;
+    bid /= jp.n_ts;
+    const int js = bid % (J / 64);
+    bid /= (J / 64);
+    const int ut = bid % jp.n_ut;
+    const int b = bid / jp.n_ut;
+    const int u0 = ut * 32, j0 = js * 64;
+    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int t_begin = ts * jp.TS, t_end = min(min(t_begin + jp.TS, p.T), Tb);
+    const bool tile_live = (t_begin < t_end) && (u0 < Ub);
+
+    f32x16 accC[2], accW[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accC[q][r] = 0.f, accW[q][r] = 0.f;
+
+    if (tile_live) {
+        for (int idx = tid; idx < 32 * 16; idx += 256) {  // C slab, transposed: Cs[j][u]
+            const int u = idx & 31, j4 = idx >> 5;
+            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u0 + u < p.U) c4 = *(const float4 *)(jp.pred_proj + ((size_t)b * p.U + u0 + u) * J + j0 + j4 * 4);
+            Cs[(j4 * 4 + 0) * kCs + u] = c4.x;
+            Cs[(j4 * 4 + 1) * kCs + u] = c4.y;
+            Cs[(j4 * 4 + 2) * kCs + u] = c4.z;
+            Cs[(j4 * 4 + 3) * kCs + u] = c4.w;
+        }
+        for (int e = tid; e < 64 * 32; e += 256) {  // W2 slab [64 j][32 v], zero-padded beyond V
+            const int jj = e >> 5, v = e & 31;
+            W2s[jj * kStagePad + v] = (v < V) ? jp.W2[(size_t)(j0 + jj) * V + v] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    const int n_iter = tile_live ? (t_end - t_begin + 3) / 4 : 0;
+    for (int it = 0; it < n_iter; ++it) {
+        const int t = t_begin + it * 4 + wave;
+        if (t < t_end) {  // wave-uniform; no workgroup barrier inside: the dl row buffer is wave-private
+            // ---- this row's dlogits tile [32 u][32 v] -> LDS
+            for (int e = lane; e < 1024; e += 64) {
+                const int uu = e >> 5, v = e & 31;
+                float x = 0.f;
+                if (u0 + uu < p.U) x = jp.dl[(((size_t)(b * p.T + t)) * p.U + u0 + uu) * 32 + v];
+                my_dl[uu * kStagePad + v] = x;
+            }
+            const float *arow = jp.enc_proj + ((size_t)b * p.T + t) * J + j0;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                // h tile in C/D layout: rows = lattice columns u, column = joint unit j = jt*32 + l31
+                const float aj = arow[jt * 32 + l31];
+                float h[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 c4 = *(const float4 *)(Cs + (jt * 32 + l31) * kCs + 8 * g + 4 * half);
+                    h[4 * g + 0] = fast_tanh(aj + c4.x);
+                    h[4 * g + 1] = fast_tanh(aj + c4.y);
+                    h[4 * g + 2] = fast_tanh(aj + c4.z);
+                    h[4 * g + 3] = fast_tanh(aj + c4.w);
+                }
+                // dh[u][j] = sum_v dl[u][v] * W2[j][v]
+                f32x16 dh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dh[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int v = 2 * s + half;
+                    dh = __builtin_amdgcn_mfma_f32_32x32x2f32(my_dl[l31 * kStagePad + v],
+                                                              W2s[(jt * 32 + l31) * kStagePad + v], dh, 0, 0, 0);
+                }
+                // dz = dh * (1 - h^2);  sum over u -> d enc_proj partial;  running sum over t -> d pred_proj
+                float colsum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float dz = dh[r] * (1.0f - h[r] * h[r]);
+                    accC[jt][r] += dz;
+                    colsum += dz;
+                }
+                colsum += __shfl_xor(colsum, 32);
+                if (lane < 32)
+                    jp.dApart[(((size_t)ut * p.B + b) * p.T + t) * J + j0 + jt * 32 + lane] = colsum;
+                // dW2[j][v] += sum_u h[u][j] * dl[u][v]   (K-slot (s, half) <-> lattice column cd_row(s, half))
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    accW[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[s], my_dl[cd_row(s, half) * kStagePad + l31],
+                                                                    accW[jt], 0, 0, 0);
+            }
+        }
+    }
+    // rows of this u-tile / J slab that no block visits (t >= T_b, or a dead tile) must read as zero
+    // in the partial buffers: they are zero-filled before the launch (hipMemsetAsync).
+
+    // ---- deterministic cross-wave reductions, then the partial buffers
+    if (!tile_live) return;
+    const int wid = (b * jp.n_ut + ut) * jp.n_ts + ts;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        // d pred_proj partial: accC[jt] is [u rows][j col]
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 32 + cd_row(r, half)) * kStagePad + l31] = accC[jt][r];
+        __syncthreads();
+        for (int e = tid; e < 1024; e += 256) {
+            const int uu = e >> 5, j = e & 31;
+            float s = 0.f;
+            for (int w = 0; w < 4; ++w) s += red[(w * 32 + uu) * kStagePad + j];
+            if (u0 + uu < p.U) jp.dCpart[(((size_t)ts * p.B + b) * p.U + u0 + uu) * J + j0 + jt * 32 + j] = s;
+        }
+        // dW2 partial: accW[jt] is [j rows][v col]
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 32 + cd_row(r, half)) * kStagePad + l31] = accW[jt][r];
+        __syncthreads();
+        for (int e = tid; e < 1024; e += 256) {
+            const int jj = e >> 5, v = e & 31;
+            float s = 0.f;
+            for (int w = 0; w < 4; ++w) s += red[(w * 32 + jj) * kStagePad + v];
+            jp.dWpart[((size_t)wid * J + j0 + jt * 32 + jj) * 32 + v] = s;
+        }
+    }
+}
+
+// out[i] = sum_p in[p*n + i]  (fixed order)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(float *out, const float *in, int nparts, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int q = 0; q < nparts; ++q) s += in[(size_t)q * n + i];
+        out[i] = s;
+    }
+}
+// out[v] = sum_p in[p*32 + v], v < V
+__global__ __launch_bounds__(64) void reduce_b2_kernel(float *out, const float *in, int nparts, int V) {
+    const int v = threadIdx.x;
+    if (v < V) {
+        float s = 0.f;
+        for (int q = 0; q < nparts; ++q) s += in[(size_t)q * 32 + v];
+        out[v] = s;
+    }
+}
+// out[j*V + v] = sum_p in[(p*J + j)*32 + v]   (drops the MFMA column padding)
+__global__ __launch_bounds__(256) void reduce_w2_kernel(float *out, const float *in, int nparts, int J, int V) {
+    const int n = J * V;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int j = i / V, v = i - j * V;
+        float s = 0.f;
+        for (int q = 0; q < nparts; ++q) s += in[((size_t)q * J + j) * 32 + v];
+        out[i] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct JointLayout {
+    WsLayout w;
+    size_t dl, dApart, dCpart, dWpart, dbpart, total;
+    int n_ut, TR, n_tr, TS, n_ts;
+};
+
+static JointLayout make_joint_layout(int T, int U, int B, int J) {
+    JointLayout L;
+    L.w = make_layout(T, U, B);
+    L.n_ut = (U + 31) / 32;
+    L.TR = 40;  // rows per phase-1 block (amortises the 128*J-byte C^T tile)
+    L.n_tr = (T + L.TR - 1) / L.TR;
+    L.n_ts = (T >= 256) ? 4 : 1;  // row splits of phase 2 (parallelism vs partial-buffer count)
+    L.TS = ((T + L.n_ts - 1) / L.n_ts + 3) / 4 * 4;
+    L.n_ts = (T + L.TS - 1) / L.TS;
+    size_t off = L.w.total;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = align_up(off + bytes, 256);
+        return o;
+    };
+    L.dl = take((size_t)B * T * U * 32 * sizeof(float));
+    L.dApart = take((size_t)L.n_ut * B * T * J * sizeof(float));
+    L.dCpart = take((size_t)L.n_ts * B * U * J * sizeof(float));
+    L.dWpart = take((size_t)B * L.n_ut * L.n_ts * J * 32 * sizeof(float));
+    L.dbpart = take((size_t)B * L.n_ut * L.n_tr * 32 * sizeof(float));
+    L.total = off;
+    return L;
+}
+
+static bool joint_supported(int J, int V) { return V >= 1 && V <= 32 && J >= 64 && (J % 64) == 0 && J <= 1024; }
+
+hipError_t joint_workspace_bytes(int T, int U, int B, int J, int V, size_t *bytes) {
+    if (!joint_supported(J, V) || sweep_K(U) == 0) return hipErrorInvalidValue;
+    *bytes = make_joint_layout(T, U, B, J).total;
+    return hipSuccess;
+}
+
+// provided by rnnt_entrypoint.hip
+bool fill_loss_params(LossParams &p, const float *acts, float *grads, const int *labels, const int *label_lengths,
+                      const int *input_lengths, const float *cost_scale, int V, int B, float *costs, void *workspace,
+                      int maxT, int maxU, int blank);
+
+template <typename K>
+static hipError_t set_lds(K kernel, size_t bytes) {
+    if (bytes <= 65536) return hipSuccess;
+    return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2,
+                             const int *labels, const int *label_lengths, const int *input_lengths,
+                             const float *cost_scale, int J, int V, int B, int T, int U, int blank, float *costs,
+                             float *d_enc_proj, float *d_pred_proj, float *dW2, float *db2, int joint_dtype,
+                             int phases, void *workspace, hipStream_t s) {
+    // phases: bit 0 = forward (costs + lattice state in the workspace), bit 1 = backward (needs that state)
+    if (!joint_supported(J, V) || joint_dtype != 0) return hipErrorInvalidValue;  // f16 MFMA joint: next round
+    if (((uintptr_t)enc_proj & 15) || ((uintptr_t)pred_proj & 15)) return hipErrorInvalidValue;
+    const JointLayout L = make_joint_layout(T, U, B, J);
+    JointParams jp;
+    if (!fill_loss_params(jp.lp, nullptr, nullptr, labels, label_lengths, input_lengths, cost_scale, V, B, costs,
+                          workspace, T, U, blank))
+        return hipErrorInvalidValue;
+    char *ws = (char *)workspace;
+    jp.enc_proj = enc_proj, jp.pred_proj = pred_proj, jp.W2 = W2, jp.b2 = b2;
+    jp.dl = (float *)(ws + L.dl);
+    jp.dApart = (float *)(ws + L.dApart);
+    jp.dCpart = (float *)(ws + L.dCpart);
+    jp.dWpart = (float *)(ws + L.dWpart);
+    jp.dbpart = (float *)(ws + L.dbpart);
+    jp.d_enc_proj = d_enc_proj, jp.d_pred_proj = d_pred_proj, jp.dW2 = dW2, jp.db2 = db2;
+    jp.J = J, jp.n_ut = L.n_ut, jp.TR = L.TR, jp.n_tr = L.n_tr, jp.TS = L.TS, jp.n_ts = L.n_ts;
+
+    const size_t shm1 = ((size_t)J * 32 + 2 * 1024 + 4 * (size_t)J + 4 * 32 * kStagePad) * sizeof(float);
+    const size_t shm2 = ((size_t)64 * 36 + 64 * kStagePad + 2 * 4 * 32 * kStagePad) * sizeof(float);
+    hipError_t e;
+    if ((e = set_lds(joint_phase1_kernel<false>, shm1)) != hipSuccess) return e;
+    if ((e = set_lds(joint_phase1_kernel<true>, shm1)) != hipSuccess) return e;
+
+    const unsigned g1 = (unsigned)B * L.n_ut * L.n_tr;
+    if (phases & 1) {
+        // forward: edge weights (W pre-filled with log zero) -> sweeps -> costs
+        if (hipMemsetAsync(jp.lp.W, kFillByte, L.w.A - L.w.W, s) != hipSuccess) return hipErrorUnknown;
+        hipLaunchKernelGGL((joint_phase1_kernel<false>), dim3(g1), dim3(256), shm1, s, jp);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = launch_sweeps(jp.lp, s)) != hipSuccess) return e;
+    }
+    if (!(phases & 2) || !d_enc_proj) return hipSuccess;  // score only
+
+    // backward: dlogits tiles, then the scatter through the joint
+    hipLaunchKernelGGL((joint_phase1_kernel<true>), dim3(g1), dim3(256), shm1, s, jp);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (hipMemsetAsync(jp.dApart, 0, L.dbpart - L.dApart, s) != hipSuccess) return hipErrorUnknown;  // dA/dC/dW partials
+    const unsigned g2 = (unsigned)B * L.n_ut * (J / 64) * L.n_ts;
+    hipLaunchKernelGGL(joint_phase2_kernel, dim3(g2), dim3(256), shm2, s, jp);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    const size_t nA = (size_t)B * T * J, nC = (size_t)B * U * J;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1024), dim3(256), 0, s, d_enc_proj, jp.dApart, L.n_ut, nA);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1024), dim3(256), 0, s, d_pred_proj, jp.dCpart, L.n_ts, nC);
+    hipLaunchKernelGGL(reduce_w2_kernel, dim3(64), dim3(256), 0, s, dW2, jp.dWpart, B * L.n_ut * L.n_ts, J, V);
+    hipLaunchKernelGGL(reduce_b2_kernel, dim3(1), dim3(64), 0, s, db2, jp.dbpart, (int)g1, V);
+    return hipGetLastError();
 }
 
 }  // namespace rnnt

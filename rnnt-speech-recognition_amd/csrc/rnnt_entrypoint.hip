@@ -18,7 +18,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
                              const int *labels, const int *label_lengths, const int *input_lengths,
                              const float *cost_scale, int J, int V, int B, int T, int U, int blank, float *costs,
                              float *d_enc_proj, float *d_pred_proj, float *dW2, float *db2, int joint_dtype,
-                             void *workspace, hipStream_t s);
+                             int phases, void *workspace, hipStream_t s);
 }  // namespace rnnt
 
 static rnntStatus_t check_options(const rnntOptions &o) {
@@ -61,6 +61,16 @@ static bool fill_params(LossParams &p, const float *acts, float *grads, const in
     p.divV = make_fastdiv((uint32_t)V);
     return true;
 }
+
+namespace rnnt {
+bool fill_loss_params(LossParams &p, const float *acts, float *grads, const int *labels, const int *label_lengths,
+                      const int *input_lengths, const float *cost_scale, int V, int B, float *costs, void *workspace,
+                      int maxT, int maxU, int blank) {
+    rnntOptions o;
+    o.loc = RNNT_GPU, o.stream = nullptr, o.blank_label = blank, o.maxT = maxT, o.maxU = maxU, o.batch_first = 1;
+    return fill_params(p, acts, grads, labels, label_lengths, input_lengths, cost_scale, V, B, costs, workspace, o);
+}
+}  // namespace rnnt
 
 static rnntStatus_t from_hip(hipError_t e) {
     if (e == hipSuccess) return RNNT_STATUS_SUCCESS;
@@ -263,25 +273,57 @@ rnntStatus_t get_joint_workspace_size(int maxT, int maxU, int minibatch, int joi
     return from_hip(joint_workspace_bytes(maxT, maxU, minibatch, joint_size, alphabet_size, size_bytes));
 }
 
-rnntStatus_t compute_rnnt_joint_loss(const float *enc_proj, const float *pred_proj, const float *W2,
-                                     const float *b2, const int *flat_labels, const int *label_lengths,
-                                     const int *input_lengths, const float *cost_scale, int joint_size,
-                                     int alphabet_size, int minibatch, float *costs, float *d_enc_proj,
-                                     float *d_pred_proj, float *dW2, float *db2, int joint_dtype, void *workspace,
-                                     rnntOptions options) {
-    if (!enc_proj || !pred_proj || !W2 || !b2 || !flat_labels || !label_lengths || !input_lengths || !costs ||
-        !workspace)
+static rnntStatus_t joint_call(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2,
+                               const int *flat_labels, const int *label_lengths, const int *input_lengths,
+                               const float *cost_scale, int joint_size, int alphabet_size, int minibatch, float *costs,
+                               float *d_enc_proj, float *d_pred_proj, float *dW2, float *db2, int joint_dtype,
+                               int phases, void *workspace, const rnntOptions &options) {
+    if (!enc_proj || !pred_proj || !W2 || !b2 || !flat_labels || !label_lengths || !input_lengths || !workspace)
         return RNNT_STATUS_INVALID_VALUE;
+    if ((phases & 1) && !costs) return RNNT_STATUS_INVALID_VALUE;
     if (joint_size <= 0 || alphabet_size <= 0 || minibatch <= 0) return RNNT_STATUS_INVALID_VALUE;
     rnntStatus_t st = check_options(options);
     if (st != RNNT_STATUS_SUCCESS) return st;
     if (options.blank_label >= alphabet_size) return RNNT_STATUS_INVALID_VALUE;
     const bool any_grad = d_enc_proj || d_pred_proj || dW2 || db2;
     if (any_grad && !(d_enc_proj && d_pred_proj && dW2 && db2)) return RNNT_STATUS_INVALID_VALUE;
+    if ((phases & 2) && !(phases & 1) && !any_grad) return RNNT_STATUS_INVALID_VALUE;
     return from_hip(launch_joint_loss(enc_proj, pred_proj, W2, b2, flat_labels, label_lengths, input_lengths,
                                       cost_scale, joint_size, alphabet_size, minibatch, options.maxT, options.maxU,
                                       options.blank_label, costs, d_enc_proj, d_pred_proj, dW2, db2, joint_dtype,
-                                      workspace, (hipStream_t)options.stream));
+                                      phases, workspace, (hipStream_t)options.stream));
+}
+
+rnntStatus_t compute_rnnt_joint_loss(const float *enc_proj, const float *pred_proj, const float *W2,
+                                     const float *b2, const int *flat_labels, const int *label_lengths,
+                                     const int *input_lengths, const float *cost_scale, int joint_size,
+                                     int alphabet_size, int minibatch, float *costs, float *d_enc_proj,
+                                     float *d_pred_proj, float *dW2, float *db2, int joint_dtype, void *workspace,
+                                     rnntOptions options) {
+    return joint_call(enc_proj, pred_proj, W2, b2, flat_labels, label_lengths, input_lengths, cost_scale, joint_size,
+                      alphabet_size, minibatch, costs, d_enc_proj, d_pred_proj, dW2, db2, joint_dtype, 3, workspace,
+                      options);
+}
+
+rnntStatus_t compute_rnnt_joint_loss_fwd(const float *enc_proj, const float *pred_proj, const float *W2,
+                                         const float *b2, const int *flat_labels, const int *label_lengths,
+                                         const int *input_lengths, int joint_size, int alphabet_size, int minibatch,
+                                         float *costs, int joint_dtype, void *workspace, rnntOptions options) {
+    return joint_call(enc_proj, pred_proj, W2, b2, flat_labels, label_lengths, input_lengths, nullptr, joint_size,
+                      alphabet_size, minibatch, costs, nullptr, nullptr, nullptr, nullptr, joint_dtype, 1, workspace,
+                      options);
+}
+
+rnntStatus_t compute_rnnt_joint_loss_bwd(const float *enc_proj, const float *pred_proj, const float *W2,
+                                         const float *b2, const int *flat_labels, const int *label_lengths,
+                                         const int *input_lengths, const float *cost_scale, int joint_size,
+                                         int alphabet_size, int minibatch, float *d_enc_proj, float *d_pred_proj,
+                                         float *dW2, float *db2, int joint_dtype, void *workspace,
+                                         rnntOptions options) {
+    if (!d_enc_proj) return RNNT_STATUS_INVALID_VALUE;
+    return joint_call(enc_proj, pred_proj, W2, b2, flat_labels, label_lengths, input_lengths, cost_scale, joint_size,
+                      alphabet_size, minibatch, nullptr, d_enc_proj, d_pred_proj, dW2, db2, joint_dtype, 2, workspace,
+                      options);
 }
 
 }  // extern "C"

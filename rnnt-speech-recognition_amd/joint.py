@@ -1,0 +1,104 @@
+"""Joint network fused with the transducer loss (host side).
+
+Reference: model.py:158-166 (broadcast add -> Dense(J, tanh) -> Dense(V)) followed by
+utils/loss.py:24-36 and TF autodiff (run_rnnt.py:284).  Here the first Dense layer is applied to the
+encoder and prediction-network outputs separately (exact factorisation, two small library GEMMs via
+torch.matmul on hipBLASLt) and libwarprnnt.so's compute_rnnt_joint_loss_* entry points do the rest:
+tanh, the J x V projection on the MFMA units, log-softmax, alpha/beta, and the gradient scatter back
+to enc_proj / pred_proj / W2 / b2, without ever materialising [B,T,U,J] or [B,T,U,V] tensors.
+PyTorch autograd chains the returned d_enc_proj / d_pred_proj into W1, b1 and the two networks.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib
+
+
+class _JointLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc_proj, pred_proj, W2, b2, labels, input_lengths, label_lengths, blank_label):
+        lib = _lib.load()
+        for name, x in (("enc_proj", enc_proj), ("pred_proj", pred_proj), ("W2", W2), ("b2", b2)):
+            if not x.is_cuda:
+                raise RuntimeError(f"rnnt_joint_loss: {name} must live on an MI355X (cuda/HIP) device; no CPU path")
+            if x.dtype != torch.float32:
+                raise TypeError(f"rnnt_joint_loss: {name} must be float32")
+        B, T, J = enc_proj.shape
+        U = pred_proj.shape[1]
+        V = W2.shape[1]
+        if pred_proj.shape != (B, U, J) or W2.shape[0] != J or b2.shape != (V,):
+            raise ValueError("rnnt_joint_loss: inconsistent shapes")
+        dev = enc_proj.device
+        ep, pp, w2, bb = (x.detach().contiguous() for x in (enc_proj, pred_proj, W2, b2))
+        labels = labels.to(device=dev, dtype=torch.int32).contiguous()
+        if labels.numel() == 0:
+            labels = torch.zeros((B, 1), dtype=torch.int32, device=dev)
+        il = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
+        ll = label_lengths.to(device=dev, dtype=torch.int32).contiguous()
+        with torch.cuda.device(dev):
+            ws = torch.empty(_lib.joint_workspace_bytes(T, U, B, J, V), dtype=torch.uint8, device=dev)
+            costs = torch.empty(B, dtype=torch.float32, device=dev)
+            opts = _lib.make_options(torch.cuda.current_stream().cuda_stream, int(blank_label), T, U)
+            st = lib.compute_rnnt_joint_loss_fwd(ep.data_ptr(), pp.data_ptr(), w2.data_ptr(), bb.data_ptr(),
+                                                 labels.data_ptr(), ll.data_ptr(), il.data_ptr(), J, V, B,
+                                                 costs.data_ptr(), 0, ws.data_ptr(), opts)
+        _lib.check(st, "compute_rnnt_joint_loss_fwd")
+        ctx.save_for_backward(ep, pp, w2, bb, labels, il, ll, ws)
+        ctx.blank = int(blank_label)
+        return costs
+
+    @staticmethod
+    def backward(ctx, grad_costs):
+        ep, pp, w2, bb, labels, il, ll, ws = ctx.saved_tensors
+        lib = _lib.load()
+        B, T, J = ep.shape
+        U, V = pp.shape[1], w2.shape[1]
+        dev = ep.device
+        scale = grad_costs.to(device=dev, dtype=torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            d_ep, d_pp, d_w2, d_b2 = (torch.empty_like(x) for x in (ep, pp, w2, bb))
+            opts = _lib.make_options(torch.cuda.current_stream().cuda_stream, ctx.blank, T, U)
+            st = lib.compute_rnnt_joint_loss_bwd(ep.data_ptr(), pp.data_ptr(), w2.data_ptr(), bb.data_ptr(),
+                                                 labels.data_ptr(), ll.data_ptr(), il.data_ptr(), scale.data_ptr(),
+                                                 J, V, B, d_ep.data_ptr(), d_pp.data_ptr(), d_w2.data_ptr(),
+                                                 d_b2.data_ptr(), 0, ws.data_ptr(), opts)
+        _lib.check(st, "compute_rnnt_joint_loss_bwd")
+        return d_ep, d_pp, d_w2, d_b2, None, None, None, None
+
+
+def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_lengths, blank_label: int = 0):
+    """costs[b] = transducer NLL of  logits = tanh((enc[:,:,None]+pred[:,None]) @ W1 + b1) @ W2 + b2.
+
+    enc [B,T,H] (encoder output), pred [B,U,H] (prediction-network output), W1 [H,J], b1 [J],
+    W2 [J,V], b2 [V]  (Keras Dense kernels are stored [in, out], model.py:162-166)."""
+    enc_proj = torch.matmul(enc, W1) + b1
+    pred_proj = torch.matmul(pred, W1)
+    return _JointLossFunction.apply(enc_proj, pred_proj, W2, b2, labels, input_lengths, label_lengths, blank_label)
+
+
+class JointLoss(torch.nn.Module):
+    """The reference's joint network (model.py:158-166) + loss as one module.  Parameters follow Keras'
+    Dense defaults: glorot-uniform kernels, zero biases."""
+
+    def __init__(self, hidden: int, joint_size: int, vocab_size: int, blank_label: int = 0):
+        super().__init__()
+        self.blank_label = blank_label
+        self.W1 = torch.nn.Parameter(torch.empty(hidden, joint_size))
+        self.b1 = torch.nn.Parameter(torch.zeros(joint_size))
+        self.W2 = torch.nn.Parameter(torch.empty(joint_size, vocab_size))
+        self.b2 = torch.nn.Parameter(torch.zeros(vocab_size))
+        for w in (self.W1, self.W2):
+            lim = math.sqrt(6.0 / (w.shape[0] + w.shape[1]))
+            torch.nn.init.uniform_(w, -lim, lim)
+
+    def forward(self, enc, pred, labels, input_lengths, label_lengths):
+        return rnnt_joint_loss(enc, pred, self.W1, self.b1, self.W2, self.b2, labels, input_lengths,
+                               label_lengths, self.blank_label)
+
+    def logits(self, enc, pred):
+        """Unfused reference form (materialises [B,T,U,V]); for decoding single cells and for tests."""
+        z = enc.unsqueeze(2) + pred.unsqueeze(1)
+        return torch.tanh(z @ self.W1 + self.b1) @ self.W2 + self.b2
