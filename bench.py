@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--shape", type=str, default="32,600,150,28", help="B,T,U,V per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused", action="store_true", help="skip the fused joint+loss measurement")
+    ap.add_argument("--joint-size", type=int, default=640, help="H = J of the fused joint (hparams.py:18,23)")
     ap.add_argument("--cpu-reps", type=int, default=3)
     return ap.parse_args()
 
@@ -69,6 +71,57 @@ def cpu_baseline(B, T, U, V, reps):
         "sample": f"full headline batch B={B} T={T} U={U} V={V}, median of {reps} runs after 1 warm-up; "
                   "OpenMP over utterances only (like the reference), torch CPU log_softmax fwd+bwd around it",
     }
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
+
+
+def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
+    """compute_rnnt_joint_loss (costs + d_enc_proj, d_pred_proj, dW2, db2) on enc_proj/pred_proj ~ N(0,1),
+    glorot W2.  Algorithmic flops per cell = 8*J*V: forward GEMM + backward recompute +
+    dh = dl.W2^T + dW2 = h^T.dl."""
+    import math
+
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    ep = torch.randn(B, T, J, generator=g).to(dev)
+    pp = torch.randn(B, U, J, generator=g).to(dev)
+    lim = math.sqrt(6.0 / (J + V))
+    W2 = ((torch.rand(J, V, generator=g) * 2 - 1) * lim).to(dev)
+    b2 = torch.zeros(V, device=dev)
+    labels = torch.randint(1, V, (B, U - 1), generator=g, dtype=torch.int32).to(dev)
+    il = torch.full((B,), T, dtype=torch.int32, device=dev)
+    ll = torch.full((B,), U - 1, dtype=torch.int32, device=dev)
+    scale = torch.full((B,), 1.0 / B, device=dev)
+    costs = torch.empty(B, device=dev)
+    d_ep, d_pp, dW2, db2 = (torch.empty_like(x) for x in (ep, pp, W2, b2))
+    try:
+        ws = torch.empty(_lib.joint_workspace_bytes(T, U, B, J, V), dtype=torch.uint8, device=dev)
+    except RuntimeError as e:
+        return {"error": str(e)}
+    opts = _lib.make_options(stream.cuda_stream, 0, T, U)
+
+    def step():
+        _lib.check(lib.compute_rnnt_joint_loss(ep.data_ptr(), pp.data_ptr(), W2.data_ptr(), b2.data_ptr(),
+                                               labels.data_ptr(), ll.data_ptr(), il.data_ptr(), scale.data_ptr(),
+                                               J, V, B, costs.data_ptr(), d_ep.data_ptr(), d_pp.data_ptr(),
+                                               dW2.data_ptr(), db2.data_ptr(), 0, ws.data_ptr(), opts), "joint")
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    cells = B * T * U
+    flops = 8.0 * J * V * cells
+    return {"workload": f"joint+loss+grads from enc_proj/pred_proj, B={B} T={T} U={U} V={V} J={J}, f32 MFMA",
+            "ms_per_step": dt * 1e3, "cells_per_s": cells / dt,
+            "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                         "algorithmic_flops_per_step": flops},
+            "workspace_GB": ws.numel() / 1e9}
 
 
 def main():
@@ -175,6 +228,11 @@ def main():
                          "unpipelined_fwd_ms": t_f * 1e3, "unpipelined_bwd_ms": t_b * 1e3},
         }
 
+    # ---- fused joint + loss (SURVEY.md 8d "P2"): reported beside the headline, not as `value` ----
+    fused = None
+    if rank == 0 and not a.no_fused:
+        fused = bench_fused_joint(lib, _lib, dev, B, T, U, V, a.joint_size, stream, max(3, min(a.steps, 10)))
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(B, T, U, V, a.cpu_reps)
@@ -187,7 +245,7 @@ def main():
             "config": {"workload": f"transducer loss+grad on given logits (warp-transducer op contract), "
                                    f"B={B} T={T} U={U} V={V} per GPU, full lengths, acts~N(0,1)",
                        "global_batch": B * world, "parallelism": f"utterance-sharded x{world}, no data-path collective"},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "fused_joint": fused,
         }
         if cpu:
             out["gpu_over_cpu"] = value / cpu["value"]

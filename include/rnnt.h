@@ -133,7 +133,7 @@ rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, const int *fl
  *                                Fully overwritten.  May all be NULL for score-only.
  *   joint_dtype                  0 = f32 MFMA (exact f32).  (1 = f16-input MFMA is reserved; this round
  *                                returns RNNT_STATUS_INVALID_VALUE for it.)
- * Limits this round: alphabet_size <= 32, joint_size a multiple of 64 (<= 1024), maxU <= 1024.
+ * Limits this round: alphabet_size <= 32, joint_size a multiple of 64 (<= 768), maxU <= 1024.
  * compute_rnnt_joint_loss      = costs and all four gradients in one call
  * compute_rnnt_joint_loss_fwd  = costs only (+ lattice state kept in `workspace`)
  * compute_rnnt_joint_loss_bwd  = the gradients, from the same inputs and that workspace (autograd split,

@@ -54,14 +54,15 @@ struct JointParams {
     int J, n_ut, TR, n_tr, TS, n_ts;
 };
 
+constexpr int kP1Waves = 8;    // phase-1 workgroup = 8 waves (2 per SIMD: one wave's tanh VALU hides the other's MFMA issue)
 constexpr int kStagePad = 33;  // row stride of the per-wave 32x32 staging tiles (bank-conflict free both ways)
 
 // ---------------------------------------------------------------------------------------------
 // phase 1: one lattice row (32 cells of one u-tile) per wave per iteration.
-// LDS: Ct [J][32] (pred_proj tile, transposed) | W2c [2][32][32] | Arow [4][J] | stage [4][32][33]
+// LDS: Ct [J][32] (pred_proj tile, transposed) | W2c [2][32][32] | Arow [8][J] | stage [8][32][33]
 // ---------------------------------------------------------------------------------------------
 template <bool BWD>
-__global__ __launch_bounds__(256) void joint_phase1_kernel(const JointParams jp) {
+__global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const JointParams jp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LossParams &p = jp.lp;
     const int J = jp.J, V = p.V;
@@ -69,8 +70,8 @@ __global__ __launch_bounds__(256) void joint_phase1_kernel(const JointParams jp)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *Ct = lds;                       // [J][32]
     float *W2c = Ct + J * 32;              // [2][32][32]
-    float *Arow = W2c + 2 * 32 * 32;       // [4][J]
-    float *stage = Arow + 4 * J;           // [4][32][kStagePad]
+    float *Arow = W2c + 2 * 32 * 32;       // [kP1Waves][J]
+    float *stage = Arow + kP1Waves * J;    // [kP1Waves][32][kStagePad]
     float *my_arow = Arow + wave * J;
     float *my_stage = stage + wave * 32 * kStagePad;
 
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void joint_phase1_kernel(const JointParams jp)
     float dbsum = 0.f;  // BWD: this lane's share of sum_cells dl[cell][v = l31] (rows cd_row(*, half))
     if (tile_live) {
         // ---- C^T tile: Ct[j][u] = pred_proj[b][u0+u][j]  (lanes run along u: conflict-free LDS writes)
-        for (int idx = tid; idx < 32 * (J / 4); idx += 256) {
+        for (int idx = tid; idx < 32 * (J / 4); idx += kP1Waves * 64) {
             const int u = idx & 31, j4 = idx >> 5;
             float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (u0 + u < p.U) c4 = *(const float4 *)(jp.pred_proj + ((size_t)b * p.U + u0 + u) * J + j4 * 4);
@@ -97,23 +98,39 @@ __global__ __launch_bounds__(256) void joint_phase1_kernel(const JointParams jp)
             Ct[(j4 * 4 + 3) * 32 + u] = c4.w;
         }
     }
-    const int n_iter = tile_live ? (t_end - t_begin + 3) / 4 : 0;
+    const int n_iter = tile_live ? (t_end - t_begin + kP1Waves - 1) / kP1Waves : 0;
     for (int it = 0; it < n_iter; ++it) {
-        const int t = t_begin + it * 4 + wave;
+        const int t = t_begin + it * kP1Waves + wave;
         const bool active = t < t_end;  // wave-uniform
         if (active)
             for (int j = lane; j < J; j += 64) my_arow[j] = jp.enc_proj[((size_t)b * p.T + t) * J + j];
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        for (int jc = 0; jc < J / 32; ++jc) {
-            float *wbuf = W2c + (jc & 1) * 1024;
-            // W2 chunk [32 j][32 v], zero-padded beyond V
-            for (int e = tid; e < 1024; e += 256) {
-                const int jj = e >> 5, v = e & 31;
-                wbuf[e] = (v < V) ? jp.W2[(size_t)(jc * 32 + jj) * V + v] : 0.f;
+        // W2 streams through LDS in [32 j][32 v] chunks (zero-padded beyond V).  Chunk jc+1 is fetched into
+        // registers BEFORE chunk jc's 16 MFMA steps and parked in the other LDS buffer after them, so the
+        // global/L2 latency hides under the matrix work and one barrier per chunk suffices.
+        constexpr int kWPT = 1024 / (kP1Waves * 64);  // W2 chunk words per thread
+        auto w2_fetch = [&](const int jc, float (&w)[kWPT]) {
+#pragma unroll
+            for (int q = 0; q < kWPT; ++q) {
+                const int e = tid + q * (kP1Waves * 64), jj = e >> 5, v = e & 31;
+                w[q] = (v < V) ? jp.W2[(size_t)(jc * 32 + jj) * V + v] : 0.f;
             }
-            __syncthreads();  // chunk (and, first time round, Ct / Arow) visible; the other buffer is free
+        };
+        auto w2_park = [&](const int jc, const float (&w)[kWPT]) {
+            float *wb = W2c + (jc & 1) * 1024;
+#pragma unroll
+            for (int q = 0; q < kWPT; ++q) wb[tid + q * (kP1Waves * 64)] = w[q];
+        };
+        float wreg[kWPT];
+        w2_fetch(0, wreg);
+        w2_park(0, wreg);
+        __syncthreads();  // chunk 0 (and, first time round, Ct / Arow) visible
+        const int nchunk = J / 32;
+        for (int jc = 0; jc < nchunk; ++jc) {
+            const float *wbuf = W2c + (jc & 1) * 1024;
+            if (jc + 1 < nchunk) w2_fetch(jc + 1, wreg);
             if (active) {
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk) {
@@ -122,6 +139,8 @@ __global__ __launch_bounds__(256) void joint_phase1_kernel(const JointParams jp)
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h, wbuf[jl * 32 + l31], acc, 0, 0, 0);
                 }
             }
+            if (jc + 1 < nchunk) w2_park(jc + 1, wreg);
+            __syncthreads();  // next chunk visible; everyone is done with the buffer it will overwrite after that
         }
         // ---- epilogue: logits tile -> LDS, then one lattice cell per lane (lanes 0..31)
         if (active) {
@@ -194,7 +213,7 @@ __global__ __launch_bounds__(256) void joint_phase1_kernel(const JointParams jp)
         __syncthreads();
         if (tid < 32) {
             float s = 0.f;
-            for (int w = 0; w < 4; ++w) s += red[w * 64 + tid] + red[w * 64 + 32 + tid];
+            for (int w = 0; w < kP1Waves; ++w) s += red[w * 64 + tid] + red[w * 64 + 32 + tid];
             jp.dbpart[(size_t)blockIdx.x * 32 + tid] = s;
         }
     }
@@ -253,16 +272,25 @@ __global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp)
     __syncthreads();
 
     const int n_iter = tile_live ? (t_end - t_begin + 3) / 4 : 0;
+    // this wave's dlogits tile of row t: 1024 floats = 16 per lane, fetched one row ahead into registers
+    auto dl_fetch = [&](const int t, float (&d)[16]) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = lane + q * 64, uu = e >> 5, v = e & 31;
+            d[q] = (t < t_end && u0 + uu < p.U) ? jp.dl[(((size_t)(b * p.T + t)) * p.U + u0 + uu) * 32 + v] : 0.f;
+        }
+    };
+    float dnext[16];
+    if (n_iter > 0) dl_fetch(t_begin + wave, dnext);
     for (int it = 0; it < n_iter; ++it) {
         const int t = t_begin + it * 4 + wave;
         if (t < t_end) {  // wave-uniform; no workgroup barrier inside: the dl row buffer is wave-private
-            // ---- this row's dlogits tile [32 u][32 v] -> LDS
-            for (int e = lane; e < 1024; e += 64) {
-                const int uu = e >> 5, v = e & 31;
-                float x = 0.f;
-                if (u0 + uu < p.U) x = jp.dl[(((size_t)(b * p.T + t)) * p.U + u0 + uu) * 32 + v];
-                my_dl[uu * kStagePad + v] = x;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int e = lane + q * 64;
+                my_dl[(e >> 5) * kStagePad + (e & 31)] = dnext[q];
             }
+            dl_fetch(t + 4, dnext);  // next row of this wave: latency hides under this row's MFMAs
             const float *arow = jp.enc_proj + ((size_t)b * p.T + t) * J + j0;
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
@@ -347,23 +375,32 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(float *out, const 
         out[i] = s;
     }
 }
-// out[v] = sum_p in[p*32 + v], v < V
-__global__ __launch_bounds__(64) void reduce_b2_kernel(float *out, const float *in, int nparts, int V) {
-    const int v = threadIdx.x;
-    if (v < V) {
-        float s = 0.f;
-        for (int q = 0; q < nparts; ++q) s += in[(size_t)q * 32 + v];
-        out[v] = s;
+// Deterministic tree: out[i] = sum_p in[p*stride_p + map(i)], 256 threads = 32 outputs x 8 partial lanes.
+// Each partial lane sums its strided share in a fixed order, then the 8 lanes are combined in order.
+template <bool W2MAP>
+__global__ __launch_bounds__(256) void reduce_small_kernel(float *out, const float *in, int nparts, int n, int J, int V) {
+    __shared__ float sm[8][33];
+    const int o = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + o;
+    float s = 0.f;
+    if (i < n) {
+        size_t base, stride;
+        if (W2MAP) {  // in is [nparts][J][32], out is [J][V]
+            const int j = i / V, v = i - j * V;
+            base = (size_t)j * 32 + v;
+            stride = (size_t)J * 32;
+        } else {  // in is [nparts][32], out is [V]
+            base = (size_t)i;
+            stride = 32;
+        }
+        for (int q = pl; q < nparts; q += 8) s += in[(size_t)q * stride + base];
     }
-}
-// out[j*V + v] = sum_p in[(p*J + j)*32 + v]   (drops the MFMA column padding)
-__global__ __launch_bounds__(256) void reduce_w2_kernel(float *out, const float *in, int nparts, int J, int V) {
-    const int n = J * V;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int j = i / V, v = i - j * V;
-        float s = 0.f;
-        for (int q = 0; q < nparts; ++q) s += in[((size_t)q * J + j) * 32 + v];
-        out[i] = s;
+    sm[pl][o] = s;
+    __syncthreads();
+    if (pl == 0 && i < n) {
+        float t = 0.f;
+        for (int k = 0; k < 8; ++k) t += sm[k][o];
+        out[i] = t;
     }
 }
 
@@ -400,7 +437,10 @@ static JointLayout make_joint_layout(int T, int U, int B, int J) {
     return L;
 }
 
-static bool joint_supported(int J, int V) { return V >= 1 && V <= 32 && J >= 64 && (J % 64) == 0 && J <= 1024; }
+static bool joint_supported(int J, int V) {
+    // J <= 768: the phase-1 workgroup keeps the whole C^T tile (128*J B) plus 8 rows of enc_proj in LDS
+    return V >= 1 && V <= 32 && J >= 64 && (J % 64) == 0 && J <= 768;
+}
 
 hipError_t joint_workspace_bytes(int T, int U, int B, int J, int V, size_t *bytes) {
     if (!joint_supported(J, V) || sweep_K(U) == 0) return hipErrorInvalidValue;
@@ -442,7 +482,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     jp.d_enc_proj = d_enc_proj, jp.d_pred_proj = d_pred_proj, jp.dW2 = dW2, jp.db2 = db2;
     jp.J = J, jp.n_ut = L.n_ut, jp.TR = L.TR, jp.n_tr = L.n_tr, jp.TS = L.TS, jp.n_ts = L.n_ts;
 
-    const size_t shm1 = ((size_t)J * 32 + 2 * 1024 + 4 * (size_t)J + 4 * 32 * kStagePad) * sizeof(float);
+    const size_t shm1 = ((size_t)J * 32 + 2 * 1024 + kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
     const size_t shm2 = ((size_t)64 * 36 + 64 * kStagePad + 2 * 4 * 32 * kStagePad) * sizeof(float);
     hipError_t e;
     if ((e = set_lds(joint_phase1_kernel<false>, shm1)) != hipSuccess) return e;
@@ -452,14 +492,14 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     if (phases & 1) {
         // forward: edge weights (W pre-filled with log zero) -> sweeps -> costs
         if (hipMemsetAsync(jp.lp.W, kFillByte, L.w.A - L.w.W, s) != hipSuccess) return hipErrorUnknown;
-        hipLaunchKernelGGL((joint_phase1_kernel<false>), dim3(g1), dim3(256), shm1, s, jp);
+        hipLaunchKernelGGL((joint_phase1_kernel<false>), dim3(g1), dim3(kP1Waves * 64), shm1, s, jp);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = launch_sweeps(jp.lp, s)) != hipSuccess) return e;
     }
     if (!(phases & 2) || !d_enc_proj) return hipSuccess;  // score only
 
     // backward: dlogits tiles, then the scatter through the joint
-    hipLaunchKernelGGL((joint_phase1_kernel<true>), dim3(g1), dim3(256), shm1, s, jp);
+    hipLaunchKernelGGL((joint_phase1_kernel<true>), dim3(g1), dim3(kP1Waves * 64), shm1, s, jp);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (hipMemsetAsync(jp.dApart, 0, L.dbpart - L.dApart, s) != hipSuccess) return hipErrorUnknown;  // dA/dC/dW partials
     const unsigned g2 = (unsigned)B * L.n_ut * (J / 64) * L.n_ts;
@@ -468,8 +508,9 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     const size_t nA = (size_t)B * T * J, nC = (size_t)B * U * J;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1024), dim3(256), 0, s, d_enc_proj, jp.dApart, L.n_ut, nA);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1024), dim3(256), 0, s, d_pred_proj, jp.dCpart, L.n_ts, nC);
-    hipLaunchKernelGGL(reduce_w2_kernel, dim3(64), dim3(256), 0, s, dW2, jp.dWpart, B * L.n_ut * L.n_ts, J, V);
-    hipLaunchKernelGGL(reduce_b2_kernel, dim3(1), dim3(64), 0, s, db2, jp.dbpart, (int)g1, V);
+    hipLaunchKernelGGL((reduce_small_kernel<true>), dim3((J * V + 31) / 32), dim3(256), 0, s, dW2, jp.dWpart,
+                       B * L.n_ut * L.n_ts, J * V, J, V);
+    hipLaunchKernelGGL((reduce_small_kernel<false>), dim3(1), dim3(256), 0, s, db2, jp.dbpart, (int)g1, V, J, V);
     return hipGetLastError();
 }
 

@@ -1,0 +1,113 @@
+"""CPU tests of the multi-GPU host logic with the gloo backend, world_size = 2.
+
+The compute engine is injected: here an autograd function backed by the float64 oracle stands in for
+the HIP engine (tests may use the oracle; the product path may not), so what is verified is the
+sharding, the 1/GLOBAL_batch scaling and the single flat-bucket SUM all-reduce (run_rnnt.py:87-88,
+278, 288, 293-294): 2 ranks must reproduce the 1-process full-batch gradients."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import rnnt_oracle as orc
+from rnnt_speech_recognition_amd import parallel
+
+
+class _OracleLoss(torch.autograd.Function):
+    """costs = transducer NLL of logits (float64 oracle), differentiable in the logits."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, il, ll):
+        costs, grads = orc.rnnt_loss_and_grad(logits.detach().numpy(), labels.numpy(), il.numpy(), ll.numpy())
+        ctx.save_for_backward(torch.from_numpy(grads))
+        return torch.from_numpy(costs)
+
+    @staticmethod
+    def backward(ctx, go):
+        (g,) = ctx.saved_tensors
+        return g * go.view(-1, 1, 1, 1), None, None, None
+
+
+def _problem(gb=5):
+    rng = np.random.default_rng(3)
+    T, U, H, J, V = 7, 4, 6, 8, 9
+    enc = torch.tensor(rng.normal(size=(gb, T, H)))
+    pred = torch.tensor(rng.normal(size=(gb, U, H)))
+    labels = torch.tensor(rng.integers(1, V, size=(gb, U - 1)))
+    il = torch.tensor([7, 5, 7, 3, 6][:gb])
+    ll = torch.tensor([3, 2, 0, 3, 1][:gb])
+    params = [torch.tensor(rng.normal(size=s) * 0.4, requires_grad=True) for s in ((H, J), (J,), (J, V), (V,))]
+    return enc, pred, labels, il, ll, params
+
+
+def _costs(enc, pred, labels, il, ll, params):
+    W1, b1, W2, b2 = params
+    z = enc.unsqueeze(2) + pred.unsqueeze(1)                 # model.py:158-160
+    logits = torch.tanh(z @ W1 + b1) @ W2 + b2               # model.py:162-166
+    return _OracleLoss.apply(logits, labels, il, ll)
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    enc, pred, labels, il, ll, params = _problem()
+    gb = enc.shape[0]
+    s_enc, s_pred, s_lab, s_il, s_ll = parallel.shard_batch([enc, pred, labels, il, ll], world, rank)
+    logged = parallel.dp_loss_step(lambda: _costs(s_enc, s_pred, s_lab, s_il, s_ll, params), params, gb)
+    out[rank] = (logged.item(), [p.grad.clone().numpy() for p in params])
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_ranks_reproduce_full_batch_gradients():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    enc, pred, labels, il, ll, params = _problem()
+    gb = enc.shape[0]
+    ref_logged = parallel.dp_loss_step(lambda: _costs(enc, pred, labels, il, ll, params), params, gb)
+    for r in range(world):
+        logged, grads = out[r]
+        assert abs(logged - ref_logged.item()) < 1e-10
+        for g, p in zip(grads, params):
+            np.testing.assert_allclose(g, p.grad.numpy(), atol=1e-10)
+    # the uneven split 5 -> 3 + 2 was exercised
+    assert parallel.shard_bounds(5, 2, 0) == (0, 3) and parallel.shard_bounds(5, 2, 1) == (3, 5)
+
+
+@pytest.mark.parametrize("gb,world", [(8, 8), (5, 2), (3, 4), (512, 8), (1, 1)])
+def test_shard_bounds_partition(gb, world):
+    covered = []
+    for r in range(world):
+        lo, hi = parallel.shard_bounds(gb, world, r)
+        assert 0 <= lo <= hi <= gb and hi - lo in (gb // world, gb // world + 1)
+        covered += list(range(lo, hi))
+    assert covered == list(range(gb))
+
+
+def test_balanced_order_is_a_permutation_and_balances_work():
+    rng = np.random.default_rng(0)
+    il = torch.tensor(rng.integers(100, 600, size=64))
+    ll = torch.tensor(rng.integers(10, 150, size=64))
+    order = parallel.balanced_order(il, ll, 8)
+    assert sorted(order.tolist()) == list(range(64))
+    work = (il * (ll + 1))[order].view(8, 8).sum(1).double()
+    naive = (il * (ll + 1)).view(8, 8).sum(1).double()
+    assert work.max() / work.min() < naive.max() / naive.min()
+
+
+def test_flat_all_reduce_is_a_noop_without_a_group():
+    t = [torch.ones(3), None, torch.arange(4.0)]
+    parallel.flat_all_reduce_(t)
+    assert t[0].tolist() == [1, 1, 1]
