@@ -29,6 +29,40 @@ __device__ __forceinline__ Cell decode(const LossParams &p, uint32_t c) {
 
 __device__ __forceinline__ int clamp_label(int lab, int V) { return min(max(lab, 0), V - 1); }
 
+// ---- cross-workgroup hand-off helpers (overlap mode; MI355X guide G16) ----
+// Payload is stored write-through (sc1) and read with sc1 loads (L2-served, never a stale L1 line);
+// flags are relaxed agent-scope counters.  No fences: every storing wave drains vmcnt before the flag.
+template <bool SC1>
+__device__ __forceinline__ float ld_f32(const float *q) {
+    return SC1 ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+}
+template <bool SC1>
+__device__ __forceinline__ double ld_f64(const double *q) {
+    return SC1 ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+}
+__device__ __forceinline__ void st_f32_wt(float *q, float v) {
+    __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_f64_wt(double *q, double v) {
+    __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// XCD (accelerator complex die) this wave runs on, 0..7.  Used ONLY to decide whether a hand-off may take
+// the "same L2" fast path; correctness never depends on where the dispatcher placed a workgroup.
+__device__ __forceinline__ int my_xcd() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+    return (int)(x & 7u);
+}
+// Bounded poll: ~1 s worst case, then flag the failure instead of hanging the device.
+__device__ __forceinline__ bool spin_until_ge(const int *flag, const int need, int *err) {
+    for (int it = 0; it < (1 << 22); ++it) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+
 // What one valid cell needs from the lattice to form its gradient (all log2 domain).
 struct CellGrad {
     float c0;     // alpha + beta - ll - lse*log2e  (add x*log2e -> log2 of softmax*occupancy)
@@ -40,25 +74,26 @@ struct CellGrad {
     float scale;
 };
 
+template <bool SC1 = false>
 __device__ __forceinline__ CellGrad cell_grad_setup(const LossParams &p, const Cell &cl, uint32_t c) {
     CellGrad g;
     const int n = cl.t + cl.u;
     const size_t sk = ((size_t)cl.b * p.Nr + n) * p.Up + cl.u;
-    const float a = p.A[sk];
-    const float bt = p.Bt[sk];
+    const float a = ld_f32<SC1>(p.A + sk);
+    const float bt = ld_f32<SC1>(p.Bt + sk);
     // offsets are kept per (block of kRebase diagonals, group of 64 lattice columns)
     const int kc = n / kRebase, kc1 = (n + 1) / kRebase;
     const int g0 = cl.u >> 6, g1 = (cl.u + 1) >> 6;
     const size_t ob = (size_t)cl.b * p.NC * p.NG;
-    const double oa = p.offA[ob + (size_t)kc * p.NG + g0];
-    const double ll2 = p.ll[2 * cl.b];
-    const float E0 = (float)(oa + p.offB[ob + (size_t)kc * p.NG + g0] - ll2);
+    const double oa = ld_f64<SC1>(p.offA + ob + (size_t)kc * p.NG + g0);
+    const double ll2 = ld_f64<SC1>(p.ll + 2 * cl.b);
+    const float E0 = (float)(oa + ld_f64<SC1>(p.offB + ob + (size_t)kc * p.NG + g0) - ll2);
     g.scale = p.cost_scale ? p.cost_scale[cl.b] : 1.0f;
     g.nl = -p.lse[c] * kLog2e;
     g.c0 = (a + bt) + E0 + g.nl;
     g.has_blank_corr = true;
     if (cl.t < cl.Tb - 1)
-        g.cb = a + p.Bt[sk + p.Up] + (float)(oa + p.offB[ob + (size_t)kc1 * p.NG + g0] - ll2);
+        g.cb = a + ld_f32<SC1>(p.Bt + sk + p.Up) + (float)(oa + ld_f64<SC1>(p.offB + ob + (size_t)kc1 * p.NG + g0) - ll2);
     else if (cl.u == cl.Ub - 1)
         g.cb = a + (float)(oa - ll2);
     else {
@@ -70,7 +105,7 @@ __device__ __forceinline__ CellGrad cell_grad_setup(const LossParams &p, const C
     g.cl = 0.f;
     if (g.has_label) {
         g.lab = clamp_label(p.labels[(size_t)cl.b * (p.U - 1) + cl.u], p.V);
-        g.cl = a + p.Bt[sk + p.Up + 1] + (float)(oa + p.offB[ob + (size_t)kc1 * p.NG + g1] - ll2);
+        g.cl = a + ld_f32<SC1>(p.Bt + sk + p.Up + 1) + (float)(oa + ld_f64<SC1>(p.offB + ob + (size_t)kc1 * p.NG + g1) - ll2);
     }
     return g;
 }

@@ -51,6 +51,7 @@ static bool fill_params(LossParams &p, const float *acts, float *grads, const in
     p.offA = (double *)(ws + w.offA);
     p.offB = (double *)(ws + w.offB);
     p.ll = (double *)(ws + w.ll);
+    p.flags = (int *)(ws + w.flags);
     p.B = B, p.T = o.maxT, p.U = o.maxU, p.V = V, p.blank = o.blank_label;
     p.b0 = 0, p.nb = B;
     p.tile = make_tile(o.maxT, o.maxU, V);
@@ -176,6 +177,43 @@ rnntStatus_t run_forward(LossParams &p, const WsLayout &w, hipStream_t s, bool g
     return RNNT_STATUS_SUCCESS;
 }
 
+// EXPERIMENTAL, opt-in (RNNT_OVERLAP=1), bit-identical to the serial schedule (tests), currently NOT faster:
+// 0.327 ms vs 0.315 ms per step at C2 (profiles/r01_notes.md has the timelines).
+// Workgroup-granular overlap of the three stages:
+//     side : [after the memsets] sweeps   -- every sweep wave polls its utterance's "lsm patches done" counter
+//     main : memsets, lsm (patches publish per utterance), grad (patches stage their logits, then poll the
+//            utterance's "sweeps done" counter), join.
+// The sweep kernel (2B one-wave workgroups) is enqueued FIRST so it is resident before the gradient patches
+// that wait on it; all polls are bounded (flags[2B] reports a timeout instead of hanging the device).
+static int overlap_enabled() {
+    const char *e = getenv("RNNT_OVERLAP");
+    return (e && e[0] == '1') ? 1 : 0;
+}
+
+rnntStatus_t run_overlapped(LossParams &p, const WsLayout &w, hipStream_t s, bool with_grad) {
+    Pipe *pipe = get_pipe();
+    if (!pipe) return RNNT_STATUS_EXECUTION_FAILED;
+    if (hipMemsetAsync(p.W, kFillByte, w.A - w.W, s) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
+    if (hipMemsetAsync(p.flags, 0, flag_words(p.B) * sizeof(int), s) != hipSuccess)
+        return RNNT_STATUS_MEMOPS_FAILED;
+    if (hipEventRecord(pipe->lsm_done[0], s) != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
+    if (hipStreamWaitEvent(pipe->side[0], pipe->lsm_done[0], 0) != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
+    hipError_t e = launch_sweeps(p, pipe->side[0], true);
+    if (e != hipSuccess) return from_hip(e);
+    if (hipEventRecord(pipe->sweep_done[0], pipe->side[0]) != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
+    e = launch_lsm(p, s, true);
+    if (e != hipSuccess) return from_hip(e);
+    // kernel boundary behind lsm = every XCD's L2 written back: the slow-path signal for the sweep waves.
+    // The gradient kernel raises it itself (its first workgroup); score-only calls need a marker kernel.
+    if (with_grad)
+        e = launch_grad(p, s, true);
+    else
+        e = launch_lsm_done_marker(p, s);
+    if (e != hipSuccess) return from_hip(e);
+    if (hipStreamWaitEvent(s, pipe->sweep_done[0], 0) != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
+    return RNNT_STATUS_SUCCESS;
+}
+
 rnntStatus_t validate(const void *acts, const void *labels, const void *ll, const void *il, const void *ws,
                       int V, int B, const rnntOptions &o) {
     if (!acts || !labels || !ll || !il || !ws) return RNNT_STATUS_INVALID_VALUE;
@@ -202,6 +240,7 @@ rnntStatus_t compute_rnnt_loss_fwd(const float *acts, const int *flat_labels, co
         return RNNT_STATUS_INVALID_VALUE;
     hipStream_t s = (hipStream_t)options.stream;
     const WsLayout w = make_layout(options.maxT, options.maxU, minibatch);
+    if (overlap_enabled() && overlap_path_ok(p, false)) return run_overlapped(p, w, s, false);
     int ng = 1;
     Pipe *pipe = nullptr;
     st = run_forward(p, w, s, false, ng, pipe);
@@ -243,6 +282,7 @@ rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, const int *fl
         return RNNT_STATUS_INVALID_VALUE;
     hipStream_t s = (hipStream_t)options.stream;
     const WsLayout w = make_layout(options.maxT, options.maxU, minibatch);
+    if (overlap_enabled() && overlap_path_ok(p, true)) return run_overlapped(p, w, s, true);
     int ng = 1;
     Pipe *pipe = nullptr;
     st = run_forward(p, w, s, true, ng, pipe);

@@ -38,7 +38,7 @@ __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" :
 // Everything one lane does for its lattice cell once the cell's V logits sit in LDS at `xs`:
 // GRAD=false: softmax denominator + the two lattice edge weights;  GRAD=true: the V gradients
 // (written back into `xs`, zeros for padded cells).
-template <int VP, bool V4, bool GRAD>
+template <int VP, bool V4, bool GRAD, bool OVL = false>
 __device__ __forceinline__ void cell_body(const LossParams &p, const Cell &cl, const uint32_t c, float *xs) {
     const int V = p.V;
     if (cl.valid) {
@@ -77,9 +77,9 @@ __device__ __forceinline__ void cell_body(const LossParams &p, const Cell &cl, c
             }
             p.lse[c] = lse;
             const size_t wi = ((size_t)cl.b * p.Nr + (cl.t + cl.u)) * p.Up + cl.u;
-            ((float2 *)p.W)[wi] = make_float2(ob, ol);
+            ((float2 *)p.W)[wi] = make_float2(ob, ol);  // plain (write-back) store even in overlap mode, see below
         } else {
-            const CellGrad g = cell_grad_setup(p, cl, c);
+            const CellGrad g = cell_grad_setup<OVL>(p, cl, c);
             const float xb = xs[p.blank];
             const float xl = g.has_label ? xs[g.lab] : 0.f;
             if (V4) {
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void cell_small_kernel(const LossParams p) {
 // min(TT,UU) consecutive words per diagonal, all issued from ONE CU (one XCD L2), so lines are
 // merged on chip instead of being touched by 16 different workgroups on 8 different L2s.
 // ---------------------------------------------------------------------------------------------
-template <int VP, bool GRAD>
+template <int VP, bool GRAD, bool OVL>
 __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -226,6 +226,13 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
                 __builtin_amdgcn_global_load_lds((glb_void *)(src + q * 4), (lds_void *)(dst + q0 * 4), 16, 0, 0);
         }
     }
+    if (OVL && GRAD) {
+        // This kernel starts only after the lsm kernel has completed (stream order): tell slow-path sweep waves.
+        if (blockIdx.x == 0 && tid == 0)
+            __hip_atomic_store(p.flags + flag_lsm_kernel_done(p.B), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the logits are on their way; only now wait until BOTH sweeps of this utterance have published
+        if (tid == 0) spin_until_ge(p.flags + flag_sweep(p.B, b), 2, p.flags + flag_err(p.B));
+    }
     wait_vm0();
     __syncthreads();
 
@@ -235,7 +242,17 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
     cl.b = b, cl.t = t0 + (int)r, cl.u = u0 + cu, cl.Tb = Tb, cl.Ub = Ub;
     cl.valid = ((int)r < rows_valid) && (cu < cols_valid);
     const uint32_t c = ((uint32_t)(b * p.T + cl.t)) * (uint32_t)p.U + (uint32_t)cl.u;
-    if (GRAD || cl.valid) cell_body<VP, true, GRAD>(p, cl, c, lds + tid * V);
+    if (GRAD || cl.valid) cell_body<VP, true, GRAD, OVL>(p, cl, c, lds + tid * V);
+    if (OVL && !GRAD) {
+        // Publish this patch.  Its W words were stored write-back: after vmcnt(0) they sit in THIS XCD's L2,
+        // which every CU of this XCD reads coherently.  The counter is kept per XCD so that the consuming
+        // sweep wave can prove that all patches of its utterance ran on its own XCD (fast path); if the
+        // dispatcher placed them elsewhere it waits for the kernel-end write-back instead (slow, still right).
+        wait_vm0();
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_fetch_add(p.flags + flag_lsm(b, my_xcd()), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     if (GRAD) {
         __syncthreads();
@@ -401,6 +418,91 @@ __device__ __forceinline__ void rebase(float (&v)[K], double &off, const int u_r
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Overlap mode (p.flags != nullptr): a sweep wave starts before the lsm pass has finished.  It waits until
+// every live patch of ITS utterance has published (one relaxed poll loop), then one agent-scope acquire
+// drops any stale L1 lines; the W rows themselves were stored write-through by the lsm pass.
+// Overlap mode job assignment.  The dispatcher hands workgroups to XCDs round-robin from a start that differs
+// per launch, so which XCD produces an utterance's W rows is only known at run time (the lsm patches count
+// themselves per XCD).  A sweep workgroup therefore CLAIMS its utterance: preferably an unclaimed one whose
+// patches are being produced on the workgroup's own XCD (then W can be read through the shared L2 with no
+// flush); once the lsm kernel is over, anything that is left.  Returns b, or -1 when all are taken.
+// Called by ONE wave of the workgroup.
+__device__ __forceinline__ int claim_utterance(const LossParams &p, const int lane) {
+    const int B = p.B, me = my_xcd();
+    int *flags = p.flags;
+    for (int it = 0; it < (1 << 22); ++it) {
+        if (__hip_atomic_load(flags + flag_nclaimed(B), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= B) return -1;
+        const bool any_xcd = __hip_atomic_load(flags + flag_lsm_kernel_done(B), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        for (int b0 = 0; b0 < B; b0 += 64) {
+            const int b = b0 + lane;
+            bool cand = false;
+            if (b < B) {
+                const int c0 = __hip_atomic_load(flags + flag_claim(B, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int here = any_xcd ? 1 : __hip_atomic_load(flags + flag_lsm(b, me), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cand = (here > 0) && (c0 == 0);
+            }
+            const unsigned long long m = __ballot(cand);
+            if (m == 0ull) continue;
+            const int bb = b0 + __builtin_ctzll(m);
+            int got = -1;
+            if (lane == 0) {
+                int expect = 0;
+                if (__hip_atomic_compare_exchange_strong(flags + flag_claim(B, bb), &expect, 1, __ATOMIC_RELAXED,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    got = bb;
+                    __hip_atomic_fetch_add(flags + flag_nclaimed(B), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            got = __shfl(got, 0);
+            if (got >= 0) return got;
+            break;  // lost the race: rescan
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    __hip_atomic_store(flags + flag_err(B), 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return -1;
+}
+
+__device__ __forceinline__ void sweep_wait_for_lsm(const LossParams &p, const int b, const int Tb, const int Ub,
+                                                   const int dir) {
+    if (p.flags == nullptr) return;
+    const int need = ((Tb + p.tile.TT - 1) / p.tile.TT) * ((Ub + p.tile.UU - 1) / p.tile.UU);
+    const int lane = threadIdx.x & 63;
+    const int me = my_xcd();
+    int *err = p.flags + flag_err(p.B);
+    bool all_here = false;
+    for (int it = 0; it < (1 << 22); ++it) {
+        // lanes 0..7 each read one per-XCD counter of this utterance
+        const int c = (lane < 8) ? __hip_atomic_load(p.flags + flag_lsm(b, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        int total = c;
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) total += __shfl_xor(total, o);
+        total = __shfl(total, 0);
+        if (total >= need) {
+            all_here = (__shfl(c, me) >= need);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+        if (it == (1 << 22) - 1) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) p.flags[flag_diag(p.B, b, dir)] = me | ((int)all_here << 8);
+    if (!all_here)  // some patch ran on another XCD: its W words become visible only at the end of the lsm kernel
+        spin_until_ge(p.flags + flag_lsm_kernel_done(p.B), 1, err);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale L1 lines; W itself is read from L2 / memory
+}
+// ... and when it is done: drain its write-through stores, then bump the utterance's "sweeps done" counter
+// (alpha and beta each add one; the gradient pass waits for 2).
+__device__ __forceinline__ void sweep_publish(const LossParams &p, const int b) {
+    if (p.flags == nullptr) return;
+    wait_vm0();
+    if ((threadIdx.x & 63) == 0)
+        __hip_atomic_fetch_add(p.flags + flag_sweep(p.B, b), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void lsm_done_marker_kernel(int *flag) {
+    __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // number of store instructions store_diag<K, true> issues (pieces of 4, 2, 1 dwords)
 constexpr int store_pieces(int K) { return K / 4 + (K % 4) / 2 + (K % 2); }
 
@@ -409,24 +511,26 @@ constexpr int store_pieces(int K) { return K / 4 + (K % 4) / 2 + (K % 2); }
 // step is known exactly (for the counted s_waitcnt at chunk boundaries).
 template <int K, bool COUNTED>
 __device__ __forceinline__ void store_diag(float *row, const int voff, const int lane, const float (&v)[K]) {
+    // All lattice stores are write-through (sc1): the gradient pass may run on another XCD while this
+    // kernel is still alive (overlap mode), and nothing on this XCD re-reads them anyway.
     if (!COUNTED) {
         float *dst = row + lane * K;
 #pragma unroll
-        for (int j = 0; j < K; ++j) dst[j] = v[j];
+        for (int j = 0; j < K; ++j) st_f32_wt(dst + j, v[j]);
     } else {
         int j = 0;
 #pragma unroll
         for (; j + 4 <= K; j += 4) {
             const f32x4 q = {v[j], v[j + 1], v[j + 2], v[j + 3]};
-            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff), "v"(q), "s"(row), "n"(j * 4));
+            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 sc1\n\ts_nop 1" ::"v"(voff), "v"(q), "s"(row), "n"(j * 4));
         }
         if (K % 4 >= 2) {
             const f32x2 q = {v[j], v[j + 1]};
-            asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff), "v"(q), "s"(row), "n"(j * 4));
+            asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 sc1\n\ts_nop 1" ::"v"(voff), "v"(q), "s"(row), "n"(j * 4));
             j += 2;
         }
         if (K % 2)
-            asm volatile("global_store_dword %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff), "v"(v[j]), "s"(row), "n"(j * 4));
+            asm volatile("global_store_dword %0, %1, %2 offset:%3 sc1\n\ts_nop 1" ::"v"(voff), "v"(v[j]), "s"(row), "n"(j * 4));
     }
 }
 
@@ -519,7 +623,7 @@ __device__ __forceinline__ void alpha_fast_steps(const LossParams &p, float (&a)
         alpha_step<K>(a, w);
         if ((n & (kRebase - 1)) == 0) {
             rebase<K>(a, off, ridge.u_at(n));
-            if (lane < p.NG) offp[(n / kRebase) * p.NG + lane] = off;
+            if (lane < p.NG) st_f64_wt(offp + (n / kRebase) * p.NG + lane, off);
         }
         store_diag<K, true>(out + (size_t)n * (64 * K), voff, lane, a);
         alpha_fast_steps<K, G, II + 1>(p, a, wq, abase, off, offp, out, voff, lane, r0, ridge);
@@ -545,7 +649,7 @@ __device__ __forceinline__ void beta_fast_steps(const LossParams &p, float (&bv)
         beta_step<K>(bv, w);
         if ((n & (kRebase - 1)) == kRebase - 1) {
             rebase<K>(bv, off, ridge.u_at(n));
-            if (lane < p.NG) offp[(n / kRebase) * p.NG + lane] = off;
+            if (lane < p.NG) st_f64_wt(offp + (n / kRebase) * p.NG + lane, off);
         }
         store_diag<K, true>(out + (size_t)n * (64 * K), voff, lane, bv);
         beta_fast_steps<K, G, II + 1>(p, bv, wq, abase, off, offp, out, voff, lane, r0, ridge);
@@ -558,6 +662,7 @@ __device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const 
     constexpr int chunkf = G * 2 * Up, n16 = chunkf / 4;
     const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
     const int Nb = Tb + Ub - 1;
+    sweep_wait_for_lsm(p, b, Tb, Ub, 0);
     const RidgeLine ridge = make_ridge(Ub, Nb);
     const float *Wb = p.W + (size_t)b * p.Nr * 2 * Up;
     float *out = p.A + (size_t)b * p.Nr * Up;  // wave-uniform; the lane offset is added at the store
@@ -570,7 +675,7 @@ __device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const 
 #pragma unroll
     for (int j = 0; j < K; ++j) a[j] = (u0 + j == 0) ? 0.f : kNeg;
     store_diag<K, false>(out, voff, lane, a);
-    if (lane < p.NG) offp[lane] = 0.0;
+    if (lane < p.NG) st_f64_wt(offp + lane, 0.0);
     double off = 0.0;
     const int last_row = Nb - 1;  // rows 0..Nb-2 feed the steps, row Nb-1 the final likelihood
     const int nchunks = last_row / G + 1;
@@ -603,7 +708,7 @@ __device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const 
                     alpha_step<K>(a, wc);
                     if ((n & (kRebase - 1)) == 0) {
                         rebase<K>(a, off, ridge.u_at(n));
-                        if (lane < p.NG) offp[(n / kRebase) * p.NG + lane] = off;
+                        if (lane < p.NG) st_f64_wt(offp + (n / kRebase) * p.NG + lane, off);
                     }
                     store_diag<K, COUNTED>(out + (size_t)n * Up, voff, lane, a);
 #pragma unroll
@@ -620,7 +725,7 @@ __device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const 
                 alpha_step<K>(a, wc);
                 if ((n & (kRebase - 1)) == 0) {
                     rebase<K>(a, off, ridge.u_at(n));
-                    if (lane < p.NG) offp[(n / kRebase) * p.NG + lane] = off;
+                    if (lane < p.NG) st_f64_wt(offp + (n / kRebase) * p.NG + lane, off);
                 }
                 store_diag<K, false>(out + (size_t)n * Up, voff, lane, a);
             }
@@ -633,10 +738,11 @@ __device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const 
         for (int j = 0; j < K; ++j)
             if (u0 + j == Ub - 1) {
                 const double ll2 = off + (double)a[j] + (double)wrow[2 * j];
-                p.ll[2 * b] = ll2;
-                p.costs[b] = (float)(-ll2 * 0.6931471805599453);
+                st_f64_wt(p.ll + 2 * b, ll2);
+                st_f32_wt(p.costs + b, (float)(-ll2 * 0.6931471805599453));
             }
     }
+    sweep_publish(p, b);
 }
 
 template <int K, int G, bool COUNTED>
@@ -645,6 +751,7 @@ __device__ void beta_sweep(const LossParams &p, float *lds, const int b, const i
     constexpr int chunkf = G * 2 * Up, n16 = chunkf / 4;
     const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
     const int Nb = Tb + Ub - 1;
+    sweep_wait_for_lsm(p, b, Tb, Ub, 1);
     const RidgeLine ridge = make_ridge(Ub, Nb);
     const float *Wb = p.W + (size_t)b * p.Nr * 2 * Up;
     float *out = p.Bt + (size_t)b * p.Nr * Up;  // wave-uniform; the lane offset is added at the store
@@ -688,7 +795,7 @@ __device__ void beta_sweep(const LossParams &p, float *lds, const int b, const i
                     beta_step<K>(bv, wc);
                     if ((n & (kRebase - 1)) == kRebase - 1) {
                         rebase<K>(bv, off, ridge.u_at(n));
-                        if (lane < p.NG) offp[(n / kRebase) * p.NG + lane] = off;
+                        if (lane < p.NG) st_f64_wt(offp + (n / kRebase) * p.NG + lane, off);
                     }
                     store_diag<K, COUNTED>(out + (size_t)n * Up, voff, lane, bv);
 #pragma unroll
@@ -706,25 +813,56 @@ __device__ void beta_sweep(const LossParams &p, float *lds, const int b, const i
                 beta_step<K>(bv, wc);
                 if (((n & (kRebase - 1)) == kRebase - 1) || n == last) {
                     rebase<K>(bv, off, ridge.u_at(n));
-                    if (lane < p.NG) offp[(n / kRebase) * p.NG + lane] = off;
+                    if (lane < p.NG) st_f64_wt(offp + (n / kRebase) * p.NG + lane, off);
                 }
                 store_diag<K, false>(out + (size_t)n * Up, voff, lane, bv);
             }
             prev_full = false;
         }
     }
-    if (lane == 0) p.ll[2 * b + 1] = off + (double)bv[0];
+    if (lane == 0) st_f64_wt(p.ll + 2 * b + 1, off + (double)bv[0]);
+    sweep_publish(p, b);
 }
 
 template <int K, int G, bool COUNTED>
 __global__ __launch_bounds__(64) void sweep_kernel(const LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int b = p.b0 + (int)(blockIdx.x >> 1);
     const int lane = threadIdx.x;
+    const int b = p.b0 + (int)(blockIdx.x >> 1);
     if (blockIdx.x & 1)
         beta_sweep<K, G, COUNTED>(p, lds, b, lane);
     else
         alpha_sweep<K, G, COUNTED>(p, lds, b, lane);
+}
+
+// Overlap-mode form: one workgroup = the alpha wave and the beta wave of one claimed utterance.  It is launched
+// with kPairLdsBytes of dynamic LDS -- far more than it uses -- so that no cell-pass workgroup fits beside it:
+// the sweep waves are the critical path and a lone wave that has to share its SIMD's issue port with
+// transcendental-heavy lsm/grad waves runs ~1.5x slower (measured), priority or not.
+constexpr size_t kPairLdsBytes = 140 * 1024;
+
+template <int K, int G>
+__global__ __launch_bounds__(128) void sweep_pair_kernel(const LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // (no static __shared__ object: it would shift the dynamic base off its 16-byte alignment)
+    int *s_job = (int *)(lds + kPairLdsBytes / sizeof(float) - 4);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float *my_lds = lds + wave * (2 * G * 2 * 64 * K);  // each direction has its own chunk buffers
+    for (;;) {
+        if (wave == 0) {
+            const int j = claim_utterance(p, lane);
+            if (lane == 0) *s_job = j;
+        }
+        __syncthreads();
+        const int b = __builtin_amdgcn_readfirstlane(*s_job);
+        __syncthreads();
+        if (b < 0) return;
+        if (wave)
+            beta_sweep<K, G, true>(p, my_lds, b, lane);
+        else
+            alpha_sweep<K, G, true>(p, my_lds, b, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -928,14 +1066,23 @@ bool tile_path_ok(const LossParams &p, bool grad) {
 }
 
 template <bool GRAD>
-static hipError_t launch_cell(const LossParams &p, hipStream_t s) {
+static hipError_t launch_cell(const LossParams &p, hipStream_t s, bool overlap) {
+    if (overlap) {  // caller checked overlap_path_ok(): patch kernels, with the hand-off protocol compiled in
+        const unsigned blocks = (unsigned)p.nb * p.tile.tiles_t * p.tile.tiles_u;
+        const size_t shm = (size_t)256 * p.V * sizeof(float) + 64;
+        if (p.V <= 32)
+            hipLaunchKernelGGL((cell_tile_kernel<32, GRAD, true>), dim3(blocks), dim3(256), shm, s, p);
+        else
+            hipLaunchKernelGGL((cell_tile_kernel<64, GRAD, true>), dim3(blocks), dim3(256), shm, s, p);
+        return hipGetLastError();
+    }
     if (tile_path_ok(p, GRAD)) {
         const unsigned blocks = (unsigned)p.nb * p.tile.tiles_t * p.tile.tiles_u;
         const size_t shm = (size_t)256 * p.V * sizeof(float) + 64;
         if (p.V <= 32)
-            hipLaunchKernelGGL((cell_tile_kernel<32, GRAD>), dim3(blocks), dim3(256), shm, s, p);
+            hipLaunchKernelGGL((cell_tile_kernel<32, GRAD, false>), dim3(blocks), dim3(256), shm, s, p);
         else
-            hipLaunchKernelGGL((cell_tile_kernel<64, GRAD>), dim3(blocks), dim3(256), shm, s, p);
+            hipLaunchKernelGGL((cell_tile_kernel<64, GRAD, false>), dim3(blocks), dim3(256), shm, s, p);
     } else if (small_path_ok(p, GRAD)) {
         const unsigned blocks = (p.cells + 255u) / 256u;
         const size_t shm = (size_t)256 * p.V * sizeof(float) + 64;
@@ -963,8 +1110,8 @@ static hipError_t launch_cell(const LossParams &p, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_lsm(const LossParams &p, hipStream_t s) { return launch_cell<false>(p, s); }
-hipError_t launch_grad(const LossParams &p, hipStream_t s) { return launch_cell<true>(p, s); }
+hipError_t launch_lsm(const LossParams &p, hipStream_t s, bool overlap) { return launch_cell<false>(p, s, overlap); }
+hipError_t launch_grad(const LossParams &p, hipStream_t s, bool overlap) { return launch_cell<true>(p, s, overlap); }
 
 // 1 (default) = register-resident single wave per (utterance, direction), explicit LDS pipeline + counted waits
 // 0           = same kernel, compiler-scheduled LDS reads, vmcnt(0) at chunk boundaries
@@ -979,7 +1126,22 @@ static int sweep_mode() {
 }
 
 template <int K, int G>
+static hipError_t launch_sweep_pair(const LossParams &p, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)sweep_pair_kernel<K, G>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPairLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nwg = p.B < 48 ? p.B : 48;  // at most 48 CUs are taken away from the bandwidth passes
+    hipLaunchKernelGGL((sweep_pair_kernel<K, G>), dim3(nwg), dim3(128), kPairLdsBytes, s, p);
+    return hipGetLastError();
+}
+
+template <int K, int G>
 static hipError_t launch_sweep_kg(const LossParams &p, hipStream_t s) {
+    if (p.flags != nullptr) return launch_sweep_pair<K, G>(p, s);
     const size_t shm = (size_t)2 * G * 2 * 64 * K * sizeof(float);
     if (sweep_mode() != 0)
         hipLaunchKernelGGL((sweep_kernel<K, G, true>), dim3(2 * p.nb), dim3(64), shm, s, p);
@@ -1002,8 +1164,20 @@ static hipError_t launch_sweep_mw(const LossParams &p, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_sweeps(const LossParams &p, hipStream_t s) {
-    if (sweep_mode() == 2) {
+hipError_t launch_lsm_done_marker(const LossParams &p, hipStream_t s) {
+    hipLaunchKernelGGL(lsm_done_marker_kernel, dim3(1), dim3(1), 0, s, p.flags + flag_lsm_kernel_done(p.B));
+    return hipGetLastError();
+}
+
+bool overlap_path_ok(const LossParams &p, bool grad) {
+    // patch kernels on both sides and the single-wave sweep (the hand-off hooks live there)
+    return tile_path_ok(p, false) && (!grad || tile_path_ok(p, true)) && sweep_mode() == 1 && sweep_K(p.U) != 0;
+}
+
+hipError_t launch_sweeps(const LossParams &p0, hipStream_t s, bool overlap) {
+    LossParams p = p0;
+    if (!overlap) p.flags = nullptr;  // the sweep kernels key the hand-off protocol on this pointer
+    if (sweep_mode() == 2 && !overlap) {
         switch (sweep_K(p.U)) {  // = number of 64-column groups
             case 1: return launch_sweep_mw<1>(p, s);
             case 2: return launch_sweep_mw<2>(p, s);

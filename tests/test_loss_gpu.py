@@ -223,6 +223,34 @@ def test_back_to_back_calls_share_side_streams():
         assert np.abs(g.cpu().numpy() - g_ref).max() <= GTOL
 
 
+def test_overlap_mode_matches_and_is_stable(monkeypatch):
+    """RNNT_OVERLAP=1: sweeps, lsm and gradient patches run concurrently and hand utterances over through
+    write-through stores + agent-scope counters.  Results must be bit-identical to the serial schedule,
+    call after call (a stale-cache bug would show up as run-to-run differences)."""
+    cases = [make_case(6, 120, 40, 28, True, seed=200 + i) for i in range(3)]
+    cases.append(make_case(32, 150, 60, 28, True, seed=300))
+    monkeypatch.setenv("RNNT_OVERLAP", "0")
+    serial = [run_hip(*c) for c in cases]
+    monkeypatch.setenv("RNNT_OVERLAP", "1")
+    for rep in range(6):
+        for c, (c_ref, g_ref) in zip(cases, serial):
+            cc, gg = run_hip(*c)
+            assert np.array_equal(cc, c_ref), rep
+            assert np.array_equal(gg, g_ref), rep
+    check(*cases[0])
+
+
+def test_overlap_mode_headline_shape(monkeypatch):
+    monkeypatch.setenv("RNNT_OVERLAP", "1")
+    acts, labels, il, ll = make_case(32, 600, 150, 28, False, seed=1234)
+    c, g = run_hip(acts, labels, il, ll)
+    monkeypatch.setenv("RNNT_OVERLAP", "0")
+    c0, g0 = run_hip(acts, labels, il, ll)
+    assert np.array_equal(c, c0) and np.array_equal(g, g0)
+    c_ref, g_ref, _, _, _ = orc.utterance_cost_and_grad(acts[5], labels[5])
+    assert abs(c[5] - c_ref) <= CTOL * abs(c_ref) and np.abs(g[5] - g_ref).max() <= GTOL
+
+
 def test_autograd_folds_upstream_gradient():
     """run_rnnt.py:278: loss = sum(costs) / global_batch; gradient reaches the logits scaled."""
     acts, labels, il, ll = make_case(4, 30, 12, 28, True, seed=61)
