@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="skip the fused joint+loss measurement")
     ap.add_argument("--joint-size", type=int, default=640, help="H = J of the fused joint (hparams.py:18,23)")
+    ap.add_argument("--e2e", action="store_true",
+                    help="also time BASELINE configs[2]: end-to-end train step, 2x320 LSTM encoder / 1x320 decoder, B=64")
     ap.add_argument("--cpu-reps", type=int, default=3)
     return ap.parse_args()
 
@@ -124,17 +126,45 @@ def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
             "workspace_GB": ws.numel() / 1e9}
 
 
+def bench_e2e(dev, world, rank, steps=8):
+    """BASELINE.json configs[2]/[3]: synthetic log-mel [B, 600, 240] -> BatchNorm -> 2 x LSTM(320, proj 320) with
+    x2 time reduction after layer 0 -> 1 x LSTM(320) prediction net -> fused joint (J=320, V=28) -> SGD step;
+    B=64 per GPU, global batch 64*world, gradients summed with one RCCL all-reduce."""
+    import rnnt_speech_recognition_amd as pkg
+
+    hp = pkg.HParams(vocab_size=28, embedding_size=320, encoder_layers=2, encoder_size=320, projection_size=320,
+                     time_reduction_index=0, pred_net_layers=1, pred_net_size=320, joint_net_size=320)
+    torch.manual_seed(1234)
+    model = pkg.Transducer(hp).to(dev)
+    batch = pkg.synthetic_batch(hp, batch=64, frames=600, max_labels=100, device=dev, seed=1234 + rank)
+    step = pkg.TrainStep(model, global_batch=64 * world)
+    for _ in range(2):
+        step(*batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        log = step(*batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"workload": "configs[2]: B=64/GPU, 600 frames x 240 feats, enc 2x320 (x2 time reduction), pred 1x320, "
+                        "J=320, V=28, SGD(1e-4, 0.9); synthetic features",
+            "ms_per_step": dt * 1e3, "utterances_per_s": 64 * world / dt, "loss": log["loss"]}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
 
     import rnnt_speech_recognition_amd as pkg
     from rnnt_speech_recognition_amd import _lib
@@ -233,6 +263,10 @@ def main():
     if rank == 0 and not a.no_fused:
         fused = bench_fused_joint(lib, _lib, dev, B, T, U, V, a.joint_size, stream, max(3, min(a.steps, 10)))
 
+    e2e = None
+    if a.e2e:
+        e2e = bench_e2e(dev, world, rank)
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(B, T, U, V, a.cpu_reps)
@@ -247,6 +281,8 @@ def main():
                        "global_batch": B * world, "parallelism": f"utterance-sharded x{world}, no data-path collective"},
             "roofline": roof, "cpu_baseline": cpu, "fused_joint": fused,
         }
+        if e2e is not None:
+            out["e2e_train_step"] = e2e
         if cpu:
             out["gpu_over_cpu"] = value / cpu["value"]
         print(json.dumps(out))

@@ -1,0 +1,70 @@
+"""The callers of the hot path: model surface on CPU, train step on GPU."""
+import numpy as np
+import pytest
+import torch
+
+import rnnt_speech_recognition_amd as pkg
+
+
+def small_hp(**kw):
+    d = dict(vocab_size=28, mel_bins=8, downsample_factor=3, embedding_size=16, encoder_layers=2, encoder_size=48,
+             projection_size=32, time_reduction_index=0, time_reduction_factor=2, pred_net_layers=1, pred_net_size=48,
+             joint_net_size=64, learning_rate=1e-3)
+    d.update(kw)
+    return pkg.HParams(**d)
+
+
+def test_time_reduction_matches_reference_reshape():
+    # model.py:8-36 with factor 2: pad T mod 2 frames, then stack pairs of frames along the feature axis
+    x = torch.arange(2 * 5 * 3, dtype=torch.float32).reshape(2, 5, 3)
+    y = pkg.TimeReduction(2)(x)
+    assert y.shape == (2, 3, 6)
+    assert torch.equal(y[0, 0], torch.cat([x[0, 0], x[0, 1]]))
+    assert torch.equal(y[0, 2], torch.cat([x[0, 4], torch.zeros(3)]))
+    assert pkg.TimeReduction(2)(torch.zeros(1, 4, 3)).shape == (1, 2, 6)
+    # lengths seen by the loss follow the same ceil (utils/loss.py:31-33)
+    assert pkg.reduced_lengths(torch.tensor([5, 4]), 2).tolist() == [3, 2]
+
+
+def test_model_shapes_and_width_check():
+    hp = small_hp()
+    m = pkg.Transducer(hp)
+    mel = torch.randn(3, 11, 24)
+    pred_inp = torch.randint(0, 28, (3, 6))
+    enc, pred = m(mel, pred_inp)
+    assert enc.shape == (3, 6, 32) and pred.shape == (3, 6, 32)  # T' = ceil(11/2); U = L+1 = 6
+    assert m.logits(mel, pred_inp).shape == (3, 6, 6, 28)
+    with pytest.raises(ValueError, match="broadcast add"):
+        pkg.Transducer(small_hp(time_reduction_index=1))  # reduction after the LAST layer: reference bug, refused
+
+
+def test_hparams_defaults_are_the_reference_ones(tmp_path):
+    hp = pkg.HParams()
+    assert (hp.mel_bins, hp.downsample_factor, hp.embedding_size, hp.encoder_layers, hp.encoder_size,
+            hp.projection_size, hp.time_reduction_index, hp.time_reduction_factor, hp.pred_net_layers,
+            hp.pred_net_size, hp.joint_net_size, hp.learning_rate, hp.vocab_size) == \
+           (80, 3, 500, 8, 2048, 640, 1, 2, 2, 2048, 640, 1e-4, 4096)  # hparams.py:3-37
+    hp.save(str(tmp_path))
+    assert pkg.HParams.load(str(tmp_path)) == hp
+
+
+@pytest.mark.gpu
+def test_train_step_reduces_loss_and_matches_unfused_loss():
+    torch.manual_seed(0)
+    dev = torch.device("cuda:0")
+    hp = small_hp()
+    m = pkg.Transducer(hp).to(dev)
+    batch = pkg.synthetic_batch(hp, batch=6, frames=40, max_labels=7, device=dev, seed=3)
+    mel, pred_inp, spec_len, lab_len, labels = batch
+    # fused loss == reference composition (materialised logits -> get_loss_fn adapter)
+    m.eval()
+    fused = m.loss(*batch)
+    unfused = pkg.get_loss_fn(hp.time_reduction_factor)(labels, m.logits(mel, pred_inp), spec_len, lab_len)
+    np.testing.assert_allclose(fused.detach().cpu().numpy(), unfused.detach().cpu().numpy(), rtol=1e-4)
+    step = pkg.TrainStep(m, global_batch=6)
+    first = step(*batch)["loss"]
+    losses = [first]
+    for _ in range(40):
+        losses.append(step(*batch)["loss"])
+    assert np.isfinite(losses).all() and losses[-1] < 0.9 * first, losses[::8]
+    assert abs(step.evaluate(*batch) - losses[-1]) < 0.5 * first
