@@ -85,15 +85,15 @@ __device__ __forceinline__ CellGrad cell_grad_setup(const LossParams &p, const C
     const int kc = n / kRebase, kc1 = (n + 1) / kRebase;
     const int g0 = cl.u >> 6, g1 = (cl.u + 1) >> 6;
     const size_t ob = (size_t)cl.b * p.NC * p.NG;
-    const double oa = ld_f64<SC1>(p.offA + ob + (size_t)kc * p.NG + g0);
+    const double oa = (double)ld_f32<SC1>(p.offA + ob + (size_t)kc * p.NG + g0);
     const double ll2 = ld_f64<SC1>(p.ll + 2 * cl.b);
-    const float E0 = (float)(oa + ld_f64<SC1>(p.offB + ob + (size_t)kc * p.NG + g0) - ll2);
+    const float E0 = (float)(oa + (double)ld_f32<SC1>(p.offB + ob + (size_t)kc * p.NG + g0) - ll2);
     g.scale = p.cost_scale ? p.cost_scale[cl.b] : 1.0f;
     g.nl = -p.lse[c] * kLog2e;
     g.c0 = (a + bt) + E0 + g.nl;
     g.has_blank_corr = true;
     if (cl.t < cl.Tb - 1)
-        g.cb = a + ld_f32<SC1>(p.Bt + sk + p.Up) + (float)(oa + ld_f64<SC1>(p.offB + ob + (size_t)kc1 * p.NG + g0) - ll2);
+        g.cb = a + ld_f32<SC1>(p.Bt + sk + p.Up) + (float)(oa + (double)ld_f32<SC1>(p.offB + ob + (size_t)kc1 * p.NG + g0) - ll2);
     else if (cl.u == cl.Ub - 1)
         g.cb = a + (float)(oa - ll2);
     else {
@@ -105,7 +105,7 @@ __device__ __forceinline__ CellGrad cell_grad_setup(const LossParams &p, const C
     g.cl = 0.f;
     if (g.has_label) {
         g.lab = clamp_label(p.labels[(size_t)cl.b * (p.U - 1) + cl.u], p.V);
-        g.cl = a + ld_f32<SC1>(p.Bt + sk + p.Up + 1) + (float)(oa + ld_f64<SC1>(p.offB + ob + (size_t)kc1 * p.NG + g1) - ll2);
+        g.cl = a + ld_f32<SC1>(p.Bt + sk + p.Up + 1) + (float)(oa + (double)ld_f32<SC1>(p.offB + ob + (size_t)kc1 * p.NG + g1) - ll2);
     }
     return g;
 }

@@ -8,7 +8,8 @@
 //                                              W[b][n][u][1] = log2 p(y_{u+1} | t=n-u, u)
 //   A, Bt          f32 [B][Nr][Up]             alpha~/beta~ lattices, log2 domain, skewed,
 //                                              stored relative to a per-block offset (kRebase diagonals)
-//   offA, offB     f64 [B][NC][NG]             the offsets (per block of kRebase diagonals and group of 64 columns)
+//   offA, offB     f32 [B][NC][NG]             the offsets (integer-valued; per block of kRebase diagonals and
+//                                              group of 64 columns)
 //   ll             f64 [B][2]                  log2-likelihood from the alpha side / beta side
 // with N = T+U-1 diagonals, Nr = N rounded up to 16 (a multiple of every chunk length), Up = 64*K (K = lattice columns per sweep lane).
 #pragma once
@@ -58,8 +59,8 @@ struct LossParams {
     float *W;
     float *A;
     float *Bt;
-    double *offA;
-    double *offB;
+    float *offA;  // integer-valued offsets, exact in f32
+    float *offB;
     double *ll;
     int *flags;  // overlap mode, see flag_* helpers: per-utterance per-XCD lsm patch counters, sweep-done counters, ...
     int B, T, U, V, blank;
@@ -121,8 +122,8 @@ inline WsLayout make_layout(int T, int U, int B) {
     w.W = take((size_t)B * w.Nr * 2 * w.Up * sizeof(float));
     w.A = take((size_t)B * w.Nr * w.Up * sizeof(float));
     w.Bt = take((size_t)B * w.Nr * w.Up * sizeof(float));
-    w.offA = take((size_t)B * w.NC * w.NG * sizeof(double));
-    w.offB = take((size_t)B * w.NC * w.NG * sizeof(double));
+    w.offA = take((size_t)B * w.NC * w.NG * sizeof(float));
+    w.offB = take((size_t)B * w.NC * w.NG * sizeof(float));
     w.ll = take((size_t)B * 2 * sizeof(double));
     w.flags = take(flag_words(B) * sizeof(int));
     w.total = off;

@@ -48,8 +48,8 @@ static bool fill_params(LossParams &p, const float *acts, float *grads, const in
     p.W = (float *)(ws + w.W);
     p.A = (float *)(ws + w.A);
     p.Bt = (float *)(ws + w.Bt);
-    p.offA = (double *)(ws + w.offA);
-    p.offB = (double *)(ws + w.offB);
+    p.offA = (float *)(ws + w.offA);
+    p.offB = (float *)(ws + w.offB);
     p.ll = (double *)(ws + w.ll);
     p.flags = (int *)(ws + w.flags);
     p.B = B, p.T = o.maxT, p.U = o.maxU, p.V = V, p.blank = o.blank_label;

@@ -399,8 +399,10 @@ __device__ __forceinline__ RidgeLine make_ridge(int Ub, int Nb) {
     return r;
 }
 
+// Returns the INTEGER amount subtracted (exact in f32, so offsets accumulate exactly in f32 too).  The ridge cell
+// (n - u_ref, u_ref) is a lattice node for every diagonal of a well-formed utterance, hence never log zero.
 template <int K>
-__device__ __forceinline__ void rebase(float (&v)[K], double &off, const int u_ref) {
+__device__ __forceinline__ float rebase(float (&v)[K], const int u_ref) {
     const int src_lane = u_ref / K, src_j = u_ref - src_lane * K;  // wave-uniform
     float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[0]), src_lane));
 #pragma unroll
@@ -408,12 +410,35 @@ __device__ __forceinline__ void rebase(float (&v)[K], double &off, const int u_r
         const float mj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[j]), src_lane));
         m = (src_j == j) ? mj : m;
     }
-    if (m > kNegTest) {
+    const float mi = rintf(m);
 #pragma unroll
-        for (int j = 0; j < K; ++j) v[j] -= m;  // log zeros stay log zeros: |m| << 1e30
-        off += (double)m;
-    }
+    for (int j = 0; j < K; ++j) v[j] -= mi;  // log zeros stay log zeros: |mi| << 1e30
+    return mi;
 }
+
+// Log of the offsets, one per block of kRebase diagonals.  Lane (kc & 63) of `hist` holds the offset of block kc;
+// every 64 blocks (and at the end) the register is flushed to the table with one coalesced store per column group.
+struct OffsetLog {
+    float *table;  // this utterance's [NC][NG] floats
+    int ng;
+    float hist;
+    int lo, hi;    // block range recorded since the last flush (lo > hi: empty)
+    __device__ __forceinline__ void init(float *t, int ng_) {
+        table = t, ng = ng_, hist = 0.f, lo = 1 << 30, hi = -1;
+    }
+    __device__ __forceinline__ void flush(const int lane) {
+        if (lo > hi) return;
+        const int kc = (lo & ~63) + lane;
+        if (kc >= lo && kc <= hi)
+            for (int g = 0; g < ng; ++g) st_f32_wt(table + (size_t)kc * ng + g, hist);
+        lo = 1 << 30, hi = -1;
+    }
+    __device__ __forceinline__ void record(const int kc, const float off, const int lane) {
+        if (lo <= hi && (kc >> 6) != (lo >> 6)) flush(lane);
+        hist = (lane == (kc & 63)) ? off : hist;
+        lo = min(lo, kc), hi = max(hi, kc);
+    }
+};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -526,11 +551,11 @@ __device__ __forceinline__ void store_diag(float *row, const int voff, const int
         }
         if (K % 4 >= 2) {
             const f32x2 q = {v[j], v[j + 1]};
-            asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 sc1\n\ts_nop 1" ::"v"(voff), "v"(q), "s"(row), "n"(j * 4));
+            asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 sc1" ::"v"(voff), "v"(q), "s"(row), "n"(j * 4));
             j += 2;
         }
         if (K % 2)
-            asm volatile("global_store_dword %0, %1, %2 offset:%3 sc1\n\ts_nop 1" ::"v"(voff), "v"(v[j]), "s"(row), "n"(j * 4));
+            asm volatile("global_store_dword %0, %1, %2 offset:%3 sc1" ::"v"(voff), "v"(v[j]), "s"(row), "n"(j * 4));
     }
 }
 
@@ -539,16 +564,12 @@ __device__ __forceinline__ void wait_vm_counted() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// Edge weights of one diagonal for this lane: w[0..K) blank edges, w[K..2K) label edges.
+// Edge weights of one diagonal for this lane: w[j] = {blank edge, label edge} of column u0 + j.
 // LDS row layout = HBM row layout = [Up][2] (blank, label interleaved per column): K 8-byte reads.
 template <int K>
-__device__ __forceinline__ void load_w(float (&w)[2 * K], const float *wrow) {
+__device__ __forceinline__ void load_w(f32x2 (&w)[K], const float *wrow) {
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        const float2 q = ((const float2 *)wrow)[j];
-        w[j] = q.x;
-        w[K + j] = q.y;
-    }
+    for (int j = 0; j < K; ++j) w[j] = ((const f32x2 *)wrow)[j];
 }
 
 // Explicitly scheduled variant of load_w for the counted sweep: K ds_read_b64 whose completion the
@@ -566,48 +587,48 @@ __device__ __forceinline__ void lds_wait() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
     __builtin_amdgcn_sched_barrier(0);  // nothing that consumes the rows may be hoisted above the wait
 }
-template <int K>
-__device__ __forceinline__ void unpack_w(float (&w)[2 * K], const f32x2 (&q)[K]) {
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        w[j] = q[j][0];
-        w[K + j] = q[j][1];
-    }
-}
 
 // One alpha step: diagonal r -> r+1 using the outgoing edge weights `w` of diagonal r.
+// {d_j, e_j} = {a_j, a_j} + {blank_j, label_j} is ONE packed add per column.
 template <int K>
-__device__ __forceinline__ void alpha_step(float (&a)[K], const float (&w)[2 * K]) {
-    float d[K], e[K];
+__device__ __forceinline__ void alpha_step(float (&a)[K], const f32x2 (&w)[K]) {
+    f32x2 de[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        d[j] = a[j] + w[j];      // blank:  (t-1,u) -> (t,u)
-        e[j] = a[j] + w[K + j];  // label:  (t,u-1) -> (t,u)
+        const f32x2 aa = {a[j], a[j]};
+        de[j] = aa + w[j];  // .x blank: (t-1,u) -> (t,u);  .y label: (t,u) -> (t,u+1)
     }
-    const float from_left = dpp_from_lower_lane(e[K - 1], kNeg);
+    const float from_left = dpp_from_lower_lane(de[K - 1][1], kNeg);
 #pragma unroll
-    for (int j = 0; j < K; ++j) a[j] = lse2(d[j], (j == 0) ? from_left : e[j - 1]);
+    for (int j = 0; j < K; ++j) a[j] = lse2(de[j][0], (j == 0) ? from_left : de[j - 1][1]);
 }
 
 // One beta step: diagonal n+1 -> n using the outgoing edge weights `w` of diagonal n.
 template <int K>
-__device__ __forceinline__ void beta_step(float (&bv)[K], const float (&w)[2 * K]) {
+__device__ __forceinline__ void beta_step(float (&bv)[K], const f32x2 (&w)[K]) {
     const float from_right = dpp_from_upper_lane(bv[0], kNeg);
     float nv[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        const float right = (j == K - 1) ? from_right : bv[j + 1];
-        nv[j] = lse2(bv[j] + w[j], right + w[K + j]);
+        const f32x2 br = {bv[j], (j == K - 1) ? from_right : bv[j + 1]};
+        const f32x2 s2 = br + w[j];
+        nv[j] = lse2(s2[0], s2[1]);
     }
 #pragma unroll
     for (int j = 0; j < K; ++j) bv[j] = nv[j];
 }
 
+// State a sweep carries from step to step besides the diagonal itself.
+struct SweepState {
+    float off;       // cumulative (integer-valued) offset: true value = stored value + off
+    OffsetLog log;
+    float *row;      // wave-uniform base of the output row of the NEXT diagonal to be stored
+};
+
 // Fully unrolled, explicitly pipelined steps of one chunk (compile-time recursion over the step index
 // II so that every LDS offset is an immediate and the two weight register sets ping-pong by name).
 template <int K, int G, int II>
-__device__ __forceinline__ void alpha_fast_steps(const LossParams &p, float (&a)[K], f32x2 (&wq)[2][K],
-                                                 const uint32_t abase, double &off, double *offp, float *out,
+__device__ __forceinline__ void alpha_fast_steps(float (&a)[K], f32x2 (&wq)[2][K], const uint32_t abase, SweepState &st,
                                                  const int voff, const int lane, const int r0, const RidgeLine &ridge) {
     if constexpr (II < G) {
         constexpr int cur = II & 1, nxt = cur ^ 1;
@@ -617,22 +638,20 @@ __device__ __forceinline__ void alpha_fast_steps(const LossParams &p, float (&a)
         } else {
             lds_wait<0>();
         }
-        float w[2 * K];
-        unpack_w<K>(w, wq[cur]);
         const int n = r0 + II + 1;
-        alpha_step<K>(a, w);
+        alpha_step<K>(a, wq[cur]);
         if ((n & (kRebase - 1)) == 0) {
-            rebase<K>(a, off, ridge.u_at(n));
-            if (lane < p.NG) st_f64_wt(offp + (n / kRebase) * p.NG + lane, off);
+            st.off += rebase<K>(a, ridge.u_at(n));
+            st.log.record(n / kRebase, st.off, lane);
         }
-        store_diag<K, true>(out + (size_t)n * (64 * K), voff, lane, a);
-        alpha_fast_steps<K, G, II + 1>(p, a, wq, abase, off, offp, out, voff, lane, r0, ridge);
+        store_diag<K, true>(st.row, voff, lane, a);
+        st.row += 64 * K;
+        alpha_fast_steps<K, G, II + 1>(a, wq, abase, st, voff, lane, r0, ridge);
     }
 }
 
 template <int K, int G, int II>
-__device__ __forceinline__ void beta_fast_steps(const LossParams &p, float (&bv)[K], f32x2 (&wq)[2][K],
-                                                const uint32_t abase, double &off, double *offp, float *out,
+__device__ __forceinline__ void beta_fast_steps(float (&bv)[K], f32x2 (&wq)[2][K], const uint32_t abase, SweepState &st,
                                                 const int voff, const int lane, const int r0, const RidgeLine &ridge) {
     if constexpr (II < G) {
         constexpr int cur = II & 1, nxt = cur ^ 1;
@@ -643,16 +662,15 @@ __device__ __forceinline__ void beta_fast_steps(const LossParams &p, float (&bv)
         } else {
             lds_wait<0>();
         }
-        float w[2 * K];
-        unpack_w<K>(w, wq[cur]);
         const int n = r0 + i;
-        beta_step<K>(bv, w);
+        beta_step<K>(bv, wq[cur]);
         if ((n & (kRebase - 1)) == kRebase - 1) {
-            rebase<K>(bv, off, ridge.u_at(n));
-            if (lane < p.NG) st_f64_wt(offp + (n / kRebase) * p.NG + lane, off);
+            st.off += rebase<K>(bv, ridge.u_at(n));
+            st.log.record(n / kRebase, st.off, lane);
         }
-        store_diag<K, true>(out + (size_t)n * (64 * K), voff, lane, bv);
-        beta_fast_steps<K, G, II + 1>(p, bv, wq, abase, off, offp, out, voff, lane, r0, ridge);
+        store_diag<K, true>(st.row, voff, lane, bv);
+        st.row -= 64 * K;
+        beta_fast_steps<K, G, II + 1>(bv, wq, abase, st, voff, lane, r0, ridge);
     }
 }
 
@@ -667,7 +685,6 @@ __device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const 
     const float *Wb = p.W + (size_t)b * p.Nr * 2 * Up;
     float *out = p.A + (size_t)b * p.Nr * Up;  // wave-uniform; the lane offset is added at the store
     const int voff = lane * K * 4;
-    double *offp = p.offA + (size_t)b * p.NC * p.NG;
     const int u0 = lane * K;
     float *buf0 = lds, *buf1 = lds + chunkf;
 
@@ -675,8 +692,11 @@ __device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const 
 #pragma unroll
     for (int j = 0; j < K; ++j) a[j] = (u0 + j == 0) ? 0.f : kNeg;
     store_diag<K, false>(out, voff, lane, a);
-    if (lane < p.NG) st_f64_wt(offp + lane, 0.0);
-    double off = 0.0;
+    SweepState st;
+    st.off = 0.f;
+    st.log.init(p.offA + (size_t)b * p.NC * p.NG, p.NG);
+    st.log.record(0, 0.f, lane);
+    st.row = out + Up;  // diagonal 1
     const int last_row = Nb - 1;  // rows 0..Nb-2 feed the steps, row Nb-1 the final likelihood
     const int nchunks = last_row / G + 1;
 
@@ -690,54 +710,38 @@ __device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const 
         const float *cur = ((ck & 1) ? buf1 : buf0) + 2 * u0;
         if (ck + 1 < nchunks) dma_rows(Wb + (size_t)(ck + 1) * chunkf, (ck & 1) ? buf0 : buf1, n16, lane);
         const int r0 = ck * G;
-        if (r0 + G <= last_row) {  // every row of this chunk feeds a step: straight-line code
-            if (COUNTED && K <= 15) {
-                // explicit software pipeline: row i+1's LDS reads are in flight under step i
-                const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
-                f32x2 wq[2][K];
-                lds_issue_row<K, 0>(wq[0], abase);
-                alpha_fast_steps<K, G, 0>(p, a, wq, abase, off, offp, out, voff, lane, r0, ridge);
-            } else {
-                float wc[2 * K], wn[2 * K];
-                load_w<K>(wc, cur);
-#pragma unroll
-                for (int i = 0; i < G; ++i) {
-                    const int n = r0 + i + 1;
-                    if (i + 1 < G) load_w<K>(wn, cur + (i + 1) * 2 * Up);  // next step's weights
-                    __builtin_amdgcn_sched_barrier(0);
-                    alpha_step<K>(a, wc);
-                    if ((n & (kRebase - 1)) == 0) {
-                        rebase<K>(a, off, ridge.u_at(n));
-                        if (lane < p.NG) st_f64_wt(offp + (n / kRebase) * p.NG + lane, off);
-                    }
-                    store_diag<K, COUNTED>(out + (size_t)n * Up, voff, lane, a);
-#pragma unroll
-                    for (int q = 0; q < 2 * K; ++q) wc[q] = wn[q];
-                }
-            }
+        if (COUNTED && K <= 15 && r0 + G <= last_row) {
+            // every row of this chunk feeds a step: straight-line code, explicit software pipeline
+            // (row i+1's LDS reads are in flight under step i)
+            const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
+            f32x2 wq[2][K];
+            lds_issue_row<K, 0>(wq[0], abase);
+            alpha_fast_steps<K, G, 0>(a, wq, abase, st, voff, lane, r0, ridge);
             prev_full = true;
         } else {
             for (int i = 0; i < G; ++i) {
                 const int n = r0 + i + 1;
                 if (n > last_row) break;
-                float wc[2 * K];
+                f32x2 wc[K];
                 load_w<K>(wc, cur + i * 2 * Up);
                 alpha_step<K>(a, wc);
                 if ((n & (kRebase - 1)) == 0) {
-                    rebase<K>(a, off, ridge.u_at(n));
-                    if (lane < p.NG) st_f64_wt(offp + (n / kRebase) * p.NG + lane, off);
+                    st.off += rebase<K>(a, ridge.u_at(n));
+                    st.log.record(n / kRebase, st.off, lane);
                 }
-                store_diag<K, false>(out + (size_t)n * Up, voff, lane, a);
+                store_diag<K, false>(st.row, voff, lane, a);
+                st.row += Up;
             }
             prev_full = false;
         }
     }
+    st.log.flush(lane);
     {
         const float *wrow = (((nchunks - 1) & 1) ? buf1 : buf0) + (last_row % G) * 2 * Up + 2 * u0;
 #pragma unroll
         for (int j = 0; j < K; ++j)
             if (u0 + j == Ub - 1) {
-                const double ll2 = off + (double)a[j] + (double)wrow[2 * j];
+                const double ll2 = (double)st.off + (double)a[j] + (double)wrow[2 * j];
                 st_f64_wt(p.ll + 2 * b, ll2);
                 st_f32_wt(p.costs + b, (float)(-ll2 * 0.6931471805599453));
             }
@@ -756,16 +760,18 @@ __device__ void beta_sweep(const LossParams &p, float *lds, const int b, const i
     const float *Wb = p.W + (size_t)b * p.Nr * 2 * Up;
     float *out = p.Bt + (size_t)b * p.Nr * Up;  // wave-uniform; the lane offset is added at the store
     const int voff = lane * K * 4;
-    double *offp = p.offB + (size_t)b * p.NC * p.NG;
     const int u0 = lane * K;
     float *buf0 = lds, *buf1 = lds + chunkf;
 
     float bv[K];  // beta on the diagonal below; starts as the virtual terminal node (Tb, Ub-1) = 0
 #pragma unroll
     for (int j = 0; j < K; ++j) bv[j] = (u0 + j == Ub - 1) ? 0.f : kNeg;
-    double off = 0.0;
     const int last = Nb - 1;
     const int ckl = last / G;
+    SweepState st;
+    st.off = 0.f;
+    st.log.init(p.offB + (size_t)b * p.NC * p.NG, p.NG);
+    st.row = out + (size_t)last * Up;
 
     dma_rows(Wb + (size_t)ckl * chunkf, (ckl & 1) ? buf1 : buf0, n16, lane);
     bool prev_full = false;
@@ -777,50 +783,32 @@ __device__ void beta_sweep(const LossParams &p, float *lds, const int b, const i
         const float *cur = ((ck & 1) ? buf1 : buf0) + 2 * u0;
         if (ck > 0) dma_rows(Wb + (size_t)(ck - 1) * chunkf, (ck & 1) ? buf0 : buf1, n16, lane);
         const int r0 = ck * G;
-        if (r0 + G - 1 < last) {  // whole chunk strictly below the first (terminal) diagonal
-            if (COUNTED && K <= 15) {
-                const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
-                f32x2 wq[2][K];
-                lds_issue_row<K, G - 1>(wq[0], abase);
-                beta_fast_steps<K, G, 0>(p, bv, wq, abase, off, offp, out, voff, lane, r0, ridge);
-            } else {
-                float wc[2 * K], wn[2 * K];
-                load_w<K>(wc, cur + (G - 1) * 2 * Up);
-#pragma unroll
-                for (int ii = 0; ii < G; ++ii) {
-                    const int i = G - 1 - ii;
-                    const int n = r0 + i;
-                    if (i > 0) load_w<K>(wn, cur + (i - 1) * 2 * Up);  // next step's weights
-                    __builtin_amdgcn_sched_barrier(0);
-                    beta_step<K>(bv, wc);
-                    if ((n & (kRebase - 1)) == kRebase - 1) {
-                        rebase<K>(bv, off, ridge.u_at(n));
-                        if (lane < p.NG) st_f64_wt(offp + (n / kRebase) * p.NG + lane, off);
-                    }
-                    store_diag<K, COUNTED>(out + (size_t)n * Up, voff, lane, bv);
-#pragma unroll
-                    for (int q = 0; q < 2 * K; ++q) wc[q] = wn[q];
-                }
-            }
+        if (COUNTED && K <= 15 && r0 + G - 1 < last) {  // whole chunk strictly below the first (terminal) diagonal
+            const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
+            f32x2 wq[2][K];
+            lds_issue_row<K, G - 1>(wq[0], abase);
+            beta_fast_steps<K, G, 0>(bv, wq, abase, st, voff, lane, r0, ridge);
             prev_full = true;
         } else {
             for (int ii = 0; ii < G; ++ii) {
                 const int i = G - 1 - ii;
                 const int n = r0 + i;
                 if (n > last) continue;
-                float wc[2 * K];
+                f32x2 wc[K];
                 load_w<K>(wc, cur + i * 2 * Up);
                 beta_step<K>(bv, wc);
                 if (((n & (kRebase - 1)) == kRebase - 1) || n == last) {
-                    rebase<K>(bv, off, ridge.u_at(n));
-                    if (lane < p.NG) st_f64_wt(offp + (n / kRebase) * p.NG + lane, off);
+                    st.off += rebase<K>(bv, ridge.u_at(n));
+                    st.log.record(n / kRebase, st.off, lane);
                 }
-                store_diag<K, false>(out + (size_t)n * Up, voff, lane, bv);
+                store_diag<K, false>(st.row, voff, lane, bv);
+                st.row -= Up;
             }
             prev_full = false;
         }
     }
-    if (lane == 0) st_f64_wt(p.ll + 2 * b + 1, off + (double)bv[0]);
+    st.log.flush(lane);
+    if (lane == 0) st_f64_wt(p.ll + 2 * b + 1, (double)st.off + (double)bv[0]);
     sweep_publish(p, b);
 }
 
@@ -959,12 +947,12 @@ __device__ __forceinline__ void sweep_mw_body(const LossParams &p, float *lds, c
     const int u = wave * 64 + lane;
     const RidgeLine ridge = make_ridge(Ub, Nb);
     float *out = (BETA ? p.Bt : p.A) + (size_t)b * p.Nr * Up;
-    double *offp = (BETA ? p.offB : p.offA) + (size_t)b * p.NC * p.NG + wave;
+    float *offp = (BETA ? p.offB : p.offA) + (size_t)b * p.NC * p.NG + wave;
     float a = BETA ? ((u == Ub - 1) ? 0.f : kNeg) : ((u == 0) ? 0.f : kNeg);
     float Ow = 0.f;  // this wave's offset: true value = stored value + Ow (always an integer)
     if (!BETA) {
         out[u] = a;
-        if (lane == 0) offp[0] = 0.0;
+        if (lane == 0) offp[0] = 0.f;
     }
     const int skew = 2 * (BETA ? NW - 1 - wave : wave);
     const bool has_nb = BETA ? (wave < NW - 1) : (wave > 0);
@@ -1012,7 +1000,7 @@ __device__ __forceinline__ void sweep_mw_body(const LossParams &p, float *lds, c
                     a -= mi;
                     Ow += mi;
                 }
-                if (lane == 0) offp[(size_t)(n / kRebase) * p.NG] = (double)Ow;
+                if (lane == 0) offp[(size_t)(n / kRebase) * p.NG] = Ow;
             }
             out[(size_t)n * Up + u] = a;
         }
