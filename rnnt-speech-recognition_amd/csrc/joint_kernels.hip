@@ -13,7 +13,8 @@
 //   phase 1  (joint_phase1_kernel)  logits tile = tanh(A_t + C_u) . W2 + b2 on v_mfma_f32_32x32x2_f32
 //            forward  epilogue: softmax denominator + lattice edge weights  (same outputs as the
 //                               lsm pass of rnnt_kernels.hip -> the alpha/beta sweeps run unchanged)
-//            backward epilogue: dlogits of the tile (V <= 32 floats per cell) into the workspace
+//                               and parks the logits tile (V <= 32 floats per cell) in the workspace
+//   dl       (joint_dl_kernel)      backward: logits tile -> dlogits in place (per-cell, memory-bound) + db2 partials
 //   phase 2  (joint_phase2_kernel)  dh = dl . W2^T,  dz = dh * (1-h^2),  d enc_proj = sum_u dz,
 //            d pred_proj = sum_t dz,  dW2 = h^T . dl   -- the "gradient scatter back through the joint".
 //            h is recomputed in the MFMA C/D register layout, which is at the same time a valid
@@ -49,7 +50,7 @@ struct JointParams {
     float *dApart;  // [n_ut][B][T][J]
     float *dCpart;  // [n_ts][B][U][J]
     float *dWpart;  // [B*n_ut*n_ts][J][32]
-    float *dbpart;  // [B*n_ut*n_tr][32]
+    float *dbpart;  // [ceil(cells/256)][32]
     float *d_enc_proj, *d_pred_proj, *dW2, *db2;
     int J, n_ut, TR, n_tr, TS, n_ts;
 };
@@ -58,10 +59,9 @@ constexpr int kP1Waves = 8;    // phase-1 workgroup = 8 waves (2 per SIMD: one w
 constexpr int kStagePad = 33;  // row stride of the per-wave 32x32 staging tiles (bank-conflict free both ways)
 
 // ---------------------------------------------------------------------------------------------
-// phase 1: one lattice row (32 cells of one u-tile) per wave per iteration.
+// phase 1 (forward): one lattice row (32 cells of one u-tile) per wave per iteration.
 // LDS: Ct [J][32] (pred_proj tile, transposed) | W2c [2][32][32] | Arow [8][J] | stage [8][32][33]
 // ---------------------------------------------------------------------------------------------
-template <bool BWD>
 __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const JointParams jp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LossParams &p = jp.lp;
@@ -85,7 +85,6 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
     const int t_begin = tr * jp.TR, t_end = min(min(t_begin + jp.TR, p.T), Tb);
     const bool tile_live = (t_begin < t_end) && (u0 < Ub);
 
-    float dbsum = 0.f;  // BWD: this lane's share of sum_cells dl[cell][v = l31] (rows cd_row(*, half))
     if (tile_live) {
         // ---- C^T tile: Ct[j][u] = pred_proj[b][u0+u][j]  (lanes run along u: conflict-free LDS writes)
         for (int idx = tid; idx < 32 * (J / 4); idx += kP1Waves * 64) {
@@ -172,62 +171,92 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
                     xs[v] += jp.b2[v];
                     m = fmaxf(m, xs[v]);
                 }
-                if (!BWD) {
-                    float s = 0.f;
-                    const float nml = -m * kLog2e;
-                    for (int v = 0; v < V; ++v) s += jex2(fmaf(xs[v], kLog2e, nml));
-                    const float lse = m + kLn2 * jlg2(s);
-                    const bool blank_stays = (cl.t < Tb - 1) || (cl.u == Ub - 1);
-                    const float ob = blank_stays ? (xs[p.blank] - lse) * kLog2e : kNeg;
-                    float ol = kNeg;
-                    if (cl.u < Ub - 1) {
-                        const int lab = min(max(p.labels[(size_t)b * (p.U - 1) + cl.u], 0), V - 1);
-                        ol = (xs[lab] - lse) * kLog2e;
-                    }
-                    p.lse[c] = lse;
-                    const size_t wi = ((size_t)b * p.Nr + (cl.t + cl.u)) * p.Up + cl.u;
-                    ((float2 *)p.W)[wi] = make_float2(ob, ol);
-                } else {
-                    const CellGrad g = cell_grad_setup(p, cl, c);
-                    const float xb = xs[p.blank];
-                    const float xl = g.has_label ? xs[g.lab] : 0.f;
-                    for (int v = 0; v < V; ++v) xs[v] = g.scale * jex2(fmaf(xs[v], kLog2e, g.c0));
-                    if (g.has_blank_corr) xs[p.blank] -= g.scale * jex2(fmaf(xb, kLog2e, g.nl) + g.cb);
-                    if (g.has_label) xs[g.lab] -= g.scale * jex2(fmaf(xl, kLog2e, g.nl) + g.cl);
-                    for (int v = V; v < 32; ++v) xs[v] = 0.f;
+                float s = 0.f;
+                const float nml = -m * kLog2e;
+                for (int v = 0; v < V; ++v) s += jex2(fmaf(xs[v], kLog2e, nml));
+                const float lse = m + kLn2 * jlg2(s);
+                const bool blank_stays = (cl.t < Tb - 1) || (cl.u == Ub - 1);
+                const float ob = blank_stays ? (xs[p.blank] - lse) * kLog2e : kNeg;
+                float ol = kNeg;
+                if (cl.u < Ub - 1) {
+                    const int lab = min(max(p.labels[(size_t)b * (p.U - 1) + cl.u], 0), V - 1);
+                    ol = (xs[lab] - lse) * kLog2e;
                 }
-            } else if (BWD) {
-                for (int v = 0; v < 32; ++v) xs[v] = 0.f;
+                p.lse[c] = lse;
+                const size_t wi = ((size_t)b * p.Nr + (cl.t + cl.u)) * p.Up + cl.u;
+                ((float2 *)p.W)[wi] = make_float2(ob, ol);
             }
+
         }
-        if (BWD) {
+        {
+            // park the logits tile (bias included) in the workspace: V <= 32 floats per cell.  The backward pass turns
+            // it into dlogits in place instead of re-running this whole MFMA pass.
             __syncthreads();
-            if (active) {
-                // dl tile -> workspace (row-major [cell][32]) and the db2 partial sums
+            if (active)
                 for (int e = lane; e < 1024; e += 64) {
                     const int uu = e >> 5, v = e & 31;
-                    if (u0 + uu < p.U) {
+                    if (u0 + uu < Ub) {
                         const size_t c = ((size_t)(b * p.T + t)) * p.U + u0 + uu;
                         jp.dl[c * 32 + v] = my_stage[uu * kStagePad + v];
                     }
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dbsum += my_stage[cd_row(r, half) * kStagePad + l31];
-            }
         }
         __syncthreads();  // staging tiles and Arow are rewritten by the next iteration
     }
-    if (BWD) {
-        // deterministic in-block reduction of the db2 partials: halves, then waves in fixed order
-        float *red = stage;  // reuse
-        __syncthreads();
-        red[tid] = dbsum;
-        __syncthreads();
-        if (tid < 32) {
-            float s = 0.f;
-            for (int w = 0; w < kP1Waves; ++w) s += red[w * 64 + tid] + red[w * 64 + 32 + tid];
-            jp.dbpart[(size_t)blockIdx.x * 32 + tid] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, step 1: dlogits from the parked logits tile (one lattice cell per lane, 128 B in / 128 B out, in place)
+// plus this workgroup's share of db2 = sum_cells dl.  Replaces a second run of phase 1.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void joint_dl_kernel(const JointParams jp) {
+    __shared__ float red[256][33];
+    const LossParams &p = jp.lp;
+    const int V = p.V, tid = threadIdx.x;
+    const uint32_t c = blockIdx.x * 256u + tid;
+    const Cell cl = decode(p, c);
+    float x[32];
+#pragma unroll
+    for (int v = 0; v < 32; ++v) x[v] = 0.f;
+    if (cl.valid) {
+        float4 *q = (float4 *)(jp.dl + (size_t)c * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 t4 = q[i];
+            x[4 * i] = t4.x, x[4 * i + 1] = t4.y, x[4 * i + 2] = t4.z, x[4 * i + 3] = t4.w;
         }
+        const CellGrad g = cell_grad_setup(p, cl, c);
+        float xb = 0.f, xl = 0.f;
+#pragma unroll
+        for (int v = 0; v < 32; ++v) {
+            xb = (v == p.blank) ? x[v] : xb;
+            xl = (g.has_label && v == g.lab) ? x[v] : xl;
+        }
+        const float cb = g.has_blank_corr ? g.scale * jex2(fmaf(xb, kLog2e, g.nl) + g.cb) : 0.f;
+        const float clb = g.has_label ? g.scale * jex2(fmaf(xl, kLog2e, g.nl) + g.cl) : 0.f;
+#pragma unroll
+        for (int v = 0; v < 32; ++v) {
+            float gv = (v < V) ? g.scale * jex2(fmaf(x[v], kLog2e, g.c0)) : 0.f;
+            gv -= (v == p.blank) ? cb : 0.f;
+            gv -= (g.has_label && v == g.lab) ? clb : 0.f;
+            x[v] = gv;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = make_float4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
+    } else if (c < p.cells) {
+        // padded cell: phase 2 reads whole 32-column tiles of every valid row, so it must find exact zeros here
+        float4 *q = (float4 *)(jp.dl + (size_t)c * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // db2 partial of this workgroup: fixed-order column sums through LDS
+#pragma unroll
+    for (int v = 0; v < 32; ++v) red[tid][v] = x[v];
+    __syncthreads();
+    if (tid < 32) {
+        float s = 0.f;
+        for (int r = 0; r < 256; ++r) s += red[r][tid];
+        jp.dbpart[(size_t)blockIdx.x * 32 + tid] = s;
     }
 }
 
@@ -449,7 +478,7 @@ static JointLayout make_joint_layout(int T, int U, int B, int J) {
     L.dApart = take((size_t)L.n_ut * B * T * J * sizeof(float));
     L.dCpart = take((size_t)L.n_ts * B * U * J * sizeof(float));
     L.dWpart = take((size_t)B * L.n_ut * L.n_ts * J * 32 * sizeof(float));
-    L.dbpart = take((size_t)B * L.n_ut * L.n_tr * 32 * sizeof(float));
+    L.dbpart = take(((size_t)B * T * U + 255) / 256 * 32 * sizeof(float));
     L.total = off;
     return L;
 }
@@ -502,21 +531,21 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     const size_t shm1 = ((size_t)J * 32 + 2 * 1024 + kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
     const size_t shm2 = ((size_t)64 * 36 + 64 * kStagePad + 2 * 4 * 32 * kStagePad) * sizeof(float);
     hipError_t e;
-    if ((e = set_lds(joint_phase1_kernel<false>, shm1)) != hipSuccess) return e;
-    if ((e = set_lds(joint_phase1_kernel<true>, shm1)) != hipSuccess) return e;
+    if ((e = set_lds(joint_phase1_kernel, shm1)) != hipSuccess) return e;
 
     const unsigned g1 = (unsigned)B * L.n_ut * L.n_tr;
     if (phases & 1) {
         // forward: edge weights (W pre-filled with log zero) -> sweeps -> costs
         if (hipMemsetAsync(jp.lp.W, kFillByte, L.w.A - L.w.W, s) != hipSuccess) return hipErrorUnknown;
-        hipLaunchKernelGGL((joint_phase1_kernel<false>), dim3(g1), dim3(kP1Waves * 64), shm1, s, jp);
+        hipLaunchKernelGGL(joint_phase1_kernel, dim3(g1), dim3(kP1Waves * 64), shm1, s, jp);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = launch_sweeps(jp.lp, s)) != hipSuccess) return e;
     }
     if (!(phases & 2) || !d_enc_proj) return hipSuccess;  // score only
 
     // backward: dlogits tiles, then the scatter through the joint
-    hipLaunchKernelGGL((joint_phase1_kernel<true>), dim3(g1), dim3(kP1Waves * 64), shm1, s, jp);
+    const unsigned gdl = (jp.lp.cells + 255u) / 256u;
+    hipLaunchKernelGGL(joint_dl_kernel, dim3(gdl), dim3(256), 0, s, jp);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (hipMemsetAsync(jp.dApart, 0, L.dbpart - L.dApart, s) != hipSuccess) return hipErrorUnknown;  // dA/dC/dW partials
     const unsigned g2 = (unsigned)B * L.n_ut * (J / 64) * L.n_ts;
@@ -527,7 +556,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1024), dim3(256), 0, s, d_pred_proj, jp.dCpart, L.n_ts, nC);
     hipLaunchKernelGGL((reduce_small_kernel<true>), dim3((J * V + 31) / 32), dim3(256), 0, s, dW2, jp.dWpart,
                        B * L.n_ut * L.n_ts, J * V, J, V);
-    hipLaunchKernelGGL((reduce_small_kernel<false>), dim3(1), dim3(256), 0, s, db2, jp.dbpart, (int)g1, V, J, V);
+    hipLaunchKernelGGL((reduce_small_kernel<false>), dim3(1), dim3(256), 0, s, db2, jp.dbpart, (int)gdl, V, J, V);
     return hipGetLastError();
 }
 
