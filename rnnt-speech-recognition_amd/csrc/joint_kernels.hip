@@ -209,49 +209,55 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
 // backward, step 1: dlogits from the parked logits tile (one lattice cell per lane, 128 B in / 128 B out, in place)
 // plus this workgroup's share of db2 = sum_cells dl.  Replaces a second run of phase 1.
 // ---------------------------------------------------------------------------------------------
+constexpr int kDlChunks = 8;  // 256-cell chunks per workgroup (fewer, fatter db2 partials)
+
 __global__ __launch_bounds__(256) void joint_dl_kernel(const JointParams jp) {
     __shared__ float red[256][33];
     const LossParams &p = jp.lp;
     const int V = p.V, tid = threadIdx.x;
-    const uint32_t c = blockIdx.x * 256u + tid;
-    const Cell cl = decode(p, c);
-    float x[32];
+    float colsum[32];
 #pragma unroll
-    for (int v = 0; v < 32; ++v) x[v] = 0.f;
-    if (cl.valid) {
-        float4 *q = (float4 *)(jp.dl + (size_t)c * 32);
+    for (int v = 0; v < 32; ++v) colsum[v] = 0.f;
+    for (int ch = 0; ch < kDlChunks; ++ch) {
+        const uint32_t c = (blockIdx.x * kDlChunks + ch) * 256u + tid;
+        const Cell cl = decode(p, c);
+        if (cl.valid) {
+            float x[32];
+            float4 *q = (float4 *)(jp.dl + (size_t)c * 32);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float4 t4 = q[i];
-            x[4 * i] = t4.x, x[4 * i + 1] = t4.y, x[4 * i + 2] = t4.z, x[4 * i + 3] = t4.w;
+            for (int i = 0; i < 8; ++i) {
+                const float4 t4 = q[i];
+                x[4 * i] = t4.x, x[4 * i + 1] = t4.y, x[4 * i + 2] = t4.z, x[4 * i + 3] = t4.w;
+            }
+            const CellGrad g = cell_grad_setup(p, cl, c);
+            float xb = 0.f, xl = 0.f;
+#pragma unroll
+            for (int v = 0; v < 32; ++v) {
+                xb = (v == p.blank) ? x[v] : xb;
+                xl = (g.has_label && v == g.lab) ? x[v] : xl;
+            }
+            const float cb = g.has_blank_corr ? g.scale * jex2(fmaf(xb, kLog2e, g.nl) + g.cb) : 0.f;
+            const float clb = g.has_label ? g.scale * jex2(fmaf(xl, kLog2e, g.nl) + g.cl) : 0.f;
+#pragma unroll
+            for (int v = 0; v < 32; ++v) {
+                float gv = (v < V) ? g.scale * jex2(fmaf(x[v], kLog2e, g.c0)) : 0.f;
+                gv -= (v == p.blank) ? cb : 0.f;
+                gv -= (g.has_label && v == g.lab) ? clb : 0.f;
+                x[v] = gv;
+                colsum[v] += gv;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[i] = make_float4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
+        } else if (c < p.cells) {
+            // padded cell: phase 2 reads whole 32-column tiles of every valid row, so it must find exact zeros here
+            float4 *q = (float4 *)(jp.dl + (size_t)c * 32);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const CellGrad g = cell_grad_setup(p, cl, c);
-        float xb = 0.f, xl = 0.f;
-#pragma unroll
-        for (int v = 0; v < 32; ++v) {
-            xb = (v == p.blank) ? x[v] : xb;
-            xl = (g.has_label && v == g.lab) ? x[v] : xl;
-        }
-        const float cb = g.has_blank_corr ? g.scale * jex2(fmaf(xb, kLog2e, g.nl) + g.cb) : 0.f;
-        const float clb = g.has_label ? g.scale * jex2(fmaf(xl, kLog2e, g.nl) + g.cl) : 0.f;
-#pragma unroll
-        for (int v = 0; v < 32; ++v) {
-            float gv = (v < V) ? g.scale * jex2(fmaf(x[v], kLog2e, g.c0)) : 0.f;
-            gv -= (v == p.blank) ? cb : 0.f;
-            gv -= (g.has_label && v == g.lab) ? clb : 0.f;
-            x[v] = gv;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) q[i] = make_float4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
-    } else if (c < p.cells) {
-        // padded cell: phase 2 reads whole 32-column tiles of every valid row, so it must find exact zeros here
-        float4 *q = (float4 *)(jp.dl + (size_t)c * 32);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // db2 partial of this workgroup: fixed-order column sums through LDS
 #pragma unroll
-    for (int v = 0; v < 32; ++v) red[tid][v] = x[v];
+    for (int v = 0; v < 32; ++v) red[tid][v] = colsum[v];
     __syncthreads();
     if (tid < 32) {
         float s = 0.f;
@@ -544,7 +550,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     if (!(phases & 2) || !d_enc_proj) return hipSuccess;  // score only
 
     // backward: dlogits tiles, then the scatter through the joint
-    const unsigned gdl = (jp.lp.cells + 255u) / 256u;
+    const unsigned gdl = (jp.lp.cells + 256u * kDlChunks - 1u) / (256u * kDlChunks);
     hipLaunchKernelGGL(joint_dl_kernel, dim3(gdl), dim3(256), 0, s, jp);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (hipMemsetAsync(jp.dApart, 0, L.dbpart - L.dApart, s) != hipSuccess) return hipErrorUnknown;  // dA/dC/dW partials
