@@ -178,7 +178,11 @@ def main():
 
     B, T, U, V = (int(v) for v in a.shape.split(","))
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    acts = torch.randn(B, T, U, V, generator=g, dtype=torch.float32).to(dev)
+    if B * T * U * V <= (1 << 28):
+        acts = torch.randn(B, T, U, V, generator=g, dtype=torch.float32).to(dev)
+    else:  # tens of GB (config 5): generate on the device
+        gd = torch.Generator(device=dev).manual_seed(1234 + rank)
+        acts = torch.randn(B, T, U, V, generator=gd, dtype=torch.float32, device=dev)
     labels = torch.randint(1, V, (B, U - 1), generator=g, dtype=torch.int32).to(dev)
     il = torch.full((B,), T, dtype=torch.int32, device=dev)
     ll = torch.full((B,), U - 1, dtype=torch.int32, device=dev)

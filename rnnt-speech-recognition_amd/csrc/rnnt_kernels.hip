@@ -265,6 +265,113 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Persistent, double-buffered form of the patch kernel (opt-in: RNNT_CELL_PATH=persist; measured slower, see launcher).
+// A workgroup walks a strided list of patches with TWO LDS buffers: the LDS-DMA of patch i+1 is issued right
+// after the barrier that publishes patch i, so it is in flight during patch i's exp/log work (and, for the
+// gradient pass, its store-back).  The one-patch-per-workgroup kernel above spends ~40 % of a workgroup's life
+// on kernel-argument and length loads before its first DMA and keeps < 2 patches per CU in their load phase;
+// here every resident workgroup always has one patch loading.
+// ---------------------------------------------------------------------------------------------
+struct PatchRect {
+    int b, t0, u0, Tb, Ub;
+    int rows_valid, cols_valid, rows_in, cols_in;
+    size_t patch0;
+};
+__device__ __forceinline__ PatchRect patch_rect(const LossParams &p, const uint32_t L) {
+    const TileGeom &tg = p.tile;
+    PatchRect r;
+    const uint32_t q1 = fdiv(L, tg.div_tu);
+    const uint32_t tu = L - q1 * (uint32_t)tg.tiles_u;
+    const uint32_t bb = fdiv(q1, tg.div_tt);
+    const uint32_t tt = q1 - bb * (uint32_t)tg.tiles_t;
+    r.b = p.b0 + (int)bb;
+    r.t0 = (int)tt * tg.TT, r.u0 = (int)tu * tg.UU;
+    r.Tb = p.input_lengths[r.b], r.Ub = p.label_lengths[r.b] + 1;
+    r.rows_valid = max(0, min(tg.TT, r.Tb - r.t0));
+    r.cols_valid = max(0, min(tg.UU, r.Ub - r.u0));
+    r.rows_in = max(0, min(tg.TT, p.T - r.t0));
+    r.cols_in = max(0, min(tg.UU, p.U - r.u0));
+    r.patch0 = ((size_t)(r.b * p.T + r.t0) * p.U + r.u0) * p.V;
+    return r;
+}
+
+template <int VP, bool GRAD>
+__global__ __launch_bounds__(256) void cell_tile_persist_kernel(const LossParams p, const uint32_t npatch) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int V = p.V;
+    const TileGeom &tg = p.tile;
+    const int row_lds = tg.UU * V;
+    const size_t row_f = (size_t)p.U * V;
+    float *buf[2] = {lds, lds + 256 * V};
+
+    // XCD-aware work list: XCD x (= blockIdx % 8, observed) owns the contiguous logical range [lo_x, hi_x);
+    // the workgroups of that XCD stride through it.
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, per_xcd = (gridDim.x + 7u - xcd) >> 3;
+    const uint32_t q = npatch >> 3, r8 = npatch & 7u;
+    const uint32_t lo = (xcd < r8) ? xcd * (q + 1u) : r8 * (q + 1u) + (xcd - r8) * q;
+    const uint32_t hi = lo + q + (xcd < r8 ? 1u : 0u);
+
+    auto issue = [&](const PatchRect &r, float *dstbuf) {  // whole row segments, 16-byte LDS-DMA
+        if (r.rows_valid == 0 || r.cols_valid == 0) return;
+        const int q_valid = r.cols_valid * V / 4;
+        for (int rr = wave; rr < r.rows_valid; rr += 4) {
+            const float *src = p.acts + r.patch0 + rr * row_f;
+            float *dst = dstbuf + rr * row_lds;
+            for (int q0 = 0; q0 < q_valid; q0 += 64) {
+                const int qq = q0 + lane;
+                if (qq < q_valid)
+                    __builtin_amdgcn_global_load_lds((glb_void *)(src + qq * 4), (lds_void *)(dst + q0 * 4), 16, 0, 0);
+            }
+        }
+    };
+
+    uint32_t L = lo + slot;
+    if (L >= hi) return;
+    PatchRect cur = patch_rect(p, L);
+    issue(cur, buf[0]);
+    const uint32_t rdiv = fdiv((uint32_t)tid, tg.divUU);
+    const int cu = tid - (int)rdiv * tg.UU;
+    for (int it = 0;; ++it) {
+        const uint32_t Ln = L + per_xcd;
+        const bool more = Ln < hi;
+        PatchRect nxt = cur;
+        if (more) nxt = patch_rect(p, Ln);  // scalar loads of the next patch's lengths overlap the DMA wait
+        wait_vm0();
+        __syncthreads();  // patch `cur` has landed in buf[it&1]; everyone is done with buf[(it+1)&1]
+        if (more) issue(nxt, buf[(it + 1) & 1]);
+        float *b0 = buf[it & 1];
+        const bool live = cur.rows_valid > 0 && cur.cols_valid > 0;
+        if (live) {
+            Cell cl;
+            cl.b = cur.b, cl.t = cur.t0 + (int)rdiv, cl.u = cur.u0 + cu, cl.Tb = cur.Tb, cl.Ub = cur.Ub;
+            cl.valid = ((int)rdiv < cur.rows_valid) && (cu < cur.cols_valid);
+            const uint32_t c = ((uint32_t)(cur.b * p.T + cl.t)) * (uint32_t)p.U + (uint32_t)cl.u;
+            if (GRAD || cl.valid) cell_body<VP, true, GRAD, false>(p, cl, c, b0 + tid * V);
+        }
+        if (GRAD) {
+            const int q_in = cur.cols_in * V / 4;
+            if (live) {
+                __syncthreads();
+                for (int rr = wave; rr < cur.rows_in; rr += 4) {
+                    const float4 *srcl = (const float4 *)(b0 + rr * row_lds);
+                    float *dstg = p.grads + cur.patch0 + rr * row_f;
+                    for (int qq = lane; qq < q_in; qq += 64) *(float4 *)(dstg + qq * 4) = srcl[qq];
+                }
+            } else {  // an all-padding patch: exact zeros, no reads
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int rr = wave; rr < cur.rows_in; rr += 4)
+                    for (int qq = lane; qq < q_in; qq += 64) *(float4 *)(p.grads + cur.patch0 + rr * row_f + qq * 4) = z;
+            }
+        }
+        if (!more) break;
+        cur = nxt;
+        L = Ln;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // General path (any V, any alignment): one lattice cell per WAVE, lanes stride over V.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void online_upd(float &m, float &s, float xv) {
@@ -1067,6 +1174,37 @@ static hipError_t launch_cell(const LossParams &p, hipStream_t s, bool overlap) 
     if (tile_path_ok(p, GRAD)) {
         const unsigned blocks = (unsigned)p.nb * p.tile.tiles_t * p.tile.tiles_u;
         const size_t shm = (size_t)256 * p.V * sizeof(float) + 64;
+        // "persist" = persistent double-buffered workgroups.  Measured at C2: lsm 83.6 us / grad 160 us with two
+        // workgroups per CU (226 us with one) versus 80 / 113 us for one patch per workgroup (5 per CU): 8 waves per
+        // CU with two barriers per patch lose to 20 waves of independent workgroups.  Opt-in only.
+        const char *pe = getenv("RNNT_CELL_PATH");
+        if (pe && pe[0] == 'p') {
+            const size_t shm2 = (size_t)2 * 256 * p.V * sizeof(float);
+            static int per_cu = -1;
+            if (per_cu < 0) {  // workgroups per CU: as many double buffers as fit in 160 KiB (query once)
+                per_cu = 2;
+                if (const char *e = getenv("RNNT_PERSIST_WG_PER_CU")) per_cu = atoi(e);
+            }
+            int wg_per_cu = (int)((size_t)160 * 1024 / shm2);
+            if (wg_per_cu > per_cu) wg_per_cu = per_cu;
+            if (wg_per_cu < 1) wg_per_cu = 1;
+            unsigned grid = 256u * (unsigned)wg_per_cu;
+            if (grid > blocks) grid = blocks;
+            hipError_t e = hipSuccess;
+            if (p.V <= 32) {
+                if (shm2 > 65536)
+                    e = hipFuncSetAttribute((const void *)cell_tile_persist_kernel<32, GRAD>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL((cell_tile_persist_kernel<32, GRAD>), dim3(grid), dim3(256), shm2, s, p, blocks);
+            } else {
+                e = hipFuncSetAttribute((const void *)cell_tile_persist_kernel<64, GRAD>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL((cell_tile_persist_kernel<64, GRAD>), dim3(grid), dim3(256), shm2, s, p, blocks);
+            }
+            return hipGetLastError();
+        }
         if (p.V <= 32)
             hipLaunchKernelGGL((cell_tile_kernel<32, GRAD, false>), dim3(blocks), dim3(256), shm, s, p);
         else

@@ -198,10 +198,11 @@ def test_sweep_variants_agree(monkeypatch, mode):
 
 
 @pytest.mark.parametrize("groups", ["1", "2", "3", "8"])
-@pytest.mark.parametrize("path", ["tile", "flat"])
+@pytest.mark.parametrize("path", ["tile", "flat", "persist"])
 def test_group_pipelining_and_cell_paths(monkeypatch, groups, path):
     """compute_rnnt_loss pipelines utterance groups over side streams (RNNT_GROUPS) and picks the
-    patch ("tile") or the 256-consecutive-cells ("flat") kernels; every combination must agree."""
+    patch ("tile"), persistent double-buffered patch ("persist") or 256-consecutive-cells ("flat") kernels; every
+    combination must agree."""
     monkeypatch.setenv("RNNT_GROUPS", groups)
     monkeypatch.setenv("RNNT_CELL_PATH", path)
     acts, labels, il, ll = make_case(7, 61, 37, 28, True, seed=int(groups) * 7 + len(path))
