@@ -64,6 +64,8 @@ struct LossParams {
     double *ll;
     int *flags;  // overlap mode, see flag_* helpers: per-utterance per-XCD lsm patch counters, sweep-done counters, ...
     int B, T, U, V, blank;
+    int tune;      // experiment bits (RNNT_TUNE): 1 = plain (not nt) gradient stores, 2 = nt logits loads (grad), 4 = nt logits loads (lsm)
+    int rev_grad;  // gradient patches in reverse order of the lsm pass (Infinity-Cache reuse)
     int b0, nb;  // this launch covers utterances [b0, b0+nb)  (group pipelining)
     int N, Nr, Up, NC, NG;  // NG = Up/64 column groups (offset tables are [NC][NG])
     uint32_t cells;  // B*T*U

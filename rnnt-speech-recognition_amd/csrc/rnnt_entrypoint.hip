@@ -54,6 +54,12 @@ static bool fill_params(LossParams &p, const float *acts, float *grads, const in
     p.flags = (int *)(ws + w.flags);
     p.B = B, p.T = o.maxT, p.U = o.maxU, p.V = V, p.blank = o.blank_label;
     p.b0 = 0, p.nb = B;
+    {
+        static const int rev = [] { const char *e = getenv("RNNT_GRAD_ORDER"); return (e && e[0] == 'f') ? 0 : 1; }();
+        static const int tune = [] { const char *e = getenv("RNNT_TUNE"); return e ? atoi(e) : 0; }();
+        p.tune = tune;
+        p.rev_grad = rev;  // RNNT_GRAD_ORDER=fwd restores the same order as the lsm pass
+    }
     p.tile = make_tile(o.maxT, o.maxU, V);
     p.N = w.N, p.Nr = w.Nr, p.Up = w.Up, p.NC = w.NC, p.NG = w.NG;
     p.cells = (uint32_t)cells;

@@ -187,6 +187,9 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
         const uint32_t nwg = gridDim.x, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
         const uint32_t q = nwg >> 3, r = nwg & 7u;
         bid = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
+        // The gradient pass walks each XCD's range backwards: the logits the lsm pass read LAST are the ones most
+        // likely still in the 256 MiB Infinity Cache.
+        if (GRAD && p.rev_grad) bid = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + ((xcd < r ? q + 1u : q) - 1u - idx);
     }
     const uint32_t q1 = fdiv(bid, tg.div_tu);
     const uint32_t tu = bid - q1 * (uint32_t)tg.tiles_u;
@@ -222,8 +225,12 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
         float *dst = lds + r * row_lds;
         for (int q0 = 0; q0 < q_valid; q0 += 64) {
             const int q = q0 + lane;
-            if (q < q_valid)
-                __builtin_amdgcn_global_load_lds((glb_void *)(src + q * 4), (lds_void *)(dst + q0 * 4), 16, 0, 0);
+            if (q < q_valid) {
+                if (p.tune & (GRAD ? 2 : 4))
+                    __builtin_amdgcn_global_load_lds((glb_void *)(src + q * 4), (lds_void *)(dst + q0 * 4), 16, 0, 2);
+                else
+                    __builtin_amdgcn_global_load_lds((glb_void *)(src + q * 4), (lds_void *)(dst + q0 * 4), 16, 0, 0);
+            }
         }
     }
     if (OVL && GRAD) {
@@ -259,7 +266,13 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
         for (int rr = wave; rr < rows_in; rr += 4) {
             const float4 *srcl = (const float4 *)(lds + rr * row_lds);
             float *dstg = p.grads + patch0 + rr * row_f;
-            for (int q = lane; q < q_in; q += 64) *(float4 *)(dstg + q * 4) = srcl[q];
+            if (!(p.tune & 1))  // gradients are written once and not re-read by this op: keep them out of L2 / Infinity Cache
+                for (int q = lane; q < q_in; q += 64) {
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(((const v4f *)srcl)[q], (v4f *)(dstg + q * 4));
+                }
+            else
+                for (int q = lane; q < q_in; q += 64) *(float4 *)(dstg + q * 4) = srcl[q];
         }
     }
 }
