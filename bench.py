@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="skip the fused joint+loss measurement")
     ap.add_argument("--joint-size", type=int, default=640, help="H = J of the fused joint (hparams.py:18,23)")
+    ap.add_argument("--fused-only", type=str, default="",
+                    help="B,T,U,V: time only the fused joint+loss on this shape (e.g. 16,1500,300,1024 = BASELINE "
+                         "config 5) and print its JSON object")
     ap.add_argument("--e2e", action="store_true",
                     help="also time BASELINE configs[2]: end-to-end train step, 2x320 LSTM encoder / 1x320 decoder, B=64")
     ap.add_argument("--cpu-reps", type=int, default=3)
@@ -76,6 +79,7 @@ def cpu_baseline(B, T, U, V, reps):
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (~2.5 PFLOP/s)
 
 
 def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
@@ -101,12 +105,14 @@ def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
     except RuntimeError as e:
         return {"error": str(e)}
     opts = _lib.make_options(stream.cuda_stream, 0, T, U)
+    f16 = V > 32  # large vocabularies run the J x V products on the f16 MFMA units (joint_dtype = 1)
 
     def step():
         _lib.check(lib.compute_rnnt_joint_loss(ep.data_ptr(), pp.data_ptr(), W2.data_ptr(), b2.data_ptr(),
                                                labels.data_ptr(), ll.data_ptr(), il.data_ptr(), scale.data_ptr(),
                                                J, V, B, costs.data_ptr(), d_ep.data_ptr(), d_pp.data_ptr(),
-                                               dW2.data_ptr(), db2.data_ptr(), 0, ws.data_ptr(), opts), "joint")
+                                               dW2.data_ptr(), db2.data_ptr(), 1 if f16 else 0, ws.data_ptr(), opts),
+                   "joint")
 
     for _ in range(2):
         step()
@@ -118,6 +124,16 @@ def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
     dt = (time.perf_counter() - t0) / reps
     cells = B * T * U
     flops = 8.0 * J * V * cells      # SURVEY.md 8(d) convention (includes a backward recompute of the logits GEMM)
+    if f16:
+        return {"workload": f"joint+loss+grads from enc_proj/pred_proj, B={B} T={T} U={U} V={V} J={J}, "
+                            "f16 MFMA joint / f32 lattice",
+                "ms_per_step": dt * 1e3, "cells_per_s": cells / dt,
+                "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                             "algorithmic_flops_per_step": flops,
+                             "note": "all four J x V products (forward, backward recompute, dh, dW2) are executed on "
+                                     "v_mfma_f32_32x32x16_f16; the only [cells x V] array is dlogits in binary16"},
+                "workspace_GB": ws.numel() / 1e9}
     executed = 6.0 * J * 32 * cells  # what the kernels issue: fwd GEMM + dh + dW2 on V padded to 32, no recompute
     return {"workload": f"joint+loss+grads from enc_proj/pred_proj, B={B} T={T} U={U} V={V} J={J}, f32 MFMA",
             "ms_per_step": dt * 1e3, "cells_per_s": cells / dt,
@@ -175,6 +191,15 @@ def main():
 
     pkg.build()
     lib = _lib.load()
+
+    if a.fused_only:
+        fB, fT, fU, fV = (int(v) for v in a.fused_only.split(","))
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            out = bench_fused_joint(lib, _lib, dev, fB, fT, fU, fV, a.joint_size, st, max(2, min(a.steps, 5)))
+        if rank == 0:
+            print(json.dumps({"fused_joint": out}))
+        return
 
     B, T, U, V = (int(v) for v in a.shape.split(","))
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)

@@ -226,3 +226,53 @@ def joint_loss_and_grads(enc, pred, W1, b1, W2, b2, labels, input_lengths, label
     out["costs"] = costs
     out["dlogits"] = g
     return out
+
+
+def _rne_half(x):
+    """Round to IEEE binary16 (round-to-nearest-even, what v_cvt_f16_f32 does) and widen back to f64."""
+    return np.asarray(x, np.float64).astype(np.float16).astype(np.float64)
+
+
+def dl_scale_f16(cost_scale, B):
+    """Power-of-two scale the f16 joint applies to dlogits before rounding them to half: 2^(14 - ceil(log2 max|s|))."""
+    s = np.ones(B) if cost_scale is None else np.broadcast_to(np.asarray(cost_scale, np.float64), (B,))
+    m = float(np.abs(s).max())
+    e = int(np.ceil(np.log2(m))) if m > 0 else 0
+    return 2.0 ** (14 - e)
+
+
+def joint_loss_and_grads_f16(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_lengths,
+                             blank=0, cost_scale=None):
+    """Oracle of the f16-MFMA joint (BASELINE config 5: "fp16 joint MFMA", fp32 lattice).
+
+    Same mathematics as joint_loss_and_grads (model.py:158-166 + utils/loss.py:24-36 + autodiff), with the operand
+    roundings the MFMA path makes stated explicitly: h = tanh(.) and W2 are rounded to binary16 before the J x V
+    product (exact products, wide accumulation), and the loss gradient w.r.t. the logits is scaled by a power of two
+    and rounded to binary16 before the two backward products (dh = dl . W2^T, dW2 = h^T . dl, db2 = sum dl).
+    tanh' = 1 - h^2 uses the unrounded h (straight-through for the rounding)."""
+    enc = np.asarray(enc, np.float64)
+    pred = np.asarray(pred, np.float64)
+    W1 = np.asarray(W1, np.float64)
+    z0 = enc[:, :, None, :] + pred[:, None, :, :]
+    h = np.tanh(z0 @ W1 + np.asarray(b1, np.float64))
+    hq = _rne_half(h)
+    W2q = _rne_half(W2)
+    y = hq @ W2q + np.asarray(b2, np.float64)
+    costs, g = rnnt_loss_and_grad(y, labels, input_lengths, label_lengths, blank, True)
+    B = y.shape[0]
+    s = np.ones(B) if cost_scale is None else np.broadcast_to(np.asarray(cost_scale, np.float64), (B,))
+    g = g * s[:, None, None, None]
+    S = dl_scale_f16(cost_scale, B)
+    gq = _rne_half(g * S) / S
+    J, V = W2q.shape
+    dW2 = hq.reshape(-1, J).T @ gq.reshape(-1, V)
+    db2 = gq.reshape(-1, V).sum(0)
+    dh = gq @ W2q.T
+    dz = dh * (1.0 - h * h)
+    db1 = dz.reshape(-1, J).sum(0)
+    d_a = dz.sum(axis=2)
+    d_c = dz.sum(axis=1)
+    H = W1.shape[0]
+    dW1 = enc.reshape(-1, H).T @ d_a.reshape(-1, J) + pred.reshape(-1, H).T @ d_c.reshape(-1, J)
+    return dict(costs=costs, d_enc=d_a @ W1.T, d_pred=d_c @ W1.T, dW1=dW1, db1=db1, dW2=dW2, db2=db2,
+                d_a=d_a, d_c=d_c, dlogits=gq)

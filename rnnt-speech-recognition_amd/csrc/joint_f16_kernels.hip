@@ -1,0 +1,749 @@
+// joint_f16_kernels.hip -- large-vocabulary joint network fused with the transducer loss on the f16 MFMA units
+// (gfx950, v_mfma_f32_32x32x16_f16).  BASELINE config 5 ("fp16 joint MFMA, fp32 lattice"): V = 1024, J = 640.
+//
+// Same path as joint_kernels.hip (model.py:158-166 + autodiff through it),
+// but the [cells x V] logits no longer fit a per-cell register tile, so the work is four GEMM-shaped kernels around
+// the unchanged alpha/beta sweeps.  Nothing of size [cells x J] is ever stored; the only [cells x V] array is the
+// loss gradient w.r.t. the logits in binary16 (2 B per logit instead of the 4+4 B of the unfused path).
+//
+//   prep      W2 -> binary16 in two layouts (MFMA-fragment-packed W2^T, row-major W2); power-of-two dlogits scale
+//   K1 logits (jh_logits_kernel<KS,false>)  logits^T tile = W2^T . h^T with h = tanh(enc_proj_t + pred_proj_u) built
+//             straight into the B-operand registers (a wave owns 32 lattice cells of one row t, h never leaves the
+//             register file); W2^T streams through LDS by LDS-DMA, 32 vocabulary rows per step, shared by 8 waves.
+//             In the transposed product a LANE owns a cell and its registers run over the vocabulary, so the
+//             log-softmax is an in-register online reduction.  Out: lse, lattice edge weights W (-> sweeps), and the
+//             blank / label logits of every cell.
+//   K2 dlogits (jh_logits_kernel<KS,true>)  same product again (recompute, 2JV flop/cell instead of 8 B/logit of
+//             HBM), epilogue forms dlogits = occupancy-weighted softmax - edge terms, scales by 2^k, rounds to binary16
+//             and writes [cells][V] through a per-wave LDS transpose (row-contiguous 256 B stores).
+//   K3 dh     (jh_dh_kernel)  dh = dl . W2^T as an "NT" GEMM (both operands K-contiguous, XOR-swizzled LDS images
+//             filled by LDS-DMA), epilogue dz = dh (1 - h^2), sum_u -> d enc_proj partials, sum_t -> d pred_proj.
+//   K4 dW2    (jh_dw_kernel)  dW2 = h^T . dl, split over ranges of cells; h^T is generated in A-fragment layout,
+//             dl rows are DMA'd row-major and read TRANSPOSED with ds_read_b64_tr_b16; db2 rides along (v_dot2).
+//
+// MFMA fragment layouts used (checked on hardware by scripts/probes/probe_f16.hip):
+//   A: lane l holds A[i = l&31][k = 8*(l>>5) + 0..7];  B: lane l holds B[k = 8*(l>>5) + 0..7][n = l&31];
+//   C/D: lane l register r holds D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
+//   ds_read_b64_tr_b16: lane p of 16-lane group g supplies &X[k0 + (p>>2)][n0 + 4*(p&3)] and receives X[k0+0..3][n0+p].
+#include "rnnt_common.h"
+#include "rnnt_cell.h"
+
+#include <math.h>
+
+namespace rnnt {
+
+typedef _Float16 f16;
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef short s4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_cvoid;
+typedef __attribute__((address_space(3))) s4 lds_s4;
+
+__device__ __forceinline__ float hex2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float hlg2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float htanh(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + hex2(x * 2.8853900817779268f));
+}
+__device__ __forceinline__ constexpr int cdrow(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ float dot8(const h8 a, const h8 b, float c) {
+    c = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1), c, false);
+    c = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3), c, false);
+    c = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 4, 5), __builtin_shufflevector(b, b, 4, 5), c, false);
+    c = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 6, 7), __builtin_shufflevector(b, b, 6, 7), c, false);
+    return c;
+}
+// XCD-aware bijective remap: XCD (blockIdx % 8) owns a contiguous range of logical work items
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
+    const uint32_t xcd = bid & 7u, idx = bid >> 3, q = nwg >> 3, r = nwg & 7u;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
+}
+
+constexpr int kDlScaleLog2 = 14;   // |dlogits * S| <= 2^14 before the binary16 rounding
+constexpr int kStageStride = 136;  // halfs per row of the K2 staging tile (128 + 8: 16-byte aligned, bank-shifted rows)
+constexpr int kTQ = 64;            // lattice rows per K4 work unit
+constexpr int kDRow = 1088;        // bytes per dl row in K4's LDS image (1024 + 64: conflict-free transposed reads)
+
+struct JhParams {
+    LossParams lp;  // lattice workspace, labels, lengths, costs, cost_scale (acts / grads unused)
+    const float *enc_proj, *pred_proj, *W2, *b2;
+    f16 *W2Tp;    // [V/32][J/16][32 v][16 j]  W2^T, packed so that one MFMA A fragment is 1 KB contiguous
+    f16 *W2h;     // [J][V]
+    f16 *dl;      // [cells][V]  dlogits * S
+    float *xbl;   // [cells][2]  blank / label logits, log2-scaled (x * log2 e)
+    float *scal;  // [0] = S, [1] = 1/S
+    float *dApart;  // [n_ut][B][T][J]
+    float *dCpart;  // [n_ts][B][U][J]
+    float *dWpart;  // [n_ranges][J][V]
+    float *dbpart;  // [n_ranges][V]
+    const f16 *zrow;  // 1 KB of zeros: stands in for dl rows beyond the tensor (u >= U) in K4
+    int J, n_ut, n_tt, n_ts, TS, n_tq, n_units, n_ranges;
+};
+
+// ---------------------------------------------------------------------------------------------
+// prep: binary16 copies of W2 and the dlogits scale
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void jh_prep_kernel(const JhParams jp) {
+    const int J = jp.J, V = jp.lp.V;
+    const size_t n = (size_t)J * V;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int j = (int)(i / V), v = (int)(i - (size_t)j * V);
+        const f16 w = (f16)jp.W2[i];
+        jp.W2h[i] = w;
+        jp.W2Tp[(((size_t)(v >> 5) * (J >> 4) + (j >> 4)) * 32 + (v & 31)) * 16 + (j & 15)] = w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float m = 1.0f;
+        if (jp.lp.cost_scale) {
+            m = 0.f;
+            for (int b = 0; b < jp.lp.B; ++b) m = fmaxf(m, fabsf(jp.lp.cost_scale[b]));
+        }
+        int e = 0;
+        if (m > 0.f) {
+            float fr = frexpf(m, &e);  // m = fr * 2^e, fr in [0.5, 1)
+            if (fr == 0.5f) --e;       // exact power of two: ceil(log2 m) = e - 1
+        }
+        const float S = ldexpf(1.0f, kDlScaleLog2 - e);
+        jp.scal[0] = S;
+        jp.scal[1] = 1.0f / S;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 / K2: workgroup = 8 waves = 8 lattice rows x 32 lattice columns; wave w owns row t0+w, lane (n, half) owns
+// column u0+n and the joint units {16 ks + 8 half + 0..7} of its h row.
+// LDS: W2^T chunk [2][J/16][32 v][16 j] (2 x 64 J bytes)  |  BWD: staging [8 waves][32 cells][kStageStride]
+// ---------------------------------------------------------------------------------------------
+template <int KS, bool BWD>
+__global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LossParams &p = jp.lp;
+    constexpr int J = KS * 16;
+    const int V = p.V;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, n = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int chunk_bytes = 64 * J;
+    char *wbuf0 = smem, *wbuf1 = smem + chunk_bytes;
+
+    int bid = blockIdx.x;
+    const int ut = bid % jp.n_ut;
+    bid /= jp.n_ut;
+    const int tt = bid % jp.n_tt;
+    const int b = bid / jp.n_tt;
+    const int u0 = ut * 32, t0 = tt * 8;
+    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    if (t0 >= Tb || u0 >= Ub) return;  // dead tile: nothing downstream reads it
+    const int t = t0 + wave;
+    const bool wave_live = t < Tb;  // wave-uniform
+    const int tc = min(t, Tb - 1), u = u0 + n, uc = min(u, p.U - 1);
+    const bool cell_valid = wave_live && (u < Ub);
+    const uint32_t c = ((uint32_t)(b * p.T + tc)) * (uint32_t)p.U + (uint32_t)uc;
+
+    auto dma_chunk = [&](const int vc, char *dst) {
+        const char *src = (const char *)jp.W2Tp + (size_t)vc * chunk_bytes + lane * 16;
+        for (int i = wave; i < KS; i += 8)  // KS = chunk_bytes / 1024 wave-instructions of 1 KB
+            __builtin_amdgcn_global_load_lds((glb_cvoid *)(src + i * 1024), (lds_void *)(dst + i * 1024), 16, 0, 0);
+    };
+    dma_chunk(0, wbuf0);
+
+    // ---- h row of this lane's cell, rounded to binary16, in MFMA B-fragment order.  The loads of k-step pair g+1 are
+    // issued before the tanh work of pair g (explicit two-deep pipeline: letting the compiler hoist all 4*KS loads
+    // would need 16*KS registers).
+    h8 hf[KS];
+    {
+        const float *erow = jp.enc_proj + ((size_t)b * p.T + tc) * J + 8 * half;
+        const float *prow = jp.pred_proj + ((size_t)b * p.U + uc) * J + 8 * half;
+        float4 cur[8], nxt[8];
+        typedef float vf4 __attribute__((ext_vector_type(4)));
+        auto vload = [](const float *q) {  // volatile: keeps its place relative to the fences below
+            const vf4 v = *(const volatile vf4 *)q;
+            return make_float4(v[0], v[1], v[2], v[3]);
+        };
+        auto fetch = [&](const int g, float4 (&d)[8]) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                d[4 * q + 0] = vload(erow + (2 * g + q) * 16);
+                d[4 * q + 1] = vload(erow + (2 * g + q) * 16 + 4);
+                d[4 * q + 2] = vload(prow + (2 * g + q) * 16);
+                d[4 * q + 3] = vload(prow + (2 * g + q) * 16 + 4);
+            }
+        };
+        fetch(0, cur);
+#pragma unroll
+        for (int g = 0; g < KS / 2; ++g) {
+            if (g + 1 < KS / 2) fetch(g + 1, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float4 e0 = cur[4 * q], e1 = cur[4 * q + 1], c0 = cur[4 * q + 2], c1 = cur[4 * q + 3];
+                h8 v;
+                v[0] = (f16)htanh(e0.x + c0.x), v[1] = (f16)htanh(e0.y + c0.y);
+                v[2] = (f16)htanh(e0.z + c0.z), v[3] = (f16)htanh(e0.w + c0.w);
+                v[4] = (f16)htanh(e1.x + c1.x), v[5] = (f16)htanh(e1.y + c1.y);
+                v[6] = (f16)htanh(e1.z + c1.z), v[7] = (f16)htanh(e1.w + c1.w);
+                hf[2 * g + q] = v;
+                asm volatile("" ::"v"(v));  // the tanh work of this pair is done before the next pair's loads issue
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
+        }
+    }
+
+    // ---- per-cell scalars
+    float xb = 0.f, xl = 0.f;  // blank / label logits
+    int lab = 0;
+    const bool has_label = cell_valid && (u < Ub - 1);
+    if (has_label) lab = clamp_label(p.labels[(size_t)b * (p.U - 1) + u], V);
+    float mref = -1.0e30f, ssum = 0.f;  // FWD: online log2-sum-exp2 state of this lane's share of the vocabulary
+    CellGrad g;                         // BWD
+    float scaleS = 0.f, c0 = -1.0e30f;
+    f16 *my_stage = (f16 *)(smem + 2 * chunk_bytes) + wave * (32 * kStageStride);
+    // FWD: the blank / label logits are picked out of the MFMA tiles (log2-scaled: y = x * log2 e).  Column v sits in
+    // chunk v >> 5, in the half-lane ((v & 31) >> 2) & 1, register (v & 3) + 4 * ((v & 31) >> 3).
+    const int vcb = p.blank >> 5, hb = ((p.blank & 31) >> 2) & 1, rb = (p.blank & 3) + 4 * ((p.blank & 31) >> 3);
+    const int vcl = lab >> 5, hl = ((lab & 31) >> 2) & 1, rl = (lab & 3) + 4 * ((lab & 31) >> 3);
+    if (BWD) {
+        if (cell_valid) {
+            Cell cl;
+            cl.b = b, cl.t = t, cl.u = u, cl.Tb = Tb, cl.Ub = Ub, cl.valid = true;
+            g = cell_grad_setup(p, cl, c);
+            scaleS = g.scale * jp.scal[0];
+            c0 = g.c0;
+            xb = jp.xbl[2 * (size_t)c], xl = jp.xbl[2 * (size_t)c + 1];  // log2-scaled
+        }
+    }
+
+    const int NC = V >> 5;
+    for (int vc = 0; vc < NC; ++vc) {
+        wait_vm();
+        __syncthreads();  // chunk vc is in LDS; every wave is done with the other buffer
+        if (vc + 1 < NC) dma_chunk(vc + 1, ((vc + 1) & 1) ? wbuf1 : wbuf0);
+        if (!wave_live) continue;
+        const char *wb = ((vc & 1) ? wbuf1 : wbuf0) + n * 32 + half * 16;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            // A fragments four k-steps ahead of their MFMAs (bounded: the compiler would otherwise hoist all KS reads)
+            h8 acur[4], anxt[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acur[q] = *(const h8 *)(wb + q * 1024);
+#pragma unroll
+            for (int g = 0; g < KS / 4; ++g) {
+                if (g + 1 < KS / 4) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) anxt[q] = *(const h8 *)(wb + (4 * (g + 1) + q) * 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[q], hf[4 * g + q], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acur[q] = anxt[q];
+            }
+        }
+        // acc[r] = logit (without bias) of this lane's cell at v = 32 vc + cdrow(r, half)
+        const float *b2p = jp.b2 + vc * 32 + 4 * half;
+        if (!BWD) {
+            float y[16];
+            float m = -1.0e30f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *(const float4 *)(b2p + 8 * q);
+                y[4 * q + 0] = (acc[4 * q + 0] + bq.x) * kLog2e;
+                y[4 * q + 1] = (acc[4 * q + 1] + bq.y) * kLog2e;
+                y[4 * q + 2] = (acc[4 * q + 2] + bq.z) * kLog2e;
+                y[4 * q + 3] = (acc[4 * q + 3] + bq.w) * kLog2e;
+                m = fmaxf(m, fmaxf(fmaxf(y[4 * q], y[4 * q + 1]), fmaxf(y[4 * q + 2], y[4 * q + 3])));
+            }
+            const float nr = fmaxf(mref, m);
+            float s = ssum * hex2(mref - nr);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += hex2(y[r] - nr);
+            ssum = s, mref = nr;
+            if (vc == vcb) {  // wave-uniform
+                float v = y[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) v = (r == rb) ? y[r] : v;
+                xb = (half == hb) ? v : xb;
+            }
+            const bool mine = has_label && (vc == vcl);
+            if (__any(mine)) {
+                float v = y[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) v = (r == rl) ? y[r] : v;
+                xl = (mine && half == hl) ? v : xl;
+            }
+        } else {
+            f16 *row = my_stage + n * kStageStride + (vc & 3) * 32 + 4 * half;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *(const float4 *)(b2p + 8 * q);
+                h4 d;
+                d[0] = (f16)(scaleS * hex2(fmaf(acc[4 * q + 0] + bq.x, kLog2e, c0)));
+                d[1] = (f16)(scaleS * hex2(fmaf(acc[4 * q + 1] + bq.y, kLog2e, c0)));
+                d[2] = (f16)(scaleS * hex2(fmaf(acc[4 * q + 2] + bq.z, kLog2e, c0)));
+                d[3] = (f16)(scaleS * hex2(fmaf(acc[4 * q + 3] + bq.w, kLog2e, c0)));
+                *(h4 *)(row + 8 * q) = d;
+            }
+            if ((vc & 3) == 3) {
+                // 128 vocabulary columns of 32 cells are staged: patch the two edge columns, then store row-contiguous
+                wait_lgkm();
+                const int vbase = (vc - 3) * 32;
+                if (cell_valid && half == 0) {
+                    const float sm_b = hex2(xb + c0);
+                    const float sm_l = hex2(xl + c0);
+                    const float cb = g.has_blank_corr ? hex2(xb + g.nl + g.cb) : 0.f;
+                    const float clb = g.has_label ? hex2(xl + g.nl + g.cl) : 0.f;
+                    const bool same = g.has_label && (g.lab == p.blank);
+                    if ((unsigned)(p.blank - vbase) < 128u)
+                        my_stage[n * kStageStride + p.blank - vbase] = (f16)(scaleS * (sm_b - cb - (same ? clb : 0.f)));
+                    if (g.has_label && !same && (unsigned)(g.lab - vbase) < 128u)
+                        my_stage[n * kStageStride + g.lab - vbase] = (f16)(scaleS * (sm_l - clb));
+                }
+                wait_lgkm();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int q = lane + 64 * i, rr = q >> 4, c16 = q & 15;
+                    if (u0 + rr < p.U) {
+                        const h8 v = *(const h8 *)(my_stage + rr * kStageStride + c16 * 8);
+                        *(h8 *)(jp.dl + ((size_t)(b * p.T + t) * p.U + u0 + rr) * V + vbase + c16 * 8) = v;
+                    }
+                }
+                wait_lgkm();  // the staging tile is rewritten by the next chunk
+            }
+        }
+    }
+
+    if (!BWD && wave_live) {
+        // merge the two half-lanes of a cell, then the same outputs as the lsm pass of rnnt_kernels.hip
+        const float m2 = __shfl_xor(mref, 32), s2 = __shfl_xor(ssum, 32);
+        const float M = fmaxf(mref, m2);
+        const float S = ssum * hex2(mref - M) + s2 * hex2(m2 - M);
+        const float lse2 = M + hlg2(S);
+        // the captured edge logits live in one of the two half-lanes of the cell
+        const float xb_o = __shfl_xor(xb, 32), xl_o = __shfl_xor(xl, 32);
+        xb = (half == hb) ? xb : xb_o;
+        xl = (half == hl) ? xl : xl_o;
+        if (cell_valid && half == 0) {
+            const bool blank_stays = (t < Tb - 1) || (u == Ub - 1);
+            const float ob = blank_stays ? (xb - lse2) : kNeg;
+            const float ol = has_label ? (xl - lse2) : kNeg;
+            p.lse[c] = lse2 * kLn2;
+            ((float2 *)p.W)[((size_t)b * p.Nr + (t + u)) * p.Up + u] = make_float2(ob, ol);
+            ((float2 *)jp.xbl)[c] = make_float2(xb, xl);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: dh = dl . W2^T  ->  dz = dh (1 - h^2) / S  ->  sum_u (d enc_proj partial), sum_t (d pred_proj partial)
+// workgroup = (utterance, u-tile of 32, 128-wide J tile, row split); 8 waves as 4 (row pairs) x 2 (64 joint units);
+// per iteration 8 lattice rows x 32 columns = 256 cells; K = V in chunks of 64.
+// LDS per stage: A = dl tile [256 cells][64 v] + B = W2 tile [128 j][64 v], 128-byte rows, 16-byte chunks XOR-swizzled
+// by (row >> 1) & 7 (conflict-free b128 fragment reads); two stages.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LossParams &p = jp.lp;
+    const int J = jp.J, V = p.V;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, n = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    constexpr int kStage = (256 + 128) * 128;
+
+    uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n_jt = J >> 7;
+    const int jt = (int)(bid % (uint32_t)n_jt);
+    bid /= (uint32_t)n_jt;
+    const int ts = (int)(bid % (uint32_t)jp.n_ts);
+    bid /= (uint32_t)jp.n_ts;
+    const int ut = (int)(bid % (uint32_t)jp.n_ut);
+    const int b = (int)(bid / (uint32_t)jp.n_ut);
+    const int u0 = ut * 32, j0 = jt * 128;
+    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int t_begin = ts * jp.TS, t_end = min(min(t_begin + jp.TS, p.T), Tb);
+    if (t_begin >= t_end || u0 >= Ub) return;
+
+    // pred_proj values of this lane's joint units at its 16 lattice columns; validity of those columns
+    float pr[2][16];
+    unsigned vmask = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int uu = u0 + cdrow(r, half);
+        if (uu < Ub) vmask |= 1u << r;
+        const size_t ro = ((size_t)b * p.U + min(uu, p.U - 1)) * J + j0 + wn * 64 + n;
+        pr[0][r] = jp.pred_proj[ro];
+        pr[1][r] = jp.pred_proj[ro + 32];
+    }
+    float accC[2][16];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accC[q][r] = 0.f;
+    const float invS = jp.scal[1];
+    const int NK = V >> 6;
+
+    for (int t_it = t_begin; t_it < t_end; t_it += 8) {
+        auto dma = [&](const int kc, char *st) {
+            // A rows: row = tl * 32 + uu  (tl = lattice row offset, uu = column offset); 32 wave-instructions
+            for (int i = wave; i < 48; i += 8) {
+                const int row = (i < 32 ? i : i - 32) * 8 + (lane >> 3);
+                const int ck = (lane & 7) ^ ((row >> 1) & 7);
+                const f16 *src;
+                if (i < 32) {
+                    const int tr = min(t_it + (row >> 5), t_end - 1), uu = min(u0 + (row & 31), p.U - 1);
+                    src = jp.dl + ((size_t)(b * p.T + tr) * p.U + uu) * V + kc * 64 + ck * 8;
+                } else {
+                    src = jp.W2h + (size_t)(j0 + row) * V + kc * 64 + ck * 8;
+                }
+                __builtin_amdgcn_global_load_lds((glb_cvoid *)src, (lds_void *)(st + i * 1024), 16, 0, 0);
+            }
+        };
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        dma(0, smem);
+        for (int kc = 0; kc < NK; ++kc) {
+            wait_vm();
+            __syncthreads();
+            if (kc + 1 < NK) dma(kc + 1, smem + ((kc + 1) & 1) * kStage);
+            const char *A = smem + (kc & 1) * kStage, *Bm = A + 256 * 128;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                h8 a[2], bf[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const int row = (2 * wm + mi) * 32 + n;
+                    a[mi] = *(const h8 *)(A + row * 128 + (((ks * 2 + half) ^ ((row >> 1) & 7)) * 16));
+                }
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int row = wn * 64 + ni * 32 + n;
+                    bf[ni] = *(const h8 *)(Bm + row * 128 + (((ks * 2 + half) ^ ((row >> 1) & 7)) * 16));
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+        // epilogue: acc[mi][ni][r] = S * dh[row t_it + 2 wm + mi][column u0 + cdrow(r, half)][unit j0 + 64 wn + 32 ni + n]
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int t = t_it + 2 * wm + mi;
+            if (t < t_end) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int j = j0 + wn * 64 + ni * 32 + n;
+                    const float ej = jp.enc_proj[((size_t)b * p.T + t) * J + j];
+                    float colsum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float h = htanh(ej + pr[ni][r]);
+                        float dz = acc[mi][ni][r] * invS * (1.0f - h * h);
+                        dz = ((vmask >> r) & 1u) ? dz : 0.f;
+                        accC[ni][r] += dz;
+                        colsum += dz;
+                    }
+                    colsum += __shfl_xor(colsum, 32);
+                    if (lane < 32) jp.dApart[(((size_t)ut * p.B + b) * p.T + t) * J + j] = colsum;
+                }
+            }
+        }
+    }
+    // d pred_proj partial: sum the four row-pair waves in a fixed order through LDS
+    __syncthreads();
+    float *red = (float *)smem;  // [wm 4][wn 2][ni 2][32 rows][33]
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(((wm * 2 + wn) * 2 + ni) * 32 + cdrow(r, half)) * 33 + n] = accC[ni][r];
+    __syncthreads();
+    for (int e = tid; e < 32 * 128; e += 512) {
+        const int uu = e >> 7, jj = e & 127, wn2 = jj >> 6, ni = (jj >> 5) & 1, nn = jj & 31;
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w) s += red[(((w * 2 + wn2) * 2 + ni) * 32 + uu) * 33 + nn];
+        if (u0 + uu < p.U) jp.dCpart[(((size_t)ts * p.B + b) * p.U + u0 + uu) * J + j0 + jj] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: dW2 = h^T . dl / S (and db2 = sum dl / S).  workgroup = (range of work units, 128-wide J tile, 512-wide V tile);
+// 8 waves as 2 (64 joint units) x 4 (128 vocabulary columns), 2 x 4 accumulator tiles each.
+// A work unit is (utterance, u-tile of 32, kTQ lattice rows); one lattice row (32 cells = 2 MFMA k-steps) per step.
+// LDS per stage: dl rows [32 cells][kDRow B] (row-major, read transposed) | h^T fragments [2 ks][4 jb][32][2][8]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LossParams &p = jp.lp;
+    const int J = jp.J, V = p.V;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, n = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wj = wave & 1, wv = wave >> 1;
+    constexpr int kDBytes = 32 * kDRow, kHBytes = 2 * 4 * 32 * 32, kStage = kDBytes + kHBytes;
+
+    uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n_vt = V >> 9, n_tiles = (J >> 7) * n_vt;
+    const int tile = (int)(bid % (uint32_t)n_tiles), range = (int)(bid / (uint32_t)n_tiles);
+    const int vt = tile % n_vt, jt = tile / n_vt;
+    const int j0 = jt * 128, v0 = vt * 512;
+    const int unit_lo = (int)((long long)jp.n_units * range / jp.n_ranges);
+    const int unit_hi = (int)((long long)jp.n_units * (range + 1) / jp.n_ranges);
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][q][r] = 0.f;
+    float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_db = (jt == 0) && (wj == 0);
+    const int jl = tid & 127, cg = tid >> 7;  // h generation: this thread's joint unit and group of 8 cells
+    const h2 ones = {(f16)1.0f, (f16)1.0f};
+
+    for (int unit = unit_lo; unit < unit_hi; ++unit) {
+        int q = unit;
+        const int tq = q % jp.n_tq;
+        q /= jp.n_tq;
+        const int ut = q % jp.n_ut;
+        const int b = q / jp.n_ut;
+        const int u0 = ut * 32;
+        const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+        const int t_begin = tq * kTQ, t_end = min(min(t_begin + kTQ, p.T), Tb);
+        if (t_begin >= t_end || u0 >= Ub) continue;  // workgroup-uniform
+        float pv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            pv[e] = jp.pred_proj[((size_t)b * p.U + min(u0 + 8 * cg + e, p.U - 1)) * J + j0 + jl];
+        auto stage = [&](const int t, char *st) {
+            for (int i = wave; i < 32; i += 8) {  // one dl row (512 columns = 1 KB) per wave-instruction
+                const f16 *src = (u0 + i < p.U) ? jp.dl + ((size_t)(b * p.T + t) * p.U + u0 + i) * V + v0 + lane * 8
+                                                : jp.zrow + lane * 8;
+                __builtin_amdgcn_global_load_lds((glb_cvoid *)src, (lds_void *)(st + i * kDRow), 16, 0, 0);
+            }
+            const float ej = jp.enc_proj[((size_t)b * p.T + t) * J + j0 + jl];
+            h8 hv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float h = htanh(ej + pv[e]);
+                hv[e] = (u0 + 8 * cg + e < Ub) ? (f16)h : (f16)0.f;  // cells beyond U_b carry no gradient
+            }
+            // fragment image: [ks = cg >> 1][jb = jl >> 5][i = jl & 31][half = cg & 1][8 cells]
+            *(h8 *)(st + kDBytes + ((((cg >> 1) * 4 + (jl >> 5)) * 32 + (jl & 31)) * 2 + (cg & 1)) * 16) = hv;
+        };
+        __syncthreads();  // the previous unit's last step is done with stage 0
+        stage(t_begin, smem);
+        for (int t = t_begin; t < t_end; ++t) {
+            const int cur = (t - t_begin) & 1;
+            wait_vm();
+            __syncthreads();
+            if (t + 1 < t_end) stage(t + 1, smem + (cur ^ 1) * kStage);
+            const char *D = smem + cur * kStage, *H = D + kDBytes;
+            const int g4 = lane >> 4, pl = lane & 15;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                h8 a[2];
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+                    a[jb] = *(const h8 *)(H + (((ks * 4 + wj * 2 + jb) * 32 + n) * 2 + half) * 16);
+                const int row0 = ks * 16 + 8 * (g4 >> 1) + (pl >> 2);
+#pragma unroll
+                for (int vb = 0; vb < 4; ++vb) {
+                    const int col = wv * 128 + vb * 32 + 16 * (g4 & 1) + 4 * (pl & 3);
+                    const char *ad = D + row0 * kDRow + col * 2;
+                    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)ad);
+                    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(ad + 4 * kDRow));
+                    const h4 lo4 = __builtin_bit_cast(h4, lo), hi4 = __builtin_bit_cast(h4, hi);
+                    const h8 bf = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[0][vb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bf, acc[0][vb], 0, 0, 0);
+                    acc[1][vb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bf, acc[1][vb], 0, 0, 0);
+                    if (do_db) {
+                        float s = dbacc[vb];
+                        s = __builtin_amdgcn_fdot2(__builtin_shufflevector(lo4, lo4, 0, 1), ones, s, false);
+                        s = __builtin_amdgcn_fdot2(__builtin_shufflevector(lo4, lo4, 2, 3), ones, s, false);
+                        s = __builtin_amdgcn_fdot2(__builtin_shufflevector(hi4, hi4, 0, 1), ones, s, false);
+                        s = __builtin_amdgcn_fdot2(__builtin_shufflevector(hi4, hi4, 2, 3), ones, s, false);
+                        dbacc[vb] = s;
+                    }
+                }
+            }
+        }
+    }
+    const float invS = jp.scal[1];
+    float *out = jp.dWpart + (size_t)range * J * V;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int vb = 0; vb < 4; ++vb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[(size_t)(j0 + wj * 64 + jb * 32 + cdrow(r, half)) * V + v0 + wv * 128 + vb * 32 + n] = acc[jb][vb][r] * invS;
+    if (do_db) {
+#pragma unroll
+        for (int vb = 0; vb < 4; ++vb) {
+            float s = dbacc[vb];
+            s += __shfl_xor(s, 32);
+            if (lane < 32) jp.dbpart[(size_t)range * V + v0 + wv * 128 + vb * 32 + n] = s * invS;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct JhLayout {
+    WsLayout w;
+    size_t W2Tp, W2h, dl, xbl, scal, dApart, dCpart, zrow, dWpart, dbpart, total;
+    int n_ut, n_tt, n_ts, TS, n_tq, n_units, n_ranges;
+};
+
+bool joint_f16_supported(int J, int V) {
+    return (J == 128 || J == 256 || J == 512 || J == 640) && V >= 512 && (V % 512) == 0 && V <= 8192;
+}
+
+static JhLayout make_jh_layout(int T, int U, int B, int J, int V) {
+    JhLayout L;
+    L.w = make_layout(T, U, B);
+    L.n_ut = (U + 31) / 32;
+    L.n_tt = (T + 7) / 8;
+    L.n_ts = (T >= 512) ? 4 : (T >= 128 ? 2 : 1);
+    L.TS = ((T + L.n_ts - 1) / L.n_ts + 7) / 8 * 8;
+    L.n_ts = (T + L.TS - 1) / L.TS;
+    L.n_tq = (T + kTQ - 1) / kTQ;
+    L.n_units = B * L.n_ut * L.n_tq;
+    const int n_tiles = (J / 128) * (V / 512);
+    int per_xcd = 32 / n_tiles;
+    if (per_xcd < 1) per_xcd = 1;
+    L.n_ranges = 8 * per_xcd;
+    if (L.n_ranges > L.n_units) L.n_ranges = L.n_units;
+    size_t off = L.w.total;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = align_up(off + bytes, 256);
+        return o;
+    };
+    const size_t cells = (size_t)B * T * U;
+    L.W2Tp = take((size_t)J * V * 2);
+    L.W2h = take((size_t)J * V * 2);
+    L.dl = take(cells * V * 2);
+    L.xbl = take(cells * 2 * sizeof(float));
+    L.scal = take(64);
+    L.dApart = take((size_t)L.n_ut * B * T * J * sizeof(float));
+    L.dCpart = take((size_t)L.n_ts * B * U * J * sizeof(float));
+    L.zrow = take(1024);
+    L.dWpart = take((size_t)L.n_ranges * J * V * sizeof(float));
+    L.dbpart = take((size_t)L.n_ranges * V * sizeof(float));
+    L.total = off;
+    return L;
+}
+
+hipError_t joint_f16_workspace_bytes(int T, int U, int B, int J, int V, size_t *bytes) {
+    if (!joint_f16_supported(J, V) || sweep_K(U) == 0) return hipErrorInvalidValue;
+    *bytes = make_jh_layout(T, U, B, J, V).total;
+    return hipSuccess;
+}
+
+bool fill_loss_params(LossParams &p, const float *acts, float *grads, const int *labels, const int *label_lengths,
+                      const int *input_lengths, const float *cost_scale, int V, int B, float *costs, void *workspace,
+                      int maxT, int maxU, int blank);
+hipError_t launch_reduce_partials(float *out, const float *in, int nparts, size_t n, hipStream_t s);
+
+template <typename K>
+static hipError_t set_lds_f16(K kernel, size_t bytes) {
+    if (bytes <= 65536) return hipSuccess;
+    return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <int KS>
+static hipError_t launch_logits(const JhParams &jp, bool bwd, unsigned grid, hipStream_t s) {
+    const size_t shm = 2 * (size_t)64 * (KS * 16) + (bwd ? (size_t)8 * 32 * kStageStride * sizeof(f16) : 0);
+    hipError_t e;
+    if (bwd) {
+        if ((e = set_lds_f16(jh_logits_kernel<KS, true>, shm)) != hipSuccess) return e;
+        hipLaunchKernelGGL((jh_logits_kernel<KS, true>), dim3(grid), dim3(512), shm, s, jp);
+    } else {
+        if ((e = set_lds_f16(jh_logits_kernel<KS, false>, shm)) != hipSuccess) return e;
+        hipLaunchKernelGGL((jh_logits_kernel<KS, false>), dim3(grid), dim3(512), shm, s, jp);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2,
+                                 const int *labels, const int *label_lengths, const int *input_lengths,
+                                 const float *cost_scale, int J, int V, int B, int T, int U, int blank, float *costs,
+                                 float *d_enc_proj, float *d_pred_proj, float *dW2, float *db2, int phases,
+                                 void *workspace, hipStream_t s) {
+    if (!joint_f16_supported(J, V)) return hipErrorInvalidValue;
+    if (((uintptr_t)enc_proj & 15) || ((uintptr_t)pred_proj & 15) || ((uintptr_t)b2 & 15)) return hipErrorInvalidValue;
+    const JhLayout L = make_jh_layout(T, U, B, J, V);
+    JhParams jp;
+    if (!fill_loss_params(jp.lp, nullptr, nullptr, labels, label_lengths, input_lengths, cost_scale, V, B, costs,
+                          workspace, T, U, blank))
+        return hipErrorInvalidValue;
+    char *ws = (char *)workspace;
+    jp.enc_proj = enc_proj, jp.pred_proj = pred_proj, jp.W2 = W2, jp.b2 = b2;
+    jp.W2Tp = (f16 *)(ws + L.W2Tp), jp.W2h = (f16 *)(ws + L.W2h), jp.dl = (f16 *)(ws + L.dl);
+    jp.xbl = (float *)(ws + L.xbl), jp.scal = (float *)(ws + L.scal);
+    jp.dApart = (float *)(ws + L.dApart), jp.dCpart = (float *)(ws + L.dCpart);
+    jp.dWpart = (float *)(ws + L.dWpart), jp.dbpart = (float *)(ws + L.dbpart);
+    jp.zrow = (const f16 *)(ws + L.zrow);
+    jp.J = J, jp.n_ut = L.n_ut, jp.n_tt = L.n_tt, jp.n_ts = L.n_ts, jp.TS = L.TS, jp.n_tq = L.n_tq;
+    jp.n_units = L.n_units, jp.n_ranges = L.n_ranges;
+
+    hipError_t e;
+    auto logits = [&](bool bwd) -> hipError_t {
+        const unsigned grid = (unsigned)B * L.n_tt * L.n_ut;
+        switch (J) {
+            case 128: return launch_logits<8>(jp, bwd, grid, s);
+            case 256: return launch_logits<16>(jp, bwd, grid, s);
+            case 512: return launch_logits<32>(jp, bwd, grid, s);
+            case 640: return launch_logits<40>(jp, bwd, grid, s);
+        }
+        return hipErrorInvalidValue;
+    };
+    // the binary16 weight copies and the scale are rebuilt by whichever phase runs (cheap; W2 or cost_scale may differ)
+    hipLaunchKernelGGL(jh_prep_kernel, dim3(256), dim3(256), 0, s, jp);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (phases & 1) {
+        if (hipMemsetAsync(jp.lp.W, kFillByte, L.w.A - L.w.W, s) != hipSuccess) return hipErrorUnknown;
+        if ((e = logits(false)) != hipSuccess) return e;
+        if ((e = launch_sweeps(jp.lp, s)) != hipSuccess) return e;
+    }
+    if (!(phases & 2) || !d_enc_proj) return hipSuccess;
+
+    if ((e = logits(true)) != hipSuccess) return e;
+    if (hipMemsetAsync(jp.dApart, 0, L.dWpart - L.dApart, s) != hipSuccess) return hipErrorUnknown;  // dA / dC partials, zero row
+    {
+        const size_t shm = 2 * (size_t)(256 + 128) * 128;
+        if ((e = set_lds_f16(jh_dh_kernel, shm)) != hipSuccess) return e;
+        const unsigned grid = (unsigned)B * L.n_ut * L.n_ts * (J / 128);
+        hipLaunchKernelGGL(jh_dh_kernel, dim3(grid), dim3(512), shm, s, jp);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    {
+        const size_t shm = 2 * (size_t)(32 * kDRow + 2 * 4 * 32 * 32);
+        if ((e = set_lds_f16(jh_dw_kernel, shm)) != hipSuccess) return e;
+        const unsigned grid = (unsigned)L.n_ranges * (J / 128) * (V / 512);
+        hipLaunchKernelGGL(jh_dw_kernel, dim3(grid), dim3(512), shm, s, jp);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if ((e = launch_reduce_partials(d_enc_proj, jp.dApart, L.n_ut, (size_t)B * T * J, s)) != hipSuccess) return e;
+    if ((e = launch_reduce_partials(d_pred_proj, jp.dCpart, L.n_ts, (size_t)B * U * J, s)) != hipSuccess) return e;
+    if ((e = launch_reduce_partials(dW2, jp.dWpart, L.n_ranges, (size_t)J * V, s)) != hipSuccess) return e;
+    return launch_reduce_partials(db2, jp.dbpart, L.n_ranges, (size_t)V, s);
+}
+
+}  // namespace rnnt

@@ -494,7 +494,25 @@ static bool joint_supported(int J, int V) {
     return V >= 1 && V <= 32 && J >= 64 && (J % 64) == 0 && J <= 768;
 }
 
+// joint_f16_kernels.hip (large vocabularies on the f16 MFMA units)
+bool joint_f16_supported(int J, int V);
+hipError_t joint_f16_workspace_bytes(int T, int U, int B, int J, int V, size_t *bytes);
+hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2,
+                                 const int *labels, const int *label_lengths, const int *input_lengths,
+                                 const float *cost_scale, int J, int V, int B, int T, int U, int blank, float *costs,
+                                 float *d_enc_proj, float *d_pred_proj, float *dW2, float *db2, int phases,
+                                 void *workspace, hipStream_t s);
+
+hipError_t launch_reduce_partials(float *out, const float *in, int nparts, size_t n, hipStream_t s) {
+    const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, s, out, in, nparts, n);
+    return hipGetLastError();
+}
+
 hipError_t joint_workspace_bytes(int T, int U, int B, int J, int V, size_t *bytes) {
+    // the two joint paths have disjoint shape domains (V <= 32: f32 MFMA; V % 512 == 0: f16 MFMA), so the
+    // workspace query needs no dtype argument; it returns the size for whichever path accepts (J, V)
+    if (V > 32) return joint_f16_workspace_bytes(T, U, B, J, V, bytes);
     if (!joint_supported(J, V) || sweep_K(U) == 0) return hipErrorInvalidValue;
     *bytes = make_joint_layout(T, U, B, J).total;
     return hipSuccess;
@@ -517,7 +535,10 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
                              float *d_enc_proj, float *d_pred_proj, float *dW2, float *db2, int joint_dtype,
                              int phases, void *workspace, hipStream_t s) {
     // phases: bit 0 = forward (costs + lattice state in the workspace), bit 1 = backward (needs that state)
-    if (!joint_supported(J, V) || joint_dtype != 0) return hipErrorInvalidValue;  // f16 MFMA joint: next round
+    if (joint_dtype == 1)
+        return launch_joint_loss_f16(enc_proj, pred_proj, W2, b2, labels, label_lengths, input_lengths, cost_scale, J, V,
+                                     B, T, U, blank, costs, d_enc_proj, d_pred_proj, dW2, db2, phases, workspace, s);
+    if (!joint_supported(J, V) || joint_dtype != 0) return hipErrorInvalidValue;
     if (((uintptr_t)enc_proj & 15) || ((uintptr_t)pred_proj & 15)) return hipErrorInvalidValue;
     const JointLayout L = make_joint_layout(T, U, B, J);
     JointParams jp;

@@ -19,7 +19,7 @@ from . import _lib
 
 class _JointLossFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, enc_proj, pred_proj, W2, b2, labels, input_lengths, label_lengths, blank_label):
+    def forward(ctx, enc_proj, pred_proj, W2, b2, labels, input_lengths, label_lengths, blank_label, joint_dtype):
         lib = _lib.load()
         for name, x in (("enc_proj", enc_proj), ("pred_proj", pred_proj), ("W2", W2), ("b2", b2)):
             if not x.is_cuda:
@@ -44,10 +44,11 @@ class _JointLossFunction(torch.autograd.Function):
             opts = _lib.make_options(torch.cuda.current_stream().cuda_stream, int(blank_label), T, U)
             st = lib.compute_rnnt_joint_loss_fwd(ep.data_ptr(), pp.data_ptr(), w2.data_ptr(), bb.data_ptr(),
                                                  labels.data_ptr(), ll.data_ptr(), il.data_ptr(), J, V, B,
-                                                 costs.data_ptr(), 0, ws.data_ptr(), opts)
+                                                 costs.data_ptr(), int(joint_dtype), ws.data_ptr(), opts)
         _lib.check(st, "compute_rnnt_joint_loss_fwd")
         ctx.save_for_backward(ep, pp, w2, bb, labels, il, ll, ws)
         ctx.blank = int(blank_label)
+        ctx.joint_dtype = int(joint_dtype)
         return costs
 
     @staticmethod
@@ -64,19 +65,33 @@ class _JointLossFunction(torch.autograd.Function):
             st = lib.compute_rnnt_joint_loss_bwd(ep.data_ptr(), pp.data_ptr(), w2.data_ptr(), bb.data_ptr(),
                                                  labels.data_ptr(), ll.data_ptr(), il.data_ptr(), scale.data_ptr(),
                                                  J, V, B, d_ep.data_ptr(), d_pp.data_ptr(), d_w2.data_ptr(),
-                                                 d_b2.data_ptr(), 0, ws.data_ptr(), opts)
+                                                 d_b2.data_ptr(), ctx.joint_dtype, ws.data_ptr(), opts)
         _lib.check(st, "compute_rnnt_joint_loss_bwd")
-        return d_ep, d_pp, d_w2, d_b2, None, None, None, None
+        return d_ep, d_pp, d_w2, d_b2, None, None, None, None, None
 
 
-def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_lengths, blank_label: int = 0):
+JOINT_DTYPES = {"f32": 0, "f16": 1}
+
+
+def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_lengths, blank_label: int = 0,
+                    joint_dtype: str = "auto"):
     """costs[b] = transducer NLL of  logits = tanh((enc[:,:,None]+pred[:,None]) @ W1 + b1) @ W2 + b2.
 
     enc [B,T,H] (encoder output), pred [B,U,H] (prediction-network output), W1 [H,J], b1 [J],
-    W2 [J,V], b2 [V]  (Keras Dense kernels are stored [in, out], model.py:162-166)."""
+    W2 [J,V], b2 [V]  (Keras Dense kernels are stored [in, out], model.py:162-166).
+
+    joint_dtype: arithmetic of the J x V product.  "f32": exact f32 MFMA, small vocabularies (V <= 32, the reference's
+    character set).  "f16": operands rounded to binary16, f32 accumulation, for large vocabularies (V a multiple of
+    512, J in {128, 256, 512, 640}) -- the counterpart of the reference's `mixed_float16` policy (run_rnnt.py:96-99);
+    the lattice stays f32 either way.  "auto" picks by V."""
+    if joint_dtype == "auto":
+        joint_dtype = "f32" if W2.shape[1] <= 32 else "f16"
+    if joint_dtype not in JOINT_DTYPES:
+        raise ValueError(f"rnnt_joint_loss: joint_dtype must be one of {sorted(JOINT_DTYPES)} or 'auto'")
     enc_proj = torch.matmul(enc, W1) + b1
     pred_proj = torch.matmul(pred, W1)
-    return _JointLossFunction.apply(enc_proj, pred_proj, W2, b2, labels, input_lengths, label_lengths, blank_label)
+    return _JointLossFunction.apply(enc_proj, pred_proj, W2, b2, labels, input_lengths, label_lengths, blank_label,
+                                    JOINT_DTYPES[joint_dtype])
 
 
 class JointLoss(torch.nn.Module):

@@ -1,0 +1,99 @@
+"""GPU parity tests of the large-vocabulary fused joint + loss path on the f16 MFMA units
+(compute_rnnt_joint_loss_* with joint_dtype = 1, through the C ABI) against the float64 oracle that states the
+same operand roundings (oracle/rnnt_oracle.py: joint_loss_and_grads_f16, restating model.py:158-166 under the
+reference's mixed_float16 policy, run_rnnt.py:96-99).
+
+Tolerances: costs relative 1e-4; every gradient tensor max|d| <= 5e-4 * max(1, max|ref|).  The gradient bound is
+wider than the f32 paths' 1e-4 for a structural reason: dlogits are rounded to binary16 (relative step 4.9e-4) before
+the two backward products, and an f32 kernel value that differs from the f64 oracle value by ~3e-6 relative lands on
+the other side of a rounding boundary for ~1 % of the elements; each such element then differs by a whole binary16
+step.  Measured: 5e-5 .. 1.3e-4 relative on d enc_proj / d pred_proj, the same with either summation order.
+The distance to the UNROUNDED joint is bounded too (costs 5e-3 relative): that is the price of binary16 operands (the
+reference's mixed_float16 policy pays the same), not a kernel error."""
+import numpy as np
+import pytest
+import torch
+
+import rnnt_speech_recognition_amd as pkg
+from oracle import rnnt_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def make(B, T, U, H, J, V, ragged, seed):
+    rng = np.random.default_rng(seed)
+    enc = rng.normal(size=(B, T, H)).astype(np.float32)
+    pred = rng.normal(size=(B, U, H)).astype(np.float32)
+    lim1, lim2 = np.sqrt(6.0 / (H + J)), np.sqrt(6.0 / (J + V))
+    W1 = rng.uniform(-lim1, lim1, size=(H, J)).astype(np.float32)
+    b1 = (0.1 * rng.normal(size=J)).astype(np.float32)
+    W2 = rng.uniform(-lim2, lim2, size=(J, V)).astype(np.float32) * 3.0
+    b2 = (0.1 * rng.normal(size=V)).astype(np.float32)
+    labels = rng.integers(1, V, size=(B, max(U - 1, 1))).astype(np.int32)[:, : max(U - 1, 0)]
+    if ragged:
+        il = rng.integers((T + 1) // 2, T + 1, size=B)
+        ll = rng.integers(U // 2, U, size=B)
+        il[0], ll[0] = T, U - 1
+    else:
+        il, ll = np.full(B, T), np.full(B, U - 1)
+    return enc, pred, W1, b1, W2, b2, labels, il.astype(np.int32), ll.astype(np.int32)
+
+
+def run(case, scale, joint_dtype="f16"):
+    enc, pred, W1, b1, W2, b2, labels, il, ll = case
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.tensor(x, device=dev)
+    params = [t(x).requires_grad_(True) for x in (enc, pred, W1, b1, W2, b2)]
+    costs = pkg.rnnt_joint_loss(*params, t(labels), t(il), t(ll), joint_dtype=joint_dtype)
+    (costs * t(scale.astype(np.float32))).sum().backward()
+    torch.cuda.synchronize()
+    return costs.detach().cpu().numpy(), [p.grad.cpu().numpy() for p in params]
+
+
+SHAPES = [
+    # B, T, U, H, J, V
+    (2, 11, 7, 16, 128, 512),     # one tile of everything
+    (2, 20, 40, 24, 256, 1024),   # two u-tiles, two J tiles, two V tiles, three row tiles
+    (1, 140, 33, 16, 128, 512),   # row splits of the dh kernel, several dW2 work units, u-tile boundary at 32/33
+    (1, 9, 5, 32, 640, 512),      # the BASELINE joint width
+    (3, 17, 12, 8, 512, 1536),    # three V tiles
+]
+
+
+@pytest.mark.parametrize("B,T,U,H,J,V", SHAPES)
+@pytest.mark.parametrize("ragged", [False, True])
+def test_joint_f16_matches_oracle(B, T, U, H, J, V, ragged):
+    case = make(B, T, U, H, J, V, ragged, seed=B + T + U + H + J + V)
+    scale = np.linspace(0.5, 1.5, B)
+    costs, grads = run(case, scale)
+    ref = orc.joint_loss_and_grads_f16(*case, cost_scale=scale)
+    np.testing.assert_allclose(costs, ref["costs"], rtol=1e-4)
+    for g, key in zip(grads, ("d_enc", "d_pred", "dW1", "db1", "dW2", "db2")):
+        tol = 5e-4 * max(1.0, np.abs(ref[key]).max())
+        assert np.abs(g - ref[key]).max() <= tol, key
+    exact = orc.joint_loss_and_grads(*case, cost_scale=scale)
+    np.testing.assert_allclose(costs, exact["costs"], rtol=5e-3)
+    enc_g, pred_g = grads[0], grads[1]
+    il, ll = case[7], case[8]
+    for b in range(B):
+        assert not enc_g[b, il[b]:].any() and not pred_g[b, ll[b] + 1:].any()
+
+
+def test_joint_f16_is_deterministic():
+    case = make(2, 40, 40, 16, 128, 512, True, seed=11)
+    scale = np.ones(2)
+    c1, g1 = run(case, scale)
+    c2, g2 = run(case, scale)
+    assert np.array_equal(c1, c2)
+    for a, b in zip(g1, g2):
+        assert np.array_equal(a, b)
+
+
+def test_joint_f16_limits_are_reported():
+    dev = torch.device("cuda:0")
+    enc, pred = torch.zeros(1, 4, 8, device=dev), torch.zeros(1, 3, 8, device=dev)
+    W1, b1 = torch.zeros(8, 128, device=dev), torch.zeros(128, device=dev)
+    W2, b2 = torch.zeros(128, 100, device=dev), torch.zeros(100, device=dev)  # V = 100: neither path takes it
+    with pytest.raises(RuntimeError, match="invalid value"):
+        pkg.rnnt_joint_loss(enc, pred, W1, b1, W2, b2, torch.ones(1, 2, dtype=torch.int32, device=dev),
+                            torch.tensor([4], device=dev), torch.tensor([2], device=dev))
