@@ -71,7 +71,8 @@ constexpr int kDRow = 1088;        // bytes per dl row in K4's LDS image (1024 +
 struct JhParams {
     LossParams lp;  // lattice workspace, labels, lengths, costs, cost_scale (acts / grads unused)
     const float *enc_proj, *pred_proj, *W2, *b2;
-    f16 *W2Tp;    // [V/32][J/16][32 v][16 j]  W2^T, packed so that one MFMA A fragment is 1 KB contiguous
+    f16 *W2Tp;    // [V/32][J/16][2 halves][32 v][8 j]  W2^T packed so that lane l of an MFMA A fragment reads
+                  // bytes [16 l, 16 l + 16) of a contiguous 1 KB block (conflict-free ds_read_b128)
     f16 *W2h;     // [J][V]
     f16 *dl;      // [cells][V]  dlogits * S
     float *xbl;   // [cells][2]  blank / label logits, log2-scaled (x * log2 e)
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void jh_prep_kernel(const JhParams jp) {
         const int j = (int)(i / V), v = (int)(i - (size_t)j * V);
         const f16 w = (f16)jp.W2[i];
         jp.W2h[i] = w;
-        jp.W2Tp[(((size_t)(v >> 5) * (J >> 4) + (j >> 4)) * 32 + (v & 31)) * 16 + (j & 15)] = w;
+        jp.W2Tp[((((size_t)(v >> 5) * (J >> 4) + (j >> 4)) * 2 + ((j >> 3) & 1)) * 32 + (v & 31)) * 8 + (j & 7)] = w;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         float m = 1.0f;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void jh_prep_kernel(const JhParams jp) {
 // ---------------------------------------------------------------------------------------------
 // K1 / K2: workgroup = 8 waves = 8 lattice rows x 32 lattice columns; wave w owns row t0+w, lane (n, half) owns
 // column u0+n and the joint units {16 ks + 8 half + 0..7} of its h row.
-// LDS: W2^T chunk [2][J/16][32 v][16 j] (2 x 64 J bytes)  |  BWD: staging [8 waves][32 cells][kStageStride]
+// LDS: W2^T chunk [2][J/16][2][32 v][8 j] (2 x 64 J bytes)  |  BWD: staging [8 waves][32 cells][kStageStride]
 // ---------------------------------------------------------------------------------------------
 template <int KS, bool BWD>
 __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
@@ -218,37 +219,8 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
         }
     }
 
-    const int NC = V >> 5;
-    for (int vc = 0; vc < NC; ++vc) {
-        wait_vm();
-        __syncthreads();  // chunk vc is in LDS; every wave is done with the other buffer
-        if (vc + 1 < NC) dma_chunk(vc + 1, ((vc + 1) & 1) ? wbuf1 : wbuf0);
-        if (!wave_live) continue;
-        const char *wb = ((vc & 1) ? wbuf1 : wbuf0) + n * 32 + half * 16;
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        {
-            // A fragments four k-steps ahead of their MFMAs (bounded: the compiler would otherwise hoist all KS reads)
-            h8 acur[4], anxt[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acur[q] = *(const h8 *)(wb + q * 1024);
-#pragma unroll
-            for (int g = 0; g < KS / 4; ++g) {
-                if (g + 1 < KS / 4) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) anxt[q] = *(const h8 *)(wb + (4 * (g + 1) + q) * 1024);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[q], hf[4 * g + q], acc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acur[q] = anxt[q];
-            }
-        }
-        // acc[r] = logit (without bias) of this lane's cell at v = 32 vc + cdrow(r, half)
+    // ---- epilogue of one 32-column chunk: acc[r] = logit (without bias) of this lane's cell at v = 32 vc + cdrow(r, half)
+    auto epilogue = [&](const f32x16 &acc, const int vc) {
         const float *b2p = jp.b2 + vc * 32 + 4 * half;
         if (!BWD) {
             float y[16];
@@ -319,7 +291,56 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
                 wait_lgkm();  // the staging tile is rewritten by the next chunk
             }
         }
+    };
+
+    // Waves w and w+4 share a SIMD.  Waves 4..7 run their epilogue one chunk late (before the next chunk's MFMAs instead
+    // of after their own), so that on every SIMD one wave is in its VALU phase while the other feeds the matrix pipe.
+    const bool late = wave >= 4;  // wave-uniform
+    const int NC = V >> 5;
+    f32x16 acc;
+    for (int vc = 0; vc < NC; ++vc) {
+        wait_vm();
+        __syncthreads();  // chunk vc is in LDS; every wave is done with the other buffer
+        if (vc + 1 < NC) dma_chunk(vc + 1, ((vc + 1) & 1) ? wbuf1 : wbuf0);
+        if (!wave_live) continue;
+        if (late && vc > 0) epilogue(acc, vc - 1);
+        const char *wb = ((vc & 1) ? wbuf1 : wbuf0) + lane * 16;
+        constexpr bool kTwoChains = !(BWD && KS > 32);  // two accumulation chains unless registers are short
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
+        {
+            // A fragments four k-steps ahead of their MFMAs (bounded: the compiler would otherwise hoist all KS reads)
+            h8 acur[4], anxt[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acur[q] = *(const h8 *)(wb + q * 1024);
+#pragma unroll
+            for (int g4 = 0; g4 < KS / 4; ++g4) {
+                if (g4 + 1 < KS / 4) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) anxt[q] = *(const h8 *)(wb + (4 * (g4 + 1) + q) * 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kTwoChains) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[0], hf[4 * g4 + 0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[1], hf[4 * g4 + 1], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[2], hf[4 * g4 + 2], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[3], hf[4 * g4 + 3], acc1, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[q], hf[4 * g4 + q], acc0, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acur[q] = anxt[q];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = kTwoChains ? acc0[r] + acc1[r] : acc0[r];
+        if (!late) epilogue(acc, vc);
     }
+    if (late && wave_live) epilogue(acc, NC - 1);
 
     if (!BWD && wave_live) {
         // merge the two half-lanes of a cell, then the same outputs as the lsm pass of rnnt_kernels.hip
@@ -347,7 +368,7 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
 // workgroup = (utterance, u-tile of 32, 128-wide J tile, row split); 8 waves as 4 (row pairs) x 2 (64 joint units);
 // per iteration 8 lattice rows x 32 columns = 256 cells; K = V in chunks of 64.
 // LDS per stage: A = dl tile [256 cells][64 v] + B = W2 tile [128 j][64 v], 128-byte rows, 16-byte chunks XOR-swizzled
-// by (row >> 1) & 7 (conflict-free b128 fragment reads); two stages.
+// by (row >> 1) & 7 (conflict-free b128 fragment reads); three stages (two chunks in flight under the MFMAs).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -356,7 +377,7 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, n = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;
-    constexpr int kStage = (256 + 128) * 128;
+    constexpr int kStage = (256 + 128) * 128;  // three stages
 
     uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
     const int n_jt = J >> 7;
@@ -390,20 +411,36 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
     const float invS = jp.scal[1];
     const int NK = V >> 6;
 
+    // DMA descriptors of this wave: wave-instructions i = wave + 8 k (k = 0..5) of the 48 that fill one stage.  i < 32 are
+    // dl rows (row = 8 i + lane/8: lattice row offset i/4, column offset 8 (i&3) + lane/8), i >= 32 are W2 rows.
+    // Everything but the lattice row t and the chunk index is fixed per lane: keep it in registers.
+    uint32_t doff[6];  // element offset inside the row block
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int i = wave + 8 * k;
+        const int row = (i < 32 ? i : i - 32) * 8 + (lane >> 3);
+        const int ck = (lane & 7) ^ ((row >> 1) & 7);
+        if (i < 32) doff[k] = (uint32_t)min(u0 + (row & 31), p.U - 1) * (uint32_t)V + (uint32_t)(ck * 8);
+        else doff[k] = (uint32_t)(j0 + row) * (uint32_t)V + (uint32_t)(ck * 8);
+    }
+    auto wait_dma = [&](const bool more_in_flight) {
+        // 6 DMA wave-instructions per stage and wave; everything older than the newest stage must have landed
+        if (more_in_flight) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
     for (int t_it = t_begin; t_it < t_end; t_it += 8) {
+        const f16 *arow[4];  // wave-uniform: dl row block of the four lattice rows this wave fetches
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int tr = min(t_it + ((wave + 8 * k) >> 2), t_end - 1);
+            arow[k] = jp.dl + (size_t)(b * p.T + tr) * p.U * V;
+        }
         auto dma = [&](const int kc, char *st) {
-            // A rows: row = tl * 32 + uu  (tl = lattice row offset, uu = column offset); 32 wave-instructions
-            for (int i = wave; i < 48; i += 8) {
-                const int row = (i < 32 ? i : i - 32) * 8 + (lane >> 3);
-                const int ck = (lane & 7) ^ ((row >> 1) & 7);
-                const f16 *src;
-                if (i < 32) {
-                    const int tr = min(t_it + (row >> 5), t_end - 1), uu = min(u0 + (row & 31), p.U - 1);
-                    src = jp.dl + ((size_t)(b * p.T + tr) * p.U + uu) * V + kc * 64 + ck * 8;
-                } else {
-                    src = jp.W2h + (size_t)(j0 + row) * V + kc * 64 + ck * 8;
-                }
-                __builtin_amdgcn_global_load_lds((glb_cvoid *)src, (lds_void *)(st + i * 1024), 16, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const f16 *src = (k < 4 ? arow[k] : jp.W2h) + doff[k] + kc * 64;
+                __builtin_amdgcn_global_load_lds((glb_cvoid *)src, (lds_void *)(st + (wave + 8 * k) * 1024), 16, 0, 0);
             }
         };
         f32x16 acc[2][2];
@@ -413,30 +450,40 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        // three LDS stages: chunks kc+1 and kc+2 are in flight while chunk kc is multiplied
+        __builtin_amdgcn_s_barrier();  // previous iteration: every wave is done with all stages
         dma(0, smem);
+        if (NK > 1) dma(1, smem + kStage);
         for (int kc = 0; kc < NK; ++kc) {
-            wait_vm();
-            __syncthreads();
-            if (kc + 1 < NK) dma(kc + 1, smem + ((kc + 1) & 1) * kStage);
-            const char *A = smem + (kc & 1) * kStage, *Bm = A + 256 * 128;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                h8 a[2], bf[2];
+            wait_dma(kc + 1 < NK);
+            __builtin_amdgcn_s_barrier();  // chunk kc complete in LDS; stage (kc+2)%3 was last read for chunk kc-1
+            asm volatile("" ::: "memory");
+            if (kc + 2 < NK) dma(kc + 2, smem + ((kc + 2) % 3) * kStage);
+            const char *A = smem + (kc % 3) * kStage, *Bm = A + 256 * 128;
+            h8 a[2][2], bf[2][2];  // fragments of k-step ks in [ks & 1]: read one k-step ahead of their MFMAs
+            auto rd = [&](const int ks, h8 (&aa)[2], h8 (&bb)[2]) {
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
                     const int row = (2 * wm + mi) * 32 + n;
-                    a[mi] = *(const h8 *)(A + row * 128 + (((ks * 2 + half) ^ ((row >> 1) & 7)) * 16));
+                    aa[mi] = *(const h8 *)(A + row * 128 + (((ks * 2 + half) ^ ((row >> 1) & 7)) * 16));
                 }
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     const int row = wn * 64 + ni * 32 + n;
-                    bf[ni] = *(const h8 *)(Bm + row * 128 + (((ks * 2 + half) ^ ((row >> 1) & 7)) * 16));
+                    bb[ni] = *(const h8 *)(Bm + row * 128 + (((ks * 2 + half) ^ ((row >> 1) & 7)) * 16));
                 }
+            };
+            rd(0, a[0], bf[0]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) rd(ks + 1, a[(ks + 1) & 1], bf[(ks + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks & 1][mi], bf[ks & 1][ni], acc[mi][ni], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // epilogue: acc[mi][ni][r] = S * dh[row t_it + 2 wm + mi][column u0 + cdrow(r, half)][unit j0 + 64 wn + 32 ni + n]
@@ -483,7 +530,8 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
 // K4: dW2 = h^T . dl / S (and db2 = sum dl / S).  workgroup = (range of work units, 128-wide J tile, 512-wide V tile);
 // 8 waves as 2 (64 joint units) x 4 (128 vocabulary columns), 2 x 4 accumulator tiles each.
 // A work unit is (utterance, u-tile of 32, kTQ lattice rows); one lattice row (32 cells = 2 MFMA k-steps) per step.
-// LDS per stage: dl rows [32 cells][kDRow B] (row-major, read transposed) | h^T fragments [2 ks][4 jb][32][2][8]
+// LDS per stage (three stages): dl rows [32 cells][kDRow B] (row-major, read transposed) | h^T fragments
+// [2 ks][4 jb][2][32][8]; plus four 512-byte enc_proj row slices
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -514,6 +562,7 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
     const int jl = tid & 127, cg = tid >> 7;  // h generation: this thread's joint unit and group of 8 cells
     const h2 ones = {(f16)1.0f, (f16)1.0f};
 
+    char *ebuf = smem + 3 * kStage;  // [4][128] enc_proj values of the workgroup's joint units, one lattice row each
     for (int unit = unit_lo; unit < unit_hi; ++unit) {
         int q = unit;
         const int tq = q % jp.n_tq;
@@ -524,41 +573,73 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
         const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
         const int t_begin = tq * kTQ, t_end = min(min(t_begin + kTQ, p.T), Tb);
         if (t_begin >= t_end || u0 >= Ub) continue;  // workgroup-uniform
+        const int nsteps = t_end - t_begin;
         float pv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             pv[e] = jp.pred_proj[((size_t)b * p.U + min(u0 + 8 * cg + e, p.U - 1)) * J + j0 + jl];
-        auto stage = [&](const int t, char *st) {
-            for (int i = wave; i < 32; i += 8) {  // one dl row (512 columns = 1 KB) per wave-instruction
+        // Three stages of (dl rows + h^T fragments), enc_proj rows one step further ahead (four small buffers): at step s
+        // the DMA of row s+2's dl and of row s+3's enc_proj slice are issued, row s+2's h^T is built, row s is multiplied.
+        auto dma_e = [&](const int s) {  // wave 0, lanes 0..31: 128 floats
+            if (wave == 0 && lane < 32) {
+                const float *src = jp.enc_proj + ((size_t)b * p.T + min(t_begin + s, t_end - 1)) * J + j0 + lane * 4;
+                __builtin_amdgcn_global_load_lds((glb_cvoid *)src, (lds_void *)(ebuf + (s & 3) * 512), 16, 0, 0);
+            }
+        };
+        auto dma_d = [&](const int s, char *st) {
+            const int t = t_begin + s;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // one dl row (512 columns = 1 KB) per wave-instruction
+                const int i = wave + 8 * k;
                 const f16 *src = (u0 + i < p.U) ? jp.dl + ((size_t)(b * p.T + t) * p.U + u0 + i) * V + v0 + lane * 8
                                                 : jp.zrow + lane * 8;
                 __builtin_amdgcn_global_load_lds((glb_cvoid *)src, (lds_void *)(st + i * kDRow), 16, 0, 0);
             }
-            const float ej = jp.enc_proj[((size_t)b * p.T + t) * J + j0 + jl];
+        };
+        auto build_h = [&](const int s, char *st) {
+            const float ej = ((const float *)(ebuf + (s & 3) * 512))[jl];
             h8 hv;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float h = htanh(ej + pv[e]);
                 hv[e] = (u0 + 8 * cg + e < Ub) ? (f16)h : (f16)0.f;  // cells beyond U_b carry no gradient
             }
-            // fragment image: [ks = cg >> 1][jb = jl >> 5][i = jl & 31][half = cg & 1][8 cells]
-            *(h8 *)(st + kDBytes + ((((cg >> 1) * 4 + (jl >> 5)) * 32 + (jl & 31)) * 2 + (cg & 1)) * 16) = hv;
+            // fragment image: [ks = cg >> 1][jb = jl >> 5][half = cg & 1][i = jl & 31][8 cells]  (lane-linear reads)
+            *(h8 *)(st + kDBytes + ((((cg >> 1) * 4 + (jl >> 5)) * 2 + (cg & 1)) * 32 + (jl & 31)) * 16) = hv;
         };
-        __syncthreads();  // the previous unit's last step is done with stage 0
-        stage(t_begin, smem);
-        for (int t = t_begin; t < t_end; ++t) {
-            const int cur = (t - t_begin) & 1;
-            wait_vm();
-            __syncthreads();
-            if (t + 1 < t_end) stage(t + 1, smem + (cur ^ 1) * kStage);
-            const char *D = smem + cur * kStage, *H = D + kDBytes;
+        wait_lgkm();
+        __builtin_amdgcn_s_barrier();  // the previous unit is done with every stage
+        asm volatile("" ::: "memory");
+        dma_e(0), dma_e(1), dma_e(2);
+        wait_vm();
+        __builtin_amdgcn_s_barrier();  // enc_proj rows 0..2 visible
+        asm volatile("" ::: "memory");
+        dma_d(0, smem);
+        build_h(0, smem);
+        if (nsteps > 1) {
+            dma_d(1, smem + kStage);
+            build_h(1, smem + kStage);
+        }
+        for (int s = 0; s < nsteps; ++s) {
+            if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // all but the newest stage's dl rows
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_lgkm();
+            __builtin_amdgcn_s_barrier();  // stage s complete (dl rows + h^T); stage (s+2)%3 free; enc_proj row s+2 visible
+            asm volatile("" ::: "memory");
+            if (s + 2 < nsteps) {
+                char *st = smem + ((s + 2) % 3) * kStage;
+                if (s + 3 < nsteps) dma_e(s + 3);
+                dma_d(s + 2, st);
+                build_h(s + 2, st);
+            }
+            const char *D = smem + (s % 3) * kStage, *H = D + kDBytes;
             const int g4 = lane >> 4, pl = lane & 15;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 h8 a[2];
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb)
-                    a[jb] = *(const h8 *)(H + (((ks * 4 + wj * 2 + jb) * 32 + n) * 2 + half) * 16);
+                    a[jb] = *(const h8 *)(H + ((ks * 4 + wj * 2 + jb) * 64 + lane) * 16);
                 const int row0 = ks * 16 + 8 * (g4 >> 1) + (pl >> 2);
 #pragma unroll
                 for (int vb = 0; vb < 4; ++vb) {
@@ -571,12 +652,12 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
                     acc[0][vb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bf, acc[0][vb], 0, 0, 0);
                     acc[1][vb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bf, acc[1][vb], 0, 0, 0);
                     if (do_db) {
-                        float s = dbacc[vb];
-                        s = __builtin_amdgcn_fdot2(__builtin_shufflevector(lo4, lo4, 0, 1), ones, s, false);
-                        s = __builtin_amdgcn_fdot2(__builtin_shufflevector(lo4, lo4, 2, 3), ones, s, false);
-                        s = __builtin_amdgcn_fdot2(__builtin_shufflevector(hi4, hi4, 0, 1), ones, s, false);
-                        s = __builtin_amdgcn_fdot2(__builtin_shufflevector(hi4, hi4, 2, 3), ones, s, false);
-                        dbacc[vb] = s;
+                        float sdb = dbacc[vb];
+                        sdb = __builtin_amdgcn_fdot2(__builtin_shufflevector(lo4, lo4, 0, 1), ones, sdb, false);
+                        sdb = __builtin_amdgcn_fdot2(__builtin_shufflevector(lo4, lo4, 2, 3), ones, sdb, false);
+                        sdb = __builtin_amdgcn_fdot2(__builtin_shufflevector(hi4, hi4, 0, 1), ones, sdb, false);
+                        sdb = __builtin_amdgcn_fdot2(__builtin_shufflevector(hi4, hi4, 2, 3), ones, sdb, false);
+                        dbacc[vb] = sdb;
                     }
                 }
             }
@@ -727,14 +808,14 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     if ((e = logits(true)) != hipSuccess) return e;
     if (hipMemsetAsync(jp.dApart, 0, L.dWpart - L.dApart, s) != hipSuccess) return hipErrorUnknown;  // dA / dC partials, zero row
     {
-        const size_t shm = 2 * (size_t)(256 + 128) * 128;
+        const size_t shm = 3 * (size_t)(256 + 128) * 128;
         if ((e = set_lds_f16(jh_dh_kernel, shm)) != hipSuccess) return e;
         const unsigned grid = (unsigned)B * L.n_ut * L.n_ts * (J / 128);
         hipLaunchKernelGGL(jh_dh_kernel, dim3(grid), dim3(512), shm, s, jp);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     {
-        const size_t shm = 2 * (size_t)(32 * kDRow + 2 * 4 * 32 * 32);
+        const size_t shm = 3 * (size_t)(32 * kDRow + 2 * 4 * 32 * 32) + 4 * 512;
         if ((e = set_lds_f16(jh_dw_kernel, shm)) != hipSuccess) return e;
         const unsigned grid = (unsigned)L.n_ranges * (J / 128) * (V / 512);
         hipLaunchKernelGGL(jh_dw_kernel, dim3(grid), dim3(512), shm, s, jp);
