@@ -6,7 +6,9 @@
 // the unchanged alpha/beta sweeps.  Nothing of size [cells x J] is ever stored; the only [cells x V] array is the
 // loss gradient w.r.t. the logits in binary16 (2 B per logit instead of the 4+4 B of the unfused path).
 //
-//   prep      W2 -> binary16 in two layouts (MFMA-fragment-packed W2^T, row-major W2); power-of-two dlogits scale
+//   prep      W2 -> binary16 in two layouts (MFMA-fragment-packed W2^T, row-major W2); power-of-two dlogits scale;
+//             tables e^{2 enc_proj}, e^{2 pred_proj}: tanh(a+c) = 1 - 2/(1 + e^{2a} e^{2c}) costs one reciprocal per
+//             (cell, joint unit) instead of an exponential and a reciprocal (the kernels are VALU-bound on it)
 //   K1 logits (jh_logits_kernel<KS,false>)  logits^T tile = W2^T . h^T with h = tanh(enc_proj_t + pred_proj_u) built
 //             straight into the B-operand registers (a wave owns 32 lattice cells of one row t, h never leaves the
 //             register file); W2^T streams through LDS by LDS-DMA, 32 vocabulary rows per step, shared by 8 waves.
@@ -47,6 +49,13 @@ __device__ __forceinline__ float hlg2(float x) { return __builtin_amdgcn_logf(x)
 __device__ __forceinline__ float htanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + hex2(x * 2.8853900817779268f));
 }
+// tanh(a + c) from the tabulated factors ea = e^{2a}, ec = e^{2c}: one multiply-add, one reciprocal, one multiply-add.
+// Exact to ~1e-7 absolute while |a|, |c| <= kExpTabLimit (both factors normal f32 numbers; an overflowing product gives +1,
+// an underflowing one -1, as tanh does).  Beyond that limit the prep kernel raises a flag and the kernels use htanh(a + c).
+__device__ __forceinline__ float htanh2(float ea, float ec) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(fmaf(ea, ec, 1.0f));
+}
+constexpr float kExpTabLimit = 43.0f;
 __device__ __forceinline__ constexpr int cdrow(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -76,7 +85,10 @@ struct JhParams {
     f16 *W2h;     // [J][V]
     f16 *dl;      // [cells][V]  dlogits * S
     float *xbl;   // [cells][2]  blank / label logits, log2-scaled (x * log2 e)
-    float *scal;  // [0] = S, [1] = 1/S
+    float *scal;  // [0] = S, [1] = 1/S, [2] != 0: some |enc_proj| or |pred_proj| exceeds kExpTabLimit (use htanh)
+    float *expE;  // [B][T][J]  e^{2 enc_proj}
+    float *expP;  // [B][U][J]  e^{2 pred_proj}
+    float *b2l;   // [V]  b2 * log2 e
     float *dApart;  // [n_ut][B][T][J]
     float *dCpart;  // [n_ts][B][U][J]
     float *dWpart;  // [n_ranges][J][V]
@@ -96,6 +108,20 @@ __global__ __launch_bounds__(256) void jh_prep_kernel(const JhParams jp) {
         const f16 w = (f16)jp.W2[i];
         jp.W2h[i] = w;
         jp.W2Tp[((((size_t)(v >> 5) * (J >> 4) + (j >> 4)) * 2 + ((j >> 3) & 1)) * 32 + (v & 31)) * 8 + (j & 7)] = w;
+    }
+    {
+        const LossParams &p = jp.lp;
+        const size_t nE = (size_t)p.B * p.T * J, nP = (size_t)p.B * p.U * J;
+        bool big = false;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nE + nP; i += (size_t)gridDim.x * 256) {
+            const float x = (i < nE) ? jp.enc_proj[i] : jp.pred_proj[i - nE];
+            big |= !(fabsf(x) <= kExpTabLimit);  // also catches NaN
+            const float ex = hex2(x * 2.8853900817779268f);
+            if (i < nE) jp.expE[i] = ex;
+            else jp.expP[i - nE] = ex;
+        }
+        if (__any(big) && (threadIdx.x & 63) == 0) jp.scal[2] = 1.0f;  // scal[2] is zeroed before the launch
+        for (int v = blockIdx.x * 256 + threadIdx.x; v < V; v += gridDim.x * 256) jp.b2l[v] = jp.b2[v] * kLog2e;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         float m = 1.0f;
@@ -156,8 +182,9 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
     // would need 16*KS registers).
     h8 hf[KS];
     {
-        const float *erow = jp.enc_proj + ((size_t)b * p.T + tc) * J + 8 * half;
-        const float *prow = jp.pred_proj + ((size_t)b * p.U + uc) * J + 8 * half;
+        const bool slow = jp.scal[2] != 0.f;  // kernel-uniform
+        const float *erow = (slow ? jp.enc_proj : jp.expE) + ((size_t)b * p.T + tc) * J + 8 * half;
+        const float *prow = (slow ? jp.pred_proj : jp.expP) + ((size_t)b * p.U + uc) * J + 8 * half;
         float4 cur[8], nxt[8];
         typedef float vf4 __attribute__((ext_vector_type(4)));
         auto vload = [](const float *q) {  // volatile: keeps its place relative to the fences below
@@ -182,10 +209,17 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
             for (int q = 0; q < 2; ++q) {
                 const float4 e0 = cur[4 * q], e1 = cur[4 * q + 1], c0 = cur[4 * q + 2], c1 = cur[4 * q + 3];
                 h8 v;
-                v[0] = (f16)htanh(e0.x + c0.x), v[1] = (f16)htanh(e0.y + c0.y);
-                v[2] = (f16)htanh(e0.z + c0.z), v[3] = (f16)htanh(e0.w + c0.w);
-                v[4] = (f16)htanh(e1.x + c1.x), v[5] = (f16)htanh(e1.y + c1.y);
-                v[6] = (f16)htanh(e1.z + c1.z), v[7] = (f16)htanh(e1.w + c1.w);
+                if (!slow) {
+                    v[0] = (f16)htanh2(e0.x, c0.x), v[1] = (f16)htanh2(e0.y, c0.y);
+                    v[2] = (f16)htanh2(e0.z, c0.z), v[3] = (f16)htanh2(e0.w, c0.w);
+                    v[4] = (f16)htanh2(e1.x, c1.x), v[5] = (f16)htanh2(e1.y, c1.y);
+                    v[6] = (f16)htanh2(e1.z, c1.z), v[7] = (f16)htanh2(e1.w, c1.w);
+                } else {
+                    v[0] = (f16)htanh(e0.x + c0.x), v[1] = (f16)htanh(e0.y + c0.y);
+                    v[2] = (f16)htanh(e0.z + c0.z), v[3] = (f16)htanh(e0.w + c0.w);
+                    v[4] = (f16)htanh(e1.x + c1.x), v[5] = (f16)htanh(e1.y + c1.y);
+                    v[6] = (f16)htanh(e1.z + c1.z), v[7] = (f16)htanh(e1.w + c1.w);
+                }
                 hf[2 * g + q] = v;
                 asm volatile("" ::"v"(v));  // the tanh work of this pair is done before the next pair's loads issue
             }
@@ -221,24 +255,31 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
 
     // ---- epilogue of one 32-column chunk: acc[r] = logit (without bias) of this lane's cell at v = 32 vc + cdrow(r, half)
     auto epilogue = [&](const f32x16 &acc, const int vc) {
-        const float *b2p = jp.b2 + vc * 32 + 4 * half;
+        const float *b2p = (BWD ? jp.b2 : jp.b2l) + vc * 32 + 4 * half;
         if (!BWD) {
+            // y = log2-scaled logits.  The running reference mref is only moved when a value exceeds it by more than
+            // 2^64 (wave-uniform rare path): s = sum 2^(y - mref) stays in f32 range and keeps full precision because
+            // mref never trails the running maximum by more than 64.
             float y[16];
             float m = -1.0e30f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bq = *(const float4 *)(b2p + 8 * q);
-                y[4 * q + 0] = (acc[4 * q + 0] + bq.x) * kLog2e;
-                y[4 * q + 1] = (acc[4 * q + 1] + bq.y) * kLog2e;
-                y[4 * q + 2] = (acc[4 * q + 2] + bq.z) * kLog2e;
-                y[4 * q + 3] = (acc[4 * q + 3] + bq.w) * kLog2e;
-                m = fmaxf(m, fmaxf(fmaxf(y[4 * q], y[4 * q + 1]), fmaxf(y[4 * q + 2], y[4 * q + 3])));
+                y[4 * q + 0] = fmaf(acc[4 * q + 0], kLog2e, bq.x);
+                y[4 * q + 1] = fmaf(acc[4 * q + 1], kLog2e, bq.y);
+                y[4 * q + 2] = fmaf(acc[4 * q + 2], kLog2e, bq.z);
+                y[4 * q + 3] = fmaf(acc[4 * q + 3], kLog2e, bq.w);
+                m = fmaxf(fmaxf(m, y[4 * q]), fmaxf(fmaxf(y[4 * q + 1], y[4 * q + 2]), y[4 * q + 3]));
             }
-            const float nr = fmaxf(mref, m);
-            float s = ssum * hex2(mref - nr);
+            if (__any(m > mref + 64.0f)) {
+                const float nr = fmaxf(mref, m);
+                ssum *= hex2(mref - nr);
+                mref = nr;
+            }
+            float s = ssum;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s += hex2(y[r] - nr);
-            ssum = s, mref = nr;
+            for (int r = 0; r < 16; ++r) s += hex2(y[r] - mref);
+            ssum = s;
             if (vc == vcb) {  // wave-uniform
                 float v = y[0];
 #pragma unroll
@@ -310,30 +351,33 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
         {
-            // A fragments four k-steps ahead of their MFMAs (bounded: the compiler would otherwise hoist all KS reads)
-            h8 acur[4], anxt[4];
+            // A fragments one group of k-steps ahead of their MFMAs (bounded: the compiler would otherwise hoist all KS
+            // reads); groups of 4, or of 2 where registers are short
+            constexpr int G = kTwoChains ? 4 : 2;
+            h8 acur[G], anxt[G];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acur[q] = *(const h8 *)(wb + q * 1024);
+            for (int q = 0; q < G; ++q) acur[q] = *(const h8 *)(wb + q * 1024);
 #pragma unroll
-            for (int g4 = 0; g4 < KS / 4; ++g4) {
-                if (g4 + 1 < KS / 4) {
+            for (int g4 = 0; g4 < KS / G; ++g4) {
+                if (g4 + 1 < KS / G) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) anxt[q] = *(const h8 *)(wb + (4 * (g4 + 1) + q) * 1024);
+                    for (int q = 0; q < G; ++q) anxt[q] = *(const h8 *)(wb + (G * (g4 + 1) + q) * 1024);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (kTwoChains) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[0], hf[4 * g4 + 0], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[1], hf[4 * g4 + 1], acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[2], hf[4 * g4 + 2], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[3], hf[4 * g4 + 3], acc1, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < G; q += 2) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[q], hf[G * g4 + q], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[q + 1], hf[G * g4 + q + 1], acc1, 0, 0, 0);
+                    }
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[q], hf[4 * g4 + q], acc0, 0, 0, 0);
+                    for (int q = 0; q < G; ++q)
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[q], hf[G * g4 + q], acc0, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acur[q] = anxt[q];
+                for (int q = 0; q < G; ++q) acur[q] = anxt[q];
             }
         }
 #pragma unroll
@@ -393,6 +437,8 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
     if (t_begin >= t_end || u0 >= Ub) return;
 
     // pred_proj values of this lane's joint units at its 16 lattice columns; validity of those columns
+    const bool slow = jp.scal[2] != 0.f;  // kernel-uniform: tabulated e^{2x} factors unusable, fall back to tanh(a + c)
+    const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
     float pr[2][16];
     unsigned vmask = 0;
 #pragma unroll
@@ -400,8 +446,8 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
         const int uu = u0 + cdrow(r, half);
         if (uu < Ub) vmask |= 1u << r;
         const size_t ro = ((size_t)b * p.U + min(uu, p.U - 1)) * J + j0 + wn * 64 + n;
-        pr[0][r] = jp.pred_proj[ro];
-        pr[1][r] = jp.pred_proj[ro + 32];
+        pr[0][r] = Ptab[ro];
+        pr[1][r] = Ptab[ro + 32];
     }
     float accC[2][16];
 #pragma unroll
@@ -494,11 +540,19 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     const int j = j0 + wn * 64 + ni * 32 + n;
-                    const float ej = jp.enc_proj[((size_t)b * p.T + t) * J + j];
+                    const float ej = Etab[((size_t)b * p.T + t) * J + j];
                     float colsum = 0.f;
+                    float hh[16];
+                    if (!slow) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) hh[r] = htanh2(ej, pr[ni][r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) hh[r] = htanh(ej + pr[ni][r]);
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float h = htanh(ej + pr[ni][r]);
+                        const float h = hh[r];
                         float dz = acc[mi][ni][r] * invS * (1.0f - h * h);
                         dz = ((vmask >> r) & 1u) ? dz : 0.f;
                         accC[ni][r] += dz;
@@ -562,6 +616,8 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
     const int jl = tid & 127, cg = tid >> 7;  // h generation: this thread's joint unit and group of 8 cells
     const h2 ones = {(f16)1.0f, (f16)1.0f};
 
+    const bool slow = jp.scal[2] != 0.f;  // kernel-uniform
+    const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
     char *ebuf = smem + 3 * kStage;  // [4][128] enc_proj values of the workgroup's joint units, one lattice row each
     for (int unit = unit_lo; unit < unit_hi; ++unit) {
         int q = unit;
@@ -577,12 +633,12 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
         float pv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            pv[e] = jp.pred_proj[((size_t)b * p.U + min(u0 + 8 * cg + e, p.U - 1)) * J + j0 + jl];
+            pv[e] = Ptab[((size_t)b * p.U + min(u0 + 8 * cg + e, p.U - 1)) * J + j0 + jl];
         // Three stages of (dl rows + h^T fragments), enc_proj rows one step further ahead (four small buffers): at step s
         // the DMA of row s+2's dl and of row s+3's enc_proj slice are issued, row s+2's h^T is built, row s is multiplied.
         auto dma_e = [&](const int s) {  // wave 0, lanes 0..31: 128 floats
             if (wave == 0 && lane < 32) {
-                const float *src = jp.enc_proj + ((size_t)b * p.T + min(t_begin + s, t_end - 1)) * J + j0 + lane * 4;
+                const float *src = Etab + ((size_t)b * p.T + min(t_begin + s, t_end - 1)) * J + j0 + lane * 4;
                 __builtin_amdgcn_global_load_lds((glb_cvoid *)src, (lds_void *)(ebuf + (s & 3) * 512), 16, 0, 0);
             }
         };
@@ -598,12 +654,17 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
         };
         auto build_h = [&](const int s, char *st) {
             const float ej = ((const float *)(ebuf + (s & 3) * 512))[jl];
+            float hh[8];
+            if (!slow) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hh[e] = htanh2(ej, pv[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hh[e] = htanh(ej + pv[e]);
+            }
             h8 hv;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float h = htanh(ej + pv[e]);
-                hv[e] = (u0 + 8 * cg + e < Ub) ? (f16)h : (f16)0.f;  // cells beyond U_b carry no gradient
-            }
+            for (int e = 0; e < 8; ++e) hv[e] = (u0 + 8 * cg + e < Ub) ? (f16)hh[e] : (f16)0.f;  // beyond U_b: no gradient
             // fragment image: [ks = cg >> 1][jb = jl >> 5][half = cg & 1][i = jl & 31][8 cells]  (lane-linear reads)
             *(h8 *)(st + kDBytes + ((((cg >> 1) * 4 + (jl >> 5)) * 2 + (cg & 1)) * 32 + (jl & 31)) * 16) = hv;
         };
@@ -687,7 +748,7 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
 // ---------------------------------------------------------------------------------------------
 struct JhLayout {
     WsLayout w;
-    size_t W2Tp, W2h, dl, xbl, scal, dApart, dCpart, zrow, dWpart, dbpart, total;
+    size_t W2Tp, W2h, dl, xbl, scal, expE, expP, b2l, dApart, dCpart, zrow, dWpart, dbpart, total;
     int n_ut, n_tt, n_ts, TS, n_tq, n_units, n_ranges;
 };
 
@@ -722,6 +783,9 @@ static JhLayout make_jh_layout(int T, int U, int B, int J, int V) {
     L.dl = take(cells * V * 2);
     L.xbl = take(cells * 2 * sizeof(float));
     L.scal = take(64);
+    L.expE = take((size_t)B * T * J * sizeof(float));
+    L.expP = take((size_t)B * U * J * sizeof(float));
+    L.b2l = take((size_t)V * sizeof(float));
     L.dApart = take((size_t)L.n_ut * B * T * J * sizeof(float));
     L.dCpart = take((size_t)L.n_ts * B * U * J * sizeof(float));
     L.zrow = take(1024);
@@ -778,6 +842,7 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     jp.enc_proj = enc_proj, jp.pred_proj = pred_proj, jp.W2 = W2, jp.b2 = b2;
     jp.W2Tp = (f16 *)(ws + L.W2Tp), jp.W2h = (f16 *)(ws + L.W2h), jp.dl = (f16 *)(ws + L.dl);
     jp.xbl = (float *)(ws + L.xbl), jp.scal = (float *)(ws + L.scal);
+    jp.expE = (float *)(ws + L.expE), jp.expP = (float *)(ws + L.expP), jp.b2l = (float *)(ws + L.b2l);
     jp.dApart = (float *)(ws + L.dApart), jp.dCpart = (float *)(ws + L.dCpart);
     jp.dWpart = (float *)(ws + L.dWpart), jp.dbpart = (float *)(ws + L.dbpart);
     jp.zrow = (const f16 *)(ws + L.zrow);
@@ -796,7 +861,8 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
         return hipErrorInvalidValue;
     };
     // the binary16 weight copies and the scale are rebuilt by whichever phase runs (cheap; W2 or cost_scale may differ)
-    hipLaunchKernelGGL(jh_prep_kernel, dim3(256), dim3(256), 0, s, jp);
+    if (hipMemsetAsync(jp.scal, 0, 64, s) != hipSuccess) return hipErrorUnknown;
+    hipLaunchKernelGGL(jh_prep_kernel, dim3(1024), dim3(256), 0, s, jp);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (phases & 1) {
         if (hipMemsetAsync(jp.lp.W, kFillByte, L.w.A - L.w.W, s) != hipSuccess) return hipErrorUnknown;
