@@ -131,9 +131,19 @@ rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, const int *fl
  *   d_enc_proj [B,maxT,J], d_pred_proj [B,maxU,J], dW2 [J,V], db2 [V]
  *                                device f32 outputs: gradients of sum_b cost_scale[b]*cost_b.
  *                                Fully overwritten.  May all be NULL for score-only.
- *   joint_dtype                  0 = f32 MFMA (exact f32).  (1 = f16-input MFMA is reserved; this round
- *                                returns RNNT_STATUS_INVALID_VALUE for it.)
- * Limits this round: alphabet_size <= 32, joint_size a multiple of 64 (<= 768), maxU <= 1024.
+ *   joint_dtype                  arithmetic of the J x V products.
+ *                                0 = f32 MFMA (exact f32), small vocabularies: alphabet_size <= 32 (the reference's
+ *                                    character set), joint_size a multiple of 64 (<= 768).
+ *                                1 = f16 MFMA, large vocabularies: alphabet_size a multiple of 512 (<= 8192),
+ *                                    joint_size in {128, 256, 512, 640}.  h = tanh(.) and W2 are rounded to binary16
+ *                                    (round-to-nearest-even) before the products, accumulation is f32; the loss gradient
+ *                                    w.r.t. the logits is scaled by 2^(14 - ceil(log2 max|cost_scale|)) and rounded to
+ *                                    binary16 before dh = dl.W2^T and dW2 = h^T.dl.  The lattice (log-softmax, alpha,
+ *                                    beta, costs) stays f32.  Counterpart of the reference's `mixed_float16` policy
+ *                                    (run_rnnt.py:96-99); oracle: oracle/rnnt_oracle.py joint_loss_and_grads_f16.
+ *                                Any other (joint_dtype, shape) combination returns RNNT_STATUS_INVALID_VALUE.
+ *                                get_joint_workspace_size needs no dtype: the two shape domains are disjoint.
+ * Both: maxU <= 1024; enc_proj, pred_proj (and b2 for joint_dtype 1) 16-byte aligned.
  * compute_rnnt_joint_loss      = costs and all four gradients in one call
  * compute_rnnt_joint_loss_fwd  = costs only (+ lattice state kept in `workspace`)
  * compute_rnnt_joint_loss_bwd  = the gradients, from the same inputs and that workspace (autograd split,
