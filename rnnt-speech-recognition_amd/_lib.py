@@ -6,7 +6,10 @@ from __future__ import annotations
 import ctypes
 import os
 
-from .build import LIB_PATH
+from .build import LIB_PATH as _DEFAULT_LIB_PATH
+
+# dev knob: load an experimental build of the library instead (scripts/build_variant.sh)
+LIB_PATH = os.environ.get("RNNT_LIBWARPRNNT", _DEFAULT_LIB_PATH)
 
 RNNT_CPU, RNNT_GPU = 0, 1
 STATUS_SUCCESS = 0

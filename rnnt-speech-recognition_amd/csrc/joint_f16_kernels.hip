@@ -31,6 +31,11 @@
 #include "rnnt_cell.h"
 
 #include <math.h>
+#ifdef JH_TRACE
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#endif
 
 namespace rnnt {
 
@@ -95,7 +100,20 @@ struct JhParams {
     float *dbpart;  // [n_ranges][V]
     const f16 *zrow;  // 1 KB of zeros: stands in for dl rows beyond the tensor (u >= U) in K4
     int J, n_ut, n_tt, n_ts, TS, n_tq, n_units, n_ranges;
+    int b2_lds_off;  // K1/K2: byte offset of the bias table in LDS, -1 = read it from global memory (does not fit)
+#ifdef JH_TRACE
+    long long *trace;  // dev builds only (-DJH_TRACE): per-wave s_memtime stamps of a few workgroups of K1
+#endif
 };
+#ifdef JH_TRACE
+constexpr int kTraceSlots = 160, kTraceBlocks = 4, kTraceStride = 4096;
+#define JT(slot)                                                                     \
+    do {                                                                             \
+        if (tr && lane == 0) tr[(slot)] = (long long)__builtin_amdgcn_s_memtime();   \
+    } while (0)
+#else
+#define JT(slot) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // prep: binary16 copies of W2 and the dlogits scale
@@ -170,65 +188,79 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
     const bool cell_valid = wave_live && (u < Ub);
     const uint32_t c = ((uint32_t)(b * p.T + tc)) * (uint32_t)p.U + (uint32_t)uc;
 
-    auto dma_chunk = [&](const int vc, char *dst) {
-        const char *src = (const char *)jp.W2Tp + (size_t)vc * chunk_bytes + lane * 16;
-        for (int i = wave; i < KS; i += 8)  // KS = chunk_bytes / 1024 wave-instructions of 1 KB
-            __builtin_amdgcn_global_load_lds((glb_cvoid *)(src + i * 1024), (lds_void *)(dst + i * 1024), 16, 0, 0);
+#ifdef JH_TRACE
+    long long *tr = nullptr;
+    if (!BWD && (blockIdx.x % kTraceStride) == kTraceStride / 2 && blockIdx.x / kTraceStride < kTraceBlocks)
+        tr = jp.trace + ((blockIdx.x / kTraceStride) * 8 + wave) * kTraceSlots;
+#endif
+    JT(0);
+    // one 1 KB piece (wave-instruction) of the LDS-DMA that brings W2^T chunk vc in; a wave owns pieces wave, wave+8, ..
+    constexpr int kPieces = (KS + 7) / 8;
+    auto dma_piece = [&](const int vc, char *dst, const int k) {
+        const int i = wave + 8 * k;
+        if (i < KS)
+            __builtin_amdgcn_global_load_lds((glb_cvoid *)((const char *)jp.W2Tp + (size_t)vc * chunk_bytes + i * 1024 + lane * 16),
+                                             (lds_void *)(dst + i * 1024), 16, 0, 0);
     };
-    dma_chunk(0, wbuf0);
+    // bias table (FWD: b2 * log2 e) in LDS behind everything else when it fits (kernel-uniform switch)
+    const bool b2_in_lds = jp.b2_lds_off >= 0;
+    const float *b2tab = BWD ? jp.b2 : jp.b2l;
+    const float *b2img = (const float *)(smem + (b2_in_lds ? jp.b2_lds_off : 0));
 
-    // ---- h row of this lane's cell, rounded to binary16, in MFMA B-fragment order.  The loads of k-step pair g+1 are
-    // issued before the tanh work of pair g (explicit two-deep pipeline: letting the compiler hoist all 4*KS loads
-    // would need 16*KS registers).
+    // ---- h row of this lane's cell, rounded to binary16, in MFMA B-fragment order.
+    // The tile's enc_proj / pred_proj rows (or their e^{2x} tables) are first brought into LDS by LDS-DMA, all pieces in
+    // flight at once: fetching them lane by lane from global memory (32-byte row pieces behind a dependent tanh chain)
+    // took 60-70k of a tile's 220k cycles.  Images (16-byte chunks; chunk c holds joint units 4c..4c+3):
+    //   Pimg [4 KS chunks][32 columns]  -- lane n of a half-wave reads consecutive chunks: conflict-free
+    //   Eimg [8 waves][4 KS chunks]     -- one row per wave, broadcast reads
+    // They overlay the W2^T buffers (and the BWD staging area), which are not in use yet.
     h8 hf[KS];
     {
         const bool slow = jp.scal[2] != 0.f;  // kernel-uniform
-        const float *erow = (slow ? jp.enc_proj : jp.expE) + ((size_t)b * p.T + tc) * J + 8 * half;
-        const float *prow = (slow ? jp.pred_proj : jp.expP) + ((size_t)b * p.U + uc) * J + 8 * half;
-        float4 cur[8], nxt[8];
-        typedef float vf4 __attribute__((ext_vector_type(4)));
-        auto vload = [](const float *q) {  // volatile: keeps its place relative to the fences below
-            const vf4 v = *(const volatile vf4 *)q;
-            return make_float4(v[0], v[1], v[2], v[3]);
-        };
-        auto fetch = [&](const int g, float4 (&d)[8]) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                d[4 * q + 0] = vload(erow + (2 * g + q) * 16);
-                d[4 * q + 1] = vload(erow + (2 * g + q) * 16 + 4);
-                d[4 * q + 2] = vload(prow + (2 * g + q) * 16);
-                d[4 * q + 3] = vload(prow + (2 * g + q) * 16 + 4);
-            }
-        };
-        fetch(0, cur);
-#pragma unroll
-        for (int g = 0; g < KS / 2; ++g) {
-            if (g + 1 < KS / 2) fetch(g + 1, nxt);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const float4 e0 = cur[4 * q], e1 = cur[4 * q + 1], c0 = cur[4 * q + 2], c1 = cur[4 * q + 3];
-                h8 v;
-                if (!slow) {
-                    v[0] = (f16)htanh2(e0.x, c0.x), v[1] = (f16)htanh2(e0.y, c0.y);
-                    v[2] = (f16)htanh2(e0.z, c0.z), v[3] = (f16)htanh2(e0.w, c0.w);
-                    v[4] = (f16)htanh2(e1.x, c1.x), v[5] = (f16)htanh2(e1.y, c1.y);
-                    v[6] = (f16)htanh2(e1.z, c1.z), v[7] = (f16)htanh2(e1.w, c1.w);
-                } else {
-                    v[0] = (f16)htanh(e0.x + c0.x), v[1] = (f16)htanh(e0.y + c0.y);
-                    v[2] = (f16)htanh(e0.z + c0.z), v[3] = (f16)htanh(e0.w + c0.w);
-                    v[4] = (f16)htanh(e1.x + c1.x), v[5] = (f16)htanh(e1.y + c1.y);
-                    v[6] = (f16)htanh(e1.z + c1.z), v[7] = (f16)htanh(e1.w + c1.w);
-                }
-                hf[2 * g + q] = v;
-                asm volatile("" ::"v"(v));  // the tanh work of this pair is done before the next pair's loads issue
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
+        const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
+        char *Pimg = smem, *Eimg = smem + KS * 4 * 32 * 16;
+        {
+            const float *prow = Ptab + ((size_t)b * p.U + uc) * J + 4 * (lane >> 5);
+            for (int i = wave; i < KS * 2; i += 8)  // piece i = chunks 2i, 2i+1 of all 32 columns
+                __builtin_amdgcn_global_load_lds((glb_cvoid *)(prow + 8 * i), (lds_void *)(Pimg + i * 1024), 16, 0, 0);
+            const float *erow = Etab + ((size_t)b * p.T + tc) * J;
+            for (int k = 0; k * 64 < KS * 4; ++k)
+                if (k * 64 + lane < KS * 4)
+                    __builtin_amdgcn_global_load_lds((glb_cvoid *)(erow + 4 * (k * 64 + lane)),
+                                                     (lds_void *)(Eimg + wave * (KS * 64) + k * 1024), 16, 0, 0);
+            if (b2_in_lds)
+                for (int i = wave; i < (V >> 8); i += 8)
+                    __builtin_amdgcn_global_load_lds((glb_cvoid *)(b2tab + i * 256 + lane * 4),
+                                                     (lds_void *)(smem + jp.b2_lds_off + i * 1024), 16, 0, 0);
         }
+        wait_vm();
+        __syncthreads();
+        const char *pl = Pimg + (2 * half * 32 + n) * 16, *el = Eimg + wave * (KS * 64) + 2 * half * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float4 e0 = *(const float4 *)(el + ks * 64), e1 = *(const float4 *)(el + ks * 64 + 16);
+            const float4 c0 = *(const float4 *)(pl + ks * 2048), c1 = *(const float4 *)(pl + ks * 2048 + 512);
+            h8 v;
+            if (!slow) {
+                v[0] = (f16)htanh2(e0.x, c0.x), v[1] = (f16)htanh2(e0.y, c0.y);
+                v[2] = (f16)htanh2(e0.z, c0.z), v[3] = (f16)htanh2(e0.w, c0.w);
+                v[4] = (f16)htanh2(e1.x, c1.x), v[5] = (f16)htanh2(e1.y, c1.y);
+                v[6] = (f16)htanh2(e1.z, c1.z), v[7] = (f16)htanh2(e1.w, c1.w);
+            } else {
+                v[0] = (f16)htanh(e0.x + c0.x), v[1] = (f16)htanh(e0.y + c0.y);
+                v[2] = (f16)htanh(e0.z + c0.z), v[3] = (f16)htanh(e0.w + c0.w);
+                v[4] = (f16)htanh(e1.x + c1.x), v[5] = (f16)htanh(e1.y + c1.y);
+                v[6] = (f16)htanh(e1.z + c1.z), v[7] = (f16)htanh(e1.w + c1.w);
+            }
+            hf[ks] = v;
+            if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the read-ahead (registers)
+        }
+        __syncthreads();  // every wave is done with the images: the W2^T buffers may be filled
     }
+#pragma unroll
+    for (int k = 0; k < kPieces; ++k) dma_piece(0, wbuf0, k);
 
+    JT(1);
     // ---- per-cell scalars
     float xb = 0.f, xl = 0.f;  // blank / label logits
     int lab = 0;
@@ -255,7 +287,28 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
 
     // ---- epilogue of one 32-column chunk: acc[r] = logit (without bias) of this lane's cell at v = 32 vc + cdrow(r, half)
     auto epilogue = [&](const f32x16 &acc, const int vc) {
-        const float *b2p = (BWD ? jp.b2 : jp.b2l) + vc * 32 + 4 * half;
+        // the four float4 of bias values this lane needs for chunk vc (typed LDS / global loads: a merged pointer would
+        // turn them into flat loads, whose wait also covers the LDS-DMA pieces in flight)
+        float4 bqs[4];
+        typedef float vf4 __attribute__((ext_vector_type(4)));
+        if (b2_in_lds) {
+            const __attribute__((address_space(3))) vf4 *q3 =
+                (const __attribute__((address_space(3))) vf4 *)(b2img + vc * 32 + 4 * half);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const vf4 v = q3[2 * q];
+                bqs[q] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        } else {
+            asm volatile("" ::: "memory");  // keep the two paths apart
+            const __attribute__((address_space(1))) vf4 *q1 =
+                (const __attribute__((address_space(1))) vf4 *)(b2tab + vc * 32 + 4 * half);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const vf4 v = q1[2 * q];
+                bqs[q] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
         if (!BWD) {
             // y = log2-scaled logits.  The running reference mref is only moved when a value exceeds it by more than
             // 2^64 (wave-uniform rare path): s = sum 2^(y - mref) stays in f32 range and keeps full precision because
@@ -264,7 +317,7 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
             float m = -1.0e30f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 bq = *(const float4 *)(b2p + 8 * q);
+                const float4 bq = bqs[q];
                 y[4 * q + 0] = fmaf(acc[4 * q + 0], kLog2e, bq.x);
                 y[4 * q + 1] = fmaf(acc[4 * q + 1], kLog2e, bq.y);
                 y[4 * q + 2] = fmaf(acc[4 * q + 2], kLog2e, bq.z);
@@ -281,6 +334,7 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
             for (int r = 0; r < 16; ++r) s += hex2(y[r] - mref);
             ssum = s;
             if (vc == vcb) {  // wave-uniform
+                asm volatile("" ::: "memory");  // keep this a branch (if-converted, it costs 17 selects per chunk)
                 float v = y[0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) v = (r == rb) ? y[r] : v;
@@ -288,6 +342,7 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
             }
             const bool mine = has_label && (vc == vcl);
             if (__any(mine)) {
+                asm volatile("" ::: "memory");
                 float v = y[0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) v = (r == rl) ? y[r] : v;
@@ -297,7 +352,7 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
             f16 *row = my_stage + n * kStageStride + (vc & 3) * 32 + 4 * half;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 bq = *(const float4 *)(b2p + 8 * q);
+                const float4 bq = bqs[q];
                 h4 d;
                 d[0] = (f16)(scaleS * hex2(fmaf(acc[4 * q + 0] + bq.x, kLog2e, c0)));
                 d[1] = (f16)(scaleS * hex2(fmaf(acc[4 * q + 1] + bq.y, kLog2e, c0)));
@@ -340,11 +395,19 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
     const int NC = V >> 5;
     f32x16 acc;
     for (int vc = 0; vc < NC; ++vc) {
+        JT(2 + 4 * vc);
         wait_vm();
         __syncthreads();  // chunk vc is in LDS; every wave is done with the other buffer
-        if (vc + 1 < NC) dma_chunk(vc + 1, ((vc + 1) & 1) ? wbuf1 : wbuf0);
+        char *nbuf = ((vc + 1) & 1) ? wbuf1 : wbuf0;
+        const bool more = vc + 1 < NC;
+        if (!wave_live && more) {
+#pragma unroll
+            for (int k = 0; k < kPieces; ++k) dma_piece(vc + 1, nbuf, k);
+        }
+        JT(3 + 4 * vc);
         if (!wave_live) continue;
         if (late && vc > 0) epilogue(acc, vc - 1);
+        JT(4 + 4 * vc);
         const char *wb = ((vc & 1) ? wbuf1 : wbuf0) + lane * 16;
         constexpr bool kTwoChains = !(BWD && KS > 32);  // two accumulation chains unless registers are short
         f32x16 acc0, acc1;
@@ -364,6 +427,11 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
                     for (int q = 0; q < G; ++q) anxt[q] = *(const h8 *)(wb + (G * (g4 + 1) + q) * 1024);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                // the next chunk's LDS-DMA pieces are issued between MFMA groups (issuing all of them at the top of the
+                // chunk cost ~150 cycles apiece with the matrix pipe idle)
+#pragma unroll
+                for (int k = 0; k < kPieces; ++k)
+                    if ((k * (KS / G)) / kPieces == g4 && more) dma_piece(vc + 1, nbuf, k);
                 if (kTwoChains) {
 #pragma unroll
                     for (int q = 0; q < G; q += 2) {
@@ -382,8 +450,10 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = kTwoChains ? acc0[r] + acc1[r] : acc0[r];
+        JT(5 + 4 * vc);
         if (!late) epilogue(acc, vc);
     }
+    JT(2 + 4 * 32);
     if (late && wave_live) epilogue(acc, NC - 1);
 
     if (!BWD && wave_live) {
@@ -814,14 +884,23 @@ static hipError_t set_lds_f16(K kernel, size_t bytes) {
 
 template <int KS>
 static hipError_t launch_logits(const JhParams &jp, bool bwd, unsigned grid, hipStream_t s) {
-    const size_t shm = 2 * (size_t)64 * (KS * 16) + (bwd ? (size_t)8 * 32 * kStageStride * sizeof(f16) : 0);
+    // W2^T double buffer (+ BWD staging), overlaid during the prologue by the enc_proj / pred_proj images; bias table last
+    size_t shm = 2 * (size_t)64 * (KS * 16) + (bwd ? (size_t)8 * 32 * kStageStride * sizeof(f16) : 0);
+    const size_t images = (size_t)KS * 4 * 32 * 16 + (size_t)8 * KS * 64;
+    if (shm < images) shm = images;
+    JhParams jq = jp;
+    jq.b2_lds_off = -1;
+    if (shm + (size_t)jp.lp.V * 4 <= 160 * 1024) {
+        jq.b2_lds_off = (int)shm;
+        shm += (size_t)jp.lp.V * 4;
+    }
     hipError_t e;
     if (bwd) {
         if ((e = set_lds_f16(jh_logits_kernel<KS, true>, shm)) != hipSuccess) return e;
-        hipLaunchKernelGGL((jh_logits_kernel<KS, true>), dim3(grid), dim3(512), shm, s, jp);
+        hipLaunchKernelGGL((jh_logits_kernel<KS, true>), dim3(grid), dim3(512), shm, s, jq);
     } else {
         if ((e = set_lds_f16(jh_logits_kernel<KS, false>, shm)) != hipSuccess) return e;
-        hipLaunchKernelGGL((jh_logits_kernel<KS, false>), dim3(grid), dim3(512), shm, s, jp);
+        hipLaunchKernelGGL((jh_logits_kernel<KS, false>), dim3(grid), dim3(512), shm, s, jq);
     }
     return hipGetLastError();
 }
@@ -849,6 +928,13 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     jp.J = J, jp.n_ut = L.n_ut, jp.n_tt = L.n_tt, jp.n_ts = L.n_ts, jp.TS = L.TS, jp.n_tq = L.n_tq;
     jp.n_units = L.n_units, jp.n_ranges = L.n_ranges;
 
+#ifdef JH_TRACE
+    static long long *trace_dev = nullptr;
+    const size_t trace_bytes = (size_t)kTraceBlocks * 8 * kTraceSlots * sizeof(long long);
+    if (!trace_dev) hipMalloc(&trace_dev, trace_bytes);
+    hipMemsetAsync(trace_dev, 0, trace_bytes, s);
+    jp.trace = trace_dev;
+#endif
     hipError_t e;
     auto logits = [&](bool bwd) -> hipError_t {
         const unsigned grid = (unsigned)B * L.n_tt * L.n_ut;
@@ -867,6 +953,18 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     if (phases & 1) {
         if (hipMemsetAsync(jp.lp.W, kFillByte, L.w.A - L.w.W, s) != hipSuccess) return hipErrorUnknown;
         if ((e = logits(false)) != hipSuccess) return e;
+#ifdef JH_TRACE
+        {
+            hipStreamSynchronize(s);
+            std::vector<long long> h(trace_bytes / sizeof(long long));
+            hipMemcpy(h.data(), trace_dev, trace_bytes, hipMemcpyDeviceToHost);
+            const char *path = getenv("JH_TRACE_FILE");
+            if (FILE *f = fopen(path ? path : "/tmp/jh_trace.bin", "wb")) {
+                fwrite(h.data(), 1, trace_bytes, f);
+                fclose(f);
+            }
+        }
+#endif
         if ((e = launch_sweeps(jp.lp, s)) != hipSuccess) return e;
     }
     if (!(phases & 2) || !d_enc_proj) return hipSuccess;
