@@ -539,26 +539,49 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
         if (i < 32) doff[k] = (uint32_t)min(u0 + (row & 31), p.U - 1) * (uint32_t)V + (uint32_t)(ck * 8);
         else doff[k] = (uint32_t)(j0 + row) * (uint32_t)V + (uint32_t)(ck * 8);
     }
-    auto wait_dma = [&](const bool more_in_flight) {
-        // 6 DMA wave-instructions per stage and wave; everything older than the newest stage must have landed
-        if (more_in_flight) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-
-    for (int t_it = t_begin; t_it < t_end; t_it += 8) {
-        const f16 *arow[4];  // wave-uniform: dl row block of the four lattice rows this wave fetches
+#ifdef JH_TRACE
+    long long *tr = (blockIdx.x == 200) ? jp.trace + (size_t)(kTraceBlocks * 8 + 8 + wave) * kTraceSlots : nullptr;
+    int tstep = 0;
+#endif
+    // The LDS stages form ONE pipeline over all (iteration, chunk) pairs of the workgroup: two chunks are always in
+    // flight, also across the epilogue of an iteration.  Prefetch cursor: iteration row tp, chunk kp, stage sp.
+    int tp = t_begin, kp = 0, sp = 0;
+    const f16 *arowP[4];  // wave-uniform dl row blocks of the prefetch iteration's four lattice rows of this wave
+    auto set_arow = [&]() {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int tr = min(t_it + ((wave + 8 * k) >> 2), t_end - 1);
-            arow[k] = jp.dl + (size_t)(b * p.T + tr) * p.U * V;
+            const int trw = min(tp + ((wave + 8 * k) >> 2), t_end - 1);
+            arowP[k] = jp.dl + (size_t)(b * p.T + trw) * p.U * V;
         }
-        auto dma = [&](const int kc, char *st) {
+    };
+    set_arow();
+    auto dma_piece = [&](const int k) {  // piece k (0..5) of the chunk under the prefetch cursor
+        const f16 *src = (k < 4 ? arowP[k] : jp.W2h) + doff[k] + kp * 64;
+        __builtin_amdgcn_global_load_lds((glb_cvoid *)src, (lds_void *)(smem + sp * kStage + (wave + 8 * k) * 1024), 16, 0, 0);
+    };
+    auto advance = [&]() {  // move the prefetch cursor to the next chunk
+        sp = (sp == 2) ? 0 : sp + 1;
+        if (++kp == NK) {
+            kp = 0;
+            tp += 8;
+            if (tp < t_end) set_arow();
+        }
+    };
+    bool pf_live = true;  // the cursor points at a chunk that exists
+    __builtin_amdgcn_s_barrier();
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const f16 *src = (k < 4 ? arow[k] : jp.W2h) + doff[k] + kc * 64;
-                __builtin_amdgcn_global_load_lds((glb_cvoid *)src, (lds_void *)(st + (wave + 8 * k) * 1024), 16, 0, 0);
-            }
-        };
+    for (int k = 0; k < 6; ++k) dma_piece(k);
+    advance();
+    pf_live = tp < t_end;
+    if (pf_live) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dma_piece(k);
+        advance();
+        pf_live = tp < t_end;
+    }
+    int sc = 0;  // stage of the chunk being multiplied
+
+    for (int t_it = t_begin; t_it < t_end; t_it += 8) {
         f32x16 acc[2][2];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -566,16 +589,33 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-        // three LDS stages: chunks kc+1 and kc+2 are in flight while chunk kc is multiplied
-        __builtin_amdgcn_s_barrier();  // previous iteration: every wave is done with all stages
-        dma(0, smem);
-        if (NK > 1) dma(1, smem + kStage);
+        // enc_proj factors of the epilogue, fetched now (their latency hides under the K loop)
+        float ejv[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                ejv[mi][ni] = Etab[((size_t)b * p.T + min(t_it + 2 * wm + mi, t_end - 1)) * J + j0 + wn * 64 + ni * 32 + n];
         for (int kc = 0; kc < NK; ++kc) {
-            wait_dma(kc + 1 < NK);
-            __builtin_amdgcn_s_barrier();  // chunk kc complete in LDS; stage (kc+2)%3 was last read for chunk kc-1
+#ifdef JH_TRACE
+            const bool tron = tr && tstep < 52;
+            if (tron && lane == 0) tr[3 * tstep] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+            // chunk (t_it, kc) must have landed.  The first chunk of an iteration follows an epilogue whose stores
+            // share vmcnt with the DMA (and may retire out of order): drain everything there (the two chunks in flight
+            // were issued before the epilogue, long ago); otherwise all but the newest stage.
+            const bool last_chunk = (t_it + 8 >= t_end) && (kc == NK - 1);
+            if (kc == 0 || last_chunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // chunk complete in LDS; the stage under the prefetch cursor is free
             asm volatile("" ::: "memory");
-            if (kc + 2 < NK) dma(kc + 2, smem + ((kc + 2) % 3) * kStage);
-            const char *A = smem + (kc % 3) * kStage, *Bm = A + 256 * 128;
+#ifdef JH_TRACE
+            if (tron && lane == 0) tr[3 * tstep + 1] = (long long)__builtin_amdgcn_s_memtime();
+            if (tron && lane == 0) tr[3 * tstep + 2] = (long long)__builtin_amdgcn_s_memtime();
+            ++tstep;
+#endif
+            if (kc == 1) asm volatile("" ::"v"(ejv[0][0]), "v"(ejv[0][1]), "v"(ejv[1][0]), "v"(ejv[1][1]));
+            const char *A = smem + sc * kStage, *Bm = A + 256 * 128;
             h8 a[2][2], bf[2][2];  // fragments of k-step ks in [ks & 1]: read one k-step ahead of their MFMAs
             auto rd = [&](const int ks, h8 (&aa)[2], h8 (&bb)[2]) {
 #pragma unroll
@@ -594,6 +634,11 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
             for (int ks = 0; ks < 4; ++ks) {
                 if (ks + 1 < 4) rd(ks + 1, a[(ks + 1) & 1], bf[(ks + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
+                // the six LDS-DMA pieces of the chunk two ahead are issued between the MFMA groups (2 + 2 + 2)
+                if (pf_live && ks < 3) {
+                    dma_piece(2 * ks);
+                    dma_piece(2 * ks + 1);
+                }
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -601,6 +646,11 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks & 1][mi], bf[ks & 1][ni], acc[mi][ni], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (pf_live) {
+                advance();
+                pf_live = tp < t_end;
+            }
+            sc = (sc == 2) ? 0 : sc + 1;
         }
         // epilogue: acc[mi][ni][r] = S * dh[row t_it + 2 wm + mi][column u0 + cdrow(r, half)][unit j0 + 64 wn + 32 ni + n]
 #pragma unroll
@@ -610,7 +660,7 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     const int j = j0 + wn * 64 + ni * 32 + n;
-                    const float ej = Etab[((size_t)b * p.T + t) * J + j];
+                    const float ej = ejv[mi][ni];
                     float colsum = 0.f;
                     float hh[16];
                     if (!slow) {
@@ -689,6 +739,10 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
     const bool slow = jp.scal[2] != 0.f;  // kernel-uniform
     const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
     char *ebuf = smem + 3 * kStage;  // [4][128] enc_proj values of the workgroup's joint units, one lattice row each
+#ifdef JH_TRACE
+    long long *tr = (blockIdx.x == 100) ? jp.trace + (size_t)(kTraceBlocks * 8 + wave) * kTraceSlots : nullptr;
+    int tstep = 0;
+#endif
     for (int unit = unit_lo; unit < unit_hi; ++unit) {
         int q = unit;
         const int tq = q % jp.n_tq;
@@ -722,6 +776,12 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
                 __builtin_amdgcn_global_load_lds((glb_cvoid *)src, (lds_void *)(st + i * kDRow), 16, 0, 0);
             }
         };
+        auto dma_d_piece = [&](const int s, char *st, const int k) {  // piece k (0..3) of the same
+            const int t = t_begin + s, i = wave + 8 * k;
+            const f16 *src = (u0 + i < p.U) ? jp.dl + ((size_t)(b * p.T + t) * p.U + u0 + i) * V + v0 + lane * 8
+                                            : jp.zrow + lane * 8;
+            __builtin_amdgcn_global_load_lds((glb_cvoid *)src, (lds_void *)(st + i * kDRow), 16, 0, 0);
+        };
         auto build_h = [&](const int s, char *st) {
             const float ej = ((const float *)(ebuf + (s & 3) * 512))[jl];
             float hh[8];
@@ -752,36 +812,75 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
             build_h(1, smem + kStage);
         }
         for (int s = 0; s < nsteps; ++s) {
+#ifdef JH_TRACE
+            const bool tron = tr && tstep < 39;
+            if (tron && lane == 0) tr[4 * tstep] = (long long)__builtin_amdgcn_s_memtime();
+#endif
             if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // all but the newest stage's dl rows
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wait_lgkm();
             __builtin_amdgcn_s_barrier();  // stage s complete (dl rows + h^T); stage (s+2)%3 free; enc_proj row s+2 visible
             asm volatile("" ::: "memory");
-            if (s + 2 < nsteps) {
-                char *st = smem + ((s + 2) % 3) * kStage;
-                if (s + 3 < nsteps) dma_e(s + 3);
-                dma_d(s + 2, st);
-                build_h(s + 2, st);
-            }
+#ifdef JH_TRACE
+            if (tron && lane == 0) tr[4 * tstep + 1] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+            // Stage s+2 is prepared WHILE stage s is multiplied: its five LDS-DMA pieces go out between the MFMA pairs of
+            // the first k-step, its h^T values (8 tanh per thread) are computed between those of the second, and are
+            // written to LDS at the end.  (Done up front, as a block, they cost 1100-1500 cycles per 32-cell step with
+            // the matrix pipe idle: all eight waves are in the same phase after every barrier.)
+            const bool pf = s + 2 < nsteps;
+            char *stn = smem + ((s + 2) % 3) * kStage;
+            float ejn = 0.f, hh[8];
+            if (pf) ejn = ((const float *)(ebuf + ((s + 2) & 3) * 512))[jl];
+#ifdef JH_TRACE
+            if (tron && lane == 0) tr[4 * tstep + 2] = (long long)__builtin_amdgcn_s_memtime();
+            if (tron && lane == 0) tr[4 * tstep + 3] = (long long)__builtin_amdgcn_s_memtime();
+            ++tstep;
+#endif
             const char *D = smem + (s % 3) * kStage, *H = D + kDBytes;
             const int g4 = lane >> 4, pl = lane & 15;
+            // all fragment reads of the step first (2 x (2 A + 8 transposed B)), then MFMA pairs with the staging work
+            // of stage s+2 between them
+            h8 a[2][2];
+            h4 blo[2][4], bhi[2][4];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                h8 a[2];
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb)
-                    a[jb] = *(const h8 *)(H + ((ks * 4 + wj * 2 + jb) * 64 + lane) * 16);
+                    a[ks][jb] = *(const h8 *)(H + ((ks * 4 + wj * 2 + jb) * 64 + lane) * 16);
                 const int row0 = ks * 16 + 8 * (g4 >> 1) + (pl >> 2);
 #pragma unroll
                 for (int vb = 0; vb < 4; ++vb) {
                     const int col = wv * 128 + vb * 32 + 16 * (g4 & 1) + 4 * (pl & 3);
                     const char *ad = D + row0 * kDRow + col * 2;
-                    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)ad);
-                    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(ad + 4 * kDRow));
-                    const h4 lo4 = __builtin_bit_cast(h4, lo), hi4 = __builtin_bit_cast(h4, hi);
+                    blo[ks][vb] = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)ad));
+                    bhi[ks][vb] = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(ad + 4 * kDRow)));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int vb = 0; vb < 4; ++vb) {
+                    const h4 lo4 = blo[ks][vb], hi4 = bhi[ks][vb];
                     const h8 bf = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
-                    acc[0][vb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bf, acc[0][vb], 0, 0, 0);
-                    acc[1][vb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bf, acc[1][vb], 0, 0, 0);
+                    acc[0][vb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][0], bf, acc[0][vb], 0, 0, 0);
+                    acc[1][vb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][1], bf, acc[1][vb], 0, 0, 0);
+                    if (pf) {
+                        if (ks == 0) {
+                            if (vb == 0 && s + 3 < nsteps) dma_e(s + 3);
+                            dma_d_piece(s + 2, stn, vb);
+                        } else {
+                            // two of this thread's eight h values of row s+2
+                            if (!slow) {
+                                hh[2 * vb] = htanh2(ejn, pv[2 * vb]);
+                                hh[2 * vb + 1] = htanh2(ejn, pv[2 * vb + 1]);
+                            } else {
+                                hh[2 * vb] = htanh(ejn + pv[2 * vb]);
+                                hh[2 * vb + 1] = htanh(ejn + pv[2 * vb + 1]);
+                            }
+                        }
+                    }
                     if (do_db) {
                         float sdb = dbacc[vb];
                         sdb = __builtin_amdgcn_fdot2(__builtin_shufflevector(lo4, lo4, 0, 1), ones, sdb, false);
@@ -790,7 +889,14 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
                         sdb = __builtin_amdgcn_fdot2(__builtin_shufflevector(hi4, hi4, 2, 3), ones, sdb, false);
                         dbacc[vb] = sdb;
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+            }
+            if (pf) {
+                h8 hv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = (u0 + 8 * cg + e < Ub) ? (f16)hh[e] : (f16)0.f;  // beyond U_b: no gradient
+                *(h8 *)(stn + kDBytes + ((((cg >> 1) * 4 + (jl >> 5)) * 2 + (cg & 1)) * 32 + (jl & 31)) * 16) = hv;
             }
         }
     }
@@ -930,7 +1036,7 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
 
 #ifdef JH_TRACE
     static long long *trace_dev = nullptr;
-    const size_t trace_bytes = (size_t)kTraceBlocks * 8 * kTraceSlots * sizeof(long long);
+    const size_t trace_bytes = (size_t)(kTraceBlocks + 2) * 8 * kTraceSlots * sizeof(long long);
     if (!trace_dev) hipMalloc(&trace_dev, trace_bytes);
     hipMemsetAsync(trace_dev, 0, trace_bytes, s);
     jp.trace = trace_dev;
@@ -988,7 +1094,20 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     if ((e = launch_reduce_partials(d_enc_proj, jp.dApart, L.n_ut, (size_t)B * T * J, s)) != hipSuccess) return e;
     if ((e = launch_reduce_partials(d_pred_proj, jp.dCpart, L.n_ts, (size_t)B * U * J, s)) != hipSuccess) return e;
     if ((e = launch_reduce_partials(dW2, jp.dWpart, L.n_ranges, (size_t)J * V, s)) != hipSuccess) return e;
-    return launch_reduce_partials(db2, jp.dbpart, L.n_ranges, (size_t)V, s);
+    e = launch_reduce_partials(db2, jp.dbpart, L.n_ranges, (size_t)V, s);
+#ifdef JH_TRACE
+    {
+        hipStreamSynchronize(s);
+        std::vector<long long> h(trace_bytes / sizeof(long long));
+        hipMemcpy(h.data(), trace_dev, trace_bytes, hipMemcpyDeviceToHost);
+        const char *path = getenv("JH_TRACE_FILE");
+        if (FILE *f = fopen(path ? path : "/tmp/jh_trace.bin", "wb")) {
+            fwrite(h.data(), 1, trace_bytes, f);
+            fclose(f);
+        }
+    }
+#endif
+    return e;
 }
 
 }  // namespace rnnt
