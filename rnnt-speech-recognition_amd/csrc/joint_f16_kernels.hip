@@ -576,7 +576,7 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
     if (pf_live) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) dma_piece(k);
-        advance();
+            advance();
         pf_live = tp < t_end;
     }
     int sc = 0;  // stage of the chunk being multiplied
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (pf_live) {
-                advance();
+                            advance();
                 pf_live = tp < t_end;
             }
             sc = (sc == 2) ? 0 : sc + 1;
