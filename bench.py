@@ -293,8 +293,14 @@ def main():
 
     # ---- fused joint + loss (SURVEY.md 8d "P2"): reported beside the headline, not as `value` ----
     fused = None
+    fused_c5 = None
     if rank == 0 and not a.no_fused:
         fused = bench_fused_joint(lib, _lib, dev, B, T, U, V, a.joint_size, stream, max(3, min(a.steps, 10)))
+        if world == 1 and (B, T, U, V) == (32, 600, 150, 28):
+            # BASELINE configs[4] (large-vocabulary stress, f16 MFMA joint / f32 lattice): a parity-test case, timed here
+            # too because it is the path's MFMA-bound corner (3 steps, ~16 GB of workspace)
+            torch.cuda.empty_cache()
+            fused_c5 = bench_fused_joint(lib, _lib, dev, 16, 1500, 300, 1024, 640, stream, 3)
 
     e2e = None
     if a.e2e:
@@ -312,7 +318,7 @@ def main():
             "config": {"workload": f"transducer loss+grad on given logits (warp-transducer op contract), "
                                    f"B={B} T={T} U={U} V={V} per GPU, full lengths, acts~N(0,1)",
                        "global_batch": B * world, "parallelism": f"utterance-sharded x{world}, no data-path collective"},
-            "roofline": roof, "cpu_baseline": cpu, "fused_joint": fused,
+            "roofline": roof, "cpu_baseline": cpu, "fused_joint": fused, "fused_joint_config5": fused_c5,
         }
         if e2e is not None:
             out["e2e_train_step"] = e2e

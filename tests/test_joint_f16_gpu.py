@@ -39,12 +39,12 @@ def make(B, T, U, H, J, V, ragged, seed):
     return enc, pred, W1, b1, W2, b2, labels, il.astype(np.int32), ll.astype(np.int32)
 
 
-def run(case, scale, joint_dtype="f16"):
+def run(case, scale, joint_dtype="f16", blank=0):
     enc, pred, W1, b1, W2, b2, labels, il, ll = case
     dev = torch.device("cuda:0")
     t = lambda x: torch.tensor(x, device=dev)
     params = [t(x).requires_grad_(True) for x in (enc, pred, W1, b1, W2, b2)]
-    costs = pkg.rnnt_joint_loss(*params, t(labels), t(il), t(ll), joint_dtype=joint_dtype)
+    costs = pkg.rnnt_joint_loss(*params, t(labels), t(il), t(ll), blank_label=blank, joint_dtype=joint_dtype)
     (costs * t(scale.astype(np.float32))).sum().backward()
     torch.cuda.synchronize()
     return costs.detach().cpu().numpy(), [p.grad.cpu().numpy() for p in params]
@@ -90,6 +90,32 @@ def test_joint_f16_large_preactivations_take_the_exact_tanh_path():
     assert np.isfinite(costs).all() and all(np.isfinite(g).all() for g in grads)
     np.testing.assert_allclose(costs, ref["costs"], rtol=1e-4)
     for g, key in zip(grads, ("d_enc", "d_pred", "dW1", "db1", "dW2", "db2")):
+        assert np.abs(g - ref[key]).max() <= 5e-4 * max(1.0, np.abs(ref[key]).max()), key
+
+
+EDGE = [
+    # B, T, U, H, J, V, blank, scale
+    (2, 1, 6, 8, 128, 512, 0, [1.0, 1.0]),         # a single frame
+    (2, 9, 1, 8, 128, 512, 0, [1.0, 0.5]),         # no labels at all (U = 1): blank-only lattice
+    (1, 1, 1, 8, 128, 512, 0, [1.0]),              # one cell
+    (2, 10, 7, 8, 128, 512, 5, [1.0, 1.0]),        # blank in the middle of a chunk
+    (2, 10, 7, 8, 128, 1024, 1023, [1.0, 1.0]),    # blank = last column of the last chunk
+    (3, 12, 5, 8, 128, 512, 0, [0.0, -0.5, 3.0]),  # zero / negative / large upstream gradients (dlogits scale 2^12)
+]
+
+
+@pytest.mark.parametrize("B,T,U,H,J,V,blank,scale", EDGE)
+def test_joint_f16_edge_cases(B, T, U, H, J, V, blank, scale):
+    enc, pred, W1, b1, W2, b2, labels, il, ll = make(B, T, U, H, J, V, B > 1, seed=T * 7 + U + blank)
+    if blank:  # labels must avoid the blank id
+        labels = np.where(labels == blank, (blank + 1) % V, labels).astype(np.int32)
+    case = (enc, pred, W1, b1, W2, b2, labels, il, ll)
+    scale = np.asarray(scale, np.float64)
+    costs, grads = run(case, scale, blank=blank)
+    ref = orc.joint_loss_and_grads_f16(*case, blank=blank, cost_scale=scale)
+    np.testing.assert_allclose(costs, ref["costs"], rtol=1e-4)
+    for g, key in zip(grads, ("d_enc", "d_pred", "dW1", "db1", "dW2", "db2")):
+        assert np.isfinite(g).all(), key
         assert np.abs(g - ref[key]).max() <= 5e-4 * max(1.0, np.abs(ref[key]).max()), key
 
 
