@@ -119,6 +119,23 @@ def test_joint_f16_edge_cases(B, T, U, H, J, V, blank, scale):
         assert np.abs(g - ref[key]).max() <= 5e-4 * max(1.0, np.abs(ref[key]).max()), key
 
 
+def test_joint_goldens(golden_dir):
+    """HIP fused joint (both dtypes) against the committed fixtures tests/golden/joint/*.npz."""
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(golden_dir, "joint", "*.npz")))
+    assert len(files) >= 2
+    for f in files:
+        z = np.load(f)
+        case = tuple(z[k] for k in ("enc", "pred", "W1", "b1", "W2", "b2", "labels", "input_lengths", "label_lengths"))
+        f16 = str(z["joint_dtype"]) == "f16"
+        costs, grads = run(case, z["cost_scale"], joint_dtype="f16" if f16 else "f32")
+        np.testing.assert_allclose(costs, z["costs"], rtol=1e-4)
+        for g, key in zip(grads, ("d_enc", "d_pred", "dW1", "db1", "dW2", "db2")):
+            tol = (5e-4 if f16 else 1e-4) * max(1.0, np.abs(z[key]).max())
+            assert np.abs(g - z[key]).max() <= tol, (os.path.basename(f), key)
+
+
 def test_joint_f16_is_deterministic():
     case = make(2, 40, 40, 16, 128, 512, True, seed=11)
     scale = np.ones(2)

@@ -159,3 +159,36 @@ def test_joint_oracle_backward_fd():
             am[idx] -= eps
             fd[idx] = (total(**{name: ap})[0] - total(**{name: am})[0]) / (2 * eps)
         np.testing.assert_allclose(out[key], fd, atol=2e-7, err_msg=name)
+
+
+def test_joint_goldens_regression(golden_dir):
+    """The committed fused-joint fixtures are what today's oracle produces (f32 joint and f16-MFMA joint)."""
+    files = sorted(glob.glob(os.path.join(golden_dir, "joint", "*.npz")))
+    assert len(files) >= 2
+    for f in files:
+        z = np.load(f)
+        fn = orc.joint_loss_and_grads if str(z["joint_dtype"]) == "f32" else orc.joint_loss_and_grads_f16
+        r = fn(z["enc"], z["pred"], z["W1"], z["b1"], z["W2"], z["b2"], z["labels"], z["input_lengths"],
+               z["label_lengths"], cost_scale=z["cost_scale"])
+        np.testing.assert_allclose(r["costs"], z["costs"], rtol=1e-12)
+        for k in ("d_enc", "d_pred", "dW1", "db1", "dW2", "db2"):
+            np.testing.assert_allclose(r[k], z[k], rtol=0, atol=1e-6 * max(1.0, np.abs(z[k]).max()))
+
+
+def test_f16_joint_oracle_stays_close_to_the_exact_joint():
+    """The stated binary16 roundings cost ~1e-4 relative on the costs and ~1e-3 on the gradients, no more."""
+    rng = np.random.default_rng(3)
+    B, T, U, H, J, V = 2, 7, 5, 6, 32, 64
+    enc, pred = rng.normal(size=(B, T, H)), rng.normal(size=(B, U, H))
+    W1, b1 = 0.3 * rng.normal(size=(H, J)), 0.1 * rng.normal(size=J)
+    W2, b2 = 0.3 * rng.normal(size=(J, V)), 0.1 * rng.normal(size=V)
+    labels = rng.integers(1, V, size=(B, U - 1))
+    il, ll = np.array([T, T - 2]), np.array([U - 1, U - 3])
+    a = orc.joint_loss_and_grads(enc, pred, W1, b1, W2, b2, labels, il, ll)
+    h = orc.joint_loss_and_grads_f16(enc, pred, W1, b1, W2, b2, labels, il, ll)
+    np.testing.assert_allclose(h["costs"], a["costs"], rtol=5e-4)
+    for k in ("d_enc", "d_pred", "dW2", "db2"):
+        assert np.abs(h[k] - a[k]).max() <= 5e-3 * max(1.0, np.abs(a[k]).max()), k
+    assert orc.dl_scale_f16(None, 3) == 2.0 ** 14
+    assert orc.dl_scale_f16([0.25, -1.0], 2) == 2.0 ** 14 and orc.dl_scale_f16([3.0], 1) == 2.0 ** 12
+    assert orc.dl_scale_f16([1.0 / 512], 1) == 2.0 ** 23
