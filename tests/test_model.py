@@ -68,3 +68,27 @@ def test_train_step_reduces_loss_and_matches_unfused_loss():
         losses.append(step(*batch)["loss"])
     assert np.isfinite(losses).all() and losses[-1] < 0.9 * first, losses[::8]
     assert abs(step.evaluate(*batch) - losses[-1]) < 0.5 * first
+
+
+@pytest.mark.gpu
+def test_word_piece_sized_model_trains_through_the_f16_joint():
+    """Vocabulary 512 / joint width 128: JointLoss picks the f16-MFMA joint on its own (reference: --fp16_run with the
+    word-piece vocabulary, hparams.py:5, run_rnnt.py:96-99).  Fused costs stay within binary16 distance of the unfused
+    f32 composition, SGD makes progress, greedy decoding runs on the trained model."""
+    torch.manual_seed(1)
+    dev = torch.device("cuda:0")
+    hp = pkg.HParams(vocab_size=512, mel_bins=4, downsample_factor=2, embedding_size=16, encoder_layers=2,
+                     encoder_size=32, projection_size=16, time_reduction_index=0, pred_net_layers=1, pred_net_size=32,
+                     joint_net_size=128, learning_rate=1e-3)
+    m = pkg.Transducer(hp).to(dev)
+    batch = pkg.synthetic_batch(hp, batch=4, frames=36, max_labels=6, device=dev, seed=5)
+    mel, pred_inp, spec_len, lab_len, labels = batch
+    m.eval()
+    fused = m.loss(*batch)
+    unfused = pkg.get_loss_fn(hp.time_reduction_factor)(labels, m.logits(mel, pred_inp), spec_len, lab_len)
+    np.testing.assert_allclose(fused.detach().cpu().numpy(), unfused.detach().cpu().numpy(), rtol=2e-3)
+    step = pkg.TrainStep(m, global_batch=4)
+    losses = [step(*batch)["loss"] for _ in range(30)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses[::6]
+    hyp = pkg.greedy_decode(m, mel, max_length=8)
+    assert hyp.shape[0] == 1 and hyp.shape[1] <= 8 and int(hyp.min() if hyp.numel() else 1) > 0
