@@ -405,7 +405,23 @@ __global__ __launch_bounds__(256) void cell_wave_kernel(const LossParams p) {
         if (!GRAD) {
             if (!cl.valid) continue;
             float m = -FLT_MAX, s = 0.f;
-            if (V4) {
+            if (V4 && V <= 2048) {
+                // the lane's share of the row fits 8 float4 registers: one pass for the maximum, one exponential per
+                // logit (the online update below costs two) -- this pass was VALU-bound at V = 1024
+                float4 q[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = lane * 4 + k * 256;
+                    q[k] = (i < V) ? *(const float4 *)(x + i) : make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+                    m = fmaxf(fmaxf(m, fmaxf(q[k].x, q[k].y)), fmaxf(q[k].z, q[k].w));
+                }
+                const float nm = -m * kLog2e;  // lanes beyond the row keep m = -FLT_MAX, s = 0 (merged below like any other)
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (lane * 4 + k * 256 < V)
+                        s += (ex2(fmaf(q[k].x, kLog2e, nm)) + ex2(fmaf(q[k].y, kLog2e, nm))) +
+                             (ex2(fmaf(q[k].z, kLog2e, nm)) + ex2(fmaf(q[k].w, kLog2e, nm)));
+            } else if (V4) {
                 for (int i = lane * 4; i < V; i += 256) {
                     const float4 q = *(const float4 *)(x + i);
                     online_upd(m, s, q.x), online_upd(m, s, q.y), online_upd(m, s, q.z), online_upd(m, s, q.w);
@@ -459,7 +475,9 @@ __global__ __launch_bounds__(256) void cell_wave_kernel(const LossParams p) {
                         if (i + k == lab) gv -= corr_l;
                         r[k] = gv;
                     }
-                    *(float4 *)(gd + i) = make_float4(r[0], r[1], r[2], r[3]);
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    const v4f out = {r[0], r[1], r[2], r[3]};
+                    __builtin_nontemporal_store(out, (v4f *)(gd + i));  // written once, never re-read by this op
                 }
             } else {
                 for (int i = lane; i < V; i += 64) {
