@@ -189,7 +189,11 @@ def main():
     import rnnt_speech_recognition_amd as pkg
     from rnnt_speech_recognition_amd import _lib
 
-    pkg.build()
+    # one rank compiles (if the in-tree library is stale at all), the others wait for it
+    if rank == 0:
+        pkg.build()
+    if world > 1:
+        dist.barrier()
     lib = _lib.load()
 
     if a.fused_only:

@@ -38,7 +38,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libwarprnnt.so (ROCm toolchain required)")
     os.makedirs(LIB_DIR, exist_ok=True)
-    tmp = LIB_PATH + ".tmp"
+    tmp = LIB_PATH + f".tmp{os.getpid()}"  # several ranks may arrive here at once
     cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
