@@ -40,6 +40,14 @@ __device__ __forceinline__ float jlg2(float x) { return __builtin_amdgcn_logf(x)
 __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + jex2(x * 2.8853900817779268f));
 }
+// tanh(a + c) from the tabulated factors ea = e^{2a}, ec = e^{2c} (joint_prep_kernel): one multiply-add, one reciprocal,
+// one multiply-add instead of an exponential and a reciprocal.  Exact to ~1e-7 while |a|, |c| <= kExpTabLimit (both
+// factors are normal f32 numbers; an overflowing product gives +1, an underflowing one -1, like tanh).  Beyond that
+// the prep kernel raises a flag and the kernels evaluate fast_tanh(a + c) on the raw projections.
+__device__ __forceinline__ float tanh_from_exp(float ea, float ec) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(fmaf(ea, ec, 1.0f));
+}
+constexpr float kExpTabLimit = 43.0f;
 // row of the 32x32 MFMA C/D tile held in register `reg` of a lane in half `half` (= lane >> 5)
 __device__ __forceinline__ constexpr int cd_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
@@ -52,8 +60,25 @@ struct JointParams {
     float *dWpart;  // [B*n_ut*n_ts][J][32]
     float *dbpart;  // [ceil(cells/256)][32]
     float *d_enc_proj, *d_pred_proj, *dW2, *db2;
+    float *expE, *expP;  // [B][T][J], [B][U][J]  e^{2 x} tables of the two projections
+    float *tflag;        // [0] != 0: some |projection| exceeds kExpTabLimit, use the raw projections + fast_tanh
     int J, n_ut, TR, n_tr, TS, n_ts;
 };
+
+// tables for tanh_from_exp + the overflow flag (zeroed before the launch)
+__global__ __launch_bounds__(256) void joint_prep_kernel(const JointParams jp) {
+    const LossParams &p = jp.lp;
+    const size_t nE = (size_t)p.B * p.T * jp.J, nP = (size_t)p.B * p.U * jp.J;
+    bool big = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nE + nP; i += (size_t)gridDim.x * 256) {
+        const float x = (i < nE) ? jp.enc_proj[i] : jp.pred_proj[i - nE];
+        big |= !(fabsf(x) <= kExpTabLimit);  // also catches NaN
+        const float ex = jex2(x * 2.8853900817779268f);
+        if (i < nE) jp.expE[i] = ex;
+        else jp.expP[i - nE] = ex;
+    }
+    if (__any(big) && (threadIdx.x & 63) == 0) jp.tflag[0] = 1.0f;
+}
 
 constexpr int kP1Waves = 8;    // phase-1 workgroup = 8 waves (2 per SIMD: one wave's tanh VALU hides the other's MFMA issue)
 constexpr int kStagePad = 33;  // row stride of the per-wave 32x32 staging tiles (bank-conflict free both ways)
@@ -74,6 +99,8 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
     float *stage = Arow + kP1Waves * J;    // [kP1Waves][32][kStagePad]
     float *my_arow = Arow + wave * J;
     float *my_stage = stage + wave * 32 * kStagePad;
+    const bool slow = jp.tflag[0] != 0.f;  // kernel-uniform
+    const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
 
     int bid = blockIdx.x;
     const int tr = bid % jp.n_tr;
@@ -90,7 +117,7 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
         for (int idx = tid; idx < 32 * (J / 4); idx += kP1Waves * 64) {
             const int u = idx & 31, j4 = idx >> 5;
             float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u0 + u < p.U) c4 = *(const float4 *)(jp.pred_proj + ((size_t)b * p.U + u0 + u) * J + j4 * 4);
+            if (u0 + u < p.U) c4 = *(const float4 *)(Ptab + ((size_t)b * p.U + u0 + u) * J + j4 * 4);
             Ct[(j4 * 4 + 0) * 32 + u] = c4.x;
             Ct[(j4 * 4 + 1) * 32 + u] = c4.y;
             Ct[(j4 * 4 + 2) * 32 + u] = c4.z;
@@ -106,7 +133,7 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
         if (active)
             for (int j = lane; j < J; j += 64) {
                 const int jc = j >> 5, r = j & 31;
-                my_arow[jc * 32 + (r & 1) * 16 + (r >> 1)] = jp.enc_proj[((size_t)b * p.T + t) * J + j];
+                my_arow[jc * 32 + (r & 1) * 16 + (r >> 1)] = Etab[((size_t)b * p.T + t) * J + j];
             }
         f32x16 acc;
 #pragma unroll
@@ -143,11 +170,20 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
                     const float4 a4 = *(const float4 *)(my_arow + jc * 32 + half * 16 + q * 4);
                     av[4 * q] = a4.x, av[4 * q + 1] = a4.y, av[4 * q + 2] = a4.z, av[4 * q + 3] = a4.w;
                 }
+                if (!slow) {
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) {
-                    const int jl = 2 * kk + half;
-                    const float h = fast_tanh(av[kk] + Ct[(jc * 32 + jl) * 32 + l31]);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h, wbuf[jl * 32 + l31], acc, 0, 0, 0);
+                    for (int kk = 0; kk < 16; ++kk) {
+                        const int jl = 2 * kk + half;
+                        const float h = tanh_from_exp(av[kk], Ct[(jc * 32 + jl) * 32 + l31]);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h, wbuf[jl * 32 + l31], acc, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) {
+                        const int jl = 2 * kk + half;
+                        const float h = fast_tanh(av[kk] + Ct[(jc * 32 + jl) * 32 + l31]);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h, wbuf[jl * 32 + l31], acc, 0, 0, 0);
+                    }
                 }
             }
             if (jc + 1 < nchunk) w2_park(jc + 1, wreg);
@@ -282,6 +318,8 @@ __global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp)
     float *dlr = W2s + 64 * kStagePad;          // [4][32][kStagePad]
     float *red = dlr + 4 * 32 * kStagePad;      // [4][32][kStagePad]
     float *my_dl = dlr + wave * 32 * kStagePad;
+    const bool slow = jp.tflag[0] != 0.f;  // kernel-uniform
+    const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
 
     int bid = blockIdx.x;
     const int ts = bid % jp.n_ts;
@@ -305,7 +343,7 @@ __global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp)
         for (int idx = tid; idx < 32 * 16; idx += 256) {  // C slab, transposed: Cs[j][u]
             const int u = idx & 31, j4 = idx >> 5;
             float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u0 + u < p.U) c4 = *(const float4 *)(jp.pred_proj + ((size_t)b * p.U + u0 + u) * J + j0 + j4 * 4);
+            if (u0 + u < p.U) c4 = *(const float4 *)(Ptab + ((size_t)b * p.U + u0 + u) * J + j0 + j4 * 4);
             Cs[(j4 * 4 + 0) * kCs + u] = c4.x;
             Cs[(j4 * 4 + 1) * kCs + u] = c4.y;
             Cs[(j4 * 4 + 2) * kCs + u] = c4.z;
@@ -344,7 +382,7 @@ __global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp)
                 my_dl[(e >> 5) * kStagePad + (e & 31)] = dnext[q];
             }
             dl_fetch(t + 4, dnext);  // next row of this wave: latency hides under this row's MFMAs
-            const float *arow = jp.enc_proj + ((size_t)b * p.T + t) * J + j0;
+            const float *arow = Etab + ((size_t)b * p.T + t) * J + j0;
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
                 // h tile in C/D layout: rows = lattice columns u, column = joint unit j = jt*32 + l31
@@ -353,10 +391,17 @@ __global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 c4 = *(const float4 *)(Cs + (jt * 32 + l31) * kCs + 8 * g + 4 * half);
-                    h[4 * g + 0] = fast_tanh(aj + c4.x);
-                    h[4 * g + 1] = fast_tanh(aj + c4.y);
-                    h[4 * g + 2] = fast_tanh(aj + c4.z);
-                    h[4 * g + 3] = fast_tanh(aj + c4.w);
+                    if (!slow) {
+                        h[4 * g + 0] = tanh_from_exp(aj, c4.x);
+                        h[4 * g + 1] = tanh_from_exp(aj, c4.y);
+                        h[4 * g + 2] = tanh_from_exp(aj, c4.z);
+                        h[4 * g + 3] = tanh_from_exp(aj, c4.w);
+                    } else {
+                        h[4 * g + 0] = fast_tanh(aj + c4.x);
+                        h[4 * g + 1] = fast_tanh(aj + c4.y);
+                        h[4 * g + 2] = fast_tanh(aj + c4.z);
+                        h[4 * g + 3] = fast_tanh(aj + c4.w);
+                    }
                 }
                 // dh[u][j] = sum_v dl[u][v] * W2[j][v]
                 f32x16 dh;
@@ -461,7 +506,7 @@ __global__ __launch_bounds__(256) void reduce_small_kernel(float *out, const flo
 // ---------------------------------------------------------------------------------------------
 struct JointLayout {
     WsLayout w;
-    size_t dl, dApart, dCpart, dWpart, dbpart, total;
+    size_t dl, dApart, dCpart, dWpart, dbpart, expE, expP, tflag, total;
     int n_ut, TR, n_tr, TS, n_ts;
 };
 
@@ -485,6 +530,9 @@ static JointLayout make_joint_layout(int T, int U, int B, int J) {
     L.dCpart = take((size_t)L.n_ts * B * U * J * sizeof(float));
     L.dWpart = take((size_t)B * L.n_ut * L.n_ts * J * 32 * sizeof(float));
     L.dbpart = take(((size_t)B * T * U + 255) / 256 * 32 * sizeof(float));
+    L.expE = take((size_t)B * T * J * sizeof(float));
+    L.expP = take((size_t)B * U * J * sizeof(float));
+    L.tflag = take(256);
     L.total = off;
     return L;
 }
@@ -553,6 +601,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     jp.dWpart = (float *)(ws + L.dWpart);
     jp.dbpart = (float *)(ws + L.dbpart);
     jp.d_enc_proj = d_enc_proj, jp.d_pred_proj = d_pred_proj, jp.dW2 = dW2, jp.db2 = db2;
+    jp.expE = (float *)(ws + L.expE), jp.expP = (float *)(ws + L.expP), jp.tflag = (float *)(ws + L.tflag);
     jp.J = J, jp.n_ut = L.n_ut, jp.TR = L.TR, jp.n_tr = L.n_tr, jp.TS = L.TS, jp.n_ts = L.n_ts;
 
     const size_t shm1 = ((size_t)J * 32 + 2 * 1024 + kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
@@ -561,6 +610,10 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     if ((e = set_lds(joint_phase1_kernel, shm1)) != hipSuccess) return e;
 
     const unsigned g1 = (unsigned)B * L.n_ut * L.n_tr;
+    // tanh tables (rebuilt by whichever phase runs: a few microseconds, and the projections may have changed)
+    if (hipMemsetAsync(jp.tflag, 0, 256, s) != hipSuccess) return hipErrorUnknown;
+    hipLaunchKernelGGL(joint_prep_kernel, dim3(1024), dim3(256), 0, s, jp);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
     if (phases & 1) {
         // forward: edge weights (W pre-filled with log zero) -> sweeps -> costs
         if (hipMemsetAsync(jp.lp.W, kFillByte, L.w.A - L.w.W, s) != hipSuccess) return hipErrorUnknown;

@@ -85,6 +85,20 @@ def test_joint_equals_unfused_composition():
     np.testing.assert_allclose(fused.detach().cpu().numpy(), unfused.detach().cpu().numpy(), rtol=2e-5)
 
 
+def test_joint_large_preactivations_take_the_exact_tanh_path():
+    """|enc_proj| > 43: the tabulated e^{2x} factors would overflow; the kernels must switch to tanh(a + c)."""
+    case = list(make(2, 13, 9, 16, 64, 28, True, seed=5))
+    case[0] = case[0] * 60.0
+    case[1] = case[1] * 60.0 + 2.0
+    scale = np.ones(2)
+    costs, grads = run(tuple(case), scale)
+    ref = orc.joint_loss_and_grads(*case, cost_scale=scale)
+    assert np.isfinite(costs).all() and all(np.isfinite(g).all() for g in grads)
+    np.testing.assert_allclose(costs, ref["costs"], rtol=1e-4)
+    for g, key in zip(grads, ("d_enc", "d_pred", "dW1", "db1", "dW2", "db2")):
+        assert np.abs(g - ref[key]).max() <= 1e-4 * max(1.0, np.abs(ref[key]).max()), key
+
+
 def test_joint_is_deterministic():
     case = make(2, 40, 40, 16, 128, 28, True, seed=11)
     scale = np.ones(2)
