@@ -28,6 +28,10 @@
 #include "rnnt_cell.h"
 
 #include <math.h>
+#ifdef JH_TRACE
+#include <stdio.h>
+#include <stdlib.h>
+#endif
 
 namespace rnnt {
 
@@ -51,6 +55,15 @@ constexpr float kExpTabLimit = 43.0f;
 // row of the 32x32 MFMA C/D tile held in register `reg` of a lane in half `half` (= lane >> 5)
 __device__ __forceinline__ constexpr int cd_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
+#ifdef JH_TRACE
+#define JT1(slot)                                                                   \
+    do {                                                                           \
+        if (trc && lane == 0) trc[(slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define JT1(slot) do { } while (0)
+#endif
+
 struct JointParams {
     LossParams lp;  // lattice workspace, labels, lengths, costs, cost_scale (acts/grads unused)
     const float *enc_proj, *pred_proj, *W2, *b2;
@@ -62,6 +75,9 @@ struct JointParams {
     float *d_enc_proj, *d_pred_proj, *dW2, *db2;
     float *expE, *expP;  // [B][T][J], [B][U][J]  e^{2 x} tables of the two projections
     float *tflag;        // [0] != 0: some |projection| exceeds kExpTabLimit, use the raw projections + fast_tanh
+#ifdef JH_TRACE
+    long long *trace;    // dev builds only: s_memtime stamps of one workgroup of phase 1 and one of phase 2
+#endif
     int J, n_ut, TR, n_tr, TS, n_ts;
 };
 
@@ -125,7 +141,12 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
         }
     }
     const int n_iter = tile_live ? (t_end - t_begin + kP1Waves - 1) / kP1Waves : 0;
+#ifdef JH_TRACE
+    long long *trc = (blockIdx.x == 1201) ? jp.trace + wave * 64 : nullptr;
+#endif
+    JT1(0);
     for (int it = 0; it < n_iter; ++it) {
+        if (it < 5) JT1(1 + 4 * it);
         const int t = t_begin + it * kP1Waves + wave;
         const bool active = t < t_end;  // wave-uniform
         // enc_proj row, de-interleaved per 32-wide chunk as [half][16] so that a lane's 16 A-side addends of a
@@ -189,6 +210,7 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
             if (jc + 1 < nchunk) w2_park(jc + 1, wreg);
             __syncthreads();  // next chunk visible; everyone is done with the buffer it will overwrite after that
         }
+        if (it < 5) JT1(2 + 4 * it);
         // ---- epilogue: logits tile -> LDS, then one lattice cell per lane (lanes 0..31)
         if (active) {
 #pragma unroll
@@ -224,6 +246,7 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
             }
 
         }
+        if (it < 5) JT1(3 + 4 * it);
         {
             // park the logits tile (bias included) in the workspace: V <= 32 floats per cell.  The backward pass turns
             // it into dlogits in place instead of re-running this whole MFMA pass.
@@ -238,6 +261,7 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
                 }
         }
         __syncthreads();  // staging tiles and Arow are rewritten by the next iteration
+        if (it < 5) JT1(4 + 4 * it);
     }
 }
 
@@ -373,8 +397,12 @@ __global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp)
     };
     float dnext[16];
     if (n_iter > 0) dl_fetch(t_begin + wave, dnext);
+#ifdef JH_TRACE
+    long long *trc = (blockIdx.x == 3001) ? jp.trace + 512 + wave * 64 : nullptr;
+#endif
     for (int it = 0; it < n_iter; ++it) {
         const int t = t_begin + it * 4 + wave;
+        if (it < 20) JT1(3 * it);
         if (t < t_end) {  // wave-uniform; no workgroup barrier inside: the dl row buffer is wave-private
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
@@ -382,6 +410,7 @@ __global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp)
                 my_dl[(e >> 5) * kStagePad + (e & 31)] = dnext[q];
             }
             dl_fetch(t + 4, dnext);  // next row of this wave: latency hides under this row's MFMAs
+            if (it < 20) JT1(3 * it + 1);
             const float *arow = Etab + ((size_t)b * p.T + t) * J + j0;
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
@@ -431,6 +460,7 @@ __global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp)
             }
         }
     }
+    JT1(60);
     // rows of this u-tile / J slab that no block visits (t >= T_b, or a dead tile) must read as zero
     // in the partial buffers: they are zero-filled before the launch (hipMemsetAsync).
 
@@ -602,6 +632,13 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     jp.dbpart = (float *)(ws + L.dbpart);
     jp.d_enc_proj = d_enc_proj, jp.d_pred_proj = d_pred_proj, jp.dW2 = dW2, jp.db2 = db2;
     jp.expE = (float *)(ws + L.expE), jp.expP = (float *)(ws + L.expP), jp.tflag = (float *)(ws + L.tflag);
+#ifdef JH_TRACE
+    static long long *trace_dev = nullptr;
+    const size_t trace_bytes = 1024 * sizeof(long long);
+    if (!trace_dev) (void)hipMalloc(&trace_dev, trace_bytes);
+    (void)hipMemsetAsync(trace_dev, 0, trace_bytes, s);
+    jp.trace = trace_dev;
+#endif
     jp.J = J, jp.n_ut = L.n_ut, jp.TR = L.TR, jp.n_tr = L.n_tr, jp.TS = L.TS, jp.n_ts = L.n_ts;
 
     const size_t shm1 = ((size_t)J * 32 + 2 * 1024 + kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
@@ -637,6 +674,18 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     hipLaunchKernelGGL((reduce_small_kernel<true>), dim3((J * V + 31) / 32), dim3(256), 0, s, dW2, jp.dWpart,
                        B * L.n_ut * L.n_ts, J * V, J, V);
     hipLaunchKernelGGL((reduce_small_kernel<false>), dim3(1), dim3(256), 0, s, db2, jp.dbpart, (int)gdl, V, J, V);
+#ifdef JH_TRACE
+    {
+        (void)hipStreamSynchronize(s);
+        long long h[1024];
+        (void)hipMemcpy(h, trace_dev, trace_bytes, hipMemcpyDeviceToHost);
+        const char *path = getenv("JH_TRACE_FILE32");
+        if (FILE *f = fopen(path ? path : "/tmp/j32_trace.bin", "wb")) {
+            fwrite(h, 1, trace_bytes, f);
+            fclose(f);
+        }
+    }
+#endif
     return hipGetLastError();
 }
 
