@@ -1275,10 +1275,16 @@ hipError_t launch_grad(const LossParams &p, hipStream_t s, bool overlap) { retur
 // 2           = skewed multi-wave kernel (one column per lane).  Measured at C2 on MI355X: 164-175 us versus
 //               112 us for mode 1 -- a lone wave issues ~1 instruction per 7 cycles whatever its kind, and the
 //               per-interval barrier/boundary bookkeeping costs more instructions than the K=3 columns it saves.
+// 3           = the multi-wave kernel with the per-step barrier replaced by progress counters in LDS (waves run free,
+//               look at each other every 8 steps).  Parity-green, 195 us at C2: without the barrier the K=1 wave is bound by
+//               its dependent chain (add, max, sub, exp2, add, log2, add, DPP ~ 150-200 cycles with no second cell to
+//               overlap it with) plus the boundary/LDS round trip; the single wave's three independent cells per lane hide
+//               exactly that latency.  U <= 192 only.
 static int sweep_mode() {
     const char *e = getenv("RNNT_SWEEP_MODE");
     if (e && e[0] == '0') return 0;
     if (e && e[0] == '2') return 2;
+    if (e && e[0] == '3') return 3;
     return 1;
 }
 
@@ -1304,6 +1310,221 @@ static hipError_t launch_sweep_kg(const LossParams &p, hipStream_t s) {
         hipLaunchKernelGGL((sweep_kernel<K, G, true>), dim3(2 * p.nb), dim3(64), shm, s, p);
     else
         hipLaunchKernelGGL((sweep_kernel<K, G, false>), dim3(2 * p.nb), dim3(64), shm, s, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-wave sweep WITHOUT per-step barriers (RNNT_SWEEP_MODE=3).  Same decomposition as sweep_mw_kernel (one lattice
+// column per lane, NW compute waves + a loader wave, W rows through an LDS ring, boundary values through a small ring),
+// but the waves run free: each publishes its progress in LDS every CH steps and checks its producer / consumer /
+// the loader only at chunk boundaries.  A wave's LDS operations complete in order, so "values written, then counter
+// written" is all the ordering the hand-off needs.  The barrier version spent ~2/3 of every step in s_barrier.
+//   wave w may run steps [s0, s0+CH)  when  producer finished step s0+CH (it prefetches one step ahead),
+//                                            the loader landed row s0+CH,
+//                                            its consumer finished step s0+CH-XS (ring slots it is about to overwrite).
+// ---------------------------------------------------------------------------------------------
+template <int NW>
+struct McCfg {
+    static constexpr int Up = 64 * NW;
+    static constexpr int IPR = (NW + 1) / 2;
+    static constexpr int RB = 64;       // W ring slots
+    static constexpr int PF = 24;       // rows in flight
+    static constexpr int CH = 8;        // steps between two looks at the neighbours' progress
+    static constexpr int XS = 4 * CH;   // boundary ring depth
+    // No deadlock (progress is published every step, the loader publishes everything it has issued before it blocks on a
+    // ring slot): with the loader stopped at row j, wave 0 can still finish every chunk that ends at or before row j-1,
+    // i.e. reach step >= j - 2 CH; every further wave trails its producer by < 2 CH; so the slowest wave reaches
+    // j - 2 CH NW, and the loader needs it at j + 5 - RB to move on.
+    static_assert(NW <= 3 && RB - 5 >= 2 * CH * NW, "W ring too small for the skew");
+    static_assert(XS - CH >= 2 * CH, "boundary ring too small: the producer must be allowed 2 CH ahead of its consumer");
+    static constexpr size_t ring_bytes = (size_t)RB * Up * 2 * sizeof(float);
+    static constexpr size_t xbuf_bytes = (size_t)XS * NW * 64 * sizeof(float2);
+    static constexpr size_t lds_bytes = ring_bytes + xbuf_bytes + 64;
+    static_assert((PF - 1) * IPR <= 63, "vmcnt budget");
+    static_assert(lds_bytes <= 160 * 1024, "LDS");
+};
+__device__ __forceinline__ int lds_peek(const uint32_t addr) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
+// Bounded: a protocol error must end in wrong numbers (caught by the parity tests), never in a hung GPU.
+__device__ __forceinline__ void lds_wait_ge(const uint32_t addr, const int need) {
+    for (int spin = 0; spin < (1 << 18); ++spin) {
+        if (lds_peek(addr) >= need) return;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void lds_post(const uint32_t addr, const int v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+template <int NW, bool BETA>
+__device__ __forceinline__ void sweep_mwc_body(const LossParams &p, float *lds, const int b, const int tid) {
+    using C = McCfg<NW>;
+    constexpr int Up = C::Up, IPR = C::IPR, PF = C::PF, RB = C::RB, XS = C::XS, CH = C::CH;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int Nb = Tb + Ub - 1, last = Nb - 1;
+    const float *Wb = p.W + (size_t)b * p.Nr * 2 * Up;
+    const int nrows = Nb;
+    const int nsteps = BETA ? Nb : Nb - 1;
+    float *wring = lds;
+    float2 *xbuf = (float2 *)((char *)lds + C::ring_bytes);
+    const uint32_t ring_base = (uint32_t)(uintptr_t)((lds_void *)wring);
+    const uint32_t xbuf_base = (uint32_t)(uintptr_t)((lds_void *)xbuf);
+    const uint32_t prog_base = xbuf_base + (uint32_t)C::xbuf_bytes;  // int prog[NW] (steps finished), then rows landed
+    if (tid <= NW) lds_post(prog_base + 4u * (uint32_t)tid, 0);
+    wg_barrier();  // the only workgroup barrier: counters initialised
+
+    if (wave == NW) {
+        // ------------------------------ loader wave ------------------------------
+        auto issue = [&](const int j) {
+            const int r = BETA ? last - j : j;
+            const float *src = Wb + (size_t)r * Up * 2;
+            const uint32_t dst = ring_base + (uint32_t)(r & (RB - 1)) * (Up * 8);
+#pragma unroll
+            for (int i = 0; i < IPR; ++i) {
+                const int k = i * 64 + lane;
+                if (k < Up / 2) {
+                    uint32_t keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                                 "s_mov_b32 m0, %0"
+                                 : "=&s"(keep)
+                                 : "v"(src + k * 4), "s"(dst + (uint32_t)i * 1024u)
+                                 : "memory");
+                }
+            }
+        };
+        for (int j = 0; j < nrows; ++j) {
+            if (j >= RB - 2 && ((j & 3) == 0 || j == RB - 2)) {
+                // ring slot of row j (and of the next three) must have been consumed by every wave (incl. its prefetch).
+                // Before blocking, everything issued so far is made visible to the waves.
+                wait_vm0();
+                if (lane == 0) lds_post(prog_base + 4u * NW, j);
+                for (int w = 0; w < NW; ++w) lds_wait_ge(prog_base + 4u * (uint32_t)w, min(j + 3 - (RB - 2), nsteps));
+            }
+            issue(j);
+            if (j >= PF - 1) {
+                wait_vm_counted<(PF - 1) * IPR>();  // rows <= j-PF+1 have landed
+                if (lane == 0) lds_post(prog_base + 4u * NW, j - PF + 2);
+            }
+        }
+        wait_vm0();
+        if (lane == 0) lds_post(prog_base + 4u * NW, nrows);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ------------------------------ compute waves ------------------------------
+    const int u = wave * 64 + lane;
+    const RidgeLine ridge = make_ridge(Ub, Nb);
+    float *out = (BETA ? p.Bt : p.A) + (size_t)b * p.Nr * Up;
+    float *offp = (BETA ? p.offB : p.offA) + (size_t)b * p.NC * p.NG + wave;
+    float a = BETA ? ((u == Ub - 1) ? 0.f : kNeg) : ((u == 0) ? 0.f : kNeg);
+    float Ow = 0.f;
+    if (!BETA) {
+        out[u] = a;
+        if (lane == 0) offp[0] = 0.f;
+    }
+    const bool has_nb = BETA ? (wave < NW - 1) : (wave > 0);      // the wave whose boundary values this one consumes
+    const bool has_cons = BETA ? (wave > 0) : (wave < NW - 1);    // the wave that consumes this one's
+    const int nbw = BETA ? wave + 1 : wave - 1, consw = BETA ? wave - 1 : wave + 1;
+    const uint32_t my_col = ring_base + (uint32_t)u * 8u;
+    const uint32_t nb_col = xbuf_base + (uint32_t)((nbw * 64) + (BETA ? 0 : 63)) * 8u;
+    const uint32_t my_prog = prog_base + 4u * (uint32_t)wave;
+    f32x2 cw = {0.f, 0.f}, cn = {kNeg, 0.f}, pw = cw, pn = cn;
+
+    auto gate = [&](const int s0) {  // everything steps [s0, s0+CH) and the prefetch of step s0+CH will touch is there
+        const int hi = s0 + CH;
+        lds_wait_ge(prog_base + 4u * NW, min(hi + 1, nrows));
+        if (has_nb) lds_wait_ge(prog_base + 4u * (uint32_t)nbw, min(hi + 1, nsteps));
+        if (has_cons) lds_wait_ge(prog_base + 4u * (uint32_t)consw, min(max(hi - XS, 0), nsteps));
+    };
+    gate(0);
+    {  // operands of step 0
+        const int r0 = BETA ? last : 0;
+        asm volatile("ds_read_b64 %0, %1" : "=v"(cw) : "v"(my_col + (uint32_t)(r0 & (RB - 1)) * (Up * 8)));
+        if (has_nb) asm volatile("ds_read_b64 %0, %1" : "=v"(cn) : "v"(nb_col));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cw), "+v"(cn));
+    }
+    for (int s0 = 0; s0 < nsteps; s0 += CH) {
+        if (s0 > 0) gate(s0);
+        const int s_end = min(s0 + CH, nsteps);
+        for (int s = s0; s < s_end; ++s) {
+            // (1) prefetch the operands of step s+1 (covered by this chunk's gate)
+            const int s1 = s + 1;
+            if (s1 < nsteps) {
+                const int r1 = BETA ? last - s1 : s1;
+                asm volatile("ds_read_b64 %0, %1" : "=v"(pw) : "v"(my_col + (uint32_t)(r1 & (RB - 1)) * (Up * 8)));
+                if (has_nb) asm volatile("ds_read_b64 %0, %1" : "=v"(pn) : "v"(nb_col + (uint32_t)(s1 & (XS - 1)) * (NW * 512)));
+            }
+            // (2) this step, entirely from registers
+            const int r = BETA ? last - s : s;
+            const int n = BETA ? r : r + 1;
+            const float nb = has_nb ? cn[0] + (cn[1] - Ow) : kNeg;  // exact: both offsets are integers
+            float2 *xs = xbuf + ((s & (XS - 1)) * NW + wave) * 64 + lane;
+            if (!BETA) {
+                const float d = a + cw[0], e = a + cw[1];
+                *xs = make_float2(e, Ow);
+                a = lse2(d, dpp_from_lower_lane(e, nb));
+            } else {
+                *xs = make_float2(a, Ow);
+                a = lse2(a + cw[0], dpp_from_upper_lane(a, nb) + cw[1]);
+            }
+            const bool reb = BETA ? (((n & (kRebase - 1)) == kRebase - 1) || n == last) : ((n & (kRebase - 1)) == 0);
+            if (reb) {
+                const int lr = min(max(ridge.u_at(n) - wave * 64, 0), 63);
+                const float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), lr));
+                if (m > kNegTest) {
+                    const float mi = rintf(m);
+                    a -= mi;
+                    Ow += mi;
+                }
+                if (lane == 0) offp[(size_t)(n / kRebase) * p.NG] = Ow;
+            }
+            out[(size_t)n * Up + u] = a;
+            // (3) prefetched operands and this step's boundary write are complete
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pw), "+v"(pn));
+            cw = pw;
+            cn = pn;
+            if (lane == 0) lds_post(my_prog, s + 1);  // this step's boundary value is in LDS: publish
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!BETA) {
+        if (u == Ub - 1) {
+            const float2 wv = ((const float2 *)wring)[(last & (RB - 1)) * Up + u];
+            const double ll2 = (double)Ow + (double)a + (double)wv.x;
+            p.ll[2 * b] = ll2;
+            p.costs[b] = (float)(-ll2 * 0.6931471805599453);
+        }
+    } else if (u == 0) {
+        p.ll[2 * b + 1] = (double)Ow + (double)a;
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__((NW + 1) * 64) void sweep_mwc_kernel(const LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = p.b0 + (int)(blockIdx.x >> 1);
+    if (blockIdx.x & 1)
+        sweep_mwc_body<NW, true>(p, lds, b, threadIdx.x);
+    else
+        sweep_mwc_body<NW, false>(p, lds, b, threadIdx.x);
+}
+template <int NW>
+static hipError_t launch_sweep_mwc(const LossParams &p, hipStream_t s) {
+    const size_t shm = McCfg<NW>::lds_bytes;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)sweep_mwc_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)shm);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((sweep_mwc_kernel<NW>), dim3(2 * p.nb), dim3((NW + 1) * 64), shm, s, p);
     return hipGetLastError();
 }
 
@@ -1334,6 +1555,14 @@ bool overlap_path_ok(const LossParams &p, bool grad) {
 hipError_t launch_sweeps(const LossParams &p0, hipStream_t s, bool overlap) {
     LossParams p = p0;
     if (!overlap) p.flags = nullptr;  // the sweep kernels key the hand-off protocol on this pointer
+    if (sweep_mode() == 3 && !overlap) {
+        switch (sweep_K(p.U)) {  // counter-synchronised multi-wave sweep: up to 3 column groups (U <= 192)
+            case 1: return launch_sweep_mwc<1>(p, s);
+            case 2: return launch_sweep_mwc<2>(p, s);
+            case 3: return launch_sweep_mwc<3>(p, s);
+            default: break;  // wider lattices: single-wave sweep below
+        }
+    }
     if (sweep_mode() == 2 && !overlap) {
         switch (sweep_K(p.U)) {  // = number of 64-column groups
             case 1: return launch_sweep_mw<1>(p, s);
