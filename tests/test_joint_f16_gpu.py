@@ -119,6 +119,20 @@ def test_joint_f16_edge_cases(B, T, U, H, J, V, blank, scale):
         assert np.abs(g - ref[key]).max() <= 5e-4 * max(1.0, np.abs(ref[key]).max()), key
 
 
+def test_joint_f16_wide_logit_range_moves_the_softmax_reference():
+    """Logits spread over +-60 nats: the lazy softmax reference of K1 must be moved (its rare path) and nothing may
+    overflow; the gradients are then essentially one-hot differences."""
+    case = list(make(2, 10, 6, 16, 128, 512, True, seed=9))
+    case[4] = (case[4] * 25.0).astype(np.float32)  # W2
+    scale = np.ones(2)
+    costs, grads = run(tuple(case), scale)
+    ref = orc.joint_loss_and_grads_f16(*case, cost_scale=scale)
+    assert np.isfinite(costs).all() and all(np.isfinite(g).all() for g in grads)
+    np.testing.assert_allclose(costs, ref["costs"], rtol=1e-4)
+    for g, key in zip(grads, ("d_enc", "d_pred", "dW1", "db1", "dW2", "db2")):
+        assert np.abs(g - ref[key]).max() <= 5e-4 * max(1.0, np.abs(ref[key]).max()), key
+
+
 def test_joint_goldens(golden_dir):
     """HIP fused joint (both dtypes) against the committed fixtures tests/golden/joint/*.npz."""
     import glob
