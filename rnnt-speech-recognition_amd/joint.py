@@ -81,17 +81,53 @@ def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_leng
     W2 [J,V], b2 [V]  (Keras Dense kernels are stored [in, out], model.py:162-166).
 
     joint_dtype: arithmetic of the J x V product.  "f32": exact f32 MFMA, small vocabularies (V <= 32, the reference's
-    character set).  "f16": operands rounded to binary16, f32 accumulation, for large vocabularies (V a multiple of
-    512, J in {128, 256, 512, 640}) -- the counterpart of the reference's `mixed_float16` policy (run_rnnt.py:96-99);
-    the lattice stays f32 either way.  "auto" picks by V."""
+    character set).  "f16": operands rounded to binary16, f32 accumulation, for large vocabularies -- the counterpart
+    of the reference's `mixed_float16` policy (run_rnnt.py:96-99); the lattice stays f32 either way.  "auto" picks by V.
+    Shapes the kernels do not take natively (f16: V a multiple of 512, J in {128, 256, 512, 640}; f32: J a multiple of
+    64) are padded up exactly (zero units / zero-probability symbols)."""
     if joint_dtype == "auto":
         joint_dtype = "f32" if W2.shape[1] <= 32 else "f16"
     if joint_dtype not in JOINT_DTYPES:
         raise ValueError(f"rnnt_joint_loss: joint_dtype must be one of {sorted(JOINT_DTYPES)} or 'auto'")
     enc_proj = torch.matmul(enc, W1) + b1
     pred_proj = torch.matmul(pred, W1)
+    # The kernels take a fixed set of (J, V) shapes; anything else is padded up here, exactly:
+    #   joint units  -- extra units get zero projections and zero W2 rows: h = tanh(0) = 0 contributes nothing;
+    #   vocabulary   -- extra columns get zero weights and a bias of -1e4: their softmax mass is exp(-1e4) = 0 in f32.
+    # Autograd slices the gradients back through the pads.
+    J, V = W2.shape
+    Jp, Vp = padded_joint_shape(J, V, joint_dtype)
+    if Jp != J:
+        enc_proj = torch.nn.functional.pad(enc_proj, (0, Jp - J))
+        pred_proj = torch.nn.functional.pad(pred_proj, (0, Jp - J))
+        W2 = torch.nn.functional.pad(W2, (0, 0, 0, Jp - J))
+    if Vp != V:
+        W2 = torch.nn.functional.pad(W2, (0, Vp - V))
+        b2 = torch.nn.functional.pad(b2, (0, Vp - V), value=_PAD_BIAS)
     return _JointLossFunction.apply(enc_proj, pred_proj, W2, b2, labels, input_lengths, label_lengths, blank_label,
                                     JOINT_DTYPES[joint_dtype])
+
+
+_PAD_BIAS = -1.0e4
+_F16_J = (128, 256, 512, 640)
+
+
+def padded_joint_shape(J: int, V: int, joint_dtype: str):
+    """(J, V) -> the nearest shape the chosen kernels accept (include/rnnt.h), or raises if there is none."""
+    if joint_dtype == "f32":
+        if V > 32:
+            raise ValueError("rnnt_joint_loss: the f32 joint takes vocabularies of at most 32 symbols; use joint_dtype='f16'")
+        Jp = (J + 63) // 64 * 64
+        if Jp > 768:
+            raise ValueError("rnnt_joint_loss: the f32 joint takes joint sizes of at most 768")
+        return Jp, V
+    Jp = next((j for j in _F16_J if j >= J), None)
+    if Jp is None:
+        raise ValueError("rnnt_joint_loss: the f16 joint takes joint sizes of at most 640")
+    Vp = (V + 511) // 512 * 512
+    if Vp > 8192:
+        raise ValueError("rnnt_joint_loss: the f16 joint takes vocabularies of at most 8192 symbols")
+    return Jp, Vp
 
 
 class JointLoss(torch.nn.Module):

@@ -160,11 +160,28 @@ def test_joint_f16_is_deterministic():
         assert np.array_equal(a, b)
 
 
+def test_joint_f16_odd_shapes_are_padded_exactly():
+    """V = 1000 (not a multiple of 512) and J = 320 (BASELINE configs 3/4's joint width): the host layer pads to the
+    kernels' shapes with zero units / zero-probability symbols; results equal the oracle on the UNPADDED problem."""
+    case = make(2, 12, 7, 16, 320, 1000, True, seed=21)
+    scale = np.array([1.0, 0.5])
+    costs, grads = run(case, scale)
+    ref = orc.joint_loss_and_grads_f16(*case, cost_scale=scale)
+    np.testing.assert_allclose(costs, ref["costs"], rtol=1e-4)
+    for g, key in zip(grads, ("d_enc", "d_pred", "dW1", "db1", "dW2", "db2")):
+        assert g.shape == ref[key].shape
+        assert np.abs(g - ref[key]).max() <= 5e-4 * max(1.0, np.abs(ref[key]).max()), key
+
+
 def test_joint_f16_limits_are_reported():
     dev = torch.device("cuda:0")
     enc, pred = torch.zeros(1, 4, 8, device=dev), torch.zeros(1, 3, 8, device=dev)
     W1, b1 = torch.zeros(8, 128, device=dev), torch.zeros(128, device=dev)
-    W2, b2 = torch.zeros(128, 100, device=dev), torch.zeros(100, device=dev)  # V = 100: neither path takes it
-    with pytest.raises(RuntimeError, match="invalid value"):
+    W2, b2 = torch.zeros(128, 9000, device=dev), torch.zeros(9000, device=dev)  # beyond the f16 joint's 8192 symbols
+    with pytest.raises(ValueError, match="at most 8192"):
         pkg.rnnt_joint_loss(enc, pred, W1, b1, W2, b2, torch.ones(1, 2, dtype=torch.int32, device=dev),
                             torch.tensor([4], device=dev), torch.tensor([2], device=dev))
+    # the raw C ABI still rejects shapes it does not implement (here V = 100 handed straight to the f16 entry point)
+    from rnnt_speech_recognition_amd import _lib
+    with pytest.raises(RuntimeError, match="invalid value"):
+        _lib.joint_workspace_bytes(4, 3, 1, 128, 100)

@@ -112,8 +112,22 @@ def test_joint_is_deterministic():
 def test_joint_limits_are_reported():
     dev = torch.device("cuda:0")
     enc, pred = torch.zeros(1, 4, 8, device=dev), torch.zeros(1, 3, 8, device=dev)
-    W1, b1 = torch.zeros(8, 48, device=dev), torch.zeros(48, device=dev)  # J = 48 is not a multiple of 64
-    W2, b2 = torch.zeros(48, 5, device=dev), torch.zeros(5, device=dev)
-    with pytest.raises(RuntimeError, match="invalid value"):
+    W1, b1 = torch.zeros(8, 832, device=dev), torch.zeros(832, device=dev)  # J = 832 > 768: beyond the f32 joint
+    W2, b2 = torch.zeros(832, 5, device=dev), torch.zeros(5, device=dev)
+    with pytest.raises(ValueError, match="at most 768"):
         pkg.rnnt_joint_loss(enc, pred, W1, b1, W2, b2, torch.ones(1, 2, dtype=torch.int32, device=dev),
                             torch.tensor([4], device=dev), torch.tensor([2], device=dev))
+    from rnnt_speech_recognition_amd import _lib
+    with pytest.raises(RuntimeError, match="invalid value"):  # the raw C ABI rejects J = 48 (not a multiple of 64)
+        _lib.joint_workspace_bytes(4, 3, 1, 48, 5)
+
+
+def test_joint_odd_joint_width_is_padded_exactly():
+    """J = 100: padded to 128 with zero units by the host layer; results equal the oracle on the unpadded problem."""
+    case = make(2, 15, 8, 12, 100, 28, True, seed=33)
+    scale = np.ones(2)
+    costs, grads = run(case, scale)
+    ref = orc.joint_loss_and_grads(*case, cost_scale=scale)
+    np.testing.assert_allclose(costs, ref["costs"], rtol=1e-4)
+    for g, key in zip(grads, ("d_enc", "d_pred", "dW1", "db1", "dW2", "db2")):
+        assert g.shape == ref[key].shape and np.abs(g - ref[key]).max() <= 1e-4 * max(1.0, np.abs(ref[key]).max()), key
