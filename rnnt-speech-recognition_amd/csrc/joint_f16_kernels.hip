@@ -79,7 +79,10 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
 
 constexpr int kDlScaleLog2 = 14;   // |dlogits * S| <= 2^14 before the binary16 rounding
 constexpr int kStageStride = 136;  // halfs per row of the K2 staging tile (128 + 8: 16-byte aligned, bank-shifted rows)
-constexpr int kTQ = 64;            // lattice rows per K4 work unit
+#ifndef JH_TQ
+#define JH_TQ 128
+#endif
+constexpr int kTQ = JH_TQ;         // lattice rows per K4 work unit
 constexpr int kDRow = 1088;        // bytes per dl row in K4's LDS image (1024 + 64: conflict-free transposed reads)
 
 struct JhParams {
