@@ -1577,12 +1577,14 @@ hipError_t launch_sweeps(const LossParams &p0, hipStream_t s, bool overlap) {
     switch (sweep_K(p.U)) {
         case 1: return launch_sweep_kg<1, 16>(p, s);
         case 2: return launch_sweep_kg<2, 16>(p, s);
-        case 3: return launch_sweep_kg<3, 8>(p, s);
-        case 4: return launch_sweep_kg<4, 8>(p, s);
-        case 6: return launch_sweep_kg<6, 4>(p, s);
-        case 8: return launch_sweep_kg<8, 4>(p, s);
-        case 12: return launch_sweep_kg<12, 2>(p, s);
-        case 16: return launch_sweep_kg<16, 2>(p, s);
+        // chunk length G (diagonals per LDS-DMA batch / wait): the longest whose two buffers fit 64 KB (measured at C2:
+        // G = 16 beats 8 by 3 % of the step, 4 loses 5 %)
+        case 3: return launch_sweep_kg<3, 16>(p, s);
+        case 4: return launch_sweep_kg<4, 16>(p, s);
+        case 6: return launch_sweep_kg<6, 8>(p, s);
+        case 8: return launch_sweep_kg<8, 8>(p, s);
+        case 12: return launch_sweep_kg<12, 4>(p, s);
+        case 16: return launch_sweep_kg<16, 4>(p, s);
         default: return hipErrorInvalidValue;  // maxU > 1024 is outside the register-resident sweep
     }
 }
