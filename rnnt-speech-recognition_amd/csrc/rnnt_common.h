@@ -22,7 +22,10 @@ constexpr float kNeg = -1.0e30f;      // "log zero" that survives additions with
 constexpr float kNegTest = -1.0e29f;  // anything below this is "log zero"
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
-constexpr int kRebase = 4;  // diagonals per precision block (alpha~/beta~ are re-based each block)
+#ifndef RNNT_REBASE
+#define RNNT_REBASE 8
+#endif
+constexpr int kRebase = RNNT_REBASE;  // diagonals per precision block (alpha~/beta~ are re-based each block)
 
 // Unsigned division by a launch-constant for n < 2^31 (Granlund-Montgomery, add-shift form).
 struct FastDiv {
