@@ -1,0 +1,130 @@
+"""CPU-side audit of the built gfx950 code objects inside libwarprnnt.so (no GPU needed): the hot kernels keep their
+state in registers (no scratch), use the instructions DESIGN.md says they use, and stay within the register budgets
+their occupancy assumptions rest on.  Guards against silent regressions (a spill in a sweep or MFMA loop costs far more
+than it looks) that parity tests cannot see."""
+import os
+import re
+import shutil
+import struct
+import subprocess
+import tempfile
+
+import pytest
+
+import rnnt_speech_recognition_amd as pkg
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+READELF, OBJDUMP = os.path.join(LLVM, "llvm-readelf"), os.path.join(LLVM, "llvm-objdump")
+pytestmark = pytest.mark.skipif(not (os.path.exists(READELF) and os.path.exists(OBJDUMP)), reason="ROCm LLVM tools absent")
+
+
+def _code_objects(so_path, out_dir):
+    """Pull the gfx950 ELF images out of the clang offload bundles embedded in .hip_fatbin."""
+    data = open(so_path, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    paths = []
+    for m in re.finditer(magic, data):
+        base = m.start()
+        (n,) = struct.unpack_from("<Q", data, base + len(magic))
+        off = base + len(magic) + 8
+        for _ in range(n):
+            eoff, esize, tlen = struct.unpack_from("<QQQ", data, off)
+            triple = data[off + 24 : off + 24 + tlen].decode()
+            off += 24 + tlen
+            if "amdgcn" in triple and "gfx950" in triple and esize:
+                p = os.path.join(out_dir, f"co{len(paths)}.elf")
+                open(p, "wb").write(data[base + eoff : base + eoff + esize])
+                paths.append(p)
+    return paths
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    so = pkg.build()
+    tmp = tempfile.mkdtemp(prefix="isa_audit_")
+    try:
+        meta, asm = {}, {}
+        for co in _code_objects(so, tmp):
+            notes = subprocess.run([READELF, "--notes", co], capture_output=True, text=True).stdout
+            cur = {}
+            for line in notes.splitlines():
+                mm = re.match(r"\s*-?\s*\.(\w+):\s*(.*)$", line)
+                if not mm:
+                    continue
+                k, v = mm.group(1), mm.group(2).strip().strip("'")
+                cur[k] = v  # (argument records repeat some keys; the kernel-level ones come last and win)
+                if k == "wavefront_size":  # last key of a kernel record in the msgpack dump
+                    if "symbol" in cur:
+                        meta[cur["symbol"]] = dict(cur)
+                    cur = {}
+            dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
+            name = None
+            for line in dis.splitlines():
+                mm = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+                if mm:
+                    name = mm.group(1)
+                    asm[name] = []
+                elif name is not None:
+                    asm[name].append(line)
+        yield meta, {k: "\n".join(v) for k, v in asm.items()}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _find(d, *needles):
+    hits = [k for k in d if all(n in k for n in needles)]
+    assert hits, needles
+    return hits
+
+
+def test_code_objects_are_gfx950_and_have_the_kernels(kernels):
+    meta, asm = kernels
+    assert len(meta) > 20
+    for needles in (("sweep_kernel", "Li3ELi16ELb1"), ("cell_tile_kernel", "Li32ELb1"), ("cell_tile_kernel", "Li32ELb0"),
+                    ("jh_logits_kernel", "Li40ELb0"), ("jh_logits_kernel", "Li40ELb1"), ("jh_dh_kernel",), ("jh_dw_kernel",),
+                    ("joint_phase1_kernel",), ("joint_phase2_kernel",)):
+        _find(meta, *needles)
+
+
+def test_hot_kernels_do_not_spill(kernels):
+    meta, _ = kernels
+    hot = [("sweep_kernel", "Li3ELi16ELb1"), ("sweep_kernel", "Li6ELi8ELb1"), ("cell_tile_kernel", "Li32ELb1ELb0"),
+           ("cell_tile_kernel", "Li32ELb0ELb0"), ("jh_logits_kernel", "Li40ELb0"), ("jh_dh_kernel",), ("jh_dw_kernel",),
+           ("joint_phase1_kernel",), ("joint_phase2_kernel",), ("joint_dl_kernel",)]
+    for needles in hot:
+        for k in _find(meta, *needles):
+            m = meta[k]
+            assert int(m["private_segment_fixed_size"]) == 0, (k, m["private_segment_fixed_size"])
+            assert int(m.get("vgpr_spill_count", "0")) == 0, k
+    # the backward logits kernel at J = 640 is allowed a handful of spilled registers outside its MFMA loop
+    for k in _find(meta, "jh_logits_kernel", "Li40ELb1"):
+        assert int(meta[k]["private_segment_fixed_size"]) <= 64, meta[k]["private_segment_fixed_size"]
+
+
+def test_register_budgets_match_the_occupancy_assumptions(kernels):
+    meta, _ = kernels
+    # 8-wave workgroups of the f16 joint: two waves per SIMD -> at most 256 unified registers per wave
+    for needles in (("jh_logits_kernel", "Li40"), ("jh_dh_kernel",), ("jh_dw_kernel",)):
+        for k in _find(meta, *needles):
+            assert int(meta[k]["vgpr_count"]) + int(meta[k].get("agpr_count", "0")) <= 256, (k, meta[k]["vgpr_count"])
+    # lane-per-cell patch kernels: five 28 KB workgroups per CU = 20 waves -> at most 96 registers for full residency
+    for k in _find(meta, "cell_tile_kernel", "Li32"):
+        assert int(meta[k]["vgpr_count"]) <= 128, (k, meta[k]["vgpr_count"])
+
+
+def test_instruction_selection(kernels):
+    _, asm = kernels
+    k1 = asm[_find(asm, "jh_logits_kernel", "Li40ELb0")[0]]
+    assert k1.count("v_mfma_f32_32x32x16_f16") >= 40 and "global_load_lds_dwordx4" in k1 and "v_cvt_pk_f16_f32" in k1
+    dw = asm[_find(asm, "jh_dw_kernel")[0]]
+    assert "ds_read_b64_tr_b16" in dw and "v_mfma_f32_32x32x16_f16" in dw and "v_dot2" in dw
+    dh = asm[_find(asm, "jh_dh_kernel")[0]]
+    assert "global_load_lds_dwordx4" in dh and dh.count("v_mfma_f32_32x32x16_f16") >= 16
+    sw = asm[_find(asm, "sweep_kernel", "Li3ELi16ELb1")[0]]
+    assert "global_load_lds_dwordx4" in sw and "v_exp_f32" in sw and "v_log_f32" in sw
+    assert "wave_shr:1" in sw or "wave_shl:1" in sw  # ONE whole-wave DPP shift per diagonal carries the neighbour column
+    assert "s_barrier" not in sw                      # single wave per lattice direction: no workgroup barrier at all
+    p1 = asm[_find(asm, "joint_phase1_kernel")[0]]
+    assert "v_mfma_f32_32x32x2_f32" in p1
+    for name, text in asm.items():
+        assert "v_mfma_f32_32x32x8" not in text  # no CDNA3-shaped f16 MFMAs: gfx950 forms only
