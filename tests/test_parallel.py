@@ -111,3 +111,37 @@ def test_flat_all_reduce_is_a_noop_without_a_group():
     t = [torch.ones(3), None, torch.arange(4.0)]
     parallel.flat_all_reduce_(t)
     assert t[0].tolist() == [1, 1, 1]
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_group_runs_the_dp_step_on_the_gpu():
+    """RCCL is present and usable on the box (backend "nccl" IS RCCL on ROCm): a one-rank process group runs the same
+    shard -> loss -> flat all-reduce step bench.py / TrainStep use with N > 1, through the HIP engine."""
+    import rnnt_speech_recognition_amd as pkg
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        rng = np.random.default_rng(0)
+        B, T, U, V = 4, 12, 6, 28
+        acts = rng.normal(size=(B, T, U, V)).astype(np.float32)
+        labels = rng.integers(1, V, size=(B, U - 1)).astype(np.int32)
+        il, ll = np.full(B, T, np.int32), np.full(B, U - 1, np.int32)
+        x = torch.tensor(acts, device=dev, requires_grad=True)
+        costs = pkg.rnnt_loss(x, torch.tensor(labels, device=dev), torch.tensor(il, device=dev), torch.tensor(ll, device=dev))
+        (costs.sum() / B).backward()
+        g = x.grad.clone()
+        parallel.flat_all_reduce_([x.grad])  # one rank: the sum over ranks is the identity
+        torch.cuda.synchronize()
+        assert torch.equal(g, x.grad)
+        t = torch.ones(3, device=dev)
+        dist.all_reduce(t)
+        assert t.tolist() == [1.0, 1.0, 1.0]
+        c_ref, g_ref = orc.rnnt_loss_and_grad(acts, labels, il, ll)
+        assert np.abs(x.grad.cpu().numpy() - g_ref / B).max() <= 1e-4
+    finally:
+        dist.destroy_process_group()
