@@ -173,7 +173,12 @@ __global__ __launch_bounds__(256) void cell_small_kernel(const LossParams p) {
 // min(TT,UU) consecutive words per diagonal, all issued from ONE CU (one XCD L2), so lines are
 // merged on chip instead of being touched by 16 different workgroups on 8 different L2s.
 // ---------------------------------------------------------------------------------------------
-template <int VP, bool GRAD, bool OVL>
+// AL = false: vocabularies that are not a multiple of 4 (the reference's 31-symbol character set): a patch row then starts
+// at an arbitrary 4-byte offset.  The row is staged from the enclosing 16-byte-aligned span, so its image sits `a` floats
+// (a = start & 3, per row) into a 16-byte-aligned LDS row; cells read their logits with scalar LDS reads, and the gradient
+// rows go back with float4 stores for the aligned interior and single floats at the two ragged ends.  Needs B*T*U*V % 4 == 0
+// (then no aligned span reaches past the tensor).
+template <int VP, bool GRAD, bool OVL, bool AL = true>
 __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -206,26 +211,55 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
     const int cols_in = max(0, min(tg.UU, p.U - u0));
     const int q_valid = cols_valid * V / 4;                     // 16-byte chunks per row that carry valid cells
     const int q_in = cols_in * V / 4;
-    const int row_lds = tg.UU * V;                              // floats per patch row in LDS
+    const int row_lds = AL ? tg.UU * V : ((tg.UU * V + 3 + 3) & ~3);  // floats per patch row in LDS (16-byte aligned rows)
     const size_t row_f = (size_t)p.U * V;                       // floats per lattice row in HBM
     const size_t patch0 = ((size_t)(b * p.T + t0) * p.U + u0) * V;
 
+    // gradient row `r` of the patch back to HBM: from the LDS image (src != nullptr) or zeros
+    auto store_row = [&](const int r, const float *src) {
+        const size_t s0 = patch0 + r * row_f;
+        if (AL) {
+            for (int q = lane; q < q_in; q += 64) {
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f v = src ? ((const v4f *)src)[q] : (v4f){0.f, 0.f, 0.f, 0.f};
+                __builtin_nontemporal_store(v, (v4f *)(p.grads + s0 + q * 4));
+            }
+        } else {
+            const int a = (int)(s0 & 3), len = cols_in * V;
+            float *base = p.grads + (s0 - a);
+            for (int q = lane; q * 4 < a + len; q += 64) {
+                const int e0 = q * 4 - a;  // element of the row segment held by the chunk's first float
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = src ? src[q * 4 + k] : 0.f;
+                if (e0 >= 0 && e0 + 3 < len) {
+                    *(float4 *)(base + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (e0 + k >= 0 && e0 + k < len) base[q * 4 + k] = v[k];
+                }
+            }
+        }
+    };
+
     if (rows_valid == 0 || cols_valid == 0) {
         if (GRAD) {  // an all-padding patch: exact zeros, no reads
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int r = wave; r < rows_in; r += 4)
-                for (int q = lane; q < q_in; q += 64) *(float4 *)(p.grads + patch0 + r * row_f + q * 4) = z;
+            for (int r = wave; r < rows_in; r += 4) store_row(r, nullptr);
         }
         return;
     }
 
     // ---- stage: each wave streams whole row segments HBM -> LDS with 16-byte LDS-DMA ----
     for (int r = wave; r < rows_valid; r += 4) {
-        const float *src = p.acts + patch0 + r * row_f;
+        const size_t s0 = patch0 + r * row_f;
+        const int a = AL ? 0 : (int)(s0 & 3);
+        const float *src = p.acts + (s0 - a);
         float *dst = lds + r * row_lds;
-        for (int q0 = 0; q0 < q_valid; q0 += 64) {
+        const int nq = AL ? q_valid : (a + cols_valid * V + 3) / 4;
+        for (int q0 = 0; q0 < nq; q0 += 64) {
             const int q = q0 + lane;
-            if (q < q_valid) {
+            if (q < nq) {
                 if (p.tune & (GRAD ? 2 : 4))
                     __builtin_amdgcn_global_load_lds((glb_void *)(src + q * 4), (lds_void *)(dst + q0 * 4), 16, 0, 2);
                 else
@@ -249,7 +283,12 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
     cl.b = b, cl.t = t0 + (int)r, cl.u = u0 + cu, cl.Tb = Tb, cl.Ub = Ub;
     cl.valid = ((int)r < rows_valid) && (cu < cols_valid);
     const uint32_t c = ((uint32_t)(b * p.T + cl.t)) * (uint32_t)p.U + (uint32_t)cl.u;
-    if (GRAD || cl.valid) cell_body<VP, true, GRAD, OVL>(p, cl, c, lds + tid * V);
+    if (AL) {
+        if (GRAD || cl.valid) cell_body<VP, true, GRAD, OVL>(p, cl, c, lds + tid * V);
+    } else if ((int)r < tg.TT) {
+        const int a = (int)((patch0 + r * row_f) & 3);
+        if (GRAD || cl.valid) cell_body<VP, false, GRAD, OVL>(p, cl, c, lds + r * row_lds + a + cu * V);
+    }
     if (OVL && !GRAD) {
         // Publish this patch.  Its W words were stored write-back: after vmcnt(0) they sit in THIS XCD's L2,
         // which every CU of this XCD reads coherently.  The counter is kept per XCD so that the consuming
@@ -261,7 +300,10 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
             __hip_atomic_fetch_add(p.flags + flag_lsm(b, my_xcd()), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
-    if (GRAD) {
+    if (GRAD && !AL) {
+        __syncthreads();
+        for (int rr = wave; rr < rows_in; rr += 4) store_row(rr, lds + rr * row_lds);
+    } else if (GRAD) {
         __syncthreads();
         for (int rr = wave; rr < rows_in; rr += 4) {
             const float4 *srcl = (const float4 *)(lds + rr * row_lds);
@@ -1183,7 +1225,10 @@ static bool small_path_ok(const LossParams &p, bool grad) {
 }
 
 bool tile_path_ok(const LossParams &p, bool grad) {
-    if (p.V > 60 || (p.V % 4) != 0) return false;
+    if (p.V > 60) return false;
+    // rows that start off a 16-byte boundary (V % 4 != 0) are staged from the enclosing aligned span: the whole tensor
+    // must end on a 16-byte boundary for that span never to leave it
+    if ((p.V % 4) != 0 && (((size_t)p.cells * (size_t)p.V) % 4) != 0) return false;
     if (((uintptr_t)p.acts & 15) != 0) return false;
     if (grad && ((uintptr_t)p.grads & 15) != 0) return false;
     const char *e = getenv("RNNT_CELL_PATH");  // "flat" forces the 256-consecutive-cells kernels
@@ -1209,7 +1254,7 @@ static hipError_t launch_cell(const LossParams &p, hipStream_t s, bool overlap) 
         // workgroups per CU (226 us with one) versus 80 / 113 us for one patch per workgroup (5 per CU): 8 waves per
         // CU with two barriers per patch lose to 20 waves of independent workgroups.  Opt-in only.
         const char *pe = getenv("RNNT_CELL_PATH");
-        if (pe && pe[0] == 'p') {
+        if (pe && pe[0] == 'p' && (p.V % 4) == 0) {
             const size_t shm2 = (size_t)2 * 256 * p.V * sizeof(float);
             static int per_cu = -1;
             if (per_cu < 0) {  // workgroups per CU: as many double buffers as fit in 160 KiB (query once)
@@ -1236,7 +1281,15 @@ static hipError_t launch_cell(const LossParams &p, hipStream_t s, bool overlap) 
             }
             return hipGetLastError();
         }
-        if (p.V <= 32)
+        if ((p.V % 4) != 0) {
+            const size_t pitch = (size_t)((p.tile.UU * p.V + 3 + 3) & ~3);
+            size_t shmu = (size_t)p.tile.TT * pitch * sizeof(float);
+            if (shmu < shm) shmu = shm;
+            if (p.V <= 32)
+                hipLaunchKernelGGL((cell_tile_kernel<32, GRAD, false, false>), dim3(blocks), dim3(256), shmu, s, p);
+            else
+                hipLaunchKernelGGL((cell_tile_kernel<64, GRAD, false, false>), dim3(blocks), dim3(256), shmu, s, p);
+        } else if (p.V <= 32)
             hipLaunchKernelGGL((cell_tile_kernel<32, GRAD, false>), dim3(blocks), dim3(256), shm, s, p);
         else
             hipLaunchKernelGGL((cell_tile_kernel<64, GRAD, false>), dim3(blocks), dim3(256), shm, s, p);
@@ -1549,7 +1602,8 @@ hipError_t launch_lsm_done_marker(const LossParams &p, hipStream_t s) {
 
 bool overlap_path_ok(const LossParams &p, bool grad) {
     // patch kernels on both sides and the single-wave sweep (the hand-off hooks live there)
-    return tile_path_ok(p, false) && (!grad || tile_path_ok(p, true)) && sweep_mode() == 1 && sweep_K(p.U) != 0;
+    return (p.V % 4) == 0 && tile_path_ok(p, false) && (!grad || tile_path_ok(p, true)) && sweep_mode() == 1 &&
+           sweep_K(p.U) != 0;
 }
 
 hipError_t launch_sweeps(const LossParams &p0, hipStream_t s, bool overlap) {
