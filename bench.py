@@ -70,9 +70,20 @@ def cpu_baseline(B, T, U, V, reps):
         if r > 0:
             times.append(dt)
     med = float(np.median(times))
+    # one thread, on a 2-utterance slice (SURVEY.md 8d asks for the 1-thread figure too): lattice part + softmax part
+    nb1 = min(2, B)
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    x1 = acts[:nb1].clone().requires_grad_(True)
+    lp1 = torch.log_softmax(x1, dim=-1)
+    _, glp1 = cpu_oracle.rnnt_cpu(lp1.detach().numpy(), labels[:nb1], il[:nb1], ll[:nb1], num_threads=1)
+    lp1.backward(torch.from_numpy(glp1) / B)
+    dt1 = time.perf_counter() - t0
+    torch.set_num_threads(ncpu)
     return {
         "value": B * T * U / med, "unit": "cells/s", "cores": min(ncpu, B), "host_cores": ncpu, "kind": "port",
         "seconds_per_step": med,
+        "single_thread": {"value": nb1 * T * U / dt1, "unit": "cells/s", "sample": f"{nb1} utterances of the same batch, one run"},
         "sample": f"full headline batch B={B} T={T} U={U} V={V}, median of {reps} runs after 1 warm-up; "
                   "OpenMP over utterances only (like the reference), torch CPU log_softmax fwd+bwd around it",
     }
@@ -295,6 +306,34 @@ def main():
                          "unpipelined_fwd_ms": t_f * 1e3, "unpipelined_bwd_ms": t_b * 1e3},
         }
 
+    # ---- ragged batch of the same padded shape (also report sum_b T_b*U_b per second) ----
+    ragged = None
+    if rank == 0:
+        gr = torch.Generator(device="cpu").manual_seed(4242)
+        il_r = torch.randint((T + 1) // 2, T + 1, (B,), generator=gr, dtype=torch.int32)
+        ll_r = torch.randint((U - 1 + 1) // 2, U, (B,), generator=gr, dtype=torch.int32)
+        il_r[0], ll_r[0] = T, U - 1
+        valid = int((il_r.long() * (ll_r.long() + 1)).sum())
+        il_d, ll_d = il_r.to(dev), ll_r.to(dev)
+
+        def step_r():
+            _lib.check(lib.compute_rnnt_loss_ex(acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), ll_d.data_ptr(),
+                                                il_d.data_ptr(), scale.data_ptr(), V, B, costs.data_ptr(),
+                                                ws.data_ptr(), opts), "compute_rnnt_loss_ex")
+
+        for _ in range(3):
+            step_r()
+        torch.cuda.synchronize()
+        t0r = time.perf_counter()
+        nr = max(5, min(a.steps, 20))
+        for _ in range(nr):
+            step_r()
+        torch.cuda.synchronize()
+        dtr = (time.perf_counter() - t0r) / nr
+        ragged = {"ms_per_step": dtr * 1e3, "valid_cells_per_s": valid / dtr, "padded_cells_per_s": B * T * U / dtr,
+                  "valid_fraction": valid / float(B * T * U),
+                  "lengths": "T_b ~ U{T/2..T}, L_b ~ U{(U-1)/2..U-1}, one full-length utterance (SURVEY.md 8d)"}
+
     # ---- fused joint + loss (SURVEY.md 8d "P2"): reported beside the headline, not as `value` ----
     fused = None
     fused_c5 = None
@@ -322,7 +361,7 @@ def main():
             "config": {"workload": f"transducer loss+grad on given logits (warp-transducer op contract), "
                                    f"B={B} T={T} U={U} V={V} per GPU, full lengths, acts~N(0,1)",
                        "global_batch": B * world, "parallelism": f"utterance-sharded x{world}, no data-path collective"},
-            "roofline": roof, "cpu_baseline": cpu, "fused_joint": fused, "fused_joint_config5": fused_c5,
+            "roofline": roof, "cpu_baseline": cpu, "ragged_batch": ragged, "fused_joint": fused, "fused_joint_config5": fused_c5,
         }
         if e2e is not None:
             out["e2e_train_step"] = e2e
