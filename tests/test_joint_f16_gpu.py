@@ -3,11 +3,12 @@
 same operand roundings (oracle/rnnt_oracle.py: joint_loss_and_grads_f16, restating model.py:158-166 under the
 reference's mixed_float16 policy, run_rnnt.py:96-99).
 
-Tolerances: costs relative 1e-4; every gradient tensor max|d| <= 5e-4 * max(1, max|ref|).  The gradient bound is
+Tolerances: costs relative 1e-4; every gradient tensor max|d| <= 1e-3 * max(1, max|ref|).  The gradient bound is
 wider than the f32 paths' 1e-4 for a structural reason: dlogits are rounded to binary16 (relative step 4.9e-4) before
 the two backward products, and an f32 kernel value that differs from the f64 oracle value by ~3e-6 relative lands on
 the other side of a rounding boundary for ~1 % of the elements; each such element then differs by a whole binary16
-step.  Measured: 5e-5 .. 1.3e-4 relative on d enc_proj / d pred_proj, the same with either summation order.
+step.  Measured: typically 5e-5 .. 4e-4, worst 6.1e-4 over 400 random cases (scripts/fuzz_parity.py); perturbing the
+oracle's own pre-rounding values by 3e-6 relative moves its gradients by 1.5e-4 (same mechanism).
 The distance to the UNROUNDED joint is bounded too (costs 5e-3 relative): that is the price of binary16 operands (the
 reference's mixed_float16 policy pays the same), not a kernel error."""
 import numpy as np
@@ -69,7 +70,7 @@ def test_joint_f16_matches_oracle(B, T, U, H, J, V, ragged):
     ref = orc.joint_loss_and_grads_f16(*case, cost_scale=scale)
     np.testing.assert_allclose(costs, ref["costs"], rtol=1e-4)
     for g, key in zip(grads, ("d_enc", "d_pred", "dW1", "db1", "dW2", "db2")):
-        tol = 5e-4 * max(1.0, np.abs(ref[key]).max())
+        tol = 1e-3 * max(1.0, np.abs(ref[key]).max())
         assert np.abs(g - ref[key]).max() <= tol, key
     exact = orc.joint_loss_and_grads(*case, cost_scale=scale)
     np.testing.assert_allclose(costs, exact["costs"], rtol=5e-3)
@@ -90,7 +91,7 @@ def test_joint_f16_large_preactivations_take_the_exact_tanh_path():
     assert np.isfinite(costs).all() and all(np.isfinite(g).all() for g in grads)
     np.testing.assert_allclose(costs, ref["costs"], rtol=1e-4)
     for g, key in zip(grads, ("d_enc", "d_pred", "dW1", "db1", "dW2", "db2")):
-        assert np.abs(g - ref[key]).max() <= 5e-4 * max(1.0, np.abs(ref[key]).max()), key
+        assert np.abs(g - ref[key]).max() <= 1e-3 * max(1.0, np.abs(ref[key]).max()), key
 
 
 EDGE = [
@@ -116,7 +117,7 @@ def test_joint_f16_edge_cases(B, T, U, H, J, V, blank, scale):
     np.testing.assert_allclose(costs, ref["costs"], rtol=1e-4)
     for g, key in zip(grads, ("d_enc", "d_pred", "dW1", "db1", "dW2", "db2")):
         assert np.isfinite(g).all(), key
-        assert np.abs(g - ref[key]).max() <= 5e-4 * max(1.0, np.abs(ref[key]).max()), key
+        assert np.abs(g - ref[key]).max() <= 1e-3 * max(1.0, np.abs(ref[key]).max()), key
 
 
 def test_joint_f16_wide_logit_range_moves_the_softmax_reference():
@@ -130,7 +131,7 @@ def test_joint_f16_wide_logit_range_moves_the_softmax_reference():
     assert np.isfinite(costs).all() and all(np.isfinite(g).all() for g in grads)
     np.testing.assert_allclose(costs, ref["costs"], rtol=1e-4)
     for g, key in zip(grads, ("d_enc", "d_pred", "dW1", "db1", "dW2", "db2")):
-        assert np.abs(g - ref[key]).max() <= 5e-4 * max(1.0, np.abs(ref[key]).max()), key
+        assert np.abs(g - ref[key]).max() <= 1e-3 * max(1.0, np.abs(ref[key]).max()), key
 
 
 def test_joint_goldens(golden_dir):
@@ -146,7 +147,7 @@ def test_joint_goldens(golden_dir):
         costs, grads = run(case, z["cost_scale"], joint_dtype="f16" if f16 else "f32")
         np.testing.assert_allclose(costs, z["costs"], rtol=1e-4)
         for g, key in zip(grads, ("d_enc", "d_pred", "dW1", "db1", "dW2", "db2")):
-            tol = (5e-4 if f16 else 1e-4) * max(1.0, np.abs(z[key]).max())
+            tol = (1e-3 if f16 else 1e-4) * max(1.0, np.abs(z[key]).max())
             assert np.abs(g - z[key]).max() <= tol, (os.path.basename(f), key)
 
 
@@ -170,7 +171,7 @@ def test_joint_f16_odd_shapes_are_padded_exactly():
     np.testing.assert_allclose(costs, ref["costs"], rtol=1e-4)
     for g, key in zip(grads, ("d_enc", "d_pred", "dW1", "db1", "dW2", "db2")):
         assert g.shape == ref[key].shape
-        assert np.abs(g - ref[key]).max() <= 5e-4 * max(1.0, np.abs(ref[key]).max()), key
+        assert np.abs(g - ref[key]).max() <= 1e-3 * max(1.0, np.abs(ref[key]).max()), key
 
 
 def test_joint_f16_limits_are_reported():
