@@ -27,13 +27,19 @@ def lengths(B, T, U):
 
 t_start = time.time()
 for case in range(n_cases):
-    kind = rng.choice(["loss", "loss", "joint", "joint16"])
+    kind = rng.choice(["loss", "loss", "loss_wide", "joint", "joint16"])
     try:
-        if kind == "loss":
-            B, T, U = int(rng.integers(1, 6)), int(rng.integers(1, 80)), int(rng.integers(1, 90))
-            V = int(rng.choice([2, 3, 5, 8, 12, 28, 29, 31, 32, 33, 47, 60, 61, 64, 100, 257]))
+        if kind in ("loss", "loss_wide"):
+            if kind == "loss":
+                B, T, U = int(rng.integers(1, 6)), int(rng.integers(1, 80)), int(rng.integers(1, 90))
+                V = int(rng.choice([2, 3, 5, 8, 12, 28, 29, 31, 32, 33, 47, 60, 61, 64, 100, 257]))
+            else:  # every sweep width (K = 2 .. 16 columns per lane), several LDS-DMA chunks and re-basing blocks
+                B, U = int(rng.integers(1, 3)), int(rng.integers(65, 1001))
+                T = int(rng.integers(20, max(21, 60000 // U)))
+                V = int(rng.choice([4, 7, 8]))
             blank = int(rng.integers(0, V)) if rng.random() < 0.3 else 0
-            acts = (rng.normal(size=(B, T, U, V)) * rng.choice([0.5, 1.0, 4.0])).astype(np.float32)
+            sc = float(rng.choice([0.5, 1.0, 4.0]))
+            acts = (rng.normal(size=(B, T, U, V)) * sc).astype(np.float32)
             pool = [v for v in range(V) if v != blank]
             labels = rng.choice(pool, size=(B, max(U - 1, 1))).astype(np.int32)[:, : max(U - 1, 0)]
             il, ll = lengths(B, T, U)
@@ -43,8 +49,10 @@ for case in range(n_cases):
             dc = float(np.abs(c.cpu().numpy() - cr).max() / max(1.0, np.abs(cr).max()))
             dg = float(np.abs(g.cpu().numpy() - gr).max())
             worst["loss_cost"], worst["loss_grad"] = max(worst["loss_cost"], dc), max(worst["loss_grad"], dg)
-            if not (dc <= 1e-4 and dg <= 1e-4):
-                fails.append((kind, B, T, U, V, blank, dc, dg))
+            # f32 lattice sums: the rounding error of every edge weight grows with its magnitude, so the bar scales with
+            # the logit spread (1e-4 for N(0,1) logits, the tests' setting)
+            if not (dc <= 1e-4 and dg <= 1e-4 * max(1.0, sc)):
+                fails.append((str(kind), B, T, U, V, blank, sc, dc, dg))
         else:
             f16 = kind == "joint16"
             B, T, U, H = int(rng.integers(1, 4)), int(rng.integers(1, 40)), int(rng.integers(1, 45)), int(rng.integers(4, 24))
