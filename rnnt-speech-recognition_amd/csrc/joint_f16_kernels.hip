@@ -464,15 +464,16 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
         const float m2 = __shfl_xor(mref, 32), s2 = __shfl_xor(ssum, 32);
         const float M = fmaxf(mref, m2);
         const float S = ssum * hex2(mref - M) + s2 * hex2(m2 - M);
-        const float lse2 = M + hlg2(S);
+        const float lgS = hlg2(S);
+        const float lse2 = M + lgS;
         // the captured edge logits live in one of the two half-lanes of the cell
         const float xb_o = __shfl_xor(xb, 32), xl_o = __shfl_xor(xl, 32);
         xb = (half == hb) ? xb : xb_o;
         xl = (half == hl) ? xl : xl_o;
         if (cell_valid && half == 0) {
             const bool blank_stays = (t < Tb - 1) || (u == Ub - 1);
-            const float ob = blank_stays ? (xb - lse2) : kNeg;
-            const float ol = has_label ? (xl - lse2) : kNeg;
+            const float ob = blank_stays ? (xb - M) - lgS : kNeg;
+            const float ol = has_label ? (xl - M) - lgS : kNeg;
             p.lse[c] = lse2 * kLn2;
             ((float2 *)p.W)[((size_t)b * p.Nr + (t + u)) * p.Up + u] = make_float2(ob, ol);
             ((float2 *)jp.xbl)[c] = make_float2(xb, xl);

@@ -232,13 +232,14 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
                 float s = 0.f;
                 const float nml = -m * kLog2e;
                 for (int v = 0; v < V; ++v) s += jex2(fmaf(xs[v], kLog2e, nml));
-                const float lse = m + kLn2 * jlg2(s);
+                const float lg2s = jlg2(s);
+                const float lse = m + kLn2 * lg2s;
                 const bool blank_stays = (cl.t < Tb - 1) || (cl.u == Ub - 1);
-                const float ob = blank_stays ? (xs[p.blank] - lse) * kLog2e : kNeg;
+                const float ob = blank_stays ? (xs[p.blank] - m) * kLog2e - lg2s : kNeg;
                 float ol = kNeg;
                 if (cl.u < Ub - 1) {
                     const int lab = min(max(p.labels[(size_t)b * (p.U - 1) + cl.u], 0), V - 1);
-                    ol = (xs[lab] - lse) * kLog2e;
+                    ol = (xs[lab] - m) * kLog2e - lg2s;
                 }
                 p.lse[c] = lse;
                 const size_t wi = ((size_t)b * p.Nr + (cl.t + cl.u)) * p.Up + cl.u;

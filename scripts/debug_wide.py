@@ -7,6 +7,47 @@ import rnnt_speech_recognition_amd as pkg
 from oracle import rnnt_oracle as orc
 
 dev = torch.device("cuda:0")
+
+
+def f32_plain_grad(x, labels):
+    """The same recurrences in plain float32 natural-log arithmetic with NO re-basing (what a straightforward f32
+    CPU/GPU transducer op does): the yardstick for "how accurate is f32 anyway" on a given input."""
+    f = np.float32
+    x = x.astype(f)
+    T, U, V = x.shape
+    m = x.max(-1, keepdims=True)
+    lp = (x - m - np.log(np.exp(x - m).sum(-1, keepdims=True, dtype=f))).astype(f)
+    lpb = lp[:, :, 0]
+    lpl = np.take_along_axis(lp[:, :U - 1], labels[None, :U - 1, None].astype(np.int64), 2)[:, :, 0]
+    NEG = f(-1e30)
+    a = np.full((T, U), NEG, f); a[0, 0] = 0
+    b = np.full((T, U), NEG, f); b[T - 1, U - 1] = lpb[T - 1, U - 1]
+    def lse(p, q):
+        mm = np.maximum(p, q)
+        return (mm + np.log1p(np.exp(-np.abs(p - q), dtype=f), dtype=f)).astype(f)
+    for n in range(1, T + U - 1):
+        u = np.arange(max(0, n - T + 1), min(n, U - 1) + 1); t = n - u
+        up = np.full(u.shape, NEG, f); lf = np.full(u.shape, NEG, f)
+        mt = t >= 1; up[mt] = a[t[mt] - 1, u[mt]] + lpb[t[mt] - 1, u[mt]]
+        mu = u >= 1; lf[mu] = a[t[mu], u[mu] - 1] + lpl[t[mu], u[mu] - 1]
+        a[t, u] = lse(up, lf)
+    for n in range(T + U - 3, -1, -1):
+        u = np.arange(max(0, n - T + 1), min(n, U - 1) + 1); t = n - u
+        dn = np.full(u.shape, NEG, f); rt = np.full(u.shape, NEG, f)
+        mt = t + 1 < T; dn[mt] = b[t[mt] + 1, u[mt]] + lpb[t[mt], u[mt]]
+        mu = u + 1 < U; rt[mu] = b[t[mu], u[mu] + 1] + lpl[t[mu], u[mu]]
+        b[t, u] = lse(dn, rt)
+    ll = b[0, 0]
+    g = np.exp(lp + (a + b - ll)[:, :, None], dtype=f)
+    gb = np.zeros((T, U), f)
+    gb[:T - 1] = np.exp(a[:T - 1] + lpb[:T - 1] + b[1:] - ll, dtype=f)
+    gb[T - 1, U - 1] = np.exp(a[T - 1, U - 1] + lpb[T - 1, U - 1] - ll, dtype=f)
+    g[:, :, 0] -= gb
+    gl = np.exp(a[:, :U - 1] + lpl + b[:, 1:] - ll, dtype=f)
+    np.subtract.at(g, (np.arange(T)[:, None], np.arange(U - 1)[None, :], labels[None, :U - 1].astype(np.int64)), gl)
+    return g
+
+
 for (T, U, V, seed, sc) in [(23, 533, 8, 0, 4.0), (84, 574, 8, 1, 4.0), (600, 150, 28, 2, 4.0), (600, 150, 28, 3, 8.0), (300, 100, 28, 4, 4.0), (84, 574, 8, 5, 1.0)]:
     rng = np.random.default_rng(seed)
     acts = (sc * rng.normal(size=(1, T, U, V))).astype(np.float32)
@@ -16,6 +57,8 @@ for (T, U, V, seed, sc) in [(23, 533, 8, 0, 4.0), (84, 574, 8, 1, 4.0), (600, 15
                                   torch.tensor(il, device=dev), torch.tensor(ll, device=dev))
     cr, gr, al, be, lp = orc.utterance_cost_and_grad(acts[0], labels[0])
     err = np.abs(g.cpu().numpy()[0] - gr)
+    with np.errstate(all="ignore"):
+        err_plain = np.abs(f32_plain_grad(acts[0], labels[0]).astype(np.float64) - gr).max()
     t, u, v = np.unravel_index(err.argmax(), err.shape)
     n = t + u
     # natural-log alpha along diagonal n, relative to the straight-line ridge cell of that diagonal
@@ -25,4 +68,4 @@ for (T, U, V, seed, sc) in [(23, 533, 8, 0, 4.0), (84, 574, 8, 1, 4.0), (600, 15
     ur = min(max(ur, us[0]), us[-1])
     print(f"T={T} U={U} V={V} x{sc}: max|dgrad|={err.max():.2e} at t={t} u={u} (grad there {gr[t,u,v]:.3f}); "
           f"alpha(t,u)-alpha(ridge cell u={ur}) = {(al[t,u]-al[n-ur,ur])/np.log(2):.1f} bits; "
-          f"alpha+beta-ll there = {(al[t,u]+be[t,u]+cr)/np.log(2):.2f} bits; diag max - ridge = {(a_diag.max()-al[n-ur,ur])/np.log(2):.1f} bits")
+          f"alpha+beta-ll there = {(al[t,u]+be[t,u]+cr)/np.log(2):.2f} bits; diag max - ridge = {(a_diag.max()-al[n-ur,ur])/np.log(2):.1f} bits; plain-f32 (no re-basing) max|dgrad|={err_plain:.2e}")

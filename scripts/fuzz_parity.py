@@ -14,6 +14,7 @@ dev = torch.device("cuda:0")
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 fails, worst = [], {"loss_cost": 0.0, "loss_grad": 0.0, "joint_grad": 0.0, "joint16_grad": 0.0}
+worst_case = {}
 t = lambda x: torch.tensor(x, device=dev)
 
 
@@ -48,6 +49,8 @@ for case in range(n_cases):
             cr, gr = orc.rnnt_loss_and_grad(acts, labels, il, ll, blank=blank)
             dc = float(np.abs(c.cpu().numpy() - cr).max() / max(1.0, np.abs(cr).max()))
             dg = float(np.abs(g.cpu().numpy() - gr).max())
+            if dg > worst["loss_grad"]:
+                worst_case["loss_grad"] = (str(kind), B, T, U, V, blank, sc)
             worst["loss_cost"], worst["loss_grad"] = max(worst["loss_cost"], dc), max(worst["loss_grad"], dg)
             # f32 lattice sums: the rounding error of every edge weight grows with its magnitude, so the bar scales with
             # the logit spread (1e-4 for N(0,1) logits, the tests' setting)
@@ -85,6 +88,7 @@ for case in range(n_cases):
     except Exception as e:  # noqa
         fails.append((kind, "EXC", repr(e)[:200]))
 print(f"{n_cases} cases in {time.time() - t_start:.1f} s; worst deviations {worst}")
+print(f"worst cases {worst_case}")
 print(f"{len(fails)} failures")
 for f in fails[:20]:
     print("  ", f)
