@@ -7,7 +7,7 @@ Tolerances: costs relative 1e-4; every gradient tensor max|d| <= 1e-3 * max(1, m
 wider than the f32 paths' 1e-4 for a structural reason: dlogits are rounded to binary16 (relative step 4.9e-4) before
 the two backward products, and an f32 kernel value that differs from the f64 oracle value by ~3e-6 relative lands on
 the other side of a rounding boundary for ~1 % of the elements; each such element then differs by a whole binary16
-step.  Measured: typically 5e-5 .. 4e-4, worst 6.1e-4 over 400 random cases (scripts/fuzz_parity.py); perturbing the
+step.  Measured: typically 5e-5 .. 4e-4, worst 6.1e-4 over 400 random cases (tests/tools/fuzz_parity.py); perturbing the
 oracle's own pre-rounding values by 3e-6 relative moves its gradients by 1.5e-4 (same mechanism).
 The distance to the UNROUNDED joint is bounded too (costs 5e-3 relative): that is the price of binary16 operands (the
 reference's mixed_float16 policy pays the same), not a kernel error."""

@@ -1,7 +1,7 @@
 """Parity margins on the GPU box: HIP path (through the C ABI) vs the float64 oracle at BASELINE shapes.
 Writes profiles/r01_accuracy.json.  (Test infrastructure: uses oracle/.)"""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import rnnt_speech_recognition_amd as pkg
 from oracle import rnnt_oracle as orc
@@ -36,4 +36,4 @@ one("C2_ragged", 16, 600, 150, 28, (0, 3, 9), ragged=True, seed=77)
 one("C1_B4_T50_U20_V28", 4, 50, 20, 28, (0, 1, 2, 3))
 one("C5_slice_B2_T300_U300_V1024", 2, 300, 300, 1024, (0, 1), seed=5)
 one("long_T1500_U300_V28", 2, 1500, 300, 28, (0,), seed=9)
-json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "accuracy.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out", "accuracy.json"), "w"), indent=1)
