@@ -560,6 +560,12 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
     };
     set_arow();
     auto dma_piece = [&](const int k) {  // piece k (0..5) of the chunk under the prefetch cursor
+#ifdef JH_K3_NOB
+        if (k >= 4) return;  // timing experiment: no W2 tile traffic (results wrong)
+#endif
+#ifdef JH_K3_NODMA
+        return;  // timing experiment: no L2 -> LDS traffic at all (results wrong)
+#endif
         const f16 *src = (k < 4 ? arowP[k] : jp.W2h) + doff[k] + kp * 64;
         __builtin_amdgcn_global_load_lds((glb_cvoid *)src, (lds_void *)(smem + sp * kStage + (wave + 8 * k) * 1024), 16, 0, 0);
     };

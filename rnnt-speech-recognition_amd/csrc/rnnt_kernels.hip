@@ -602,17 +602,19 @@ __device__ __forceinline__ float rebase(float (&v)[K], const int u_ref) {
 // every 64 blocks (and at the end) the register is flushed to the table with one coalesced store per column group.
 struct OffsetLog {
     float *table;  // this utterance's [NC][NG] floats
-    int ng;
+    int ng;        // NG (row length of the table)
+    int g0, gn;    // column groups this wave writes: [g0, g0 + gn)
     float hist;
     int lo, hi;    // block range recorded since the last flush (lo > hi: empty)
-    __device__ __forceinline__ void init(float *t, int ng_) {
-        table = t, ng = ng_, hist = 0.f, lo = 1 << 30, hi = -1;
+    __device__ __forceinline__ void init(float *t, int ng_) { init(t, ng_, 0, ng_); }
+    __device__ __forceinline__ void init(float *t, int ng_, int g0_, int gn_) {
+        table = t, ng = ng_, g0 = g0_, gn = gn_, hist = 0.f, lo = 1 << 30, hi = -1;
     }
     __device__ __forceinline__ void flush(const int lane) {
         if (lo > hi) return;
         const int kc = (lo & ~63) + lane;
         if (kc >= lo && kc <= hi)
-            for (int g = 0; g < ng; ++g) st_f32_wt(table + (size_t)kc * ng + g, hist);
+            for (int g = g0; g < g0 + gn; ++g) st_f32_wt(table + (size_t)kc * ng + g, hist);
         lo = 1 << 30, hi = -1;
     }
     __device__ __forceinline__ void record(const int kc, const float off, const int lane) {
@@ -710,36 +712,44 @@ __global__ void lsm_done_marker_kernel(int *flag) {
     __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// number of store instructions store_diag<K, true> issues (pieces of 4, 2, 1 dwords)
-constexpr int store_pieces(int K) { return K / 4 + (K % 4) / 2 + (K % 2); }
+// number of store instructions store_diag<K, true> issues (pieces of 4 dwords, then one of 3, 2 or 1)
+constexpr int store_pieces(int K) { return K / 4 + ((K % 4) ? 1 : 0); }
 
 // Write one diagonal's K values of this lane: `row` is the wave-uniform row base (SGPR pair), `voff`
 // the lane's byte offset.  COUNTED: explicit instructions so that the number of VMEM operations per
 // step is known exactly (for the counted s_waitcnt at chunk boundaries).
-template <int K, bool COUNTED>
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+// OFF: compile-time byte offset added to `row` (the 13-bit signed immediate of the store: |OFF| + 4 K <= 4096), so that
+// consecutive diagonals can share one SGPR row base.
+template <int K, bool COUNTED, int OFF = 0>
 __device__ __forceinline__ void store_diag(float *row, const int voff, const int lane, const float (&v)[K]) {
     // All lattice stores are write-through (sc1): the gradient pass may run on another XCD while this
     // kernel is still alive (overlap mode), and nothing on this XCD re-reads them anyway.
     if (!COUNTED) {
-        float *dst = row + lane * K;
+        float *dst = row + lane * K + OFF / 4;
 #pragma unroll
         for (int j = 0; j < K; ++j) st_f32_wt(dst + j, v[j]);
     } else {
+        static_assert(OFF + 4 * K <= 4096 && OFF >= -4096, "store offset outside the immediate range");
         int j = 0;
 #pragma unroll
         for (; j + 4 <= K; j += 4) {
             const f32x4 q = {v[j], v[j + 1], v[j + 2], v[j + 3]};
-            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 sc1\n\ts_nop 1" ::"v"(voff), "v"(q), "s"(row), "n"(j * 4));
+            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 sc1\n\ts_nop 1" ::"v"(voff), "v"(q), "s"(row), "n"(OFF + j * 4));
         }
-        if (K % 4 >= 2) {
+        if (K % 4 == 3) {
+            const f32x3 q = {v[j], v[j + 1], v[j + 2]};
+            asm volatile("global_store_dwordx3 %0, %1, %2 offset:%3 sc1" ::"v"(voff), "v"(q), "s"(row), "n"(OFF + j * 4));
+        } else if (K % 4 == 2) {
             const f32x2 q = {v[j], v[j + 1]};
-            asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 sc1" ::"v"(voff), "v"(q), "s"(row), "n"(j * 4));
-            j += 2;
+            asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 sc1" ::"v"(voff), "v"(q), "s"(row), "n"(OFF + j * 4));
+        } else if (K % 4 == 1) {
+            asm volatile("global_store_dword %0, %1, %2 offset:%3 sc1" ::"v"(voff), "v"(v[j]), "s"(row), "n"(OFF + j * 4));
         }
-        if (K % 2)
-            asm volatile("global_store_dword %0, %1, %2 offset:%3 sc1" ::"v"(voff), "v"(v[j]), "s"(row), "n"(j * 4));
     }
 }
+// diagonals that can share one row base through the store immediate (forward: offsets 0 .. (R-1) Up 4)
+constexpr int rows_per_base(int K) { return (4096 - 4 * K) / (64 * K * 4) + 1 > 16 ? 16 : (4096 - 4 * K) / (64 * K * 4) + 1; }
 
 template <int N>
 __device__ __forceinline__ void wait_vm_counted() {
@@ -785,6 +795,46 @@ __device__ __forceinline__ void alpha_step(float (&a)[K], const f32x2 (&w)[K]) {
     for (int j = 0; j < K; ++j) a[j] = lse2(de[j][0], (j == 0) ? from_left : de[j - 1][1]);
 }
 
+// The same steps for the unrolled chunks.  Two instructions less per diagonal:
+//  * the value DPP shifts into the edge lane (lane 0 / lane 63) is log zero; instead of re-materialising that
+//    constant every step (the DPP move overwrites its `old` operand), the previous step's shifted register is passed
+//    as `old`: its edge lane still holds log zero (the move never writes it);
+//  * fmaxf on a DPP result makes the compiler canonicalise it first (v_max x, x); v_max_f32 itself quiets NaNs.
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float lse2v(float a, float b) {
+    const float d = a - b;
+    return vmax(a, b) + lg2(1.0f + ex2(-fabsf(d)));
+}
+template <int K>
+__device__ __forceinline__ void alpha_step_c(float (&a)[K], const f32x2 (&w)[K], float &edge) {
+    f32x2 de[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const f32x2 aa = {a[j], a[j]};
+        de[j] = aa + w[j];
+    }
+    edge = dpp_from_lower_lane(de[K - 1][1], edge);
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = lse2v(de[j][0], (j == 0) ? edge : de[j - 1][1]);
+}
+template <int K>
+__device__ __forceinline__ void beta_step_c(float (&bv)[K], const f32x2 (&w)[K], float &edge) {
+    edge = dpp_from_upper_lane(bv[0], edge);
+    float nv[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const f32x2 br = {bv[j], (j == K - 1) ? edge : bv[j + 1]};
+        const f32x2 s2 = br + w[j];
+        nv[j] = lse2v(s2[0], s2[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) bv[j] = nv[j];
+}
+
 // One beta step: diagonal n+1 -> n using the outgoing edge weights `w` of diagonal n.
 template <int K>
 __device__ __forceinline__ void beta_step(float (&bv)[K], const f32x2 (&w)[K]) {
@@ -805,6 +855,7 @@ struct SweepState {
     float off;       // cumulative (integer-valued) offset: true value = stored value + off
     OffsetLog log;
     float *row;      // wave-uniform base of the output row of the NEXT diagonal to be stored
+    float edge;      // what DPP shifted in last (edge lane: log zero, see alpha_step_c)
 };
 
 // Fully unrolled, explicitly pipelined steps of one chunk (compile-time recursion over the step index
@@ -821,13 +872,14 @@ __device__ __forceinline__ void alpha_fast_steps(float (&a)[K], f32x2 (&wq)[2][K
             lds_wait<0>();
         }
         const int n = r0 + II + 1;
-        alpha_step<K>(a, wq[cur]);
+        alpha_step_c<K>(a, wq[cur], st.edge);
         if ((n & (kRebase - 1)) == 0) {
             st.off += rebase<K>(a, ridge.u_at(n));
             st.log.record(n / kRebase, st.off, lane);
         }
-        store_diag<K, true>(st.row, voff, lane, a);
-        st.row += 64 * K;
+        constexpr int R = rows_per_base(K);
+        store_diag<K, true, (II % R) * 64 * K * 4>(st.row, voff, lane, a);
+        if constexpr (II % R == R - 1 || II == G - 1) st.row += (II % R + 1) * 64 * K;
         alpha_fast_steps<K, G, II + 1>(a, wq, abase, st, voff, lane, r0, ridge);
     }
 }
@@ -845,13 +897,14 @@ __device__ __forceinline__ void beta_fast_steps(float (&bv)[K], f32x2 (&wq)[2][K
             lds_wait<0>();
         }
         const int n = r0 + i;
-        beta_step<K>(bv, wq[cur]);
+        beta_step_c<K>(bv, wq[cur], st.edge);
         if ((n & (kRebase - 1)) == kRebase - 1) {
             st.off += rebase<K>(bv, ridge.u_at(n));
             st.log.record(n / kRebase, st.off, lane);
         }
-        store_diag<K, true>(st.row, voff, lane, bv);
-        st.row -= 64 * K;
+        constexpr int R = rows_per_base(K);
+        store_diag<K, true, -(II % R) * 64 * K * 4>(st.row, voff, lane, bv);
+        if constexpr (II % R == R - 1 || II == G - 1) st.row -= (II % R + 1) * 64 * K;
         beta_fast_steps<K, G, II + 1>(bv, wq, abase, st, voff, lane, r0, ridge);
     }
 }
@@ -876,6 +929,7 @@ __device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const 
     store_diag<K, false>(out, voff, lane, a);
     SweepState st;
     st.off = 0.f;
+    st.edge = kNeg;
     st.log.init(p.offA + (size_t)b * p.NC * p.NG, p.NG);
     st.log.record(0, 0.f, lane);
     st.row = out + Up;  // diagonal 1
@@ -952,6 +1006,7 @@ __device__ void beta_sweep(const LossParams &p, float *lds, const int b, const i
     const int ckl = last / G;
     SweepState st;
     st.off = 0.f;
+    st.edge = kNeg;
     st.log.init(p.offB + (size_t)b * p.NC * p.NG, p.NG);
     st.row = out + (size_t)last * Up;
 
@@ -1340,6 +1395,7 @@ static int sweep_mode() {
     if (e && e[0] == '0') return 0;
     if (e && e[0] == '2') return 2;
     if (e && e[0] == '3') return 3;
+    if (e && e[0] == '4') return 4;
     return 1;
 }
 
@@ -1602,6 +1658,377 @@ hipError_t launch_lsm_done_marker(const LossParams &p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split sweep (RNNT_SWEEP_MODE=4): the columns of an utterance are shared by TWO waves per direction -- the low wave
+// owns columns [0, 64 KA) with KA columns per lane, the high wave [64 KA, 64 (KA + KB)) with KB -- so each wave issues
+// about half the instructions per diagonal of the single-wave sweep (which is issue-bound: 6 transcendentals + ~30 other
+// instructions per diagonal at K = 3).  Each wave is the single-wave sweep on its own columns (own LDS-DMA double buffer,
+// counted waits, fully unrolled chunks of G diagonals, own integer re-basing against its column nearest the ridge); the
+// only coupling is the value that crosses the column boundary once per diagonal:
+//   alpha: the low wave's label edge out of column 64 KA - 1 feeds the high wave's column 64 KA;
+//   beta : the high wave's beta of column 64 KA feeds the low wave's label edge of column 64 KA - 1.
+// The producer writes {value, its offset} into an LDS array indexed by the diagonal (never reused: no back-pressure, so
+// the producer never waits and there is no cycle to deadlock on) and publishes a counter after every chunk; the consumer
+// runs one chunk behind, checks the counter once per chunk (bounded poll) and reads one entry per diagonal together
+// with its weight rows.  Both offsets are integers, so  value + (producer offset - consumer offset)  is exact.
+// A high wave whose columns lie beyond U_b has nothing to do and exits; the low wave then reads {log zero, 0}.
+// ---------------------------------------------------------------------------------------------
+template <int K, int G, int UPT>
+__device__ __forceinline__ void dma_rows_part(const float *g, float *l, const int lane) {
+    constexpr int per_row = 32 * K, total = G * per_row;  // 16-byte units: one row segment, the whole chunk
+    static_assert(total % 64 == 0, "chunk segment must be whole wave-instructions");
+#pragma unroll
+    for (int i0 = 0; i0 < total; i0 += 64) {
+        const int k = i0 + lane;
+        const int row = k / per_row, c = k - row * per_row;
+        __builtin_amdgcn_global_load_lds((glb_void *)(g + (size_t)row * (2 * UPT) + c * 4), (lds_void *)(l + i0 * 4), 16, 0, 0);
+    }
+}
+constexpr int dma_part_pieces(int K, int G) { return G * 32 * K / 64; }
+
+// Re-base against the wave's own column `u_local` (0 .. 64 K - 1); skipped while that cell is still log zero.
+template <int K>
+__device__ __forceinline__ float rebase_local(float (&v)[K], const int u_local) {
+    const int src_lane = u_local / K, src_j = u_local - src_lane * K;  // wave-uniform
+    float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[0]), src_lane));
+#pragma unroll
+    for (int j = 1; j < K; ++j) {
+        const float mj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[j]), src_lane));
+        m = (src_j == j) ? mj : m;
+    }
+    if (!(m > kNegTest)) return 0.f;
+    const float mi = rintf(m);
+#pragma unroll
+    for (int j = 0; j < K; ++j) v[j] -= mi;
+    return mi;
+}
+
+// alpha step with an explicit value entering column 0 of lane 0 (`fill`); returns nothing, `e_last` = label edge out of
+// the lane's last column (lane 63's is what crosses to the next wave).
+template <int K>
+__device__ __forceinline__ void alpha_step_x(float (&a)[K], const f32x2 (&w)[K], const float fill, float &e_last) {
+    f32x2 de[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const f32x2 aa = {a[j], a[j]};
+        de[j] = aa + w[j];
+    }
+    e_last = de[K - 1][1];
+    const float from_left = dpp_from_lower_lane(e_last, fill);
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = lse2(de[j][0], (j == 0) ? from_left : de[j - 1][1]);
+}
+template <int K>
+__device__ __forceinline__ void beta_step_x(float (&bv)[K], const f32x2 (&w)[K], const float fill) {
+    const float from_right = dpp_from_upper_lane(bv[0], fill);
+    float nv[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const f32x2 br = {bv[j], (j == K - 1) ? from_right : bv[j + 1]};
+        const f32x2 s2 = br + w[j];
+        nv[j] = lse2(s2[0], s2[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) bv[j] = nv[j];
+}
+
+__device__ __forceinline__ int ridge_local(const RidgeLine &ridge, const int n, const int cb, const int width) {
+    return min(max(ridge.u_at(n) - cb, 0), width - 1);
+}
+
+template <int K, int G, int UPT, int II, bool PROD>
+__device__ __forceinline__ void alpha_split_steps(float (&a)[K], f32x2 (&wq)[2][K], f32x2 (&xq)[2], const uint32_t abase,
+                                                  const uint32_t xaddr, SweepState &st, const int voff, const int lane,
+                                                  const int r0, const RidgeLine &ridge, const int cb) {
+    if constexpr (II < G) {
+        constexpr int cur = II & 1, nxt = cur ^ 1;
+        if constexpr (II + 1 < G) {
+            lds_issue_row<K, II + 1>(wq[nxt], abase);
+            if constexpr (!PROD) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xq[nxt]) : "v"(xaddr), "n"((II + 1) * 8));
+            lds_wait<K + (PROD ? 0 : 1)>();  // row II (and the boundary entry II) landed; the newest reads stay in flight
+        } else {
+            lds_wait<0>();
+        }
+        const int n = r0 + II + 1;
+        float fill = kNeg, e_last;
+        if constexpr (!PROD) fill = xq[cur][0] + (xq[cur][1] - st.off);
+        alpha_step_x<K>(a, wq[cur], fill, e_last);
+        if constexpr (PROD) {
+            const f32x2 o = {e_last, st.off};  // relative to the offset the diagonal-r values carry (before this step's re-base)
+            asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xaddr), "v"(o), "n"(II * 8) : "memory");
+        }
+        if ((n & (kRebase - 1)) == 0) {
+            st.off += rebase_local<K>(a, ridge_local(ridge, n, cb, 64 * K));
+            st.log.record(n / kRebase, st.off, lane);
+        }
+        store_diag<K, true>(st.row, voff, lane, a);
+        st.row += UPT;
+        alpha_split_steps<K, G, UPT, II + 1, PROD>(a, wq, xq, abase, xaddr, st, voff, lane, r0, ridge, cb);
+    }
+}
+
+template <int K, int G, int UPT, int II, bool PROD>
+__device__ __forceinline__ void beta_split_steps(float (&bv)[K], f32x2 (&wq)[2][K], f32x2 (&xq)[2], const uint32_t abase,
+                                                 const uint32_t xaddr, SweepState &st, const int voff, const int lane,
+                                                 const int r0, const RidgeLine &ridge, const int cb) {
+    if constexpr (II < G) {
+        constexpr int cur = II & 1, nxt = cur ^ 1;
+        constexpr int i = G - 1 - II;
+        if constexpr (i > 0) {
+            lds_issue_row<K, i - 1>(wq[nxt], abase);
+            if constexpr (!PROD) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xq[nxt]) : "v"(xaddr), "n"((i - 1) * 8));
+            lds_wait<K + (PROD ? 0 : 1)>();
+        } else {
+            lds_wait<0>();
+        }
+        const int n = r0 + i;
+        float fill = kNeg;
+        if constexpr (!PROD) fill = xq[cur][0] + (xq[cur][1] - st.off);
+        if constexpr (PROD) {
+            const f32x2 o = {bv[0], st.off};  // beta of the diagonal below, before this step
+            asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xaddr), "v"(o), "n"(i * 8) : "memory");
+        }
+        beta_step_x<K>(bv, wq[cur], fill);
+        if ((n & (kRebase - 1)) == kRebase - 1) {
+            st.off += rebase_local<K>(bv, ridge_local(ridge, n, cb, 64 * K));
+            st.log.record(n / kRebase, st.off, lane);
+        }
+        store_diag<K, true>(st.row, voff, lane, bv);
+        st.row -= UPT;
+        beta_split_steps<K, G, UPT, II + 1, PROD>(bv, wq, xq, abase, xaddr, st, voff, lane, r0, ridge, cb);
+    }
+}
+
+// LDS-side plumbing of one split-sweep wave
+struct SplitLink {
+    float2 *ring;      // [Nr] boundary entries {value, producer offset}, indexed by the diagonal
+    float2 *trash;     // [64 + G] dump for the producer lanes that are not the boundary lane
+    uint32_t prog;     // LDS byte address of the producer's progress counter
+    bool peer;         // the other wave of this direction is alive
+};
+
+template <int K, int G, int UPT, bool PROD>
+__device__ void alpha_split_sweep(const LossParams &p, float *buf0, float *buf1, const SplitLink &lk, const int b,
+                                  const int lane, const int cb) {
+    constexpr int Wd = 64 * K, chunkf = G * 2 * Wd;
+    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int Nb = Tb + Ub - 1;
+    const RidgeLine ridge = make_ridge(Ub, Nb);
+    const float *Wb = p.W + (size_t)b * p.Nr * 2 * UPT + 2 * cb;
+    float *out = p.A + (size_t)b * p.Nr * UPT + cb;
+    const int voff = lane * K * 4;
+    const int u0 = cb + lane * K;
+    const uint32_t ring_a = (uint32_t)(uintptr_t)((lds_void *)lk.ring);
+    const uint32_t trash_a = (uint32_t)(uintptr_t)((lds_void *)lk.trash);
+
+    float a[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = (u0 + j == 0) ? 0.f : kNeg;
+    store_diag<K, false>(out, voff, lane, a);
+    SweepState st;
+    st.off = 0.f;
+    st.edge = kNeg;
+    st.log.init(p.offA + (size_t)b * p.NC * p.NG, p.NG, cb / 64, K);
+    st.log.record(0, 0.f, lane);
+    st.row = out + UPT;
+    const int last_row = Nb - 1;
+    const int nchunks = last_row / G + 1;
+
+    dma_rows_part<K, G, UPT>(Wb, buf0, lane);
+    bool prev_full = false;
+    for (int ck = 0; ck < nchunks; ++ck) {
+        if (prev_full)
+            wait_vm_counted<G * store_pieces(K)>();
+        else
+            wait_vm0();
+        const float *cur = ((ck & 1) ? buf1 : buf0) + 2 * lane * K;
+        if (ck + 1 < nchunks) dma_rows_part<K, G, UPT>(Wb + (size_t)(ck + 1) * G * 2 * UPT, (ck & 1) ? buf0 : buf1, lane);
+        const int r0 = ck * G;
+        const int hi = min(r0 + G, last_row);  // this chunk's steps consume the boundary entries r0 .. hi-1
+        if (!PROD && lk.peer) lds_wait_ge(lk.prog, hi);
+        if (r0 + G <= last_row) {
+            const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
+            const uint32_t xaddr = PROD ? ((lane == 63) ? ring_a + (uint32_t)r0 * 8u : trash_a + (uint32_t)lane * 8u)
+                                        : ring_a + (uint32_t)r0 * 8u;
+            f32x2 wq[2][K], xq[2];
+            lds_issue_row<K, 0>(wq[0], abase);
+            if (!PROD) asm volatile("ds_read_b64 %0, %1" : "=v"(xq[0]) : "v"(xaddr));
+            alpha_split_steps<K, G, UPT, 0, PROD>(a, wq, xq, abase, xaddr, st, voff, lane, r0, ridge, cb);
+            prev_full = true;
+        } else {
+            for (int i = 0; i < G; ++i) {
+                const int r = r0 + i, n = r + 1;
+                if (n > last_row) break;
+                f32x2 wc[K];
+                load_w<K>(wc, cur + i * 2 * Wd);
+                float fill = kNeg, e_last;
+                if (!PROD) {
+                    const float2 x = lk.ring[r];
+                    fill = x.x + (x.y - st.off);
+                }
+                alpha_step_x<K>(a, wc, fill, e_last);
+                if (PROD && lane == 63) lk.ring[r] = make_float2(e_last, st.off);
+                if ((n & (kRebase - 1)) == 0) {
+                    st.off += rebase_local<K>(a, ridge_local(ridge, n, cb, Wd));
+                    st.log.record(n / kRebase, st.off, lane);
+                }
+                store_diag<K, false>(st.row, voff, lane, a);
+                st.row += UPT;
+            }
+            prev_full = false;
+        }
+        if (PROD) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this chunk's boundary entries are in LDS
+            if (lane == 0) lds_post(lk.prog, hi);
+        }
+    }
+    st.log.flush(lane);
+    {
+        const float *wrow = (((nchunks - 1) & 1) ? buf1 : buf0) + (last_row % G) * 2 * Wd + 2 * lane * K;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (u0 + j == Ub - 1) {
+                const double ll2 = (double)st.off + (double)a[j] + (double)wrow[2 * j];
+                st_f64_wt(p.ll + 2 * b, ll2);
+                st_f32_wt(p.costs + b, (float)(-ll2 * 0.6931471805599453));
+            }
+    }
+}
+
+template <int K, int G, int UPT, bool PROD>
+__device__ void beta_split_sweep(const LossParams &p, float *buf0, float *buf1, const SplitLink &lk, const int b,
+                                 const int lane, const int cb) {
+    constexpr int Wd = 64 * K, chunkf = G * 2 * Wd;
+    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int Nb = Tb + Ub - 1;
+    const RidgeLine ridge = make_ridge(Ub, Nb);
+    const float *Wb = p.W + (size_t)b * p.Nr * 2 * UPT + 2 * cb;
+    float *out = p.Bt + (size_t)b * p.Nr * UPT + cb;
+    const int voff = lane * K * 4;
+    const int u0 = cb + lane * K;
+    const uint32_t ring_a = (uint32_t)(uintptr_t)((lds_void *)lk.ring);
+    const uint32_t trash_a = (uint32_t)(uintptr_t)((lds_void *)lk.trash);
+
+    float bv[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) bv[j] = (u0 + j == Ub - 1) ? 0.f : kNeg;
+    const int last = Nb - 1;
+    const int ckl = last / G;
+    SweepState st;
+    st.off = 0.f;
+    st.edge = kNeg;
+    st.log.init(p.offB + (size_t)b * p.NC * p.NG, p.NG, cb / 64, K);
+    st.row = out + (size_t)last * UPT;
+
+    dma_rows_part<K, G, UPT>(Wb + (size_t)ckl * G * 2 * UPT, (ckl & 1) ? buf1 : buf0, lane);
+    bool prev_full = false;
+    for (int ck = ckl; ck >= 0; --ck) {
+        if (prev_full)
+            wait_vm_counted<G * store_pieces(K)>();
+        else
+            wait_vm0();
+        const float *cur = ((ck & 1) ? buf1 : buf0) + 2 * lane * K;
+        if (ck > 0) dma_rows_part<K, G, UPT>(Wb + (size_t)(ck - 1) * G * 2 * UPT, (ck & 1) ? buf0 : buf1, lane);
+        const int r0 = ck * G;
+        const int done = last - r0 + 1;  // steps finished once this chunk is (entries last .. r0 written)
+        if (!PROD && lk.peer) lds_wait_ge(lk.prog, done);
+        if (r0 + G - 1 < last) {
+            const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
+            const uint32_t xaddr = PROD ? ((lane == 0) ? ring_a + (uint32_t)r0 * 8u : trash_a + (uint32_t)lane * 8u)
+                                        : ring_a + (uint32_t)r0 * 8u;
+            f32x2 wq[2][K], xq[2];
+            lds_issue_row<K, G - 1>(wq[0], abase);
+            if (!PROD) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xq[0]) : "v"(xaddr), "n"((G - 1) * 8));
+            beta_split_steps<K, G, UPT, 0, PROD>(bv, wq, xq, abase, xaddr, st, voff, lane, r0, ridge, cb);
+            prev_full = true;
+        } else {
+            for (int ii = 0; ii < G; ++ii) {
+                const int i = G - 1 - ii;
+                const int n = r0 + i;
+                if (n > last) continue;
+                f32x2 wc[K];
+                load_w<K>(wc, cur + i * 2 * Wd);
+                float fill = kNeg;
+                if (!PROD) {
+                    const float2 x = lk.ring[n];
+                    fill = x.x + (x.y - st.off);
+                }
+                if (PROD && lane == 0) lk.ring[n] = make_float2(bv[0], st.off);
+                beta_step_x<K>(bv, wc, fill);
+                if (((n & (kRebase - 1)) == kRebase - 1) || n == last) {
+                    st.off += rebase_local<K>(bv, ridge_local(ridge, n, cb, Wd));
+                    st.log.record(n / kRebase, st.off, lane);
+                }
+                store_diag<K, false>(st.row, voff, lane, bv);
+                st.row -= UPT;
+            }
+            prev_full = false;
+        }
+        if (PROD) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) lds_post(lk.prog, done);
+        }
+    }
+    st.log.flush(lane);
+    if (lane == 0 && cb == 0) st_f64_wt(p.ll + 2 * b + 1, (double)st.off + (double)bv[0]);
+}
+
+template <int KA, int KB, int G>
+constexpr size_t split_lds_floats() { return (size_t)2 * (2 * G * 2 * 64 * KA) + (size_t)2 * (2 * G * 2 * 64 * KB); }
+
+template <int KA, int KB, int G>
+__global__ __launch_bounds__(256) void sweep_split_kernel(const LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int UPT = 64 * (KA + KB);
+    constexpr int fA = 2 * G * 2 * 64 * KA, fB = 2 * G * 2 * 64 * KB;  // floats per wave (two chunk buffers)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = p.b0 + (int)blockIdx.x;
+    const int Ub = p.label_lengths[b] + 1;
+    const bool peer = 64 * KA < Ub;  // the high waves own live columns
+    float *bA0 = lds, *bA1 = bA0 + fA, *bB0 = bA1 + fB, *bB1 = bB0 + fA;  // alpha low, alpha high, beta low, beta high
+    float2 *ringA = (float2 *)(bB1 + fB), *ringB = ringA + p.Nr;
+    float2 *trash = ringB + p.Nr;  // two dumps of 64 + G entries
+    int *prog = (int *)(trash + 2 * (64 + G));
+    if (tid < 2) prog[tid] = 0;
+    if (!peer)
+        for (int i = tid; i < 2 * p.Nr; i += 256) ringA[i] = make_float2(kNeg, 0.f);
+    __syncthreads();
+    SplitLink lk;
+    lk.peer = peer;
+    if (wave < 2) {
+        lk.ring = ringA, lk.trash = trash, lk.prog = (uint32_t)(uintptr_t)((lds_void *)prog);
+        if (wave == 0)
+            alpha_split_sweep<KA, G, UPT, true>(p, bA0, bA0 + fA / 2, lk, b, lane, 0);
+        else if (peer)
+            alpha_split_sweep<KB, G, UPT, false>(p, bA1, bA1 + fB / 2, lk, b, lane, 64 * KA);
+    } else {
+        lk.ring = ringB, lk.trash = trash + 64 + G, lk.prog = (uint32_t)(uintptr_t)((lds_void *)(prog + 1));
+        if (wave == 2)
+            beta_split_sweep<KA, G, UPT, false>(p, bB0, bB0 + fA / 2, lk, b, lane, 0);
+        else if (peer)
+            beta_split_sweep<KB, G, UPT, true>(p, bB1, bB1 + fB / 2, lk, b, lane, 64 * KA);
+    }
+}
+
+template <int KA, int KB, int G>
+static hipError_t launch_sweep_split(const LossParams &p, hipStream_t s, bool *done) {
+    const size_t shm = split_lds_floats<KA, KB, G>() * sizeof(float) + (size_t)2 * p.Nr * sizeof(float2) +
+                       (size_t)2 * (64 + G) * sizeof(float2) + 16;
+    *done = false;
+    if (shm > 160 * 1024) return hipSuccess;  // boundary arrays do not fit: the caller falls back to the single wave
+    static size_t attr_bytes = 0;
+    if (shm > 64 * 1024 && shm > attr_bytes) {
+        hipError_t e = hipFuncSetAttribute((const void *)sweep_split_kernel<KA, KB, G>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        if (e != hipSuccess) return e;
+        attr_bytes = 160 * 1024;
+    }
+    hipLaunchKernelGGL((sweep_split_kernel<KA, KB, G>), dim3(p.nb), dim3(256), shm, s, p);
+    *done = true;
+    return hipGetLastError();
+}
+
 bool overlap_path_ok(const LossParams &p, bool grad) {
     // patch kernels on both sides and the single-wave sweep (the hand-off hooks live there)
     return (p.V % 4) == 0 && tile_path_ok(p, false) && (!grad || tile_path_ok(p, true)) && sweep_mode() == 1 &&
@@ -1611,6 +2038,19 @@ bool overlap_path_ok(const LossParams &p, bool grad) {
 hipError_t launch_sweeps(const LossParams &p0, hipStream_t s, bool overlap) {
     LossParams p = p0;
     if (!overlap) p.flags = nullptr;  // the sweep kernels key the hand-off protocol on this pointer
+    if (sweep_mode() == 4 && !overlap) {
+        bool done = false;
+        hipError_t e = hipSuccess;
+        switch (sweep_K(p.U)) {  // two waves per direction (see sweep_split_kernel); G as large as the LDS allows
+            case 2: e = launch_sweep_split<1, 1, 16>(p, s, &done); break;
+            case 3: e = launch_sweep_split<2, 1, 16>(p, s, &done); break;
+            case 4: e = launch_sweep_split<2, 2, 8>(p, s, &done); break;
+            case 6: e = launch_sweep_split<3, 3, 8>(p, s, &done); break;
+            case 8: e = launch_sweep_split<4, 4, 4>(p, s, &done); break;
+            default: break;
+        }
+        if (e != hipSuccess || done) return e;
+    }
     if (sweep_mode() == 3 && !overlap) {
         switch (sweep_K(p.U)) {  // counter-synchronised multi-wave sweep: up to 3 column groups (U <= 192)
             case 1: return launch_sweep_mwc<1>(p, s);
