@@ -731,6 +731,9 @@ __device__ __forceinline__ void store_diag(float *row, const int voff, const int
         for (int j = 0; j < K; ++j) st_f32_wt(dst + j, v[j]);
     } else {
         static_assert(OFF + 4 * K <= 4096 && OFF >= -4096, "store offset outside the immediate range");
+#ifdef SWEEP_EXP_NOSTORE
+        return;  // timing experiment (results wrong, counted waits over-wait harmlessly)
+#endif
         int j = 0;
 #pragma unroll
         for (; j + 4 <= K; j += 4) {
@@ -805,34 +808,72 @@ __device__ __forceinline__ float vmax(float a, float b) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-__device__ __forceinline__ float lse2v(float a, float b) {
-    const float d = a - b;
-    return vmax(a, b) + lg2(1.0f + ex2(-fabsf(d)));
+// Stage-major log-add of K independent (u, l) pairs: a lone wave stalls on every instruction that consumes the result of
+// the one just before it, so the K chains are issued stage by stage (sub x K, exp2 x K, max x K, add x K, log2 x K, add x K)
+// with scheduling fences in between -- every consumer is K instructions behind its producer.
+#define SWEEP_FENCE() __builtin_amdgcn_sched_barrier(0)
+template <int K>
+__device__ __forceinline__ void lse2_staged(float (&out)[K], const float (&u)[K], const float (&l)[K]) {
+    float d[K], e[K], m[K];
+#pragma unroll
+    for (int j = K - 1; j >= 0; --j) d[j] = u[j] - l[j];  // column 0 last: its l comes out of the DPP move
+    SWEEP_FENCE();
+#pragma unroll
+    for (int j = K - 1; j >= 0; --j) e[j] = ex2(-fabsf(d[j]));
+#ifdef SWEEP_EXP_NOTRANS  // timing experiment (results wrong): no transcendentals
+#pragma unroll
+    for (int j = K - 1; j >= 0; --j) out[j] = vmax(u[j], l[j]) + (1.0f - fabsf(d[j]) * 1e-9f);
+    return;
+#endif
+    SWEEP_FENCE();
+#pragma unroll
+    for (int j = K - 1; j >= 0; --j) m[j] = vmax(u[j], l[j]);
+    SWEEP_FENCE();
+#pragma unroll
+    for (int j = K - 1; j >= 0; --j) e[j] = 1.0f + e[j];
+    SWEEP_FENCE();
+#pragma unroll
+    for (int j = K - 1; j >= 0; --j) e[j] = lg2(e[j]);
+    SWEEP_FENCE();
+#pragma unroll
+    for (int j = K - 1; j >= 0; --j) out[j] = m[j] + e[j];
+    SWEEP_FENCE();
 }
 template <int K>
 __device__ __forceinline__ void alpha_step_c(float (&a)[K], const f32x2 (&w)[K], float &edge) {
     f32x2 de[K];
+    SWEEP_FENCE();
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
+    for (int j = K - 1; j >= 0; --j) {  // last column first: the DPP move waits for it
         const f32x2 aa = {a[j], a[j]};
         de[j] = aa + w[j];
     }
+    SWEEP_FENCE();
     edge = dpp_from_lower_lane(de[K - 1][1], edge);
+    float u[K], l[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) a[j] = lse2v(de[j][0], (j == 0) ? edge : de[j - 1][1]);
+    for (int j = 0; j < K; ++j) u[j] = de[j][0], l[j] = (j == 0) ? edge : de[j - 1][1];
+    SWEEP_FENCE();
+    lse2_staged<K>(a, u, l);
 }
 template <int K>
 __device__ __forceinline__ void beta_step_c(float (&bv)[K], const f32x2 (&w)[K], float &edge) {
+    SWEEP_FENCE();
     edge = dpp_from_upper_lane(bv[0], edge);
-    float nv[K];
+    f32x2 s2[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
+    for (int j = 0; j < K; ++j) {  // last column last: it waits for the DPP move
         const f32x2 br = {bv[j], (j == K - 1) ? edge : bv[j + 1]};
-        const f32x2 s2 = br + w[j];
-        nv[j] = lse2v(s2[0], s2[1]);
+        s2[j] = br + w[j];
     }
+    SWEEP_FENCE();
+    float u[K], l[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) bv[j] = nv[j];
+    for (int j = 0; j < K; ++j) u[K - 1 - j] = s2[j][0], l[K - 1 - j] = s2[j][1];  // reversed: lse2_staged takes its index 0 last
+    float nv[K];
+    lse2_staged<K>(nv, u, l);
+#pragma unroll
+    for (int j = 0; j < K; ++j) bv[j] = nv[K - 1 - j];
 }
 
 // One beta step: diagonal n+1 -> n using the outgoing edge weights `w` of diagonal n.
