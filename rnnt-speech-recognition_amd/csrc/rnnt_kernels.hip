@@ -1840,6 +1840,13 @@ __device__ __forceinline__ void beta_split_steps(float (&bv)[K], f32x2 (&wq)[2][
     }
 }
 
+#ifdef SPLIT_TRACE
+__device__ long long *g_split_trace = nullptr;  // [4 waves][256] s_memtime at every chunk start of workgroup 0 (dev tool)
+#define SPLIT_STAMP(w, i) \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (i) < 256) g_split_trace[(w) * 256 + (i)] = (long long)__builtin_amdgcn_s_memtime()
+#else
+#define SPLIT_STAMP(w, i)
+#endif
 // LDS-side plumbing of one split-sweep wave
 struct SplitLink {
     float2 *ring;      // [Nr] boundary entries {value, producer offset}, indexed by the diagonal
@@ -1886,7 +1893,9 @@ __device__ void alpha_split_sweep(const LossParams &p, float *buf0, float *buf1,
         if (ck + 1 < nchunks) dma_rows_part<K, G, UPT>(Wb + (size_t)(ck + 1) * G * 2 * UPT, (ck & 1) ? buf0 : buf1, lane);
         const int r0 = ck * G;
         const int hi = min(r0 + G, last_row);  // this chunk's steps consume the boundary entries r0 .. hi-1
+        SPLIT_STAMP(PROD ? 0 : 1, 2 * ck);
         if (!PROD && lk.peer) lds_wait_ge(lk.prog, hi);
+        SPLIT_STAMP(PROD ? 0 : 1, 2 * ck + 1);
         if (r0 + G <= last_row) {
             const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
             const uint32_t xaddr = PROD ? ((lane == 63) ? ring_a + (uint32_t)r0 * 8u : trash_a + (uint32_t)lane * 8u)
@@ -1972,7 +1981,9 @@ __device__ void beta_split_sweep(const LossParams &p, float *buf0, float *buf1, 
         if (ck > 0) dma_rows_part<K, G, UPT>(Wb + (size_t)(ck - 1) * G * 2 * UPT, (ck & 1) ? buf0 : buf1, lane);
         const int r0 = ck * G;
         const int done = last - r0 + 1;  // steps finished once this chunk is (entries last .. r0 written)
+        SPLIT_STAMP(PROD ? 3 : 2, 2 * (ckl - ck));
         if (!PROD && lk.peer) lds_wait_ge(lk.prog, done);
+        SPLIT_STAMP(PROD ? 3 : 2, 2 * (ckl - ck) + 1);
         if (r0 + G - 1 < last) {
             const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
             const uint32_t xaddr = PROD ? ((lane == 0) ? ring_a + (uint32_t)r0 * 8u : trash_a + (uint32_t)lane * 8u)
@@ -2065,7 +2076,27 @@ static hipError_t launch_sweep_split(const LossParams &p, hipStream_t s, bool *d
         if (e != hipSuccess) return e;
         attr_bytes = 160 * 1024;
     }
+#ifdef SPLIT_TRACE
+    static long long *trace_dev = nullptr;
+    if (!trace_dev) {
+        hipMalloc(&trace_dev, 4 * 256 * sizeof(long long));
+        hipMemcpyToSymbol(HIP_SYMBOL(g_split_trace), &trace_dev, sizeof(trace_dev));
+    }
+    hipMemsetAsync(trace_dev, 0, 4 * 256 * sizeof(long long), s);
+#endif
     hipLaunchKernelGGL((sweep_split_kernel<KA, KB, G>), dim3(p.nb), dim3(256), shm, s, p);
+#ifdef SPLIT_TRACE
+    {
+        hipStreamSynchronize(s);
+        long long h[4 * 256];
+        hipMemcpy(h, trace_dev, sizeof(h), hipMemcpyDeviceToHost);
+        const char *path = getenv("SPLIT_TRACE_FILE");
+        if (FILE *f = fopen(path ? path : "/tmp/split_trace.bin", "wb")) {
+            fwrite(h, 1, sizeof(h), f);
+            fclose(f);
+        }
+    }
+#endif
     *done = true;
     return hipGetLastError();
 }

@@ -80,6 +80,33 @@ __global__ __launch_bounds__(64) void k(int mode, int steps, long long *out, flo
             for (int j = 0; j < K; ++j) cur[j] = nxt[j];
         }
         sink64[lane] = a[0] + a[1] + a[2];
+    } else if (mode >= 3) {
+        // linear f32 again with parts removed: mode 3 no LDS reads, 4 no stores, 5 neither, 6 neither and no DPP
+        float a[K], edge = 0.f;
+        for (int j = 0; j < K; ++j) a[j] = (lane == 0 && j == 0) ? 1.f : 0.f;
+        f32x2 cur[K], nxt[K];
+        for (int j = 0; j < K; ++j) cur[j] = w[0][lane * K + j], nxt[j] = cur[j];
+        const bool rd = (mode == 4), st = (mode == 3), dp = (mode != 6);
+#pragma unroll 16
+        for (int s = 0; s < steps; ++s) {
+            if (rd)
+                for (int j = 0; j < K; ++j) nxt[j] = w[(s + 1) & (ROWS - 1)][lane * K + j];
+            float e[K];
+            for (int j = 0; j < K; ++j) e[j] = a[j] * cur[j][1];
+            if (dp) edge = dpp_shr(e[K - 1], edge);
+            else edge = e[K - 1] * 0.5f;
+            for (int j = 0; j < K; ++j) a[j] = __builtin_fmaf(a[j], cur[j][0], (j == 0) ? edge : e[j - 1]);
+            if ((s & 7) == 7) {
+                const int bits = __builtin_amdgcn_readlane(__float_as_int(a[0]), (s >> 3) & 63);
+                const int ex = ((bits >> 23) & 0xff) - 127;
+                if (ex > -120)
+                    for (int j = 0; j < K; ++j) a[j] = __builtin_ldexpf(a[j], -ex);
+            }
+            if (st)
+                for (int j = 0; j < K; ++j) __builtin_nontemporal_store(a[j], dst + ((size_t)(s & 2047) * 64 + lane) * K + j);
+            for (int j = 0; j < K; ++j) cur[j] = nxt[j];
+        }
+        sink[lane] = a[0] + a[1] + a[2];
     } else {
         float a[K], edge = 0.f;
         for (int j = 0; j < K; ++j) a[j] = (lane == 0 && j == 0) ? 1.f : 0.f;
@@ -115,8 +142,8 @@ int main() {
     hipMalloc(&out, blocks * sizeof(long long));
     hipMalloc(&sink, (size_t)blocks * 64 * K * 2048 * sizeof(float));
     hipMalloc(&sink64, (size_t)blocks * 64 * K * 2048 * sizeof(double));
-    const char *names[3] = {"log2-domain f32", "linear f64", "linear f32"};
-    for (int mode = 0; mode < 3; ++mode) {
+    const char *names[7] = {"log2-domain f32", "linear f64", "linear f32", "lin f32 -lds", "lin f32 -store", "lin f32 -lds-store", "lin f32 -lds-store-dpp"};
+    for (int mode = 0; mode < 7; ++mode) {
         for (int rep = 0; rep < 2; ++rep) {
             hipEvent_t e0, e1;
             hipEventCreate(&e0), hipEventCreate(&e1);
