@@ -560,6 +560,9 @@ __device__ __forceinline__ float lse2(float a, float b) {
 
 // Stream `n16` 16-byte units global -> LDS (destination lane-linear, as LDS-DMA requires).
 __device__ __forceinline__ void dma_rows(const float *g, float *l, int n16, int lane) {
+#ifdef SWEEP_EXP_NODMA  // timing experiment (results wrong): the chunk buffers are never filled
+    return;
+#endif
     for (int i0 = 0; i0 < n16; i0 += 64) {
         const int k = i0 + lane;
         if (k < n16) __builtin_amdgcn_global_load_lds((glb_void *)(g + (size_t)k * 4), (lds_void *)(l + i0 * 4), 16, 0, 0);
@@ -773,6 +776,11 @@ __device__ __forceinline__ void load_w(f32x2 (&w)[K], const float *wrow) {
 // LDS byte address of row 0 of the chunk buffer; the row/column offsets are immediates.
 template <int K, int ROW>
 __device__ __forceinline__ void lds_issue_row(f32x2 (&q)[K], const uint32_t addr) {
+#ifdef SWEEP_EXP_NOLDS  // timing experiment (results wrong): the weight registers keep whatever they hold
+#pragma unroll
+    for (int j = 0; j < K; ++j) asm volatile("" : "+v"(q[j]) : "v"(addr));
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < K; ++j)
         asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(q[j]) : "v"(addr), "n"(ROW * 2 * 64 * K * 4 + j * 8));
@@ -1437,6 +1445,7 @@ static int sweep_mode() {
     if (e && e[0] == '2') return 2;
     if (e && e[0] == '3') return 3;
     if (e && e[0] == '4') return 4;
+    if (e && e[0] == '5') return 5;
     return 1;
 }
 
@@ -2101,6 +2110,202 @@ static hipError_t launch_sweep_split(const LossParams &p, hipStream_t s, bool *d
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Default sweep: the single-wave sweep above with the LDS-DMA moved to a LOADER wave of the same workgroup.
+// Issuing the 24 `global_load_lds` pieces of a chunk from the sweeping wave itself cost it ~1/4 of its time (a piece takes
+// 60-100 issue cycles and the wave issues in order: -23 us of 85 with the DMA knocked out); the loader has nothing else to
+// do.  NB chunk buffers form a ring; two LDS counters: `landed` (chunks complete in LDS, loader -> sweeper) and `consumed`
+// (chunks the sweeper is done with, sweeper -> loader).  The loader waits on `consumed` only when it is NB - 1 chunks ahead,
+// the sweeper on `landed` only when the loader is behind: no cycle.  All polls are bounded.
+// ---------------------------------------------------------------------------------------------
+struct LdLink {
+    uint32_t landed, consumed;  // LDS byte addresses of the two counters
+};
+
+template <int K, int G, int NB, bool BETA>
+__device__ void sweep_loader(const LossParams &p, float *bufs, const LdLink lk, const int b, const int lane) {
+    constexpr int Up = 64 * K, chunkf = G * 2 * Up, n16 = chunkf / 4, pieces = n16 / 64;
+    static_assert(n16 % 64 == 0 && pieces <= 63, "chunk must be whole wave-instructions within the vmcnt range");
+    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int nchunks = (Tb + Ub - 2) / G + 1;
+    const float *Wb = p.W + (size_t)b * p.Nr * 2 * Up;
+    for (int i = 0; i < nchunks; ++i) {
+        const int ck = BETA ? nchunks - 1 - i : i;
+        if (i >= NB) lds_wait_ge(lk.consumed, i - NB + 1);  // ring slot i % NB is free again
+        dma_rows(Wb + (size_t)ck * chunkf, bufs + (i % NB) * chunkf, n16, lane);
+        if (i > 0) {
+            wait_vm_counted<pieces>();  // loads return in order: everything but the chunk just issued has landed
+            if (lane == 0) lds_post(lk.landed, i);
+        }
+    }
+    wait_vm0();
+    if (lane == 0) lds_post(lk.landed, nchunks);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <int K, int G, int NB>
+__device__ void alpha_sweep_ld(const LossParams &p, float *bufs, const LdLink lk, const int b, const int lane) {
+    constexpr int Up = 64 * K, chunkf = G * 2 * Up;
+    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int Nb = Tb + Ub - 1;
+    const RidgeLine ridge = make_ridge(Ub, Nb);
+    float *out = p.A + (size_t)b * p.Nr * Up;
+    const int voff = lane * K * 4;
+    const int u0 = lane * K;
+
+    float a[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = (u0 + j == 0) ? 0.f : kNeg;
+    store_diag<K, false>(out, voff, lane, a);
+    SweepState st;
+    st.off = 0.f;
+    st.edge = kNeg;
+    st.log.init(p.offA + (size_t)b * p.NC * p.NG, p.NG);
+    st.log.record(0, 0.f, lane);
+    st.row = out + Up;
+    const int last_row = Nb - 1;
+    const int nchunks = last_row / G + 1;
+
+    for (int ck = 0; ck < nchunks; ++ck) {
+        lds_wait_ge(lk.landed, ck + 1);
+        const float *cur = bufs + (ck % NB) * chunkf + 2 * u0;
+        const int r0 = ck * G;
+        if (K <= 15 && r0 + G <= last_row) {
+            const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
+            f32x2 wq[2][K];
+            lds_issue_row<K, 0>(wq[0], abase);
+            alpha_fast_steps<K, G, 0>(a, wq, abase, st, voff, lane, r0, ridge);
+        } else {
+            for (int i = 0; i < G; ++i) {
+                const int n = r0 + i + 1;
+                if (n > last_row) break;
+                f32x2 wc[K];
+                load_w<K>(wc, cur + i * 2 * Up);
+                alpha_step<K>(a, wc);
+                if ((n & (kRebase - 1)) == 0) {
+                    st.off += rebase<K>(a, ridge.u_at(n));
+                    st.log.record(n / kRebase, st.off, lane);
+                }
+                store_diag<K, false>(st.row, voff, lane, a);
+                st.row += Up;
+            }
+        }
+        if (ck + 1 < nchunks) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read of this chunk's buffer has returned
+            if (lane == 0) lds_post(lk.consumed, ck + 1);
+        }
+    }
+    st.log.flush(lane);
+    {
+        const float *wrow = bufs + ((nchunks - 1) % NB) * chunkf + (last_row % G) * 2 * Up + 2 * u0;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (u0 + j == Ub - 1) {
+                const double ll2 = (double)st.off + (double)a[j] + (double)wrow[2 * j];
+                st_f64_wt(p.ll + 2 * b, ll2);
+                st_f32_wt(p.costs + b, (float)(-ll2 * 0.6931471805599453));
+            }
+    }
+}
+
+template <int K, int G, int NB>
+__device__ void beta_sweep_ld(const LossParams &p, float *bufs, const LdLink lk, const int b, const int lane) {
+    constexpr int Up = 64 * K, chunkf = G * 2 * Up;
+    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int Nb = Tb + Ub - 1;
+    const RidgeLine ridge = make_ridge(Ub, Nb);
+    float *out = p.Bt + (size_t)b * p.Nr * Up;
+    const int voff = lane * K * 4;
+    const int u0 = lane * K;
+
+    float bv[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) bv[j] = (u0 + j == Ub - 1) ? 0.f : kNeg;
+    const int last = Nb - 1;
+    const int ckl = last / G;
+    SweepState st;
+    st.off = 0.f;
+    st.edge = kNeg;
+    st.log.init(p.offB + (size_t)b * p.NC * p.NG, p.NG);
+    st.row = out + (size_t)last * Up;
+
+    for (int ck = ckl; ck >= 0; --ck) {
+        const int i_ring = ckl - ck;  // the loader's chunk index
+        lds_wait_ge(lk.landed, i_ring + 1);
+        const float *cur = bufs + (i_ring % NB) * chunkf + 2 * u0;
+        const int r0 = ck * G;
+        if (K <= 15 && r0 + G - 1 < last) {
+            const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
+            f32x2 wq[2][K];
+            lds_issue_row<K, G - 1>(wq[0], abase);
+            beta_fast_steps<K, G, 0>(bv, wq, abase, st, voff, lane, r0, ridge);
+        } else {
+            for (int ii = 0; ii < G; ++ii) {
+                const int i = G - 1 - ii;
+                const int n = r0 + i;
+                if (n > last) continue;
+                f32x2 wc[K];
+                load_w<K>(wc, cur + i * 2 * Up);
+                beta_step<K>(bv, wc);
+                if (((n & (kRebase - 1)) == kRebase - 1) || n == last) {
+                    st.off += rebase<K>(bv, ridge.u_at(n));
+                    st.log.record(n / kRebase, st.off, lane);
+                }
+                store_diag<K, false>(st.row, voff, lane, bv);
+                st.row -= Up;
+            }
+        }
+        if (ck > 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) lds_post(lk.consumed, i_ring + 1);
+        }
+    }
+    st.log.flush(lane);
+    if (lane == 0) st_f64_wt(p.ll + 2 * b + 1, (double)st.off + (double)bv[0]);
+}
+
+template <int K, int G, int NB>
+__global__ __launch_bounds__(128) void sweep_ld_kernel(const LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int chunkf = G * 2 * 64 * K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = p.b0 + (int)(blockIdx.x >> 1);
+    const bool beta = (blockIdx.x & 1) != 0;
+    int *ctr = (int *)(lds + NB * chunkf);
+    if (tid < 2) ctr[tid] = 0;
+    __syncthreads();
+    LdLink lk;
+    lk.landed = (uint32_t)(uintptr_t)((lds_void *)ctr);
+    lk.consumed = lk.landed + 4u;
+    if (wave == 1) {
+        if (beta)
+            sweep_loader<K, G, NB, true>(p, lds, lk, b, lane);
+        else
+            sweep_loader<K, G, NB, false>(p, lds, lk, b, lane);
+    } else {
+        if (beta)
+            beta_sweep_ld<K, G, NB>(p, lds, lk, b, lane);
+        else
+            alpha_sweep_ld<K, G, NB>(p, lds, lk, b, lane);
+    }
+}
+
+template <int K, int G>
+static hipError_t launch_sweep_ld(const LossParams &p, hipStream_t s) {
+    constexpr int NB = 3;
+    constexpr size_t shm = (size_t)NB * G * 2 * 64 * K * sizeof(float) + 16;
+    static_assert(shm <= 160 * 1024, "chunk ring exceeds the LDS");
+    static bool attr_set = false;
+    if (shm > 64 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)sweep_ld_kernel<K, G, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((sweep_ld_kernel<K, G, NB>), dim3(2 * p.nb), dim3(128), shm, s, p);
+    return hipGetLastError();
+}
+
 bool overlap_path_ok(const LossParams &p, bool grad) {
     // patch kernels on both sides and the single-wave sweep (the hand-off hooks live there)
     return (p.V % 4) == 0 && tile_path_ok(p, false) && (!grad || tile_path_ok(p, true)) && sweep_mode() == 1 &&
@@ -2142,7 +2347,20 @@ hipError_t launch_sweeps(const LossParams &p0, hipStream_t s, bool overlap) {
             default: break;  // wider lattices: register-resident single-wave sweep below
         }
     }
-    switch (sweep_K(p.U)) {
+    if (sweep_mode() == 1 && !overlap) {
+        switch (sweep_K(p.U)) {  // sweeping wave + loader wave (see sweep_ld_kernel); same chunk lengths as below
+            case 1: return launch_sweep_ld<1, 16>(p, s);
+            case 2: return launch_sweep_ld<2, 16>(p, s);
+            case 3: return launch_sweep_ld<3, 16>(p, s);
+            case 4: return launch_sweep_ld<4, 16>(p, s);
+            case 6: return launch_sweep_ld<6, 8>(p, s);
+            case 8: return launch_sweep_ld<8, 8>(p, s);
+            case 12: return launch_sweep_ld<12, 4>(p, s);
+            case 16: return launch_sweep_ld<16, 4>(p, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    switch (sweep_K(p.U)) {  // RNNT_SWEEP_MODE=5 (the sweeping wave issues its own LDS-DMA), 0, and the overlap mode
         case 1: return launch_sweep_kg<1, 16>(p, s);
         case 2: return launch_sweep_kg<2, 16>(p, s);
         // chunk length G (diagonals per LDS-DMA batch / wait): the longest whose two buffers fit 64 KB (measured at C2:

@@ -185,11 +185,11 @@ def test_bitwise_determinism():
     assert np.array_equal(c1, c2) and np.array_equal(g1, g2)
 
 
-@pytest.mark.parametrize("mode", ["0", "1", "2", "3", "4"])
+@pytest.mark.parametrize("mode", ["0", "1", "2", "3", "4", "5"])
 def test_sweep_variants_agree(monkeypatch, mode):
-    """RNNT_SWEEP_MODE=1 (single wave, explicit LDS pipeline + counted waits), 0 (same kernel, compiler-scheduled),
-    2 (skewed multi-wave kernel, barrier per step), 3 (multi-wave, counter-synchronised) and 4 (two waves per
-    direction, each the single-wave sweep on half the columns) must all meet the parity bar."""
+    """RNNT_SWEEP_MODE=1 (default: sweeping wave + loader wave), 5 (the sweeping wave issues its own LDS-DMA), 0 (as 5,
+    compiler-scheduled), 2 (skewed multi-wave kernel, barrier per step), 3 (multi-wave, counter-synchronised) and 4 (two
+    waves per direction, each the single-wave sweep on half the columns) must all meet the parity bar."""
     monkeypatch.setenv("RNNT_SWEEP_MODE", mode)
     acts, labels, il, ll = make_case(3, 200, 150, 28, True, seed=41)
     check(acts, labels, il, ll)
