@@ -1510,11 +1510,14 @@ __device__ __forceinline__ int lds_peek(const uint32_t addr) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 // Bounded: a protocol error must end in wrong numbers (caught by the parity tests), never in a hung GPU.
-__device__ __forceinline__ void lds_wait_ge(const uint32_t addr, const int need) {
+__device__ __forceinline__ int lds_wait_ge(const uint32_t addr, const int need) {  // returns the value it saw
+    int v = 0;
     for (int spin = 0; spin < (1 << 18); ++spin) {
-        if (lds_peek(addr) >= need) return;
+        v = lds_peek(addr);
+        if (v >= need) return v;
         __builtin_amdgcn_s_sleep(1);
     }
+    return v;
 }
 __device__ __forceinline__ void lds_post(const uint32_t addr, const int v) {
     asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
@@ -2166,8 +2169,9 @@ __device__ void alpha_sweep_ld(const LossParams &p, float *bufs, const LdLink lk
     const int last_row = Nb - 1;
     const int nchunks = last_row / G + 1;
 
+    int have = 0;  // chunks known to have landed (the loader runs up to NB - 1 ahead: most chunks need no look at the counter)
     for (int ck = 0; ck < nchunks; ++ck) {
-        lds_wait_ge(lk.landed, ck + 1);
+        if (have < ck + 1) have = lds_wait_ge(lk.landed, ck + 1);
         const float *cur = bufs + (ck % NB) * chunkf + 2 * u0;
         const int r0 = ck * G;
         if (K <= 15 && r0 + G <= last_row) {
@@ -2229,9 +2233,10 @@ __device__ void beta_sweep_ld(const LossParams &p, float *bufs, const LdLink lk,
     st.log.init(p.offB + (size_t)b * p.NC * p.NG, p.NG);
     st.row = out + (size_t)last * Up;
 
+    int have = 0;
     for (int ck = ckl; ck >= 0; --ck) {
         const int i_ring = ckl - ck;  // the loader's chunk index
-        lds_wait_ge(lk.landed, i_ring + 1);
+        if (have < i_ring + 1) have = lds_wait_ge(lk.landed, i_ring + 1);
         const float *cur = bufs + (i_ring % NB) * chunkf + 2 * u0;
         const int r0 = ck * G;
         if (K <= 15 && r0 + G - 1 < last) {
@@ -2293,7 +2298,7 @@ __global__ __launch_bounds__(128) void sweep_ld_kernel(const LossParams p) {
 
 template <int K, int G>
 static hipError_t launch_sweep_ld(const LossParams &p, hipStream_t s) {
-    constexpr int NB = 3;
+    constexpr int NB = ((size_t)4 * G * 2 * 64 * K * sizeof(float) + 16 <= 128 * 1024) ? 4 : 3;
     constexpr size_t shm = (size_t)NB * G * 2 * 64 * K * sizeof(float) + 16;
     static_assert(shm <= 160 * 1024, "chunk ring exceeds the LDS");
     static bool attr_set = false;
@@ -2351,7 +2356,10 @@ hipError_t launch_sweeps(const LossParams &p0, hipStream_t s, bool overlap) {
         switch (sweep_K(p.U)) {  // sweeping wave + loader wave (see sweep_ld_kernel); same chunk lengths as below
             case 1: return launch_sweep_ld<1, 16>(p, s);
             case 2: return launch_sweep_ld<2, 16>(p, s);
-            case 3: return launch_sweep_ld<3, 16>(p, s);
+#ifndef SWEEP_LD_G3
+#define SWEEP_LD_G3 16
+#endif
+            case 3: return launch_sweep_ld<3, SWEEP_LD_G3>(p, s);
             case 4: return launch_sweep_ld<4, 16>(p, s);
             case 6: return launch_sweep_ld<6, 8>(p, s);
             case 8: return launch_sweep_ld<8, 8>(p, s);
