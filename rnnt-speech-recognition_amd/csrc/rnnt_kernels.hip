@@ -321,113 +321,6 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Persistent, double-buffered form of the patch kernel (opt-in: RNNT_CELL_PATH=persist; measured slower, see launcher).
-// A workgroup walks a strided list of patches with TWO LDS buffers: the LDS-DMA of patch i+1 is issued right
-// after the barrier that publishes patch i, so it is in flight during patch i's exp/log work (and, for the
-// gradient pass, its store-back).  The one-patch-per-workgroup kernel above spends ~40 % of a workgroup's life
-// on kernel-argument and length loads before its first DMA and keeps < 2 patches per CU in their load phase;
-// here every resident workgroup always has one patch loading.
-// ---------------------------------------------------------------------------------------------
-struct PatchRect {
-    int b, t0, u0, Tb, Ub;
-    int rows_valid, cols_valid, rows_in, cols_in;
-    size_t patch0;
-};
-__device__ __forceinline__ PatchRect patch_rect(const LossParams &p, const uint32_t L) {
-    const TileGeom &tg = p.tile;
-    PatchRect r;
-    const uint32_t q1 = fdiv(L, tg.div_tu);
-    const uint32_t tu = L - q1 * (uint32_t)tg.tiles_u;
-    const uint32_t bb = fdiv(q1, tg.div_tt);
-    const uint32_t tt = q1 - bb * (uint32_t)tg.tiles_t;
-    r.b = p.b0 + (int)bb;
-    r.t0 = (int)tt * tg.TT, r.u0 = (int)tu * tg.UU;
-    r.Tb = p.input_lengths[r.b], r.Ub = p.label_lengths[r.b] + 1;
-    r.rows_valid = max(0, min(tg.TT, r.Tb - r.t0));
-    r.cols_valid = max(0, min(tg.UU, r.Ub - r.u0));
-    r.rows_in = max(0, min(tg.TT, p.T - r.t0));
-    r.cols_in = max(0, min(tg.UU, p.U - r.u0));
-    r.patch0 = ((size_t)(r.b * p.T + r.t0) * p.U + r.u0) * p.V;
-    return r;
-}
-
-template <int VP, bool GRAD>
-__global__ __launch_bounds__(256) void cell_tile_persist_kernel(const LossParams p, const uint32_t npatch) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int V = p.V;
-    const TileGeom &tg = p.tile;
-    const int row_lds = tg.UU * V;
-    const size_t row_f = (size_t)p.U * V;
-    float *buf[2] = {lds, lds + 256 * V};
-
-    // XCD-aware work list: XCD x (= blockIdx % 8, observed) owns the contiguous logical range [lo_x, hi_x);
-    // the workgroups of that XCD stride through it.
-    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, per_xcd = (gridDim.x + 7u - xcd) >> 3;
-    const uint32_t q = npatch >> 3, r8 = npatch & 7u;
-    const uint32_t lo = (xcd < r8) ? xcd * (q + 1u) : r8 * (q + 1u) + (xcd - r8) * q;
-    const uint32_t hi = lo + q + (xcd < r8 ? 1u : 0u);
-
-    auto issue = [&](const PatchRect &r, float *dstbuf) {  // whole row segments, 16-byte LDS-DMA
-        if (r.rows_valid == 0 || r.cols_valid == 0) return;
-        const int q_valid = r.cols_valid * V / 4;
-        for (int rr = wave; rr < r.rows_valid; rr += 4) {
-            const float *src = p.acts + r.patch0 + rr * row_f;
-            float *dst = dstbuf + rr * row_lds;
-            for (int q0 = 0; q0 < q_valid; q0 += 64) {
-                const int qq = q0 + lane;
-                if (qq < q_valid)
-                    __builtin_amdgcn_global_load_lds((glb_void *)(src + qq * 4), (lds_void *)(dst + q0 * 4), 16, 0, 0);
-            }
-        }
-    };
-
-    uint32_t L = lo + slot;
-    if (L >= hi) return;
-    PatchRect cur = patch_rect(p, L);
-    issue(cur, buf[0]);
-    const uint32_t rdiv = fdiv((uint32_t)tid, tg.divUU);
-    const int cu = tid - (int)rdiv * tg.UU;
-    for (int it = 0;; ++it) {
-        const uint32_t Ln = L + per_xcd;
-        const bool more = Ln < hi;
-        PatchRect nxt = cur;
-        if (more) nxt = patch_rect(p, Ln);  // scalar loads of the next patch's lengths overlap the DMA wait
-        wait_vm0();
-        __syncthreads();  // patch `cur` has landed in buf[it&1]; everyone is done with buf[(it+1)&1]
-        if (more) issue(nxt, buf[(it + 1) & 1]);
-        float *b0 = buf[it & 1];
-        const bool live = cur.rows_valid > 0 && cur.cols_valid > 0;
-        if (live) {
-            Cell cl;
-            cl.b = cur.b, cl.t = cur.t0 + (int)rdiv, cl.u = cur.u0 + cu, cl.Tb = cur.Tb, cl.Ub = cur.Ub;
-            cl.valid = ((int)rdiv < cur.rows_valid) && (cu < cur.cols_valid);
-            const uint32_t c = ((uint32_t)(cur.b * p.T + cl.t)) * (uint32_t)p.U + (uint32_t)cl.u;
-            if (GRAD || cl.valid) cell_body<VP, true, GRAD, false>(p, cl, c, b0 + tid * V);
-        }
-        if (GRAD) {
-            const int q_in = cur.cols_in * V / 4;
-            if (live) {
-                __syncthreads();
-                for (int rr = wave; rr < cur.rows_in; rr += 4) {
-                    const float4 *srcl = (const float4 *)(b0 + rr * row_lds);
-                    float *dstg = p.grads + cur.patch0 + rr * row_f;
-                    for (int qq = lane; qq < q_in; qq += 64) *(float4 *)(dstg + qq * 4) = srcl[qq];
-                }
-            } else {  // an all-padding patch: exact zeros, no reads
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int rr = wave; rr < cur.rows_in; rr += 4)
-                    for (int qq = lane; qq < q_in; qq += 64) *(float4 *)(p.grads + cur.patch0 + rr * row_f + qq * 4) = z;
-            }
-        }
-        if (!more) break;
-        cur = nxt;
-        L = Ln;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // General path (any V, any alignment): one lattice cell per WAVE, lanes stride over V.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void online_upd(float &m, float &s, float xv) {
@@ -1140,185 +1033,6 @@ __global__ __launch_bounds__(128) void sweep_pair_kernel(const LossParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Skewed multi-wave sweep (maxU <= 512): NW compute waves with ONE lattice column per lane plus one
-// loader wave, per (utterance, direction).
-//   * the workgroup advances in lockstep "intervals" separated by one s_barrier; in interval `it`
-//     compute wave w works on its step it - skew(w).  The only cross-wave dependency (the value that
-//     crosses the 64-column boundary) was therefore produced one interval earlier and already sits in
-//     LDS: no communication latency on the dependent chain, ~1/K of the single-wave instruction count.
-//   * the loader wave streams W rows HBM -> LDS ring by LDS-DMA, PF rows ahead, and is the only wave
-//     that ever waits on vmcnt (counted), so the compute waves' stores stay fire-and-forget.
-//   * precision: every wave re-bases its own 64 columns every kRebase diagonals by an INTEGER amount
-//     (exact in f32); the value handed across a wave boundary is converted with the (exact) offset
-//     difference.  Offsets are recorded per (block, column group) for the gradient pass.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <int NW>
-struct MwCfg {
-    static constexpr int Up = 64 * NW;
-    static constexpr int IPR = (NW + 1) / 2;                                       // 1-KiB DMA instructions per W row
-    static constexpr int RB = (NW <= 4) ? 64 : 32;                                  // ring slots (power of two)
-    static constexpr int PF = (NW <= 2) ? 40 : (NW <= 4) ? 30 : (NW == 6) ? 16 : 12;  // rows in flight
-    static constexpr int XS = 4;                                                    // boundary-value ring depth
-    static constexpr size_t lds_bytes = (size_t)RB * Up * 2 * sizeof(float) + (size_t)XS * NW * 64 * sizeof(float2);
-    static_assert((PF - 2) * IPR <= 63, "vmcnt budget");
-    static_assert(PF + 2 * NW - 2 <= RB, "ring too small for the skew");
-};
-
-template <int NW, bool BETA>
-__device__ __forceinline__ void sweep_mw_body(const LossParams &p, float *lds, const int b, const int tid) {
-    using C = MwCfg<NW>;
-    constexpr int Up = C::Up, IPR = C::IPR, PF = C::PF, RB = C::RB, XS = C::XS;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
-    const int Nb = Tb + Ub - 1, last = Nb - 1;
-    const float *Wb = p.W + (size_t)b * p.Nr * 2 * Up;
-    const int nrows = Nb;                          // W rows 0..Nb-1 are consumed
-    const int nsteps = BETA ? Nb : Nb - 1;
-    const int NI = nsteps + 2 * (NW - 1);          // lockstep intervals (waves are skewed by TWO intervals)
-    float *wring = lds;                            // [RB][Up][2]
-    float2 *xbuf = (float2 *)(wring + RB * Up * 2);  // [XS][NW][64] {boundary value, offset it is relative to}
-    const uint32_t ring_base = (uint32_t)(uintptr_t)((lds_void *)wring);
-    const uint32_t xbuf_base = (uint32_t)(uintptr_t)((lds_void *)xbuf);
-
-    if (wave == NW) {
-        // ------------------------------ loader wave ------------------------------
-        // LDS-DMA through inline asm: hipcc must not see an LDS-DMA in this kernel, otherwise it guards
-        // every LDS read of the compute waves with vmcnt(0) (i.e. stalls them on their own stores).
-        // M0 carries the wave-uniform LDS destination and is saved/restored inside the statement.
-        auto issue = [&](const int j) {
-            const int r = BETA ? last - j : j;
-            const float *src = Wb + (size_t)r * Up * 2;
-            const uint32_t dst = ring_base + (uint32_t)(r & (RB - 1)) * (Up * 8);
-#pragma unroll
-            for (int i = 0; i < IPR; ++i) {
-                const int k = i * 64 + lane;
-                if (k < Up / 2) {
-                    uint32_t keep;
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                                 "s_mov_b32 m0, %0"
-                                 : "=&s"(keep)
-                                 : "v"(src + k * 4), "s"(dst + (uint32_t)i * 1024u)
-                                 : "memory");
-                }
-            }
-        };
-        // Invariant: when interval `it` begins, rows (in consumption order) j <= it+1 have landed, because the
-        // leading compute wave prefetches row it+1 during interval it.
-        int issued = 0;
-        const int npro = min(PF, nrows);
-        for (; issued < npro; ++issued) issue(issued);
-        if (nrows >= PF)
-            wait_vm_counted<(PF - 2) * IPR>();  // rows 0 and 1 have landed
-        else
-            wait_vm0();
-        wg_barrier();
-        for (int it = 0; it < NI; ++it) {
-            if (issued < nrows) {
-                issue(issued);
-                ++issued;
-            }
-            if (issued < nrows)
-                wait_vm_counted<(PF - 2) * IPR>();  // rows <= it+2 have landed
-            else
-                wait_vm0();
-            wg_barrier();
-        }
-        return;
-    }
-
-    // ------------------------------ compute waves ------------------------------
-    const int u = wave * 64 + lane;
-    const RidgeLine ridge = make_ridge(Ub, Nb);
-    float *out = (BETA ? p.Bt : p.A) + (size_t)b * p.Nr * Up;
-    float *offp = (BETA ? p.offB : p.offA) + (size_t)b * p.NC * p.NG + wave;
-    float a = BETA ? ((u == Ub - 1) ? 0.f : kNeg) : ((u == 0) ? 0.f : kNeg);
-    float Ow = 0.f;  // this wave's offset: true value = stored value + Ow (always an integer)
-    if (!BETA) {
-        out[u] = a;
-        if (lane == 0) offp[0] = 0.f;
-    }
-    const int skew = 2 * (BETA ? NW - 1 - wave : wave);
-    const bool has_nb = BETA ? (wave < NW - 1) : (wave > 0);
-    const int nbw = BETA ? wave + 1 : wave - 1;
-    const uint32_t my_col = ring_base + (uint32_t)u * 8u;                                       // + slot * Up*8
-    const uint32_t nb_col = xbuf_base + (uint32_t)((nbw * 64) + (BETA ? 0 : 63)) * 8u;           // + slot * NW*512
-    f32x2 cw = {0.f, 0.f}, cn = {kNeg, 0.f};  // weights / neighbour value of the step about to run
-    f32x2 pw = cw, pn = cn;                   // ... of the step after it (in flight during the interval)
-
-    wg_barrier();
-    for (int it = -1; it < NI; ++it) {
-        const int s = it - skew;
-        const int s1 = s + 1;
-        // (1) prefetch for NEXT interval's step: issued first so that the LDS latency hides under this step
-        const bool pre = (s1 >= 0) && (s1 < nsteps);
-        if (pre) {
-            const int r1 = BETA ? last - s1 : s1;
-            const uint32_t wa = my_col + (uint32_t)(r1 & (RB - 1)) * (Up * 8);
-            asm volatile("ds_read_b64 %0, %1" : "=v"(pw) : "v"(wa));
-            if (has_nb) {
-                const uint32_t na = nb_col + (uint32_t)(s1 & (XS - 1)) * (NW * 512);
-                asm volatile("ds_read_b64 %0, %1" : "=v"(pn) : "v"(na));
-            }
-        }
-        // (2) this interval's step, entirely from registers
-        if (s >= 0 && s < nsteps) {
-            const int r = BETA ? last - s : s;  // W row consumed
-            const int n = BETA ? r : r + 1;     // diagonal produced
-            const float nb = has_nb ? cn[0] + (cn[1] - Ow) : kNeg;  // exact: both offsets are integers
-            float2 *xs = xbuf + ((s & (XS - 1)) * NW + wave) * 64 + lane;
-            if (!BETA) {
-                const float d = a + cw[0], e = a + cw[1];
-                *xs = make_float2(e, Ow);
-                a = lse2(d, dpp_from_lower_lane(e, nb));
-            } else {
-                *xs = make_float2(a, Ow);
-                a = lse2(a + cw[0], dpp_from_upper_lane(a, nb) + cw[1]);
-            }
-            const bool reb = BETA ? (((n & (kRebase - 1)) == kRebase - 1) || n == last) : ((n & (kRebase - 1)) == 0);
-            if (reb) {
-                const int lr = min(max(ridge.u_at(n) - wave * 64, 0), 63);  // own lane nearest the ridge line
-                const float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), lr));
-                if (m > kNegTest) {
-                    const float mi = rintf(m);
-                    a -= mi;
-                    Ow += mi;
-                }
-                if (lane == 0) offp[(size_t)(n / kRebase) * p.NG] = Ow;
-            }
-            out[(size_t)n * Up + u] = a;
-        }
-        // (3) the prefetched registers become valid here (nothing may touch them before this wait)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pw), "+v"(pn));
-        cw = pw;
-        cn = pn;
-        wg_barrier();
-    }
-    if (!BETA) {
-        if (u == Ub - 1) {
-            const float2 wv = ((const float2 *)wring)[(last & (RB - 1)) * Up + u];
-            const double ll2 = (double)Ow + (double)a + (double)wv.x;
-            p.ll[2 * b] = ll2;
-            p.costs[b] = (float)(-ll2 * 0.6931471805599453);
-        }
-    } else if (u == 0) {
-        p.ll[2 * b + 1] = (double)Ow + (double)a;
-    }
-}
-
-template <int NW>
-__global__ __launch_bounds__((NW + 1) * 64) void sweep_mw_kernel(const LossParams p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int b = p.b0 + (int)(blockIdx.x >> 1);
-    if (blockIdx.x & 1)
-        sweep_mw_body<NW, true>(p, lds, b, threadIdx.x);
-    else
-        sweep_mw_body<NW, false>(p, lds, b, threadIdx.x);
-}
-
-// ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
 static bool small_path_ok(const LossParams &p, bool grad) {
@@ -1356,37 +1070,6 @@ static hipError_t launch_cell(const LossParams &p, hipStream_t s, bool overlap) 
     if (tile_path_ok(p, GRAD)) {
         const unsigned blocks = (unsigned)p.nb * p.tile.tiles_t * p.tile.tiles_u;
         const size_t shm = (size_t)256 * p.V * sizeof(float) + 64;
-        // "persist" = persistent double-buffered workgroups.  Measured at C2: lsm 83.6 us / grad 160 us with two
-        // workgroups per CU (226 us with one) versus 80 / 113 us for one patch per workgroup (5 per CU): 8 waves per
-        // CU with two barriers per patch lose to 20 waves of independent workgroups.  Opt-in only.
-        const char *pe = getenv("RNNT_CELL_PATH");
-        if (pe && pe[0] == 'p' && (p.V % 4) == 0) {
-            const size_t shm2 = (size_t)2 * 256 * p.V * sizeof(float);
-            static int per_cu = -1;
-            if (per_cu < 0) {  // workgroups per CU: as many double buffers as fit in 160 KiB (query once)
-                per_cu = 2;
-                if (const char *e = getenv("RNNT_PERSIST_WG_PER_CU")) per_cu = atoi(e);
-            }
-            int wg_per_cu = (int)((size_t)160 * 1024 / shm2);
-            if (wg_per_cu > per_cu) wg_per_cu = per_cu;
-            if (wg_per_cu < 1) wg_per_cu = 1;
-            unsigned grid = 256u * (unsigned)wg_per_cu;
-            if (grid > blocks) grid = blocks;
-            hipError_t e = hipSuccess;
-            if (p.V <= 32) {
-                if (shm2 > 65536)
-                    e = hipFuncSetAttribute((const void *)cell_tile_persist_kernel<32, GRAD>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
-                if (e != hipSuccess) return e;
-                hipLaunchKernelGGL((cell_tile_persist_kernel<32, GRAD>), dim3(grid), dim3(256), shm2, s, p, blocks);
-            } else {
-                e = hipFuncSetAttribute((const void *)cell_tile_persist_kernel<64, GRAD>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
-                if (e != hipSuccess) return e;
-                hipLaunchKernelGGL((cell_tile_persist_kernel<64, GRAD>), dim3(grid), dim3(256), shm2, s, p, blocks);
-            }
-            return hipGetLastError();
-        }
         if ((p.V % 4) != 0) {
             const size_t pitch = (size_t)((p.tile.UU * p.V + 3 + 3) & ~3);
             size_t shmu = (size_t)p.tile.TT * pitch * sizeof(float);
@@ -1429,21 +1112,15 @@ static hipError_t launch_cell(const LossParams &p, hipStream_t s, bool overlap) 
 hipError_t launch_lsm(const LossParams &p, hipStream_t s, bool overlap) { return launch_cell<false>(p, s, overlap); }
 hipError_t launch_grad(const LossParams &p, hipStream_t s, bool overlap) { return launch_cell<true>(p, s, overlap); }
 
-// 1 (default) = register-resident single wave per (utterance, direction), explicit LDS pipeline + counted waits
-// 0           = same kernel, compiler-scheduled LDS reads, vmcnt(0) at chunk boundaries
-// 2           = skewed multi-wave kernel (one column per lane).  Measured at C2 on MI355X: 164-175 us versus
-//               112 us for mode 1 -- a lone wave issues ~1 instruction per 7 cycles whatever its kind, and the
-//               per-interval barrier/boundary bookkeeping costs more instructions than the K=3 columns it saves.
-// 3           = the multi-wave kernel with the per-step barrier replaced by progress counters in LDS (waves run free,
-//               look at each other every 8 steps).  Parity-green, 195 us at C2: without the barrier the K=1 wave is bound by
-//               its dependent chain (add, max, sub, exp2, add, log2, add, DPP ~ 150-200 cycles with no second cell to
-//               overlap it with) plus the boundary/LDS round trip; the single wave's three independent cells per lane hide
-//               exactly that latency.  U <= 192 only.
+// RNNT_SWEEP_MODE: 1 (default) = sweeping wave + loader wave per (utterance, direction) (sweep_ld_kernel)
+//                  5 = one wave that also issues its own LDS-DMA (sweep_kernel; also what the overlap mode runs)
+//                  0 = as 5 with compiler-scheduled LDS reads and vmcnt(0) at chunk boundaries
+//                  4 = two sweeping waves per direction sharing the columns (sweep_split_kernel)
+// Two older multi-wave forms with one lattice column per lane (a barrier per diagonal: 164-175 us at C2; LDS progress
+// counters instead of the barrier: 195 us) were removed; profiles/r01_notes.md keeps their measurements.
 static int sweep_mode() {
     const char *e = getenv("RNNT_SWEEP_MODE");
     if (e && e[0] == '0') return 0;
-    if (e && e[0] == '2') return 2;
-    if (e && e[0] == '3') return 3;
     if (e && e[0] == '4') return 4;
     if (e && e[0] == '5') return 5;
     return 1;
@@ -1475,35 +1152,9 @@ static hipError_t launch_sweep_kg(const LossParams &p, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Multi-wave sweep WITHOUT per-step barriers (RNNT_SWEEP_MODE=3).  Same decomposition as sweep_mw_kernel (one lattice
-// column per lane, NW compute waves + a loader wave, W rows through an LDS ring, boundary values through a small ring),
-// but the waves run free: each publishes its progress in LDS every CH steps and checks its producer / consumer /
-// the loader only at chunk boundaries.  A wave's LDS operations complete in order, so "values written, then counter
-// written" is all the ordering the hand-off needs.  The barrier version spent ~2/3 of every step in s_barrier.
-//   wave w may run steps [s0, s0+CH)  when  producer finished step s0+CH (it prefetches one step ahead),
-//                                            the loader landed row s0+CH,
-//                                            its consumer finished step s0+CH-XS (ring slots it is about to overwrite).
+// LDS progress counters shared by the waves of one sweep workgroup.  A wave's LDS operations complete in order, so
+// "data written, then counter written" is all the ordering a hand-off needs.
 // ---------------------------------------------------------------------------------------------
-template <int NW>
-struct McCfg {
-    static constexpr int Up = 64 * NW;
-    static constexpr int IPR = (NW + 1) / 2;
-    static constexpr int RB = 64;       // W ring slots
-    static constexpr int PF = 24;       // rows in flight
-    static constexpr int CH = 8;        // steps between two looks at the neighbours' progress
-    static constexpr int XS = 4 * CH;   // boundary ring depth
-    // No deadlock (progress is published every step, the loader publishes everything it has issued before it blocks on a
-    // ring slot): with the loader stopped at row j, wave 0 can still finish every chunk that ends at or before row j-1,
-    // i.e. reach step >= j - 2 CH; every further wave trails its producer by < 2 CH; so the slowest wave reaches
-    // j - 2 CH NW, and the loader needs it at j + 5 - RB to move on.
-    static_assert(NW <= 3 && RB - 5 >= 2 * CH * NW, "W ring too small for the skew");
-    static_assert(XS - CH >= 2 * CH, "boundary ring too small: the producer must be allowed 2 CH ahead of its consumer");
-    static constexpr size_t ring_bytes = (size_t)RB * Up * 2 * sizeof(float);
-    static constexpr size_t xbuf_bytes = (size_t)XS * NW * 64 * sizeof(float2);
-    static constexpr size_t lds_bytes = ring_bytes + xbuf_bytes + 64;
-    static_assert((PF - 1) * IPR <= 63, "vmcnt budget");
-    static_assert(lds_bytes <= 160 * 1024, "LDS");
-};
 __device__ __forceinline__ int lds_peek(const uint32_t addr) {
     int v;
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
@@ -1521,189 +1172,6 @@ __device__ __forceinline__ int lds_wait_ge(const uint32_t addr, const int need) 
 }
 __device__ __forceinline__ void lds_post(const uint32_t addr, const int v) {
     asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-
-template <int NW, bool BETA>
-__device__ __forceinline__ void sweep_mwc_body(const LossParams &p, float *lds, const int b, const int tid) {
-    using C = McCfg<NW>;
-    constexpr int Up = C::Up, IPR = C::IPR, PF = C::PF, RB = C::RB, XS = C::XS, CH = C::CH;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
-    const int Nb = Tb + Ub - 1, last = Nb - 1;
-    const float *Wb = p.W + (size_t)b * p.Nr * 2 * Up;
-    const int nrows = Nb;
-    const int nsteps = BETA ? Nb : Nb - 1;
-    float *wring = lds;
-    float2 *xbuf = (float2 *)((char *)lds + C::ring_bytes);
-    const uint32_t ring_base = (uint32_t)(uintptr_t)((lds_void *)wring);
-    const uint32_t xbuf_base = (uint32_t)(uintptr_t)((lds_void *)xbuf);
-    const uint32_t prog_base = xbuf_base + (uint32_t)C::xbuf_bytes;  // int prog[NW] (steps finished), then rows landed
-    if (tid <= NW) lds_post(prog_base + 4u * (uint32_t)tid, 0);
-    wg_barrier();  // the only workgroup barrier: counters initialised
-
-    if (wave == NW) {
-        // ------------------------------ loader wave ------------------------------
-        auto issue = [&](const int j) {
-            const int r = BETA ? last - j : j;
-            const float *src = Wb + (size_t)r * Up * 2;
-            const uint32_t dst = ring_base + (uint32_t)(r & (RB - 1)) * (Up * 8);
-#pragma unroll
-            for (int i = 0; i < IPR; ++i) {
-                const int k = i * 64 + lane;
-                if (k < Up / 2) {
-                    uint32_t keep;
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                                 "s_mov_b32 m0, %0"
-                                 : "=&s"(keep)
-                                 : "v"(src + k * 4), "s"(dst + (uint32_t)i * 1024u)
-                                 : "memory");
-                }
-            }
-        };
-        for (int j = 0; j < nrows; ++j) {
-            if (j >= RB - 2 && ((j & 3) == 0 || j == RB - 2)) {
-                // ring slot of row j (and of the next three) must have been consumed by every wave (incl. its prefetch).
-                // Before blocking, everything issued so far is made visible to the waves.
-                wait_vm0();
-                if (lane == 0) lds_post(prog_base + 4u * NW, j);
-                for (int w = 0; w < NW; ++w) lds_wait_ge(prog_base + 4u * (uint32_t)w, min(j + 3 - (RB - 2), nsteps));
-            }
-            issue(j);
-            if (j >= PF - 1) {
-                wait_vm_counted<(PF - 1) * IPR>();  // rows <= j-PF+1 have landed
-                if (lane == 0) lds_post(prog_base + 4u * NW, j - PF + 2);
-            }
-        }
-        wait_vm0();
-        if (lane == 0) lds_post(prog_base + 4u * NW, nrows);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        return;
-    }
-
-    // ------------------------------ compute waves ------------------------------
-    const int u = wave * 64 + lane;
-    const RidgeLine ridge = make_ridge(Ub, Nb);
-    float *out = (BETA ? p.Bt : p.A) + (size_t)b * p.Nr * Up;
-    float *offp = (BETA ? p.offB : p.offA) + (size_t)b * p.NC * p.NG + wave;
-    float a = BETA ? ((u == Ub - 1) ? 0.f : kNeg) : ((u == 0) ? 0.f : kNeg);
-    float Ow = 0.f;
-    if (!BETA) {
-        out[u] = a;
-        if (lane == 0) offp[0] = 0.f;
-    }
-    const bool has_nb = BETA ? (wave < NW - 1) : (wave > 0);      // the wave whose boundary values this one consumes
-    const bool has_cons = BETA ? (wave > 0) : (wave < NW - 1);    // the wave that consumes this one's
-    const int nbw = BETA ? wave + 1 : wave - 1, consw = BETA ? wave - 1 : wave + 1;
-    const uint32_t my_col = ring_base + (uint32_t)u * 8u;
-    const uint32_t nb_col = xbuf_base + (uint32_t)((nbw * 64) + (BETA ? 0 : 63)) * 8u;
-    const uint32_t my_prog = prog_base + 4u * (uint32_t)wave;
-    f32x2 cw = {0.f, 0.f}, cn = {kNeg, 0.f}, pw = cw, pn = cn;
-
-    auto gate = [&](const int s0) {  // everything steps [s0, s0+CH) and the prefetch of step s0+CH will touch is there
-        const int hi = s0 + CH;
-        lds_wait_ge(prog_base + 4u * NW, min(hi + 1, nrows));
-        if (has_nb) lds_wait_ge(prog_base + 4u * (uint32_t)nbw, min(hi + 1, nsteps));
-        if (has_cons) lds_wait_ge(prog_base + 4u * (uint32_t)consw, min(max(hi - XS, 0), nsteps));
-    };
-    gate(0);
-    {  // operands of step 0
-        const int r0 = BETA ? last : 0;
-        asm volatile("ds_read_b64 %0, %1" : "=v"(cw) : "v"(my_col + (uint32_t)(r0 & (RB - 1)) * (Up * 8)));
-        if (has_nb) asm volatile("ds_read_b64 %0, %1" : "=v"(cn) : "v"(nb_col));
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cw), "+v"(cn));
-    }
-    for (int s0 = 0; s0 < nsteps; s0 += CH) {
-        if (s0 > 0) gate(s0);
-        const int s_end = min(s0 + CH, nsteps);
-        for (int s = s0; s < s_end; ++s) {
-            // (1) prefetch the operands of step s+1 (covered by this chunk's gate)
-            const int s1 = s + 1;
-            if (s1 < nsteps) {
-                const int r1 = BETA ? last - s1 : s1;
-                asm volatile("ds_read_b64 %0, %1" : "=v"(pw) : "v"(my_col + (uint32_t)(r1 & (RB - 1)) * (Up * 8)));
-                if (has_nb) asm volatile("ds_read_b64 %0, %1" : "=v"(pn) : "v"(nb_col + (uint32_t)(s1 & (XS - 1)) * (NW * 512)));
-            }
-            // (2) this step, entirely from registers
-            const int r = BETA ? last - s : s;
-            const int n = BETA ? r : r + 1;
-            const float nb = has_nb ? cn[0] + (cn[1] - Ow) : kNeg;  // exact: both offsets are integers
-            float2 *xs = xbuf + ((s & (XS - 1)) * NW + wave) * 64 + lane;
-            if (!BETA) {
-                const float d = a + cw[0], e = a + cw[1];
-                *xs = make_float2(e, Ow);
-                a = lse2(d, dpp_from_lower_lane(e, nb));
-            } else {
-                *xs = make_float2(a, Ow);
-                a = lse2(a + cw[0], dpp_from_upper_lane(a, nb) + cw[1]);
-            }
-            const bool reb = BETA ? (((n & (kRebase - 1)) == kRebase - 1) || n == last) : ((n & (kRebase - 1)) == 0);
-            if (reb) {
-                const int lr = min(max(ridge.u_at(n) - wave * 64, 0), 63);
-                const float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), lr));
-                if (m > kNegTest) {
-                    const float mi = rintf(m);
-                    a -= mi;
-                    Ow += mi;
-                }
-                if (lane == 0) offp[(size_t)(n / kRebase) * p.NG] = Ow;
-            }
-            out[(size_t)n * Up + u] = a;
-            // (3) prefetched operands and this step's boundary write are complete
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pw), "+v"(pn));
-            cw = pw;
-            cn = pn;
-            if (lane == 0) lds_post(my_prog, s + 1);  // this step's boundary value is in LDS: publish
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (!BETA) {
-        if (u == Ub - 1) {
-            const float2 wv = ((const float2 *)wring)[(last & (RB - 1)) * Up + u];
-            const double ll2 = (double)Ow + (double)a + (double)wv.x;
-            p.ll[2 * b] = ll2;
-            p.costs[b] = (float)(-ll2 * 0.6931471805599453);
-        }
-    } else if (u == 0) {
-        p.ll[2 * b + 1] = (double)Ow + (double)a;
-    }
-}
-
-template <int NW>
-__global__ __launch_bounds__((NW + 1) * 64) void sweep_mwc_kernel(const LossParams p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int b = p.b0 + (int)(blockIdx.x >> 1);
-    if (blockIdx.x & 1)
-        sweep_mwc_body<NW, true>(p, lds, b, threadIdx.x);
-    else
-        sweep_mwc_body<NW, false>(p, lds, b, threadIdx.x);
-}
-template <int NW>
-static hipError_t launch_sweep_mwc(const LossParams &p, hipStream_t s) {
-    const size_t shm = McCfg<NW>::lds_bytes;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)sweep_mwc_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)shm);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((sweep_mwc_kernel<NW>), dim3(2 * p.nb), dim3((NW + 1) * 64), shm, s, p);
-    return hipGetLastError();
-}
-
-template <int NW>
-static hipError_t launch_sweep_mw(const LossParams &p, hipStream_t s) {
-    const size_t shm = MwCfg<NW>::lds_bytes;
-    static bool attr_set = false;
-    if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
-        hipError_t e = hipFuncSetAttribute((const void *)sweep_mw_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)shm);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((sweep_mw_kernel<NW>), dim3(2 * p.nb), dim3((NW + 1) * 64), shm, s, p);
-    return hipGetLastError();
 }
 
 hipError_t launch_lsm_done_marker(const LossParams &p, hipStream_t s) {
@@ -2332,25 +1800,6 @@ hipError_t launch_sweeps(const LossParams &p0, hipStream_t s, bool overlap) {
             default: break;
         }
         if (e != hipSuccess || done) return e;
-    }
-    if (sweep_mode() == 3 && !overlap) {
-        switch (sweep_K(p.U)) {  // counter-synchronised multi-wave sweep: up to 3 column groups (U <= 192)
-            case 1: return launch_sweep_mwc<1>(p, s);
-            case 2: return launch_sweep_mwc<2>(p, s);
-            case 3: return launch_sweep_mwc<3>(p, s);
-            default: break;  // wider lattices: single-wave sweep below
-        }
-    }
-    if (sweep_mode() == 2 && !overlap) {
-        switch (sweep_K(p.U)) {  // = number of 64-column groups
-            case 1: return launch_sweep_mw<1>(p, s);
-            case 2: return launch_sweep_mw<2>(p, s);
-            case 3: return launch_sweep_mw<3>(p, s);
-            case 4: return launch_sweep_mw<4>(p, s);
-            case 6: return launch_sweep_mw<6>(p, s);
-            case 8: return launch_sweep_mw<8>(p, s);
-            default: break;  // wider lattices: register-resident single-wave sweep below
-        }
     }
     if (sweep_mode() == 1 && !overlap) {
         switch (sweep_K(p.U)) {  // sweeping wave + loader wave (see sweep_ld_kernel); same chunk lengths as below
