@@ -235,11 +235,11 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
                 const float lg2s = jlg2(s);
                 const float lse = m + kLn2 * lg2s;
                 const bool blank_stays = (cl.t < Tb - 1) || (cl.u == Ub - 1);
-                const float ob = blank_stays ? (xs[p.blank] - m) * kLog2e - lg2s : kNeg;
+                const float ob = blank_stays ? fmaf(xs[p.blank] - m, kLog2e, -lg2s) : kNeg;
                 float ol = kNeg;
                 if (cl.u < Ub - 1) {
                     const int lab = min(max(p.labels[(size_t)b * (p.U - 1) + cl.u], 0), V - 1);
-                    ol = (xs[lab] - m) * kLog2e - lg2s;
+                    ol = fmaf(xs[lab] - m, kLog2e, -lg2s);
                 }
                 p.lse[c] = lse;
                 const size_t wi = ((size_t)b * p.Nr + (cl.t + cl.u)) * p.Up + cl.u;

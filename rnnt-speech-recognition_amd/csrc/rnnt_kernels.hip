@@ -70,11 +70,11 @@ __device__ __forceinline__ void cell_body(const LossParams &p, const Cell &cl, c
             const float lse = m + kLn2 * lg2s;
             // a blank from the last frame leaves the lattice unless it is THE terminal transition
             const bool blank_stays = (cl.t < cl.Tb - 1) || (cl.u == cl.Ub - 1);
-            const float ob = blank_stays ? (xs[p.blank] - m) * kLog2e - lg2s : kNeg;
+            const float ob = blank_stays ? fmaf(xs[p.blank] - m, kLog2e, -lg2s) : kNeg;
             float ol = kNeg;
             if (cl.u < cl.Ub - 1) {
                 const int lab = clamp_label(p.labels[(size_t)cl.b * (p.U - 1) + cl.u], V);
-                ol = (xs[lab] - m) * kLog2e - lg2s;
+                ol = fmaf(xs[lab] - m, kLog2e, -lg2s);
             }
             p.lse[c] = lse;
             const size_t wi = ((size_t)cl.b * p.Nr + (cl.t + cl.u)) * p.Up + cl.u;
@@ -376,11 +376,11 @@ __global__ __launch_bounds__(256) void cell_wave_kernel(const LossParams p) {
                 const float lg2s = lg2(s);
             const float lse = m + kLn2 * lg2s;
                 const bool blank_stays = (cl.t < cl.Tb - 1) || (cl.u == cl.Ub - 1);
-                const float ob = blank_stays ? (x[p.blank] - m) * kLog2e - lg2s : kNeg;
+                const float ob = blank_stays ? fmaf(x[p.blank] - m, kLog2e, -lg2s) : kNeg;
                 float ol = kNeg;
                 if (cl.u < cl.Ub - 1) {
                     const int lab = clamp_label(p.labels[(size_t)cl.b * (p.U - 1) + cl.u], V);
-                    ol = (x[lab] - m) * kLog2e - lg2s;
+                    ol = fmaf(x[lab] - m, kLog2e, -lg2s);
                 }
                 p.lse[c] = lse;
                 const size_t wi = ((size_t)cl.b * p.Nr + (cl.t + cl.u)) * p.Up + cl.u;
