@@ -1128,12 +1128,10 @@ static int sweep_mode() {
 
 template <int K, int G>
 static hipError_t launch_sweep_pair(const LossParams &p, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    {
         hipError_t e = hipFuncSetAttribute((const void *)sweep_pair_kernel<K, G>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPairLdsBytes);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const int nwg = p.B < 48 ? p.B : 48;  // at most 48 CUs are taken away from the bandwidth passes
     hipLaunchKernelGGL((sweep_pair_kernel<K, G>), dim3(nwg), dim3(128), kPairLdsBytes, s, p);
@@ -1549,12 +1547,10 @@ static hipError_t launch_sweep_split(const LossParams &p, hipStream_t s, bool *d
                        (size_t)2 * (64 + G) * sizeof(float2) + 16;
     *done = false;
     if (shm > 160 * 1024) return hipSuccess;  // boundary arrays do not fit: the caller falls back to the single wave
-    static size_t attr_bytes = 0;
-    if (shm > 64 * 1024 && shm > attr_bytes) {
+    if (shm > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)sweep_split_kernel<KA, KB, G>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         if (e != hipSuccess) return e;
-        attr_bytes = 160 * 1024;
     }
 #ifdef SPLIT_TRACE
     static long long *trace_dev = nullptr;
@@ -1769,11 +1765,9 @@ static hipError_t launch_sweep_ld(const LossParams &p, hipStream_t s) {
     constexpr int NB = ((size_t)4 * G * 2 * 64 * K * sizeof(float) + 16 <= 128 * 1024) ? 4 : 3;
     constexpr size_t shm = (size_t)NB * G * 2 * 64 * K * sizeof(float) + 16;
     static_assert(shm <= 160 * 1024, "chunk ring exceeds the LDS");
-    static bool attr_set = false;
-    if (shm > 64 * 1024 && !attr_set) {
+    if (shm > 64 * 1024) {  // per device and cheap: set on every launch (a process may drive several GPUs)
         hipError_t e = hipFuncSetAttribute((const void *)sweep_ld_kernel<K, G, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL((sweep_ld_kernel<K, G, NB>), dim3(2 * p.nb), dim3(128), shm, s, p);
     return hipGetLastError();
