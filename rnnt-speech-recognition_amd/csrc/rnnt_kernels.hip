@@ -1583,7 +1583,8 @@ static hipError_t launch_sweep_split(const LossParams &p, hipStream_t s, bool *d
 // 60-100 issue cycles and the wave issues in order: -23 us of 85 with the DMA knocked out); the loader has nothing else to
 // do.  NB chunk buffers form a ring; two LDS counters: `landed` (chunks complete in LDS, loader -> sweeper) and `consumed`
 // (chunks the sweeper is done with, sweeper -> loader).  The loader waits on `consumed` only when it is NB - 1 chunks ahead,
-// the sweeper on `landed` only when the loader is behind: no cycle.  All polls are bounded.
+// the sweeper on `landed` only when the loader is behind: no cycle.  All polls are bounded; a sweeper whose poll gives up
+// reports NaN as the utterance's cost (never a plausible number).
 // ---------------------------------------------------------------------------------------------
 struct LdLink {
     uint32_t landed, consumed;  // LDS byte addresses of the two counters
@@ -1634,8 +1635,12 @@ __device__ void alpha_sweep_ld(const LossParams &p, float *bufs, const LdLink lk
     const int nchunks = last_row / G + 1;
 
     int have = 0;  // chunks known to have landed (the loader runs up to NB - 1 ahead: most chunks need no look at the counter)
+    bool timed_out = false;  // a bounded poll gave up: the result must not look valid
     for (int ck = 0; ck < nchunks; ++ck) {
-        if (have < ck + 1) have = lds_wait_ge(lk.landed, ck + 1);
+        if (have < ck + 1) {
+            have = lds_wait_ge(lk.landed, ck + 1);
+            timed_out |= have < ck + 1;
+        }
         const float *cur = bufs + (ck % NB) * chunkf + 2 * u0;
         const int r0 = ck * G;
         if (K <= 15 && r0 + G <= last_row) {
@@ -1669,7 +1674,7 @@ __device__ void alpha_sweep_ld(const LossParams &p, float *bufs, const LdLink lk
 #pragma unroll
         for (int j = 0; j < K; ++j)
             if (u0 + j == Ub - 1) {
-                const double ll2 = (double)st.off + (double)a[j] + (double)wrow[2 * j];
+                const double ll2 = timed_out ? (double)NAN : (double)st.off + (double)a[j] + (double)wrow[2 * j];
                 st_f64_wt(p.ll + 2 * b, ll2);
                 st_f32_wt(p.costs + b, (float)(-ll2 * 0.6931471805599453));
             }
@@ -1698,9 +1703,13 @@ __device__ void beta_sweep_ld(const LossParams &p, float *bufs, const LdLink lk,
     st.row = out + (size_t)last * Up;
 
     int have = 0;
+    bool timed_out = false;
     for (int ck = ckl; ck >= 0; --ck) {
         const int i_ring = ckl - ck;  // the loader's chunk index
-        if (have < i_ring + 1) have = lds_wait_ge(lk.landed, i_ring + 1);
+        if (have < i_ring + 1) {
+            have = lds_wait_ge(lk.landed, i_ring + 1);
+            timed_out |= have < i_ring + 1;
+        }
         const float *cur = bufs + (i_ring % NB) * chunkf + 2 * u0;
         const int r0 = ck * G;
         if (K <= 15 && r0 + G - 1 < last) {
@@ -1730,7 +1739,8 @@ __device__ void beta_sweep_ld(const LossParams &p, float *bufs, const LdLink lk,
         }
     }
     st.log.flush(lane);
-    if (lane == 0) st_f64_wt(p.ll + 2 * b + 1, (double)st.off + (double)bv[0]);
+    if (lane == 0) st_f64_wt(p.ll + 2 * b + 1, timed_out ? (double)NAN : (double)st.off + (double)bv[0]);
+    if (timed_out && lane == 0) st_f32_wt(p.costs + b, NAN);  // the alpha side may have finished normally
 }
 
 template <int K, int G, int NB>
