@@ -198,6 +198,17 @@ def test_sweep_variants_agree(monkeypatch, mode):
         check(acts, labels, il, ll)
 
 
+@pytest.mark.parametrize("mode", ["1", "5"])
+@pytest.mark.parametrize("shape", [(1, 40, 700, 4), (2, 24, 1024, 4), (2, 3000, 20, 8), (1, 1, 130, 8), (3, 90, 1, 8)])
+def test_widest_and_longest_lattices(monkeypatch, mode, shape):
+    """Every column-width instantiation of the sweeps (up to 16 columns per lane = U 1024), thousands of diagonals, and
+    the degenerate single-row / single-column lattices, on the default (loader wave) and the self-loading kernel."""
+    monkeypatch.setenv("RNNT_SWEEP_MODE", mode)
+    B, T, U, V = shape
+    acts, labels, il, ll = make_case(B, T, U, V, True, seed=T + U)
+    check(acts, labels, il, ll)
+
+
 @pytest.mark.parametrize("groups", ["1", "2", "3", "8"])
 @pytest.mark.parametrize("path", ["tile", "flat"])
 def test_group_pipelining_and_cell_paths(monkeypatch, groups, path):
