@@ -36,7 +36,10 @@
 namespace rnnt {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 jf16;
+typedef _Float16 jh8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void jglb_cvoid;
 
 __device__ __forceinline__ float jex2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float jlg2(float x) { return __builtin_amdgcn_logf(x); }
@@ -75,6 +78,7 @@ struct JointParams {
     float *d_enc_proj, *d_pred_proj, *dW2, *db2;
     float *expE, *expP;  // [B][T][J], [B][U][J]  e^{2 x} tables of the two projections
     float *tflag;        // [0] != 0: some |projection| exceeds kExpTabLimit, use the raw projections + fast_tanh
+    jf16 *W2s;           // [J/16][2 (hi, lo)][64 lanes][8]: W2 as binary16 hi + lo parts in MFMA B-fragment order (phase 1s)
 #ifdef JH_TRACE
     long long *trace;    // dev builds only: s_memtime stamps of one workgroup of phase 1 and one of phase 2
 #endif
@@ -94,6 +98,22 @@ __global__ __launch_bounds__(256) void joint_prep_kernel(const JointParams jp) {
         else jp.expP[i - nE] = ex;
     }
     if (__any(big) && (threadIdx.x & 63) == 0) jp.tflag[0] = 1.0f;
+    // W2 = hi + lo with both parts binary16 (22 significand bits together), laid out as the B fragments of
+    // v_mfma_f32_32x32x16_f16: lane l of k-step ks holds W2[16 ks + 8 (l >> 5) + 0..7][l & 31] (zero beyond V)
+    const int nfrag = (jp.J / 16) * 64;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nfrag; i += gridDim.x * 256) {
+        const int ks = i >> 6, l = i & 63, v = l & 31;
+        jh8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = 16 * ks + 8 * (l >> 5) + e;
+            const float w = (v < p.V) ? jp.W2[(size_t)j * p.V + v] : 0.f;
+            hi[e] = (jf16)w;
+            lo[e] = (jf16)(w - (float)hi[e]);
+        }
+        *(jh8 *)(jp.W2s + ((size_t)(ks * 2 + 0) * 64 + l) * 8) = hi;
+        *(jh8 *)(jp.W2s + ((size_t)(ks * 2 + 1) * 64 + l) * 8) = lo;
+    }
 }
 
 constexpr int kP1Waves = 8;    // phase-1 workgroup = 8 waves (2 per SIMD: one wave's tanh VALU hides the other's MFMA issue)
@@ -263,6 +283,150 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
         }
         __syncthreads();  // staging tiles and Arow are rewritten by the next iteration
         if (it < 5) JT1(4 + 4 * it);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// phase 1, split-precision form (default): the same tile, epilogue and outputs as joint_phase1_kernel, but the J x V
+// product runs on v_mfma_f32_32x32x16_f16 with BOTH operands split into binary16 hi + lo parts:
+//     h . W2  =  h_hi . W_hi  +  h_lo . W_hi  +  h_hi . W_lo      (+ h_lo . W_lo ~ 2^-22, dropped)
+// Products of binary16 numbers are exact in f32 and the accumulation is f32, so the logits carry f32-grade error (NumPy
+// emulation at J = 640: rms 4.4e-7 against 3.2e-7 for an f32 matmul) while three of these MFMAs cover 16 joint units in 96
+// matrix-pipe cycles instead of 512 for eight v_mfma_f32_32x32x2_f32.  The kernel becomes bound by the tanh generation.
+// A lane (cell i = lane & 31, half = lane >> 5) builds the 8 consecutive joint units 16 ks + 8 half + 0..7 of its cell.
+// LDS: Ct [J][32] | W2 hi/lo fragments of 4 k-steps, double-buffered by LDS-DMA [2][8 KB] | Arow [8][J] | stage [8][32][33]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kP1Waves * 64) void joint_phase1s_kernel(const JointParams jp) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const LossParams &p = jp.lp;
+    const int J = jp.J, V = p.V;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *Ct = lds;                                  // [J][32]
+    char *W2c = (char *)(Ct + J * 32);                // [2][8192]
+    float *Arow = (float *)(W2c + 2 * 8192);          // [kP1Waves][J]
+    float *stage = Arow + kP1Waves * J;               // [kP1Waves][32][kStagePad]
+    float *my_arow = Arow + wave * J;
+    float *my_stage = stage + wave * 32 * kStagePad;
+    const bool slow = jp.tflag[0] != 0.f;  // kernel-uniform
+    const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
+
+    int bid = blockIdx.x;
+    const int tr = bid % jp.n_tr;
+    bid /= jp.n_tr;
+    const int ut = bid % jp.n_ut;
+    const int b = bid / jp.n_ut;
+    const int u0 = ut * 32;
+    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int t_begin = tr * jp.TR, t_end = min(min(t_begin + jp.TR, p.T), Tb);
+    const bool tile_live = (t_begin < t_end) && (u0 < Ub);
+
+    if (tile_live) {
+        for (int idx = tid; idx < 32 * (J / 4); idx += kP1Waves * 64) {
+            const int u = idx & 31, j4 = idx >> 5;
+            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u0 + u < p.U) c4 = *(const float4 *)(Ptab + ((size_t)b * p.U + u0 + u) * J + j4 * 4);
+            Ct[(j4 * 4 + 0) * 32 + u] = c4.x;
+            Ct[(j4 * 4 + 1) * 32 + u] = c4.y;
+            Ct[(j4 * 4 + 2) * 32 + u] = c4.z;
+            Ct[(j4 * 4 + 3) * 32 + u] = c4.w;
+        }
+    }
+    const int n_iter = tile_live ? (t_end - t_begin + kP1Waves - 1) / kP1Waves : 0;
+    const int nchunk = J / 64;  // 4 k-steps (64 joint units, 8 KB of hi/lo fragments) per chunk; wave w copies KB w
+    auto w2_dma = [&](const int jc) {
+        const char *src = (const char *)jp.W2s + (size_t)jc * 8192 + wave * 1024 + lane * 16;
+        __builtin_amdgcn_global_load_lds((jglb_cvoid *)src, (lds_void *)(W2c + (jc & 1) * 8192 + wave * 1024), 16, 0, 0);
+    };
+    for (int it = 0; it < n_iter; ++it) {
+        const int t = t_begin + it * kP1Waves + wave;
+        const bool active = t < t_end;  // wave-uniform
+        if (active)
+            for (int j = lane; j < J; j += 64) my_arow[j] = Etab[((size_t)b * p.T + t) * J + j];
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        w2_dma(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // chunk 0 (and, first time round, Ct / Arow) visible
+        for (int jc = 0; jc < nchunk; ++jc) {
+            const char *wbuf = W2c + (jc & 1) * 8192;
+            if (jc + 1 < nchunk) w2_dma(jc + 1);
+            if (active) {
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const int j0 = jc * 64 + k4 * 16 + 8 * half;
+                    const float4 a0 = *(const float4 *)(my_arow + j0), a1 = *(const float4 *)(my_arow + j0 + 4);
+                    const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    float h[8];
+                    if (!slow) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) h[e] = tanh_from_exp(av[e], Ct[(j0 + e) * 32 + l31]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) h[e] = fast_tanh(av[e] + Ct[(j0 + e) * 32 + l31]);
+                    }
+                    jh8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        hi[e] = (jf16)h[e];
+                        lo[e] = (jf16)(h[e] - (float)hi[e]);
+                    }
+                    const jh8 wh = *(const jh8 *)(wbuf + k4 * 2048 + lane * 16);
+                    const jh8 wl = *(const jh8 *)(wbuf + k4 * 2048 + 1024 + lane * 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, wh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo, wh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, wl, acc, 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's piece of the next chunk has landed
+            __syncthreads();  // next chunk visible; everyone is done with the buffer it will overwrite after that
+        }
+        // ---- epilogue: identical to joint_phase1_kernel (logits tile -> LDS, one lattice cell per lane, park the tile)
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) my_stage[cd_row(r, half) * kStagePad + l31] = acc[r];
+        }
+        __syncthreads();
+        if (active && lane < 32) {
+            Cell cl;
+            cl.b = b, cl.t = t, cl.u = u0 + lane, cl.Tb = Tb, cl.Ub = Ub;
+            cl.valid = cl.u < Ub;
+            float *xs = my_stage + lane * kStagePad;
+            if (cl.valid) {
+                const uint32_t c = ((uint32_t)(b * p.T + t)) * (uint32_t)p.U + (uint32_t)cl.u;
+                float m = -INFINITY;
+                for (int v = 0; v < V; ++v) {
+                    xs[v] += jp.b2[v];
+                    m = fmaxf(m, xs[v]);
+                }
+                float ssum = 0.f;
+                const float nml = -m * kLog2e;
+                for (int v = 0; v < V; ++v) ssum += jex2(fmaf(xs[v], kLog2e, nml));
+                const float lg2s = jlg2(ssum);
+                const float lse = m + kLn2 * lg2s;
+                const bool blank_stays = (cl.t < Tb - 1) || (cl.u == Ub - 1);
+                const float ob = blank_stays ? fmaf(xs[p.blank] - m, kLog2e, -lg2s) : kNeg;
+                float ol = kNeg;
+                if (cl.u < Ub - 1) {
+                    const int lab = min(max(p.labels[(size_t)b * (p.U - 1) + cl.u], 0), V - 1);
+                    ol = fmaf(xs[lab] - m, kLog2e, -lg2s);
+                }
+                p.lse[c] = lse;
+                const size_t wi = ((size_t)b * p.Nr + (cl.t + cl.u)) * p.Up + cl.u;
+                ((float2 *)p.W)[wi] = make_float2(ob, ol);
+            }
+        }
+        __syncthreads();
+        if (active)
+            for (int e = lane; e < 1024; e += 64) {
+                const int uu = e >> 5, v = e & 31;
+                if (u0 + uu < Ub) {
+                    const size_t c = ((size_t)(b * p.T + t)) * p.U + u0 + uu;
+                    jp.dl[c * 32 + v] = my_stage[uu * kStagePad + v];
+                }
+            }
+        __syncthreads();  // staging tiles and Arow are rewritten by the next iteration
     }
 }
 
@@ -537,7 +701,7 @@ __global__ __launch_bounds__(256) void reduce_small_kernel(float *out, const flo
 // ---------------------------------------------------------------------------------------------
 struct JointLayout {
     WsLayout w;
-    size_t dl, dApart, dCpart, dWpart, dbpart, expE, expP, tflag, total;
+    size_t dl, dApart, dCpart, dWpart, dbpart, expE, expP, tflag, W2s, total;
     int n_ut, TR, n_tr, TS, n_ts;
 };
 
@@ -564,6 +728,7 @@ static JointLayout make_joint_layout(int T, int U, int B, int J) {
     L.expE = take((size_t)B * T * J * sizeof(float));
     L.expP = take((size_t)B * U * J * sizeof(float));
     L.tflag = take(256);
+    L.W2s = take((size_t)J * 32 * 2 * sizeof(jf16));
     L.total = off;
     return L;
 }
@@ -633,6 +798,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     jp.dbpart = (float *)(ws + L.dbpart);
     jp.d_enc_proj = d_enc_proj, jp.d_pred_proj = d_pred_proj, jp.dW2 = dW2, jp.db2 = db2;
     jp.expE = (float *)(ws + L.expE), jp.expP = (float *)(ws + L.expP), jp.tflag = (float *)(ws + L.tflag);
+    jp.W2s = (jf16 *)(ws + L.W2s);
 #ifdef JH_TRACE
     static long long *trace_dev = nullptr;
     const size_t trace_bytes = 1024 * sizeof(long long);
@@ -655,7 +821,15 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     if (phases & 1) {
         // forward: edge weights (W pre-filled with log zero) -> sweeps -> costs
         if (hipMemsetAsync(jp.lp.W, kFillByte, L.w.A - L.w.W, s) != hipSuccess) return hipErrorUnknown;
-        hipLaunchKernelGGL(joint_phase1_kernel, dim3(g1), dim3(kP1Waves * 64), shm1, s, jp);
+        // RNNT_JOINT_P1=f32: the v_mfma_f32_32x32x2_f32 form (kept for A/B runs); default: split-precision f16 MFMAs
+        static const bool p1_f32 = [] { const char *v = getenv("RNNT_JOINT_P1"); return v && v[0] == 'f'; }();
+        if (p1_f32) {
+            hipLaunchKernelGGL(joint_phase1_kernel, dim3(g1), dim3(kP1Waves * 64), shm1, s, jp);
+        } else {
+            const size_t shm1s = (size_t)J * 32 * sizeof(float) + 2 * 8192 + (kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
+            if ((e = set_lds(joint_phase1s_kernel, shm1s)) != hipSuccess) return e;
+            hipLaunchKernelGGL(joint_phase1s_kernel, dim3(g1), dim3(kP1Waves * 64), shm1s, s, jp);
+        }
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = launch_sweeps(jp.lp, s)) != hipSuccess) return e;
     }
