@@ -659,6 +659,218 @@ __global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// phase 2, split-precision form (default): same block decomposition, partial buffers and reductions as
+// joint_phase2_kernel, with both products on v_mfma_f32_32x32x16_f16 and every operand as binary16 hi + lo parts
+// (three MFMAs per 16-wide k-step, see joint_phase1s_kernel):
+//   dh[u][j]   = sum_v dl[u][v] W2[j][v]   A = dl rows (k = v, 8 consecutive per lane), B = W2^T fragments kept in registers
+//   dW2[j][v] += sum_u h[u][j] dl[u][v]    A = h straight from the C/D layout of the h tile: the k-slots of a k-step are
+//                                          assigned to the lattice columns cd_row(8 ks + e, half), and dl is gathered in the
+//                                          same order for B, so the registers that hold h ARE the A fragments
+// dl is multiplied by a power of two S_b (|S_b dl| <= 2^14, from this utterance's cost_scale) before it is split, so small
+// upstream gradients do not fall into binary16's subnormals; dh and the dW2 partial are divided by S_b again (exact).
+// LDS: Cs [64 j][36] | dlr [4][32 u][36] | red [4][32][33]
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split_h8(const float (&x)[8], jh8 &hi, jh8 &lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        hi[e] = (jf16)x[e];
+        lo[e] = (jf16)(x[e] - (float)hi[e]);
+    }
+}
+__device__ __forceinline__ f32x16 mfma3(const jh8 ahi, const jh8 alo, const jh8 bhi, const jh8 blo, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc, 0, 0, 0);
+    return acc;
+}
+
+#ifndef P2S_WG_PER_CU
+#define P2S_WG_PER_CU 2  // 227 VGPRs, no spills: 3.18 ms per fused step at C2; 3 (168 VGPRs, 57 spilled) 5.37 ms; 1 (284) 4.42 ms
+#endif
+__global__ __launch_bounds__(256, P2S_WG_PER_CU) void joint_phase2s_kernel(const JointParams jp) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const LossParams &p = jp.lp;
+    const int J = jp.J, V = p.V;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int kCs = 36;                     // row stride of Cs and of the dl tiles: 16-byte aligned, conflict-free b128 reads
+    float *Cs = lds;                            // [64][kCs]
+    float *dlr = Cs + 64 * kCs;                 // [4][32][kCs]
+    float *red = dlr + 4 * 32 * kCs;            // [4][32][kStagePad]
+    jh8 *wfrag = (jh8 *)(red + 4 * 32 * kStagePad);  // [jt 2][ks 2][hi, lo][64 lanes]: B fragments of dh (8 KB)
+    float *my_dl = dlr + wave * 32 * kCs;
+    const bool slow = jp.tflag[0] != 0.f;  // kernel-uniform
+    const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
+
+    int bid = blockIdx.x;
+    const int ts = bid % jp.n_ts;
+    bid /= jp.n_ts;
+    const int js = bid % (J / 64);
+    bid /= (J / 64);
+    const int ut = bid % jp.n_ut;
+    const int b = bid / jp.n_ut;
+    const int u0 = ut * 32, j0 = js * 64;
+    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int t_begin = ts * jp.TS, t_end = min(min(t_begin + jp.TS, p.T), Tb);
+    const bool tile_live = (t_begin < t_end) && (u0 < Ub);
+
+    // |dl| <= 2 |cost_scale[b]| (joint_dl_kernel): S = 2^(13 - e) with |cost_scale[b]| < 2^e
+    float S = 1.0f, invS = 1.0f;
+    {
+        const float cs = p.cost_scale ? fabsf(p.cost_scale[b]) : 1.0f;
+        if (cs > 0.f && cs < 3.0e38f) {
+            const int e = ilogbf(cs) + 1;
+            S = ldexpf(1.0f, 13 - e), invS = ldexpf(1.0f, e - 13);
+        }
+    }
+
+    f32x16 accC[2], accW[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accC[q][r] = 0.f, accW[q][r] = 0.f;
+
+    if (tile_live) {
+        for (int idx = tid; idx < 32 * 16; idx += 256) {  // C slab, transposed: Cs[j][u]
+            const int u = idx & 31, j4 = idx >> 5;
+            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u0 + u < p.U) c4 = *(const float4 *)(Ptab + ((size_t)b * p.U + u0 + u) * J + j0 + j4 * 4);
+            Cs[(j4 * 4 + 0) * kCs + u] = c4.x;
+            Cs[(j4 * 4 + 1) * kCs + u] = c4.y;
+            Cs[(j4 * 4 + 2) * kCs + u] = c4.z;
+            Cs[(j4 * 4 + 3) * kCs + u] = c4.w;
+        }
+    }
+    // B fragments of dh = dl . W2^T (row-independent): lane (j = jt*32 + l31, half), k-step ks: W2[j0 + j][16 ks + 8 half + 0..7];
+    // built once per workgroup (wave w builds (jt, ks) = (w >> 1, w & 1)) and read back from LDS where they are used
+    {
+        const int jt = wave >> 1, ks = wave & 1;
+        float w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int v = 16 * ks + 8 * half + e;
+            w[e] = (v < V) ? jp.W2[(size_t)(j0 + jt * 32 + l31) * V + v] : 0.f;
+        }
+        jh8 hi, lo;
+        split_h8(w, hi, lo);
+        wfrag[((jt * 2 + ks) * 2 + 0) * 64 + lane] = hi;
+        wfrag[((jt * 2 + ks) * 2 + 1) * 64 + lane] = lo;
+    }
+    __syncthreads();
+
+    const int n_iter = tile_live ? (t_end - t_begin + 3) / 4 : 0;
+    auto dl_fetch = [&](const int t, float (&d)[16]) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = lane + q * 64, uu = e >> 5, v = e & 31;
+            d[q] = (t < t_end && u0 + uu < p.U) ? jp.dl[(((size_t)(b * p.T + t)) * p.U + u0 + uu) * 32 + v] : 0.f;
+        }
+    };
+    float dnext[16];
+    if (n_iter > 0) dl_fetch(t_begin + wave, dnext);
+    for (int it = 0; it < n_iter; ++it) {
+        const int t = t_begin + it * 4 + wave;
+        if (t < t_end) {  // wave-uniform; no workgroup barrier inside: the dl row buffer is wave-private
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int e = lane + q * 64;
+                my_dl[(e >> 5) * kCs + (e & 31)] = dnext[q] * S;
+            }
+            dl_fetch(t + 4, dnext);  // next row of this wave: latency hides under this row's work
+            // fragments of the (scaled) dl tile: A of dh (row u = l31, k = v) and B of dW2 (k = lattice column, n = v = l31)
+            jh8 dahi[2], dalo[2], dbhi[2], dblo[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const float4 x0 = *(const float4 *)(my_dl + l31 * kCs + 16 * ks + 8 * half);
+                const float4 x1 = *(const float4 *)(my_dl + l31 * kCs + 16 * ks + 8 * half + 4);
+                const float xa[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                split_h8(xa, dahi[ks], dalo[ks]);
+                float xb[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xb[e] = my_dl[cd_row(8 * ks + e, half) * kCs + l31];
+                split_h8(xb, dbhi[ks], dblo[ks]);
+            }
+            const float *arow = Etab + ((size_t)b * p.T + t) * J + j0;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                // h tile in C/D layout: rows = lattice columns u, column = joint unit j = jt*32 + l31
+                const float aj = arow[jt * 32 + l31];
+                float h[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 c4 = *(const float4 *)(Cs + (jt * 32 + l31) * kCs + 8 * g + 4 * half);
+                    if (!slow) {
+                        h[4 * g + 0] = tanh_from_exp(aj, c4.x);
+                        h[4 * g + 1] = tanh_from_exp(aj, c4.y);
+                        h[4 * g + 2] = tanh_from_exp(aj, c4.z);
+                        h[4 * g + 3] = tanh_from_exp(aj, c4.w);
+                    } else {
+                        h[4 * g + 0] = fast_tanh(aj + c4.x);
+                        h[4 * g + 1] = fast_tanh(aj + c4.y);
+                        h[4 * g + 2] = fast_tanh(aj + c4.z);
+                        h[4 * g + 3] = fast_tanh(aj + c4.w);
+                    }
+                }
+                // S dh[u][j] = sum_v (S dl[u][v]) W2[j][v]
+                f32x16 dh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dh[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    dh = mfma3(dahi[ks], dalo[ks], wfrag[((jt * 2 + ks) * 2 + 0) * 64 + lane],
+                               wfrag[((jt * 2 + ks) * 2 + 1) * 64 + lane], dh);
+                // dz = dh * (1 - h^2);  sum over u -> d enc_proj partial;  running sum over t -> d pred_proj
+                float colsum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float dz = dh[r] * invS * (1.0f - h[r] * h[r]);
+                    accC[jt][r] += dz;
+                    colsum += dz;
+                }
+                colsum += __shfl_xor(colsum, 32);
+                if (lane < 32)
+                    jp.dApart[(((size_t)ut * p.B + b) * p.T + t) * J + j0 + jt * 32 + lane] = colsum;
+                // S dW2[j][v] += sum_u h[u][j] (S dl[u][v]): k-slot (ks, half, e) <-> lattice column cd_row(8 ks + e, half)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const float hk[8] = {h[8 * ks], h[8 * ks + 1], h[8 * ks + 2], h[8 * ks + 3],
+                                         h[8 * ks + 4], h[8 * ks + 5], h[8 * ks + 6], h[8 * ks + 7]};
+                    jh8 hhi, hlo;
+                    split_h8(hk, hhi, hlo);
+                    accW[jt] = mfma3(hhi, hlo, dbhi[ks], dblo[ks], accW[jt]);
+                }
+            }
+        }
+    }
+    // ---- deterministic cross-wave reductions, then the partial buffers (as in joint_phase2_kernel)
+    if (!tile_live) return;
+    const int wid = (b * jp.n_ut + ut) * jp.n_ts + ts;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 32 + cd_row(r, half)) * kStagePad + l31] = accC[jt][r];
+        __syncthreads();
+        for (int e = tid; e < 1024; e += 256) {
+            const int uu = e >> 5, j = e & 31;
+            float sum = 0.f;
+            for (int w = 0; w < 4; ++w) sum += red[(w * 32 + uu) * kStagePad + j];
+            if (u0 + uu < p.U) jp.dCpart[(((size_t)ts * p.B + b) * p.U + u0 + uu) * J + j0 + jt * 32 + j] = sum;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 32 + cd_row(r, half)) * kStagePad + l31] = accW[jt][r] * invS;
+        __syncthreads();
+        for (int e = tid; e < 1024; e += 256) {
+            const int jj = e >> 5, v = e & 31;
+            float sum = 0.f;
+            for (int w = 0; w < 4; ++w) sum += red[(w * 32 + jj) * kStagePad + v];
+            jp.dWpart[((size_t)wid * J + j0 + jt * 32 + jj) * 32 + v] = sum;
+        }
+    }
+}
+
 // out[i] = sum_p in[p*n + i]  (fixed order)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(float *out, const float *in, int nparts, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -841,7 +1053,13 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (hipMemsetAsync(jp.dApart, 0, L.dbpart - L.dApart, s) != hipSuccess) return hipErrorUnknown;  // dA/dC/dW partials
     const unsigned g2 = (unsigned)B * L.n_ut * (J / 64) * L.n_ts;
-    hipLaunchKernelGGL(joint_phase2_kernel, dim3(g2), dim3(256), shm2, s, jp);
+    static const bool p2_f32 = [] { const char *v = getenv("RNNT_JOINT_P2"); return v && v[0] == 'f'; }();
+    if (p2_f32) {  // RNNT_JOINT_P2=f32: the v_mfma_f32_32x32x2_f32 form (kept for A/B runs)
+        hipLaunchKernelGGL(joint_phase2_kernel, dim3(g2), dim3(256), shm2, s, jp);
+    } else {
+        const size_t shm2s = ((size_t)64 * 36 + 4 * 32 * 36 + 4 * 32 * kStagePad) * sizeof(float) + 8192;
+        hipLaunchKernelGGL(joint_phase2s_kernel, dim3(g2), dim3(256), shm2s, s, jp);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const size_t nA = (size_t)B * T * J, nC = (size_t)B * U * J;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1024), dim3(256), 0, s, d_enc_proj, jp.dApart, L.n_ut, nA);
