@@ -80,7 +80,7 @@ def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_leng
     enc [B,T,H] (encoder output), pred [B,U,H] (prediction-network output), W1 [H,J], b1 [J],
     W2 [J,V], b2 [V]  (Keras Dense kernels are stored [in, out], model.py:162-166).
 
-    joint_dtype: arithmetic of the J x V product.  "f32": exact f32 MFMA, small vocabularies (V <= 32, the reference's
+    joint_dtype: arithmetic of the J x V product.  "f32": f32-grade products (binary16 hi + lo operands on the f16 MFMA units, f32 accumulation), small vocabularies (V <= 32, the reference's
     character set).  "f16": operands rounded to binary16, f32 accumulation, for large vocabularies -- the counterpart
     of the reference's `mixed_float16` policy (run_rnnt.py:96-99); the lattice stays f32 either way.  "auto" picks by V.
     Shapes the kernels do not take natively (f16: V a multiple of 512, J in {128, 256, 512, 640}; f32: J a multiple of

@@ -90,7 +90,8 @@ def test_hot_kernels_do_not_spill(kernels):
     meta, _ = kernels
     hot = [("sweep_ld_kernel",), ("sweep_kernel", "Li3ELi16ELb1"), ("sweep_kernel", "Li6ELi8ELb1"), ("cell_tile_kernel", "Li32ELb1ELb0"),
            ("cell_tile_kernel", "Li32ELb0ELb0"), ("jh_logits_kernel", "Li40ELb0"), ("jh_dh_kernel",), ("jh_dw_kernel",),
-           ("joint_phase1_kernel",), ("joint_phase2_kernel",), ("joint_dl_kernel",)]
+           ("joint_phase1_kernel",), ("joint_phase2_kernel",), ("joint_dl_kernel",), ("joint_phase1s_kernel",),
+           ("joint_phase2s_kernel",)]
     for needles in hot:
         for k in _find(meta, *needles):
             m = meta[k]
@@ -107,6 +108,9 @@ def test_register_budgets_match_the_occupancy_assumptions(kernels):
     for needles in (("jh_logits_kernel", "Li40"), ("jh_dh_kernel",), ("jh_dw_kernel",)):
         for k in _find(meta, *needles):
             assert int(meta[k]["vgpr_count"]) + int(meta[k].get("agpr_count", "0")) <= 256, (k, meta[k]["vgpr_count"])
+    # split-precision phase 2: two 4-wave workgroups per CU -> at most 256 registers
+    for k in _find(meta, "joint_phase2s_kernel"):
+        assert int(meta[k]["vgpr_count"]) + int(meta[k].get("agpr_count", "0")) <= 256, (k, meta[k]["vgpr_count"])
     # lane-per-cell patch kernels: five 28 KB workgroups per CU = 20 waves -> at most 96 registers for full residency
     for k in _find(meta, "cell_tile_kernel", "Li32"):
         assert int(meta[k]["vgpr_count"]) <= 128, (k, meta[k]["vgpr_count"])
@@ -130,5 +134,9 @@ def test_instruction_selection(kernels):
     assert ld.count("v_exp_f32") >= 96 and ld.count("v_log_f32") >= 96  # 2 directions x 16 unrolled diagonals x 3 columns
     p1 = asm[_find(asm, "joint_phase1_kernel")[0]]
     assert "v_mfma_f32_32x32x2_f32" in p1
+    # default f32-parity joint: split-precision products (hi + lo binary16 operands) on the f16 MFMA units
+    for name in ("joint_phase1s_kernel", "joint_phase2s_kernel"):
+        ks = asm[_find(asm, name)[0]]
+        assert ks.count("v_mfma_f32_32x32x16_f16") >= 12 and "v_cvt_pk" in ks and "v_mfma_f32_32x32x2_f32" not in ks
     for name, text in asm.items():
         assert "v_mfma_f32_32x32x8" not in text  # no CDNA3-shaped f16 MFMAs: gfx950 forms only
