@@ -286,6 +286,32 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
     }
 }
 
+typedef _Float16 jh2 __attribute__((ext_vector_type(2)));
+// x -> binary16 hi (round to nearest even) and lo = binary16(x - hi).  The residual is one v_fma_mix_f32 per value: it reads
+// the binary16 operand straight out of the packed register (no v_cvt_f32_f16), hi * -1 + x is exact in f32.
+__device__ __forceinline__ void split_pair(const float x0, const float x1, jh2 &hi, jh2 &lo) {
+    hi[0] = (jf16)x0, hi[1] = (jf16)x1;
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(x1));
+    lo[0] = (jf16)l0, lo[1] = (jf16)l1;
+}
+__device__ __forceinline__ void split_h8(const float (&x)[8], jh8 &hi, jh8 &lo) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        jh2 h2, l2;
+        split_pair(x[e], x[e + 1], h2, l2);
+        hi[e] = h2[0], hi[e + 1] = h2[1];
+        lo[e] = l2[0], lo[e + 1] = l2[1];
+    }
+}
+__device__ __forceinline__ f32x16 mfma3(const jh8 ahi, const jh8 alo, const jh8 bhi, const jh8 blo, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc, 0, 0, 0);
+    return acc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // phase 1, split-precision form (default): the same tile, epilogue and outputs as joint_phase1_kernel, but the J x V
 // product runs on v_mfma_f32_32x32x16_f16 with BOTH operands split into binary16 hi + lo parts:
@@ -367,11 +393,7 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1s_kernel(const Join
                         for (int e = 0; e < 8; ++e) h[e] = fast_tanh(av[e] + Ct[(j0 + e) * 32 + l31]);
                     }
                     jh8 hi, lo;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        hi[e] = (jf16)h[e];
-                        lo[e] = (jf16)(h[e] - (float)hi[e]);
-                    }
+                    split_h8(h, hi, lo);
                     const jh8 wh = *(const jh8 *)(wbuf + k4 * 2048 + lane * 16);
                     const jh8 wl = *(const jh8 *)(wbuf + k4 * 2048 + 1024 + lane * 16);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, wh, acc, 0, 0, 0);
@@ -671,20 +693,6 @@ __global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp)
 // upstream gradients do not fall into binary16's subnormals; dh and the dW2 partial are divided by S_b again (exact).
 // LDS: Cs [64 j][36] | dlr [4][32 u][36] | red [4][32][33]
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void split_h8(const float (&x)[8], jh8 &hi, jh8 &lo) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        hi[e] = (jf16)x[e];
-        lo[e] = (jf16)(x[e] - (float)hi[e]);
-    }
-}
-__device__ __forceinline__ f32x16 mfma3(const jh8 ahi, const jh8 alo, const jh8 bhi, const jh8 blo, f32x16 acc) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc, 0, 0, 0);
-    return acc;
-}
-
 #ifndef P2S_WG_PER_CU
 #define P2S_WG_PER_CU 2  // 227 VGPRs, no spills: 3.18 ms per fused step at C2; 3 (168 VGPRs, 57 spilled) 5.37 ms; 1 (284) 4.42 ms
 #endif
