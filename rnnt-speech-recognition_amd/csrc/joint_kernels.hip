@@ -465,17 +465,30 @@ __global__ __launch_bounds__(256) void joint_dl_kernel(const JointParams jp) {
     float colsum[32];
 #pragma unroll
     for (int v = 0; v < 32; ++v) colsum[v] = 0.f;
+    const size_t total = (size_t)p.cells * 32;
     for (int ch = 0; ch < kDlChunks; ++ch) {
-        const uint32_t c = (blockIdx.x * kDlChunks + ch) * 256u + tid;
-        const Cell cl = decode(p, c);
-        if (cl.valid) {
-            float x[32];
-            float4 *q = (float4 *)(jp.dl + (size_t)c * 32);
+        const uint32_t c0 = (blockIdx.x * kDlChunks + ch) * 256u;
+        if (c0 >= p.cells) break;  // workgroup-uniform
+        const uint32_t c = c0 + tid;
+        // the chunk's 256 tiles are 32 KB of contiguous memory: move them with fully coalesced 16-byte accesses and hand
+        // every lane its own cell through LDS (a lane reading its 128 bytes directly uses a quarter of every request)
+        float4 *g4 = (float4 *)(jp.dl + (size_t)c0 * 32);
+        __syncthreads();  // the previous chunk's write-back is done with `red`
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float4 t4 = q[i];
-                x[4 * i] = t4.x, x[4 * i + 1] = t4.y, x[4 * i + 2] = t4.z, x[4 * i + 3] = t4.w;
+        for (int i = 0; i < 8; ++i) {
+            const int e = i * 256 + tid;  // float4 index inside the chunk: cell e >> 3, columns 4 (e & 7) ..
+            if ((size_t)c0 * 32 + (size_t)e * 4 < total) {
+                const float4 t4 = g4[e];
+                float *r = &red[e >> 3][4 * (e & 7)];
+                r[0] = t4.x, r[1] = t4.y, r[2] = t4.z, r[3] = t4.w;
             }
+        }
+        __syncthreads();
+        const Cell cl = decode(p, c);
+        float x[32];
+#pragma unroll
+        for (int v = 0; v < 32; ++v) x[v] = red[tid][v];
+        if (cl.valid) {
             const CellGrad g = cell_grad_setup(p, cl, c);
             float xb = 0.f, xl = 0.f;
 #pragma unroll
@@ -493,16 +506,25 @@ __global__ __launch_bounds__(256) void joint_dl_kernel(const JointParams jp) {
                 x[v] = gv;
                 colsum[v] += gv;
             }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) q[i] = make_float4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
-        } else if (c < p.cells) {
+        } else {
             // padded cell: phase 2 reads whole 32-column tiles of every valid row, so it must find exact zeros here
-            float4 *q = (float4 *)(jp.dl + (size_t)c * 32);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int v = 0; v < 32; ++v) x[v] = 0.f;
+        }
+#pragma unroll
+        for (int v = 0; v < 32; ++v) red[tid][v] = x[v];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = i * 256 + tid;
+            if ((size_t)c0 * 32 + (size_t)e * 4 < total) {
+                const float *r = &red[e >> 3][4 * (e & 7)];
+                g4[e] = make_float4(r[0], r[1], r[2], r[3]);
+            }
         }
     }
     // db2 partial of this workgroup: fixed-order column sums through LDS
+    __syncthreads();
 #pragma unroll
     for (int v = 0; v < 32; ++v) red[tid][v] = colsum[v];
     __syncthreads();
