@@ -73,6 +73,16 @@ def test_kat(golden_dir):
     np.testing.assert_allclose(g, np.array(k["grads_wrt_logits"]), atol=1e-5, rtol=0)
 
 
+def test_kat_b2(golden_dir):
+    """Upstream's two-utterance known-answer vector (tests/golden/kat_b2.json): published costs and gradients."""
+    with open(os.path.join(golden_dir, "kat_b2.json")) as f:
+        k = json.load(f)
+    x = np.array(k["logits_flat"], np.float32).reshape(k["B"], k["T"], k["U"], k["V"])
+    c, g = run_hip(x, k["labels"], k["input_lengths"], k["label_lengths"], k["blank"])
+    np.testing.assert_allclose(c, k["costs_published"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(g.reshape(-1), k["grads_wrt_logits_flat_published"], atol=1e-5, rtol=0)
+
+
 def test_goldens(golden_dir):
     files = sorted(glob.glob(os.path.join(golden_dir, "*.npz")))
     assert len(files) >= 5

@@ -37,6 +37,31 @@ def test_kat_c_restatement(golden_dir):
     np.testing.assert_allclose(g, np.array(k["grads_wrt_logits"]), atol=1e-6, rtol=0)
 
 
+def _kat_b2(golden_dir):
+    with open(os.path.join(golden_dir, "kat_b2.json")) as f:
+        k = json.load(f)
+    x = np.array(k["logits_flat"], np.float64).reshape(k["B"], k["T"], k["U"], k["V"])
+    g = np.array(k["grads_wrt_logits_flat_published"]).reshape(x.shape)
+    return k, x, g
+
+
+def test_kat_b2_upstream_two_utterance_vector(golden_dir):
+    """Second external anchor: upstream's B=2 T=4 U=3 V=3 vector (published costs and gradients, 6-7 decimals)."""
+    k, x, g_pub = _kat_b2(golden_dir)
+    costs, grads = orc.rnnt_loss_and_grad(x, np.array(k["labels"]), k["input_lengths"], k["label_lengths"], blank=k["blank"])
+    np.testing.assert_allclose(costs, k["costs_published"], atol=5e-7, rtol=0)
+    np.testing.assert_allclose(grads, g_pub, atol=1e-6, rtol=0)
+
+
+def test_kat_b2_c_restatement(golden_dir):
+    k, x, g_pub = _kat_b2(golden_dir)
+    lp = orc.log_softmax(x)
+    costs, glp = cpu_oracle.rnnt_cpu(lp, k["labels"], k["input_lengths"], k["label_lengths"], blank=k["blank"])
+    np.testing.assert_allclose(costs, k["costs_published"], atol=3e-6, rtol=0)
+    g = glp - np.exp(lp) * glp.sum(-1, keepdims=True)
+    np.testing.assert_allclose(g, g_pub, atol=2e-6, rtol=0)
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_finite_differences(fused):
     rng = np.random.default_rng(7)
