@@ -20,6 +20,7 @@
 #ifndef MI355X_RNNT_H
 #define MI355X_RNNT_H
 
+#include <stdbool.h>
 #include <stddef.h>
 
 #ifdef __cplusplus
@@ -52,8 +53,8 @@ typedef struct rnntOptions {
     };
     int blank_label; /* reference never passes it -> op default 0 (utils/vocabulary.py:3-6) */
     int maxT;        /* acts.shape[1] */
-    int maxU;        /* acts.shape[2] = L_max + 1 (utils/preprocessing.py:177-183) */
-    int batch_first; /* must be non-zero: acts is [B, maxT, maxU, V] row-major */
+    int maxU;        /* acts.shape[2] = L_max + 1 (utils/preprocessing.py:177-183); at most 1024, see below */
+    bool batch_first; /* must be true: acts is [B, maxT, maxU, V] row-major (1 byte, as upstream) */
 } rnntOptions;
 
 /* Replaces upstream get_warprnnt_version(). */
@@ -63,8 +64,19 @@ int get_warprnnt_version(void);
 const char *rnntGetStatusString(rnntStatus_t status);
 
 /* Replaces upstream get_workspace_size(maxT, maxU, minibatch, gpu, &size_bytes).
- * `gpu` must be non-zero.  The size depends on (maxT, maxU, minibatch) only. */
-rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, int gpu, size_t *size_bytes);
+ * `gpu` must be true.  The size depends on (maxT, maxU, minibatch) only. */
+rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool gpu, size_t *size_bytes);
+
+/* Deliberate limits of this library (upstream has none of them; all are reported as RNNT_STATUS_INVALID_VALUE at
+ * enqueue time, never as wrong numbers):
+ *   maxU <= 1024       the alpha/beta sweeps keep a whole anti-diagonal in the registers of ONE wavefront (64 lanes x
+ *                      up to 16 lattice columns); longer label sequences would need a multi-wave sweep with a barrier
+ *                      per diagonal, which is a different (slower) kernel that has not been written;
+ *   B*maxT*maxU < 2^31 cell indices are 32-bit;
+ *   workspace 256-byte aligned.
+ * Out-of-range per-utterance lengths (T_b < 1, T_b > maxT, L_b < 0, L_b > maxU-1) are device data and cannot be
+ * checked at enqueue time: the kernels clamp them into the tensor (no out-of-bounds access) and report that
+ * utterance with a NaN cost and NaN gradients.  Labels outside [0, alphabet_size) are clamped into range. */
 
 /* Replaces upstream compute_rnnt_loss(...): the body of the WarpRNNT TensorFlow op that
  * utils/loss.py:34-35 calls.

@@ -42,7 +42,7 @@ class rnntOptions(ctypes.Structure):
         ("blank_label", ctypes.c_int),
         ("maxT", ctypes.c_int),
         ("maxU", ctypes.c_int),
-        ("batch_first", ctypes.c_int),
+        ("batch_first", ctypes.c_bool),
     ]
 
 
@@ -72,7 +72,7 @@ def load():
     lib.rnntGetStatusString.restype = ctypes.c_char_p
     lib.rnntGetStatusString.argtypes = [ci]
     lib.get_workspace_size.restype = ci
-    lib.get_workspace_size.argtypes = [ci, ci, ci, ci, ctypes.POINTER(ctypes.c_size_t)]
+    lib.get_workspace_size.argtypes = [ci, ci, ci, ctypes.c_bool, ctypes.POINTER(ctypes.c_size_t)]
     lib.compute_rnnt_loss.restype = ci
     lib.compute_rnnt_loss.argtypes = [vp, vp, vp, vp, vp, ci, ci, vp, vp, rnntOptions]
     lib.compute_rnnt_loss_fwd.restype = ci
@@ -109,7 +109,7 @@ def make_options(stream: int, blank: int, maxT: int, maxU: int, loc: int = RNNT_
     o.blank_label = blank
     o.maxT = maxT
     o.maxU = maxU
-    o.batch_first = 1
+    o.batch_first = True
     return o
 
 
@@ -122,5 +122,5 @@ def joint_workspace_bytes(maxT: int, maxU: int, minibatch: int, joint_size: int,
 
 def workspace_bytes(maxT: int, maxU: int, minibatch: int) -> int:
     n = ctypes.c_size_t(0)
-    check(load().get_workspace_size(maxT, maxU, minibatch, 1, ctypes.byref(n)), "get_workspace_size")
+    check(load().get_workspace_size(maxT, maxU, minibatch, True, ctypes.byref(n)), "get_workspace_size")
     return int(n.value)

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
     const int tt = bid % jp.n_tt;
     const int b = bid / jp.n_tt;
     const int u0 = ut * 32, t0 = tt * 8;
-    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int Tb = length_T(p, b), Ub = length_U(p, b);
     if (t0 >= Tb || u0 >= Ub) return;  // dead tile: nothing downstream reads it
     const int t = t0 + wave;
     const bool wave_live = t < Tb;  // wave-uniform
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
     const int ut = (int)(bid % (uint32_t)jp.n_ut);
     const int b = (int)(bid / (uint32_t)jp.n_ut);
     const int u0 = ut * 32, j0 = jt * 128;
-    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int Tb = length_T(p, b), Ub = length_U(p, b);
     const int t_begin = ts * jp.TS, t_end = min(min(t_begin + jp.TS, p.T), Tb);
     if (t_begin >= t_end || u0 >= Ub) return;
 
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
         const int ut = q % jp.n_ut;
         const int b = q / jp.n_ut;
         const int u0 = ut * 32;
-        const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+        const int Tb = length_T(p, b), Ub = length_U(p, b);
         const int t_begin = tq * kTQ, t_end = min(min(t_begin + kTQ, p.T), Tb);
         if (t_begin >= t_end || u0 >= Ub) continue;  // workgroup-uniform
         const int nsteps = t_end - t_begin;

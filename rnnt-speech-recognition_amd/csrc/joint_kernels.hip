@@ -55,6 +55,7 @@ __device__ __forceinline__ float tanh_from_exp(float ea, float ec) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(fmaf(ea, ec, 1.0f));
 }
 constexpr float kExpTabLimit = 43.0f;
+constexpr float kSplitLimit = 60000.0f;  // |W2| beyond this leaves binary16's range (65504): no hi/lo split
 // row of the 32x32 MFMA C/D tile held in register `reg` of a lane in half `half` (= lane >> 5)
 __device__ __forceinline__ constexpr int cd_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
@@ -78,6 +79,8 @@ struct JointParams {
     float *d_enc_proj, *d_pred_proj, *dW2, *db2;
     float *expE, *expP;  // [B][T][J], [B][U][J]  e^{2 x} tables of the two projections
     float *tflag;        // [0] != 0: some |projection| exceeds kExpTabLimit, use the raw projections + fast_tanh
+                         // [1] != 0: some |W2| is outside the binary16 range: the plain f32 MFMA kernels run instead of the
+                         //           split-precision ones (both are enqueued; the one the flag does not select exits at once)
     jf16 *W2s;           // [J/16][2 (hi, lo)][64 lanes][8]: W2 as binary16 hi + lo parts in MFMA B-fragment order (phase 1s)
 #ifdef JH_TRACE
     long long *trace;    // dev builds only: s_memtime stamps of one workgroup of phase 1 and one of phase 2
@@ -108,6 +111,7 @@ __global__ __launch_bounds__(256) void joint_prep_kernel(const JointParams jp) {
         for (int e = 0; e < 8; ++e) {
             const int j = 16 * ks + 8 * (l >> 5) + e;
             const float w = (v < p.V) ? jp.W2[(size_t)j * p.V + v] : 0.f;
+            if (!(fabsf(w) <= kSplitLimit)) jp.tflag[1] = 1.0f;  // also catches NaN / inf
             hi[e] = (jf16)w;
             lo[e] = (jf16)(w - (float)hi[e]);
         }
@@ -135,6 +139,7 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
     float *stage = Arow + kP1Waves * J;    // [kP1Waves][32][kStagePad]
     float *my_arow = Arow + wave * J;
     float *my_stage = stage + wave * 32 * kStagePad;
+    if (jp.tflag[1] == 0.f) return;  // W2 fits binary16 hi + lo parts: joint_phase1s_kernel does this launch's work
     const bool slow = jp.tflag[0] != 0.f;  // kernel-uniform
     const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
 
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
     const int ut = bid % jp.n_ut;
     const int b = bid / jp.n_ut;
     const int u0 = ut * 32;
-    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int Tb = length_T(p, b), Ub = length_U(p, b);
     const int t_begin = tr * jp.TR, t_end = min(min(t_begin + jp.TR, p.T), Tb);
     const bool tile_live = (t_begin < t_end) && (u0 < Ub);
 
@@ -334,6 +339,7 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1s_kernel(const Join
     float *stage = Arow + kP1Waves * J;               // [kP1Waves][32][kStagePad]
     float *my_arow = Arow + wave * J;
     float *my_stage = stage + wave * 32 * kStagePad;
+    if (jp.tflag[1] != 0.f) return;  // some |W2| outside the binary16 range: joint_phase1_kernel (plain f32 MFMAs) runs instead
     const bool slow = jp.tflag[0] != 0.f;  // kernel-uniform
     const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
 
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1s_kernel(const Join
     const int ut = bid % jp.n_ut;
     const int b = bid / jp.n_ut;
     const int u0 = ut * 32;
-    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int Tb = length_T(p, b), Ub = length_U(p, b);
     const int t_begin = tr * jp.TR, t_end = min(min(t_begin + jp.TR, p.T), Tb);
     const bool tile_live = (t_begin < t_end) && (u0 < Ub);
 
@@ -551,6 +557,7 @@ __global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp)
     float *dlr = W2s + 64 * kStagePad;          // [4][32][kStagePad]
     float *red = dlr + 4 * 32 * kStagePad;      // [4][32][kStagePad]
     float *my_dl = dlr + wave * 32 * kStagePad;
+    if (jp.tflag[1] == 0.f) return;  // joint_phase2s_kernel does this launch's work
     const bool slow = jp.tflag[0] != 0.f;  // kernel-uniform
     const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
 
@@ -562,7 +569,7 @@ __global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp)
     const int ut = bid % jp.n_ut;
     const int b = bid / jp.n_ut;
     const int u0 = ut * 32, j0 = js * 64;
-    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int Tb = length_T(p, b), Ub = length_U(p, b);
     const int t_begin = ts * jp.TS, t_end = min(min(t_begin + jp.TS, p.T), Tb);
     const bool tile_live = (t_begin < t_end) && (u0 < Ub);
 
@@ -730,6 +737,7 @@ __global__ __launch_bounds__(256, P2S_WG_PER_CU) void joint_phase2s_kernel(const
     float *red = dlr + 4 * 32 * kCs;            // [4][32][kStagePad]
     jh8 *wfrag = (jh8 *)(red + 4 * 32 * kStagePad);  // [jt 2][ks 2][hi, lo][64 lanes]: B fragments of dh (8 KB)
     float *my_dl = dlr + wave * 32 * kCs;
+    if (jp.tflag[1] != 0.f) return;  // joint_phase2_kernel (plain f32 MFMAs) runs instead
     const bool slow = jp.tflag[0] != 0.f;  // kernel-uniform
     const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
 
@@ -741,7 +749,7 @@ __global__ __launch_bounds__(256, P2S_WG_PER_CU) void joint_phase2s_kernel(const
     const int ut = bid % jp.n_ut;
     const int b = bid / jp.n_ut;
     const int u0 = ut * 32, j0 = js * 64;
-    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int Tb = length_T(p, b), Ub = length_U(p, b);
     const int t_begin = ts * jp.TS, t_end = min(min(t_begin + jp.TS, p.T), Tb);
     const bool tile_live = (t_begin < t_end) && (u0 < Ub);
 
@@ -1063,15 +1071,12 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     if (phases & 1) {
         // forward: edge weights (W pre-filled with log zero) -> sweeps -> costs
         if (hipMemsetAsync(jp.lp.W, kFillByte, L.w.A - L.w.W, s) != hipSuccess) return hipErrorUnknown;
-        // RNNT_JOINT_P1=f32: the v_mfma_f32_32x32x2_f32 form (kept for A/B runs); default: split-precision f16 MFMAs
-        static const bool p1_f32 = [] { const char *v = getenv("RNNT_JOINT_P1"); return v && v[0] == 'f'; }();
-        if (p1_f32) {
-            hipLaunchKernelGGL(joint_phase1_kernel, dim3(g1), dim3(kP1Waves * 64), shm1, s, jp);
-        } else {
-            const size_t shm1s = (size_t)J * 32 * sizeof(float) + 2 * 8192 + (kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
-            if ((e = set_lds(joint_phase1s_kernel, shm1s)) != hipSuccess) return e;
-            hipLaunchKernelGGL(joint_phase1s_kernel, dim3(g1), dim3(kP1Waves * 64), shm1s, s, jp);
-        }
+        // Both forms are enqueued; the prep kernel's range flag (tflag[1], device data) decides which one works and which one
+        // exits at once: split-precision f16 MFMAs whenever W2 fits binary16 hi + lo parts, plain f32 MFMAs otherwise.
+        const size_t shm1s = (size_t)J * 32 * sizeof(float) + 2 * 8192 + (kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
+        if ((e = set_lds(joint_phase1s_kernel, shm1s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(joint_phase1s_kernel, dim3(g1), dim3(kP1Waves * 64), shm1s, s, jp);
+        hipLaunchKernelGGL(joint_phase1_kernel, dim3(g1), dim3(kP1Waves * 64), shm1, s, jp);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = launch_sweeps(jp.lp, s)) != hipSuccess) return e;
     }
@@ -1083,12 +1088,10 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (hipMemsetAsync(jp.dApart, 0, L.dbpart - L.dApart, s) != hipSuccess) return hipErrorUnknown;  // dA/dC/dW partials
     const unsigned g2 = (unsigned)B * L.n_ut * (J / 64) * L.n_ts;
-    static const bool p2_f32 = [] { const char *v = getenv("RNNT_JOINT_P2"); return v && v[0] == 'f'; }();
-    if (p2_f32) {  // RNNT_JOINT_P2=f32: the v_mfma_f32_32x32x2_f32 form (kept for A/B runs)
-        hipLaunchKernelGGL(joint_phase2_kernel, dim3(g2), dim3(256), shm2, s, jp);
-    } else {
+    {
         const size_t shm2s = ((size_t)64 * 36 + 4 * 32 * 36 + 4 * 32 * kStagePad) * sizeof(float) + 8192;
         hipLaunchKernelGGL(joint_phase2s_kernel, dim3(g2), dim3(256), shm2s, s, jp);
+        hipLaunchKernelGGL(joint_phase2_kernel, dim3(g2), dim3(256), shm2, s, jp);  // exits at once unless tflag[1] is set
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const size_t nA = (size_t)B * T * J, nC = (size_t)B * U * J;

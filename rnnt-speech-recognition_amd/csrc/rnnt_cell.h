@@ -5,6 +5,16 @@
 
 namespace rnnt {
 
+// Lengths as the kernels use them: clamped into the tensor, so that a caller's out-of-range T_b / L_b can never index
+// outside acts / grads / the workspace slabs.  An utterance whose lengths had to be clamped is reported with a NaN cost
+// and NaN gradients (lengths_invalid, consumed by the alpha sweep) instead of a plausible number.
+__device__ __forceinline__ int length_T(const LossParams &p, const int b) { return min(max(p.input_lengths[b], 1), p.T); }
+__device__ __forceinline__ int length_U(const LossParams &p, const int b) { return min(max(p.label_lengths[b] + 1, 1), p.U); }
+__device__ __forceinline__ bool lengths_invalid(const LossParams &p, const int b) {
+    const int t = p.input_lengths[b], l = p.label_lengths[b];
+    return t < 1 || t > p.T || l < 0 || l > p.U - 1;
+}
+
 struct Cell {
     int b, t, u, Tb, Ub;
     bool valid;
@@ -20,8 +30,8 @@ __device__ __forceinline__ Cell decode(const LossParams &p, uint32_t c) {
         const uint32_t b = fdiv(row, p.divT);
         r.t = (int)(row - b * (uint32_t)p.T);
         r.b = (int)b;
-        r.Tb = p.input_lengths[b];
-        r.Ub = p.label_lengths[b] + 1;
+        r.Tb = length_T(p, (int)b);
+        r.Ub = length_U(p, (int)b);
         r.valid = (r.t < r.Tb) && (r.u < r.Ub);
     }
     return r;

@@ -65,11 +65,8 @@ struct LossParams {
     float *offA;  // integer-valued offsets, exact in f32
     float *offB;
     double *ll;
-    int *flags;  // overlap mode, see flag_* helpers: per-utterance per-XCD lsm patch counters, sweep-done counters, ...
     int B, T, U, V, blank;
-    int tune;      // experiment bits (RNNT_TUNE): 1 = plain (not nt) gradient stores, 2 = nt logits loads (grad), 4 = nt logits loads (lsm)
-    int rev_grad;  // gradient patches in reverse order of the lsm pass (Infinity-Cache reuse)
-    int b0, nb;  // this launch covers utterances [b0, b0+nb)  (group pipelining)
+    int b0, nb;  // this launch covers utterances [b0, b0+nb)
     int N, Nr, Up, NC, NG;  // NG = Up/64 column groups (offset tables are [NC][NG])
     uint32_t cells;  // B*T*U
     FastDiv divU, divT, divV;
@@ -77,27 +74,11 @@ struct LossParams {
 };
 
 struct WsLayout {
-    size_t lse, W, A, Bt, offA, offB, ll, flags, total;
+    size_t lse, W, A, Bt, offA, offB, ll, total;
     int N, Nr, Up, NC, NG;
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-
-// Layout of LossParams::flags (ints), zeroed before every overlapped call:
-//   [b*8 + x]        lsm patches of utterance b that finished on XCD x
-//   [8B + b]         sweeps of utterance b that finished (alpha and beta add one each)
-//   [9B]             error: a bounded poll timed out
-//   [9B + 1]         the whole lsm kernel has completed (set by a marker kernel behind it)
-__host__ __device__ inline int flag_lsm(int b, int xcd) { return b * 8 + xcd; }
-__host__ __device__ inline int flag_sweep(int B, int b) { return 8 * B + b; }
-__host__ __device__ inline int flag_err(int B) { return 9 * B; }
-__host__ __device__ inline int flag_lsm_kernel_done(int B) { return 9 * B + 1; }
-//   [9B + 16 + 2b + dir]  diagnostics: XCD the sweep wave ran on | (took the same-L2 fast path) << 8
-__host__ __device__ inline int flag_diag(int B, int b, int dir) { return 9 * B + 16 + 2 * b + dir; }
-//   [11B + 16 + 2b + dir]  claim word of sweep job (b, dir); [13B + 16] number of claimed jobs
-__host__ __device__ inline int flag_claim(int B, int job) { return 11 * B + 16 + job; }
-__host__ __device__ inline int flag_nclaimed(int B) { return 13 * B + 16; }
-inline size_t flag_words(int B) { return (size_t)13 * B + 32; }
 
 // Lattice columns per lane in the sweeps (one of the instantiated widths); 0 = unsupported (U > 1024).
 inline int sweep_K(int U) {
@@ -130,7 +111,6 @@ inline WsLayout make_layout(int T, int U, int B) {
     w.offA = take((size_t)B * w.NC * w.NG * sizeof(float));
     w.offB = take((size_t)B * w.NC * w.NG * sizeof(float));
     w.ll = take((size_t)B * 2 * sizeof(double));
-    w.flags = take(flag_words(B) * sizeof(int));
     w.total = off;
     return w;
 }
@@ -153,12 +133,8 @@ inline TileGeom make_tile(int T, int U, int V) {
 
 // kernel launchers (rnnt_kernels.hip); return hipError_t from the launch
 bool tile_path_ok(const LossParams &p, bool grad);
-// `overlap`: the three stages run concurrently and hand utterances to each other through p.flags
-// (write-through stores + relaxed agent-scope counters); only valid on the patch + single-wave paths.
-hipError_t launch_lsm(const LossParams &p, hipStream_t s, bool overlap = false);
-hipError_t launch_sweeps(const LossParams &p, hipStream_t s, bool overlap = false);
-hipError_t launch_grad(const LossParams &p, hipStream_t s, bool overlap = false);
-bool overlap_path_ok(const LossParams &p, bool grad);
-hipError_t launch_lsm_done_marker(const LossParams &p, hipStream_t s);
+hipError_t launch_lsm(const LossParams &p, hipStream_t s);
+hipError_t launch_sweeps(const LossParams &p, hipStream_t s);
+hipError_t launch_grad(const LossParams &p, hipStream_t s);
 
 }  // namespace rnnt

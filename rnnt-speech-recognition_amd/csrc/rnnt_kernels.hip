@@ -38,7 +38,7 @@ __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" :
 // Everything one lane does for its lattice cell once the cell's V logits sit in LDS at `xs`:
 // GRAD=false: softmax denominator + the two lattice edge weights;  GRAD=true: the V gradients
 // (written back into `xs`, zeros for padded cells).
-template <int VP, bool V4, bool GRAD, bool OVL = false>
+template <int VP, bool V4, bool GRAD>
 __device__ __forceinline__ void cell_body(const LossParams &p, const Cell &cl, const uint32_t c, float *xs) {
     const int V = p.V;
     if (cl.valid) {
@@ -78,9 +78,9 @@ __device__ __forceinline__ void cell_body(const LossParams &p, const Cell &cl, c
             }
             p.lse[c] = lse;
             const size_t wi = ((size_t)cl.b * p.Nr + (cl.t + cl.u)) * p.Up + cl.u;
-            ((float2 *)p.W)[wi] = make_float2(ob, ol);  // plain (write-back) store even in overlap mode, see below
+            ((float2 *)p.W)[wi] = make_float2(ob, ol);
         } else {
-            const CellGrad g = cell_grad_setup<OVL>(p, cl, c);
+            const CellGrad g = cell_grad_setup(p, cl, c);
             const float xb = xs[p.blank];
             const float xl = g.has_label ? xs[g.lab] : 0.f;
             if (V4) {
@@ -109,65 +109,6 @@ __device__ __forceinline__ void cell_body(const LossParams &p, const Cell &cl, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// Small-vocabulary path (V <= VP <= 64): one lattice cell per LANE.
-// A 256-thread workgroup owns 256 consecutive cells = one contiguous 1024*V-byte span of acts.
-// ---------------------------------------------------------------------------------------------
-template <int VP, bool V4, bool GRAD>
-__global__ __launch_bounds__(256) void cell_small_kernel(const LossParams p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x;
-    const int V = p.V;
-    const uint32_t c0 = blockIdx.x * 256u;
-    const uint32_t c = c0 + (uint32_t)tid;
-    const Cell cl = decode(p, c);
-
-    unsigned long long *bm = (unsigned long long *)(lds + 256 * V);
-    const unsigned long long msk = __ballot(cl.valid);
-    if ((tid & 63) == 0) bm[tid >> 6] = msk;
-    __syncthreads();
-    const bool any = (bm[0] | bm[1] | bm[2] | bm[3]) != 0ull;
-
-    const uint32_t nchunk = 64u * (uint32_t)V;  // 16-byte chunks in this block's span
-    const size_t fbase = (size_t)c0 * V;
-    const size_t total = (size_t)p.cells * V;
-
-    if (!any) {
-        if (GRAD) {  // an all-padding span: exact zeros, no reads
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (uint32_t k = tid; k < nchunk; k += 256)
-                if (fbase + (size_t)k * 4 < total) *(float4 *)(p.grads + fbase + (size_t)k * 4) = z;
-        }
-        return;
-    }
-
-    // ---- stage this span's logits HBM -> LDS with 16-byte LDS-DMA (lane-linear destination) ----
-    const float *gsrc = p.acts + fbase;
-    for (uint32_t k0 = 0; k0 < nchunk; k0 += 256) {
-        const uint32_t k = k0 + (uint32_t)tid;
-        if (k < nchunk) {
-            const uint32_t f0 = k * 4u;
-            const uint32_t ca = fdiv(f0, p.divV);
-            const uint32_t cb = V4 ? ca : min(fdiv(f0 + 3u, p.divV), 255u);
-            const bool need = (((bm[ca >> 6] >> (ca & 63)) | (bm[cb >> 6] >> (cb & 63))) & 1ull) != 0ull;
-            if (need)
-                __builtin_amdgcn_global_load_lds((glb_void *)(gsrc + f0),
-                                                 (lds_void *)(lds + (k0 + ((uint32_t)tid & ~63u)) * 4u), 16, 0, 0);
-        }
-    }
-    wait_vm0();
-    __syncthreads();
-
-    cell_body<VP, V4, GRAD>(p, cl, c, lds + tid * V);
-
-    if (GRAD) {
-        __syncthreads();
-        float *gdst = p.grads + fbase;
-        for (uint32_t k = tid; k < nchunk; k += 256)
-            if (fbase + (size_t)k * 4 < total) *(float4 *)(gdst + (size_t)k * 4) = ((const float4 *)lds)[k];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Small-vocabulary TILE path (V % 4 == 0): a workgroup owns a TT x UU patch of one utterance's
 // lattice instead of 256 consecutive cells.  HBM reads are TT row segments of UU*V*4 contiguous
 // bytes; the diagonal-major (skewed) W / alpha~ / beta~ accesses of a patch fall into runs of up to
@@ -179,7 +120,7 @@ __global__ __launch_bounds__(256) void cell_small_kernel(const LossParams p) {
 // (a = start & 3, per row) into a 16-byte-aligned LDS row; cells read their logits with scalar LDS reads, and the gradient
 // rows go back with float4 stores for the aligned interior and single floats at the two ragged ends.  Needs B*T*U*V % 4 == 0
 // (then no aligned span reaches past the tensor).
-template <int VP, bool GRAD, bool OVL, bool AL = true>
+template <int VP, bool GRAD, bool AL = true>
 __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -195,7 +136,7 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
         bid = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
         // The gradient pass walks each XCD's range backwards: the logits the lsm pass read LAST are the ones most
         // likely still in the 256 MiB Infinity Cache.
-        if (GRAD && p.rev_grad) bid = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + ((xcd < r ? q + 1u : q) - 1u - idx);
+        if (GRAD) bid = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + ((xcd < r ? q + 1u : q) - 1u - idx);
     }
     const uint32_t q1 = fdiv(bid, tg.div_tu);
     const uint32_t tu = bid - q1 * (uint32_t)tg.tiles_u;
@@ -203,7 +144,7 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
     const uint32_t tt = q1 - bb * (uint32_t)tg.tiles_t;
     const int b = p.b0 + (int)bb;
     const int t0 = (int)tt * tg.TT, u0 = (int)tu * tg.UU;
-    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int Tb = length_T(p, b), Ub = length_U(p, b);
 
     // The valid part of a patch is a rectangle known to the whole workgroup: no per-cell bookkeeping.
     const int rows_valid = max(0, min(tg.TT, Tb - t0));         // lattice rows with t < T_b
@@ -261,19 +202,10 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
         for (int q0 = 0; q0 < nq; q0 += 64) {
             const int q = q0 + lane;
             if (q < nq) {
-                if (p.tune & (GRAD ? 2 : 4))
-                    __builtin_amdgcn_global_load_lds((glb_void *)(src + q * 4), (lds_void *)(dst + q0 * 4), 16, 0, 2);
-                else
-                    __builtin_amdgcn_global_load_lds((glb_void *)(src + q * 4), (lds_void *)(dst + q0 * 4), 16, 0, 0);
+                // default cache policy: non-temporal loads lose the Infinity-Cache reuse between the two cell passes
+                __builtin_amdgcn_global_load_lds((glb_void *)(src + q * 4), (lds_void *)(dst + q0 * 4), 16, 0, 0);
             }
         }
-    }
-    if (OVL && GRAD) {
-        // This kernel starts only after the lsm kernel has completed (stream order): tell slow-path sweep waves.
-        if (blockIdx.x == 0 && tid == 0)
-            __hip_atomic_store(p.flags + flag_lsm_kernel_done(p.B), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // the logits are on their way; only now wait until BOTH sweeps of this utterance have published
-        if (tid == 0) spin_until_ge(p.flags + flag_sweep(p.B, b), 2, p.flags + flag_err(p.B));
     }
     wait_vm0();
     __syncthreads();
@@ -285,22 +217,11 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
     cl.valid = ((int)r < rows_valid) && (cu < cols_valid);
     const uint32_t c = ((uint32_t)(b * p.T + cl.t)) * (uint32_t)p.U + (uint32_t)cl.u;
     if (AL) {
-        if (GRAD || cl.valid) cell_body<VP, true, GRAD, OVL>(p, cl, c, lds + tid * V);
+        if (GRAD || cl.valid) cell_body<VP, true, GRAD>(p, cl, c, lds + tid * V);
     } else if ((int)r < tg.TT) {
         const int a = (int)((patch0 + r * row_f) & 3);
-        if (GRAD || cl.valid) cell_body<VP, false, GRAD, OVL>(p, cl, c, lds + r * row_lds + a + cu * V);
+        if (GRAD || cl.valid) cell_body<VP, false, GRAD>(p, cl, c, lds + r * row_lds + a + cu * V);
     }
-    if (OVL && !GRAD) {
-        // Publish this patch.  Its W words were stored write-back: after vmcnt(0) they sit in THIS XCD's L2,
-        // which every CU of this XCD reads coherently.  The counter is kept per XCD so that the consuming
-        // sweep wave can prove that all patches of its utterance ran on its own XCD (fast path); if the
-        // dispatcher placed them elsewhere it waits for the kernel-end write-back instead (slow, still right).
-        wait_vm0();
-        __syncthreads();
-        if (tid == 0)
-            __hip_atomic_fetch_add(p.flags + flag_lsm(b, my_xcd()), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-
     if (GRAD && !AL) {
         __syncthreads();
         for (int rr = wave; rr < rows_in; rr += 4) store_row(rr, lds + rr * row_lds);
@@ -309,13 +230,11 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
         for (int rr = wave; rr < rows_in; rr += 4) {
             const float4 *srcl = (const float4 *)(lds + rr * row_lds);
             float *dstg = p.grads + patch0 + rr * row_f;
-            if (!(p.tune & 1))  // gradients are written once and not re-read by this op: keep them out of L2 / Infinity Cache
-                for (int q = lane; q < q_in; q += 64) {
-                    typedef float v4f __attribute__((ext_vector_type(4)));
-                    __builtin_nontemporal_store(((const v4f *)srcl)[q], (v4f *)(dstg + q * 4));
-                }
-            else
-                for (int q = lane; q < q_in; q += 64) *(float4 *)(dstg + q * 4) = srcl[q];
+            // gradients are written once and not re-read by this op: keep them out of L2 / Infinity Cache
+            for (int q = lane; q < q_in; q += 64) {
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(((const v4f *)srcl)[q], (v4f *)(dstg + q * 4));
+            }
         }
     }
 }
@@ -453,9 +372,6 @@ __device__ __forceinline__ float lse2(float a, float b) {
 
 // Stream `n16` 16-byte units global -> LDS (destination lane-linear, as LDS-DMA requires).
 __device__ __forceinline__ void dma_rows(const float *g, float *l, int n16, int lane) {
-#ifdef SWEEP_EXP_NODMA  // timing experiment (results wrong): the chunk buffers are never filled
-    return;
-#endif
     for (int i0 = 0; i0 < n16; i0 += 64) {
         const int k = i0 + lane;
         if (k < n16) __builtin_amdgcn_global_load_lds((glb_void *)(g + (size_t)k * 4), (lds_void *)(l + i0 * 4), 16, 0, 0);
@@ -523,91 +439,6 @@ struct OffsetLog {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Overlap mode (p.flags != nullptr): a sweep wave starts before the lsm pass has finished.  It waits until
-// every live patch of ITS utterance has published (one relaxed poll loop), then one agent-scope acquire
-// drops any stale L1 lines; the W rows themselves were stored write-through by the lsm pass.
-// Overlap mode job assignment.  The dispatcher hands workgroups to XCDs round-robin from a start that differs
-// per launch, so which XCD produces an utterance's W rows is only known at run time (the lsm patches count
-// themselves per XCD).  A sweep workgroup therefore CLAIMS its utterance: preferably an unclaimed one whose
-// patches are being produced on the workgroup's own XCD (then W can be read through the shared L2 with no
-// flush); once the lsm kernel is over, anything that is left.  Returns b, or -1 when all are taken.
-// Called by ONE wave of the workgroup.
-__device__ __forceinline__ int claim_utterance(const LossParams &p, const int lane) {
-    const int B = p.B, me = my_xcd();
-    int *flags = p.flags;
-    for (int it = 0; it < (1 << 22); ++it) {
-        if (__hip_atomic_load(flags + flag_nclaimed(B), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= B) return -1;
-        const bool any_xcd = __hip_atomic_load(flags + flag_lsm_kernel_done(B), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        for (int b0 = 0; b0 < B; b0 += 64) {
-            const int b = b0 + lane;
-            bool cand = false;
-            if (b < B) {
-                const int c0 = __hip_atomic_load(flags + flag_claim(B, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int here = any_xcd ? 1 : __hip_atomic_load(flags + flag_lsm(b, me), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                cand = (here > 0) && (c0 == 0);
-            }
-            const unsigned long long m = __ballot(cand);
-            if (m == 0ull) continue;
-            const int bb = b0 + __builtin_ctzll(m);
-            int got = -1;
-            if (lane == 0) {
-                int expect = 0;
-                if (__hip_atomic_compare_exchange_strong(flags + flag_claim(B, bb), &expect, 1, __ATOMIC_RELAXED,
-                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    got = bb;
-                    __hip_atomic_fetch_add(flags + flag_nclaimed(B), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            got = __shfl(got, 0);
-            if (got >= 0) return got;
-            break;  // lost the race: rescan
-        }
-        __builtin_amdgcn_s_sleep(4);
-    }
-    __hip_atomic_store(flags + flag_err(B), 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return -1;
-}
-
-__device__ __forceinline__ void sweep_wait_for_lsm(const LossParams &p, const int b, const int Tb, const int Ub,
-                                                   const int dir) {
-    if (p.flags == nullptr) return;
-    const int need = ((Tb + p.tile.TT - 1) / p.tile.TT) * ((Ub + p.tile.UU - 1) / p.tile.UU);
-    const int lane = threadIdx.x & 63;
-    const int me = my_xcd();
-    int *err = p.flags + flag_err(p.B);
-    bool all_here = false;
-    for (int it = 0; it < (1 << 22); ++it) {
-        // lanes 0..7 each read one per-XCD counter of this utterance
-        const int c = (lane < 8) ? __hip_atomic_load(p.flags + flag_lsm(b, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        int total = c;
-#pragma unroll
-        for (int o = 4; o > 0; o >>= 1) total += __shfl_xor(total, o);
-        total = __shfl(total, 0);
-        if (total >= need) {
-            all_here = (__shfl(c, me) >= need);
-            break;
-        }
-        __builtin_amdgcn_s_sleep(8);
-        if (it == (1 << 22) - 1) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (lane == 0) p.flags[flag_diag(p.B, b, dir)] = me | ((int)all_here << 8);
-    if (!all_here)  // some patch ran on another XCD: its W words become visible only at the end of the lsm kernel
-        spin_until_ge(p.flags + flag_lsm_kernel_done(p.B), 1, err);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale L1 lines; W itself is read from L2 / memory
-}
-// ... and when it is done: drain its write-through stores, then bump the utterance's "sweeps done" counter
-// (alpha and beta each add one; the gradient pass waits for 2).
-__device__ __forceinline__ void sweep_publish(const LossParams &p, const int b) {
-    if (p.flags == nullptr) return;
-    wait_vm0();
-    if ((threadIdx.x & 63) == 0)
-        __hip_atomic_fetch_add(p.flags + flag_sweep(p.B, b), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ void lsm_done_marker_kernel(int *flag) {
-    __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // number of store instructions store_diag<K, true> issues (pieces of 4 dwords, then one of 3, 2 or 1)
 constexpr int store_pieces(int K) { return K / 4 + ((K % 4) ? 1 : 0); }
 
@@ -620,16 +451,13 @@ typedef float f32x3 __attribute__((ext_vector_type(3)));
 template <int K, bool COUNTED, int OFF = 0>
 __device__ __forceinline__ void store_diag(float *row, const int voff, const int lane, const float (&v)[K]) {
     // All lattice stores are write-through (sc1): the gradient pass may run on another XCD while this
-    // kernel is still alive (overlap mode), and nothing on this XCD re-reads them anyway.
+    // kernel is still alive, and nothing on this XCD re-reads them anyway.
     if (!COUNTED) {
         float *dst = row + lane * K + OFF / 4;
 #pragma unroll
         for (int j = 0; j < K; ++j) st_f32_wt(dst + j, v[j]);
     } else {
         static_assert(OFF + 4 * K <= 4096 && OFF >= -4096, "store offset outside the immediate range");
-#ifdef SWEEP_EXP_NOSTORE
-        return;  // timing experiment (results wrong, counted waits over-wait harmlessly)
-#endif
         int j = 0;
 #pragma unroll
         for (; j + 4 <= K; j += 4) {
@@ -669,11 +497,6 @@ __device__ __forceinline__ void load_w(f32x2 (&w)[K], const float *wrow) {
 // LDS byte address of row 0 of the chunk buffer; the row/column offsets are immediates.
 template <int K, int ROW>
 __device__ __forceinline__ void lds_issue_row(f32x2 (&q)[K], const uint32_t addr) {
-#ifdef SWEEP_EXP_NOLDS  // timing experiment (results wrong): the weight registers keep whatever they hold
-#pragma unroll
-    for (int j = 0; j < K; ++j) asm volatile("" : "+v"(q[j]) : "v"(addr));
-    return;
-#endif
 #pragma unroll
     for (int j = 0; j < K; ++j)
         asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(q[j]) : "v"(addr), "n"(ROW * 2 * 64 * K * 4 + j * 8));
@@ -721,11 +544,6 @@ __device__ __forceinline__ void lse2_staged(float (&out)[K], const float (&u)[K]
     SWEEP_FENCE();
 #pragma unroll
     for (int j = K - 1; j >= 0; --j) e[j] = ex2(-fabsf(d[j]));
-#ifdef SWEEP_EXP_NOTRANS  // timing experiment (results wrong): no transcendentals
-#pragma unroll
-    for (int j = K - 1; j >= 0; --j) out[j] = vmax(u[j], l[j]) + (1.0f - fabsf(d[j]) * 1e-9f);
-    return;
-#endif
     SWEEP_FENCE();
 #pragma unroll
     for (int j = K - 1; j >= 0; --j) m[j] = vmax(u[j], l[j]);
@@ -851,199 +669,9 @@ __device__ __forceinline__ void beta_fast_steps(float (&bv)[K], f32x2 (&wq)[2][K
     }
 }
 
-template <int K, int G, bool COUNTED>
-__device__ void alpha_sweep(const LossParams &p, float *lds, const int b, const int lane) {
-    constexpr int Up = 64 * K;
-    constexpr int chunkf = G * 2 * Up, n16 = chunkf / 4;
-    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
-    const int Nb = Tb + Ub - 1;
-    sweep_wait_for_lsm(p, b, Tb, Ub, 0);
-    const RidgeLine ridge = make_ridge(Ub, Nb);
-    const float *Wb = p.W + (size_t)b * p.Nr * 2 * Up;
-    float *out = p.A + (size_t)b * p.Nr * Up;  // wave-uniform; the lane offset is added at the store
-    const int voff = lane * K * 4;
-    const int u0 = lane * K;
-    float *buf0 = lds, *buf1 = lds + chunkf;
-
-    float a[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) a[j] = (u0 + j == 0) ? 0.f : kNeg;
-    store_diag<K, false>(out, voff, lane, a);
-    SweepState st;
-    st.off = 0.f;
-    st.edge = kNeg;
-    st.log.init(p.offA + (size_t)b * p.NC * p.NG, p.NG);
-    st.log.record(0, 0.f, lane);
-    st.row = out + Up;  // diagonal 1
-    const int last_row = Nb - 1;  // rows 0..Nb-2 feed the steps, row Nb-1 the final likelihood
-    const int nchunks = last_row / G + 1;
-
-    dma_rows(Wb, buf0, n16, lane);
-    bool prev_full = false;
-    for (int ck = 0; ck < nchunks; ++ck) {
-        if (COUNTED && prev_full)
-            wait_vm_counted<G * store_pieces(K)>();
-        else
-            wait_vm0();
-        const float *cur = ((ck & 1) ? buf1 : buf0) + 2 * u0;
-        if (ck + 1 < nchunks) dma_rows(Wb + (size_t)(ck + 1) * chunkf, (ck & 1) ? buf0 : buf1, n16, lane);
-        const int r0 = ck * G;
-        if (COUNTED && K <= 15 && r0 + G <= last_row) {
-            // every row of this chunk feeds a step: straight-line code, explicit software pipeline
-            // (row i+1's LDS reads are in flight under step i)
-            const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
-            f32x2 wq[2][K];
-            lds_issue_row<K, 0>(wq[0], abase);
-            alpha_fast_steps<K, G, 0>(a, wq, abase, st, voff, lane, r0, ridge);
-            prev_full = true;
-        } else {
-            for (int i = 0; i < G; ++i) {
-                const int n = r0 + i + 1;
-                if (n > last_row) break;
-                f32x2 wc[K];
-                load_w<K>(wc, cur + i * 2 * Up);
-                alpha_step<K>(a, wc);
-                if ((n & (kRebase - 1)) == 0) {
-                    st.off += rebase<K>(a, ridge.u_at(n));
-                    st.log.record(n / kRebase, st.off, lane);
-                }
-                store_diag<K, false>(st.row, voff, lane, a);
-                st.row += Up;
-            }
-            prev_full = false;
-        }
-    }
-    st.log.flush(lane);
-    {
-        const float *wrow = (((nchunks - 1) & 1) ? buf1 : buf0) + (last_row % G) * 2 * Up + 2 * u0;
-#pragma unroll
-        for (int j = 0; j < K; ++j)
-            if (u0 + j == Ub - 1) {
-                const double ll2 = (double)st.off + (double)a[j] + (double)wrow[2 * j];
-                st_f64_wt(p.ll + 2 * b, ll2);
-                st_f32_wt(p.costs + b, (float)(-ll2 * 0.6931471805599453));
-            }
-    }
-    sweep_publish(p, b);
-}
-
-template <int K, int G, bool COUNTED>
-__device__ void beta_sweep(const LossParams &p, float *lds, const int b, const int lane) {
-    constexpr int Up = 64 * K;
-    constexpr int chunkf = G * 2 * Up, n16 = chunkf / 4;
-    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
-    const int Nb = Tb + Ub - 1;
-    sweep_wait_for_lsm(p, b, Tb, Ub, 1);
-    const RidgeLine ridge = make_ridge(Ub, Nb);
-    const float *Wb = p.W + (size_t)b * p.Nr * 2 * Up;
-    float *out = p.Bt + (size_t)b * p.Nr * Up;  // wave-uniform; the lane offset is added at the store
-    const int voff = lane * K * 4;
-    const int u0 = lane * K;
-    float *buf0 = lds, *buf1 = lds + chunkf;
-
-    float bv[K];  // beta on the diagonal below; starts as the virtual terminal node (Tb, Ub-1) = 0
-#pragma unroll
-    for (int j = 0; j < K; ++j) bv[j] = (u0 + j == Ub - 1) ? 0.f : kNeg;
-    const int last = Nb - 1;
-    const int ckl = last / G;
-    SweepState st;
-    st.off = 0.f;
-    st.edge = kNeg;
-    st.log.init(p.offB + (size_t)b * p.NC * p.NG, p.NG);
-    st.row = out + (size_t)last * Up;
-
-    dma_rows(Wb + (size_t)ckl * chunkf, (ckl & 1) ? buf1 : buf0, n16, lane);
-    bool prev_full = false;
-    for (int ck = ckl; ck >= 0; --ck) {
-        if (COUNTED && prev_full)
-            wait_vm_counted<G * store_pieces(K)>();
-        else
-            wait_vm0();
-        const float *cur = ((ck & 1) ? buf1 : buf0) + 2 * u0;
-        if (ck > 0) dma_rows(Wb + (size_t)(ck - 1) * chunkf, (ck & 1) ? buf0 : buf1, n16, lane);
-        const int r0 = ck * G;
-        if (COUNTED && K <= 15 && r0 + G - 1 < last) {  // whole chunk strictly below the first (terminal) diagonal
-            const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
-            f32x2 wq[2][K];
-            lds_issue_row<K, G - 1>(wq[0], abase);
-            beta_fast_steps<K, G, 0>(bv, wq, abase, st, voff, lane, r0, ridge);
-            prev_full = true;
-        } else {
-            for (int ii = 0; ii < G; ++ii) {
-                const int i = G - 1 - ii;
-                const int n = r0 + i;
-                if (n > last) continue;
-                f32x2 wc[K];
-                load_w<K>(wc, cur + i * 2 * Up);
-                beta_step<K>(bv, wc);
-                if (((n & (kRebase - 1)) == kRebase - 1) || n == last) {
-                    st.off += rebase<K>(bv, ridge.u_at(n));
-                    st.log.record(n / kRebase, st.off, lane);
-                }
-                store_diag<K, false>(st.row, voff, lane, bv);
-                st.row -= Up;
-            }
-            prev_full = false;
-        }
-    }
-    st.log.flush(lane);
-    if (lane == 0) st_f64_wt(p.ll + 2 * b + 1, (double)st.off + (double)bv[0]);
-    sweep_publish(p, b);
-}
-
-template <int K, int G, bool COUNTED>
-__global__ __launch_bounds__(64) void sweep_kernel(const LossParams p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x;
-    const int b = p.b0 + (int)(blockIdx.x >> 1);
-    if (blockIdx.x & 1)
-        beta_sweep<K, G, COUNTED>(p, lds, b, lane);
-    else
-        alpha_sweep<K, G, COUNTED>(p, lds, b, lane);
-}
-
-// Overlap-mode form: one workgroup = the alpha wave and the beta wave of one claimed utterance.  It is launched
-// with kPairLdsBytes of dynamic LDS -- far more than it uses -- so that no cell-pass workgroup fits beside it:
-// the sweep waves are the critical path and a lone wave that has to share its SIMD's issue port with
-// transcendental-heavy lsm/grad waves runs ~1.5x slower (measured), priority or not.
-constexpr size_t kPairLdsBytes = 140 * 1024;
-
-template <int K, int G>
-__global__ __launch_bounds__(128) void sweep_pair_kernel(const LossParams p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    // (no static __shared__ object: it would shift the dynamic base off its 16-byte alignment)
-    int *s_job = (int *)(lds + kPairLdsBytes / sizeof(float) - 4);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    float *my_lds = lds + wave * (2 * G * 2 * 64 * K);  // each direction has its own chunk buffers
-    for (;;) {
-        if (wave == 0) {
-            const int j = claim_utterance(p, lane);
-            if (lane == 0) *s_job = j;
-        }
-        __syncthreads();
-        const int b = __builtin_amdgcn_readfirstlane(*s_job);
-        __syncthreads();
-        if (b < 0) return;
-        if (wave)
-            beta_sweep<K, G, true>(p, my_lds, b, lane);
-        else
-            alpha_sweep<K, G, true>(p, my_lds, b, lane);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
-static bool small_path_ok(const LossParams &p, bool grad) {
-    if (p.V > 60) return false;  // 256*V*4 B of LDS must stay under the 64 KiB dynamic limit
-    const size_t total = (size_t)p.cells * p.V;
-    if (total % 4 != 0 || total >= (1ull << 31)) return false;
-    if (((uintptr_t)p.acts & 15) != 0) return false;
-    if (grad && ((uintptr_t)p.grads & 15) != 0) return false;
-    return true;
-}
-
 bool tile_path_ok(const LossParams &p, bool grad) {
     if (p.V > 60) return false;
     // rows that start off a 16-byte boundary (V % 4 != 0) are staged from the enclosing aligned span: the whole tensor
@@ -1051,22 +679,12 @@ bool tile_path_ok(const LossParams &p, bool grad) {
     if ((p.V % 4) != 0 && (((size_t)p.cells * (size_t)p.V) % 4) != 0) return false;
     if (((uintptr_t)p.acts & 15) != 0) return false;
     if (grad && ((uintptr_t)p.grads & 15) != 0) return false;
-    const char *e = getenv("RNNT_CELL_PATH");  // "flat" forces the 256-consecutive-cells kernels
-    if (e && e[0] == 'f') return false;
     return true;
 }
 
+// Patch kernels (one lattice cell per lane) for V <= 60 and 16-byte-aligned tensors; otherwise one cell per wave.
 template <bool GRAD>
-static hipError_t launch_cell(const LossParams &p, hipStream_t s, bool overlap) {
-    if (overlap) {  // caller checked overlap_path_ok(): patch kernels, with the hand-off protocol compiled in
-        const unsigned blocks = (unsigned)p.nb * p.tile.tiles_t * p.tile.tiles_u;
-        const size_t shm = (size_t)256 * p.V * sizeof(float) + 64;
-        if (p.V <= 32)
-            hipLaunchKernelGGL((cell_tile_kernel<32, GRAD, true>), dim3(blocks), dim3(256), shm, s, p);
-        else
-            hipLaunchKernelGGL((cell_tile_kernel<64, GRAD, true>), dim3(blocks), dim3(256), shm, s, p);
-        return hipGetLastError();
-    }
+static hipError_t launch_cell(const LossParams &p, hipStream_t s) {
     if (tile_path_ok(p, GRAD)) {
         const unsigned blocks = (unsigned)p.nb * p.tile.tiles_t * p.tile.tiles_u;
         const size_t shm = (size_t)256 * p.V * sizeof(float) + 64;
@@ -1075,28 +693,13 @@ static hipError_t launch_cell(const LossParams &p, hipStream_t s, bool overlap) 
             size_t shmu = (size_t)p.tile.TT * pitch * sizeof(float);
             if (shmu < shm) shmu = shm;
             if (p.V <= 32)
-                hipLaunchKernelGGL((cell_tile_kernel<32, GRAD, false, false>), dim3(blocks), dim3(256), shmu, s, p);
+                hipLaunchKernelGGL((cell_tile_kernel<32, GRAD, false>), dim3(blocks), dim3(256), shmu, s, p);
             else
-                hipLaunchKernelGGL((cell_tile_kernel<64, GRAD, false, false>), dim3(blocks), dim3(256), shmu, s, p);
+                hipLaunchKernelGGL((cell_tile_kernel<64, GRAD, false>), dim3(blocks), dim3(256), shmu, s, p);
         } else if (p.V <= 32)
-            hipLaunchKernelGGL((cell_tile_kernel<32, GRAD, false>), dim3(blocks), dim3(256), shm, s, p);
+            hipLaunchKernelGGL((cell_tile_kernel<32, GRAD>), dim3(blocks), dim3(256), shm, s, p);
         else
-            hipLaunchKernelGGL((cell_tile_kernel<64, GRAD, false>), dim3(blocks), dim3(256), shm, s, p);
-    } else if (small_path_ok(p, GRAD)) {
-        const unsigned blocks = (p.cells + 255u) / 256u;
-        const size_t shm = (size_t)256 * p.V * sizeof(float) + 64;
-        const bool v4 = (p.V % 4) == 0;
-        if (p.V <= 32) {
-            if (v4)
-                hipLaunchKernelGGL((cell_small_kernel<32, true, GRAD>), dim3(blocks), dim3(256), shm, s, p);
-            else
-                hipLaunchKernelGGL((cell_small_kernel<32, false, GRAD>), dim3(blocks), dim3(256), shm, s, p);
-        } else {
-            if (v4)
-                hipLaunchKernelGGL((cell_small_kernel<64, true, GRAD>), dim3(blocks), dim3(256), shm, s, p);
-            else
-                hipLaunchKernelGGL((cell_small_kernel<64, false, GRAD>), dim3(blocks), dim3(256), shm, s, p);
-        }
+            hipLaunchKernelGGL((cell_tile_kernel<64, GRAD>), dim3(blocks), dim3(256), shm, s, p);
     } else {
         const bool v4 = (p.V % 4) == 0 && ((uintptr_t)p.acts & 15) == 0 && (!GRAD || ((uintptr_t)p.grads & 15) == 0);
         unsigned blocks = (p.cells + 3u) / 4u;
@@ -1109,45 +712,8 @@ static hipError_t launch_cell(const LossParams &p, hipStream_t s, bool overlap) 
     return hipGetLastError();
 }
 
-hipError_t launch_lsm(const LossParams &p, hipStream_t s, bool overlap) { return launch_cell<false>(p, s, overlap); }
-hipError_t launch_grad(const LossParams &p, hipStream_t s, bool overlap) { return launch_cell<true>(p, s, overlap); }
-
-// RNNT_SWEEP_MODE: 1 (default) = sweeping wave + loader wave per (utterance, direction) (sweep_ld_kernel)
-//                  5 = one wave that also issues its own LDS-DMA (sweep_kernel; also what the overlap mode runs)
-//                  0 = as 5 with compiler-scheduled LDS reads and vmcnt(0) at chunk boundaries
-//                  4 = two sweeping waves per direction sharing the columns (sweep_split_kernel)
-// Two older multi-wave forms with one lattice column per lane (a barrier per diagonal: 164-175 us at C2; LDS progress
-// counters instead of the barrier: 195 us) were removed; profiles/r01_notes.md keeps their measurements.
-static int sweep_mode() {
-    const char *e = getenv("RNNT_SWEEP_MODE");
-    if (e && e[0] == '0') return 0;
-    if (e && e[0] == '4') return 4;
-    if (e && e[0] == '5') return 5;
-    return 1;
-}
-
-template <int K, int G>
-static hipError_t launch_sweep_pair(const LossParams &p, hipStream_t s) {
-    {
-        hipError_t e = hipFuncSetAttribute((const void *)sweep_pair_kernel<K, G>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPairLdsBytes);
-        if (e != hipSuccess) return e;
-    }
-    const int nwg = p.B < 48 ? p.B : 48;  // at most 48 CUs are taken away from the bandwidth passes
-    hipLaunchKernelGGL((sweep_pair_kernel<K, G>), dim3(nwg), dim3(128), kPairLdsBytes, s, p);
-    return hipGetLastError();
-}
-
-template <int K, int G>
-static hipError_t launch_sweep_kg(const LossParams &p, hipStream_t s) {
-    if (p.flags != nullptr) return launch_sweep_pair<K, G>(p, s);
-    const size_t shm = (size_t)2 * G * 2 * 64 * K * sizeof(float);
-    if (sweep_mode() != 0)
-        hipLaunchKernelGGL((sweep_kernel<K, G, true>), dim3(2 * p.nb), dim3(64), shm, s, p);
-    else
-        hipLaunchKernelGGL((sweep_kernel<K, G, false>), dim3(2 * p.nb), dim3(64), shm, s, p);
-    return hipGetLastError();
-}
+hipError_t launch_lsm(const LossParams &p, hipStream_t s) { return launch_cell<false>(p, s); }
+hipError_t launch_grad(const LossParams &p, hipStream_t s) { return launch_cell<true>(p, s); }
 
 // ---------------------------------------------------------------------------------------------
 // LDS progress counters shared by the waves of one sweep workgroup.  A wave's LDS operations complete in order, so
@@ -1172,411 +738,6 @@ __device__ __forceinline__ void lds_post(const uint32_t addr, const int v) {
     asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
-hipError_t launch_lsm_done_marker(const LossParams &p, hipStream_t s) {
-    hipLaunchKernelGGL(lsm_done_marker_kernel, dim3(1), dim3(1), 0, s, p.flags + flag_lsm_kernel_done(p.B));
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------
-// Split sweep (RNNT_SWEEP_MODE=4): the columns of an utterance are shared by TWO waves per direction -- the low wave
-// owns columns [0, 64 KA) with KA columns per lane, the high wave [64 KA, 64 (KA + KB)) with KB -- so each wave issues
-// about half the instructions per diagonal of the single-wave sweep (which is issue-bound: 6 transcendentals + ~30 other
-// instructions per diagonal at K = 3).  Each wave is the single-wave sweep on its own columns (own LDS-DMA double buffer,
-// counted waits, fully unrolled chunks of G diagonals, own integer re-basing against its column nearest the ridge); the
-// only coupling is the value that crosses the column boundary once per diagonal:
-//   alpha: the low wave's label edge out of column 64 KA - 1 feeds the high wave's column 64 KA;
-//   beta : the high wave's beta of column 64 KA feeds the low wave's label edge of column 64 KA - 1.
-// The producer writes {value, its offset} into an LDS array indexed by the diagonal (never reused: no back-pressure, so
-// the producer never waits and there is no cycle to deadlock on) and publishes a counter after every chunk; the consumer
-// runs one chunk behind, checks the counter once per chunk (bounded poll) and reads one entry per diagonal together
-// with its weight rows.  Both offsets are integers, so  value + (producer offset - consumer offset)  is exact.
-// A high wave whose columns lie beyond U_b has nothing to do and exits; the low wave then reads {log zero, 0}.
-// ---------------------------------------------------------------------------------------------
-template <int K, int G, int UPT>
-__device__ __forceinline__ void dma_rows_part(const float *g, float *l, const int lane) {
-    constexpr int per_row = 32 * K, total = G * per_row;  // 16-byte units: one row segment, the whole chunk
-    static_assert(total % 64 == 0, "chunk segment must be whole wave-instructions");
-#pragma unroll
-    for (int i0 = 0; i0 < total; i0 += 64) {
-        const int k = i0 + lane;
-        const int row = k / per_row, c = k - row * per_row;
-        __builtin_amdgcn_global_load_lds((glb_void *)(g + (size_t)row * (2 * UPT) + c * 4), (lds_void *)(l + i0 * 4), 16, 0, 0);
-    }
-}
-constexpr int dma_part_pieces(int K, int G) { return G * 32 * K / 64; }
-
-// Re-base against the wave's own column `u_local` (0 .. 64 K - 1); skipped while that cell is still log zero.
-template <int K>
-__device__ __forceinline__ float rebase_local(float (&v)[K], const int u_local) {
-    const int src_lane = u_local / K, src_j = u_local - src_lane * K;  // wave-uniform
-    float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[0]), src_lane));
-#pragma unroll
-    for (int j = 1; j < K; ++j) {
-        const float mj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[j]), src_lane));
-        m = (src_j == j) ? mj : m;
-    }
-    if (!(m > kNegTest)) return 0.f;
-    const float mi = rintf(m);
-#pragma unroll
-    for (int j = 0; j < K; ++j) v[j] -= mi;
-    return mi;
-}
-
-// alpha step with an explicit value entering column 0 of lane 0 (`fill`); returns nothing, `e_last` = label edge out of
-// the lane's last column (lane 63's is what crosses to the next wave).
-template <int K>
-__device__ __forceinline__ void alpha_step_x(float (&a)[K], const f32x2 (&w)[K], const float fill, float &e_last) {
-    f32x2 de[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        const f32x2 aa = {a[j], a[j]};
-        de[j] = aa + w[j];
-    }
-    e_last = de[K - 1][1];
-    const float from_left = dpp_from_lower_lane(e_last, fill);
-#pragma unroll
-    for (int j = 0; j < K; ++j) a[j] = lse2(de[j][0], (j == 0) ? from_left : de[j - 1][1]);
-}
-template <int K>
-__device__ __forceinline__ void beta_step_x(float (&bv)[K], const f32x2 (&w)[K], const float fill) {
-    const float from_right = dpp_from_upper_lane(bv[0], fill);
-    float nv[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        const f32x2 br = {bv[j], (j == K - 1) ? from_right : bv[j + 1]};
-        const f32x2 s2 = br + w[j];
-        nv[j] = lse2(s2[0], s2[1]);
-    }
-#pragma unroll
-    for (int j = 0; j < K; ++j) bv[j] = nv[j];
-}
-
-__device__ __forceinline__ int ridge_local(const RidgeLine &ridge, const int n, const int cb, const int width) {
-    return min(max(ridge.u_at(n) - cb, 0), width - 1);
-}
-
-template <int K, int G, int UPT, int II, bool PROD>
-__device__ __forceinline__ void alpha_split_steps(float (&a)[K], f32x2 (&wq)[2][K], f32x2 (&xq)[2], const uint32_t abase,
-                                                  const uint32_t xaddr, SweepState &st, const int voff, const int lane,
-                                                  const int r0, const RidgeLine &ridge, const int cb) {
-    if constexpr (II < G) {
-        constexpr int cur = II & 1, nxt = cur ^ 1;
-        if constexpr (II + 1 < G) {
-            lds_issue_row<K, II + 1>(wq[nxt], abase);
-            if constexpr (!PROD) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xq[nxt]) : "v"(xaddr), "n"((II + 1) * 8));
-            lds_wait<K + (PROD ? 0 : 1)>();  // row II (and the boundary entry II) landed; the newest reads stay in flight
-        } else {
-            lds_wait<0>();
-        }
-        const int n = r0 + II + 1;
-        float fill = kNeg, e_last;
-        if constexpr (!PROD) fill = xq[cur][0] + (xq[cur][1] - st.off);
-        alpha_step_x<K>(a, wq[cur], fill, e_last);
-        if constexpr (PROD) {
-            const f32x2 o = {e_last, st.off};  // relative to the offset the diagonal-r values carry (before this step's re-base)
-            asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xaddr), "v"(o), "n"(II * 8) : "memory");
-        }
-        if ((n & (kRebase - 1)) == 0) {
-            st.off += rebase_local<K>(a, ridge_local(ridge, n, cb, 64 * K));
-            st.log.record(n / kRebase, st.off, lane);
-        }
-        store_diag<K, true>(st.row, voff, lane, a);
-        st.row += UPT;
-        alpha_split_steps<K, G, UPT, II + 1, PROD>(a, wq, xq, abase, xaddr, st, voff, lane, r0, ridge, cb);
-    }
-}
-
-template <int K, int G, int UPT, int II, bool PROD>
-__device__ __forceinline__ void beta_split_steps(float (&bv)[K], f32x2 (&wq)[2][K], f32x2 (&xq)[2], const uint32_t abase,
-                                                 const uint32_t xaddr, SweepState &st, const int voff, const int lane,
-                                                 const int r0, const RidgeLine &ridge, const int cb) {
-    if constexpr (II < G) {
-        constexpr int cur = II & 1, nxt = cur ^ 1;
-        constexpr int i = G - 1 - II;
-        if constexpr (i > 0) {
-            lds_issue_row<K, i - 1>(wq[nxt], abase);
-            if constexpr (!PROD) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xq[nxt]) : "v"(xaddr), "n"((i - 1) * 8));
-            lds_wait<K + (PROD ? 0 : 1)>();
-        } else {
-            lds_wait<0>();
-        }
-        const int n = r0 + i;
-        float fill = kNeg;
-        if constexpr (!PROD) fill = xq[cur][0] + (xq[cur][1] - st.off);
-        if constexpr (PROD) {
-            const f32x2 o = {bv[0], st.off};  // beta of the diagonal below, before this step
-            asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xaddr), "v"(o), "n"(i * 8) : "memory");
-        }
-        beta_step_x<K>(bv, wq[cur], fill);
-        if ((n & (kRebase - 1)) == kRebase - 1) {
-            st.off += rebase_local<K>(bv, ridge_local(ridge, n, cb, 64 * K));
-            st.log.record(n / kRebase, st.off, lane);
-        }
-        store_diag<K, true>(st.row, voff, lane, bv);
-        st.row -= UPT;
-        beta_split_steps<K, G, UPT, II + 1, PROD>(bv, wq, xq, abase, xaddr, st, voff, lane, r0, ridge, cb);
-    }
-}
-
-#ifdef SPLIT_TRACE
-__device__ long long *g_split_trace = nullptr;  // [4 waves][256] s_memtime at every chunk start of workgroup 0 (dev tool)
-#define SPLIT_STAMP(w, i) \
-    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (i) < 256) g_split_trace[(w) * 256 + (i)] = (long long)__builtin_amdgcn_s_memtime()
-#else
-#define SPLIT_STAMP(w, i)
-#endif
-// LDS-side plumbing of one split-sweep wave
-struct SplitLink {
-    float2 *ring;      // [Nr] boundary entries {value, producer offset}, indexed by the diagonal
-    float2 *trash;     // [64 + G] dump for the producer lanes that are not the boundary lane
-    uint32_t prog;     // LDS byte address of the producer's progress counter
-    bool peer;         // the other wave of this direction is alive
-};
-
-template <int K, int G, int UPT, bool PROD>
-__device__ void alpha_split_sweep(const LossParams &p, float *buf0, float *buf1, const SplitLink &lk, const int b,
-                                  const int lane, const int cb) {
-    constexpr int Wd = 64 * K, chunkf = G * 2 * Wd;
-    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
-    const int Nb = Tb + Ub - 1;
-    const RidgeLine ridge = make_ridge(Ub, Nb);
-    const float *Wb = p.W + (size_t)b * p.Nr * 2 * UPT + 2 * cb;
-    float *out = p.A + (size_t)b * p.Nr * UPT + cb;
-    const int voff = lane * K * 4;
-    const int u0 = cb + lane * K;
-    const uint32_t ring_a = (uint32_t)(uintptr_t)((lds_void *)lk.ring);
-    const uint32_t trash_a = (uint32_t)(uintptr_t)((lds_void *)lk.trash);
-
-    float a[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) a[j] = (u0 + j == 0) ? 0.f : kNeg;
-    store_diag<K, false>(out, voff, lane, a);
-    SweepState st;
-    st.off = 0.f;
-    st.edge = kNeg;
-    st.log.init(p.offA + (size_t)b * p.NC * p.NG, p.NG, cb / 64, K);
-    st.log.record(0, 0.f, lane);
-    st.row = out + UPT;
-    const int last_row = Nb - 1;
-    const int nchunks = last_row / G + 1;
-
-    dma_rows_part<K, G, UPT>(Wb, buf0, lane);
-    bool prev_full = false;
-    for (int ck = 0; ck < nchunks; ++ck) {
-        if (prev_full)
-            wait_vm_counted<G * store_pieces(K)>();
-        else
-            wait_vm0();
-        const float *cur = ((ck & 1) ? buf1 : buf0) + 2 * lane * K;
-        if (ck + 1 < nchunks) dma_rows_part<K, G, UPT>(Wb + (size_t)(ck + 1) * G * 2 * UPT, (ck & 1) ? buf0 : buf1, lane);
-        const int r0 = ck * G;
-        const int hi = min(r0 + G, last_row);  // this chunk's steps consume the boundary entries r0 .. hi-1
-        SPLIT_STAMP(PROD ? 0 : 1, 2 * ck);
-        if (!PROD && lk.peer) lds_wait_ge(lk.prog, hi);
-        SPLIT_STAMP(PROD ? 0 : 1, 2 * ck + 1);
-        if (r0 + G <= last_row) {
-            const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
-            const uint32_t xaddr = PROD ? ((lane == 63) ? ring_a + (uint32_t)r0 * 8u : trash_a + (uint32_t)lane * 8u)
-                                        : ring_a + (uint32_t)r0 * 8u;
-            f32x2 wq[2][K], xq[2];
-            lds_issue_row<K, 0>(wq[0], abase);
-            if (!PROD) asm volatile("ds_read_b64 %0, %1" : "=v"(xq[0]) : "v"(xaddr));
-            alpha_split_steps<K, G, UPT, 0, PROD>(a, wq, xq, abase, xaddr, st, voff, lane, r0, ridge, cb);
-            prev_full = true;
-        } else {
-            for (int i = 0; i < G; ++i) {
-                const int r = r0 + i, n = r + 1;
-                if (n > last_row) break;
-                f32x2 wc[K];
-                load_w<K>(wc, cur + i * 2 * Wd);
-                float fill = kNeg, e_last;
-                if (!PROD) {
-                    const float2 x = lk.ring[r];
-                    fill = x.x + (x.y - st.off);
-                }
-                alpha_step_x<K>(a, wc, fill, e_last);
-                if (PROD && lane == 63) lk.ring[r] = make_float2(e_last, st.off);
-                if ((n & (kRebase - 1)) == 0) {
-                    st.off += rebase_local<K>(a, ridge_local(ridge, n, cb, Wd));
-                    st.log.record(n / kRebase, st.off, lane);
-                }
-                store_diag<K, false>(st.row, voff, lane, a);
-                st.row += UPT;
-            }
-            prev_full = false;
-        }
-        if (PROD) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this chunk's boundary entries are in LDS
-            if (lane == 0) lds_post(lk.prog, hi);
-        }
-    }
-    st.log.flush(lane);
-    {
-        const float *wrow = (((nchunks - 1) & 1) ? buf1 : buf0) + (last_row % G) * 2 * Wd + 2 * lane * K;
-#pragma unroll
-        for (int j = 0; j < K; ++j)
-            if (u0 + j == Ub - 1) {
-                const double ll2 = (double)st.off + (double)a[j] + (double)wrow[2 * j];
-                st_f64_wt(p.ll + 2 * b, ll2);
-                st_f32_wt(p.costs + b, (float)(-ll2 * 0.6931471805599453));
-            }
-    }
-}
-
-template <int K, int G, int UPT, bool PROD>
-__device__ void beta_split_sweep(const LossParams &p, float *buf0, float *buf1, const SplitLink &lk, const int b,
-                                 const int lane, const int cb) {
-    constexpr int Wd = 64 * K, chunkf = G * 2 * Wd;
-    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
-    const int Nb = Tb + Ub - 1;
-    const RidgeLine ridge = make_ridge(Ub, Nb);
-    const float *Wb = p.W + (size_t)b * p.Nr * 2 * UPT + 2 * cb;
-    float *out = p.Bt + (size_t)b * p.Nr * UPT + cb;
-    const int voff = lane * K * 4;
-    const int u0 = cb + lane * K;
-    const uint32_t ring_a = (uint32_t)(uintptr_t)((lds_void *)lk.ring);
-    const uint32_t trash_a = (uint32_t)(uintptr_t)((lds_void *)lk.trash);
-
-    float bv[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) bv[j] = (u0 + j == Ub - 1) ? 0.f : kNeg;
-    const int last = Nb - 1;
-    const int ckl = last / G;
-    SweepState st;
-    st.off = 0.f;
-    st.edge = kNeg;
-    st.log.init(p.offB + (size_t)b * p.NC * p.NG, p.NG, cb / 64, K);
-    st.row = out + (size_t)last * UPT;
-
-    dma_rows_part<K, G, UPT>(Wb + (size_t)ckl * G * 2 * UPT, (ckl & 1) ? buf1 : buf0, lane);
-    bool prev_full = false;
-    for (int ck = ckl; ck >= 0; --ck) {
-        if (prev_full)
-            wait_vm_counted<G * store_pieces(K)>();
-        else
-            wait_vm0();
-        const float *cur = ((ck & 1) ? buf1 : buf0) + 2 * lane * K;
-        if (ck > 0) dma_rows_part<K, G, UPT>(Wb + (size_t)(ck - 1) * G * 2 * UPT, (ck & 1) ? buf0 : buf1, lane);
-        const int r0 = ck * G;
-        const int done = last - r0 + 1;  // steps finished once this chunk is (entries last .. r0 written)
-        SPLIT_STAMP(PROD ? 3 : 2, 2 * (ckl - ck));
-        if (!PROD && lk.peer) lds_wait_ge(lk.prog, done);
-        SPLIT_STAMP(PROD ? 3 : 2, 2 * (ckl - ck) + 1);
-        if (r0 + G - 1 < last) {
-            const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
-            const uint32_t xaddr = PROD ? ((lane == 0) ? ring_a + (uint32_t)r0 * 8u : trash_a + (uint32_t)lane * 8u)
-                                        : ring_a + (uint32_t)r0 * 8u;
-            f32x2 wq[2][K], xq[2];
-            lds_issue_row<K, G - 1>(wq[0], abase);
-            if (!PROD) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xq[0]) : "v"(xaddr), "n"((G - 1) * 8));
-            beta_split_steps<K, G, UPT, 0, PROD>(bv, wq, xq, abase, xaddr, st, voff, lane, r0, ridge, cb);
-            prev_full = true;
-        } else {
-            for (int ii = 0; ii < G; ++ii) {
-                const int i = G - 1 - ii;
-                const int n = r0 + i;
-                if (n > last) continue;
-                f32x2 wc[K];
-                load_w<K>(wc, cur + i * 2 * Wd);
-                float fill = kNeg;
-                if (!PROD) {
-                    const float2 x = lk.ring[n];
-                    fill = x.x + (x.y - st.off);
-                }
-                if (PROD && lane == 0) lk.ring[n] = make_float2(bv[0], st.off);
-                beta_step_x<K>(bv, wc, fill);
-                if (((n & (kRebase - 1)) == kRebase - 1) || n == last) {
-                    st.off += rebase_local<K>(bv, ridge_local(ridge, n, cb, Wd));
-                    st.log.record(n / kRebase, st.off, lane);
-                }
-                store_diag<K, false>(st.row, voff, lane, bv);
-                st.row -= UPT;
-            }
-            prev_full = false;
-        }
-        if (PROD) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) lds_post(lk.prog, done);
-        }
-    }
-    st.log.flush(lane);
-    if (lane == 0 && cb == 0) st_f64_wt(p.ll + 2 * b + 1, (double)st.off + (double)bv[0]);
-}
-
-template <int KA, int KB, int G>
-constexpr size_t split_lds_floats() { return (size_t)2 * (2 * G * 2 * 64 * KA) + (size_t)2 * (2 * G * 2 * 64 * KB); }
-
-template <int KA, int KB, int G>
-__global__ __launch_bounds__(256) void sweep_split_kernel(const LossParams p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int UPT = 64 * (KA + KB);
-    constexpr int fA = 2 * G * 2 * 64 * KA, fB = 2 * G * 2 * 64 * KB;  // floats per wave (two chunk buffers)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = p.b0 + (int)blockIdx.x;
-    const int Ub = p.label_lengths[b] + 1;
-    const bool peer = 64 * KA < Ub;  // the high waves own live columns
-    float *bA0 = lds, *bA1 = bA0 + fA, *bB0 = bA1 + fB, *bB1 = bB0 + fA;  // alpha low, alpha high, beta low, beta high
-    float2 *ringA = (float2 *)(bB1 + fB), *ringB = ringA + p.Nr;
-    float2 *trash = ringB + p.Nr;  // two dumps of 64 + G entries
-    int *prog = (int *)(trash + 2 * (64 + G));
-    if (tid < 2) prog[tid] = 0;
-    if (!peer)
-        for (int i = tid; i < 2 * p.Nr; i += 256) ringA[i] = make_float2(kNeg, 0.f);
-    __syncthreads();
-    SplitLink lk;
-    lk.peer = peer;
-    if (wave < 2) {
-        lk.ring = ringA, lk.trash = trash, lk.prog = (uint32_t)(uintptr_t)((lds_void *)prog);
-        if (wave == 0)
-            alpha_split_sweep<KA, G, UPT, true>(p, bA0, bA0 + fA / 2, lk, b, lane, 0);
-        else if (peer)
-            alpha_split_sweep<KB, G, UPT, false>(p, bA1, bA1 + fB / 2, lk, b, lane, 64 * KA);
-    } else {
-        lk.ring = ringB, lk.trash = trash + 64 + G, lk.prog = (uint32_t)(uintptr_t)((lds_void *)(prog + 1));
-        if (wave == 2)
-            beta_split_sweep<KA, G, UPT, false>(p, bB0, bB0 + fA / 2, lk, b, lane, 0);
-        else if (peer)
-            beta_split_sweep<KB, G, UPT, true>(p, bB1, bB1 + fB / 2, lk, b, lane, 64 * KA);
-    }
-}
-
-template <int KA, int KB, int G>
-static hipError_t launch_sweep_split(const LossParams &p, hipStream_t s, bool *done) {
-    const size_t shm = split_lds_floats<KA, KB, G>() * sizeof(float) + (size_t)2 * p.Nr * sizeof(float2) +
-                       (size_t)2 * (64 + G) * sizeof(float2) + 16;
-    *done = false;
-    if (shm > 160 * 1024) return hipSuccess;  // boundary arrays do not fit: the caller falls back to the single wave
-    if (shm > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)sweep_split_kernel<KA, KB, G>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-        if (e != hipSuccess) return e;
-    }
-#ifdef SPLIT_TRACE
-    static long long *trace_dev = nullptr;
-    if (!trace_dev) {
-        hipMalloc(&trace_dev, 4 * 256 * sizeof(long long));
-        hipMemcpyToSymbol(HIP_SYMBOL(g_split_trace), &trace_dev, sizeof(trace_dev));
-    }
-    hipMemsetAsync(trace_dev, 0, 4 * 256 * sizeof(long long), s);
-#endif
-    hipLaunchKernelGGL((sweep_split_kernel<KA, KB, G>), dim3(p.nb), dim3(256), shm, s, p);
-#ifdef SPLIT_TRACE
-    {
-        hipStreamSynchronize(s);
-        long long h[4 * 256];
-        hipMemcpy(h, trace_dev, sizeof(h), hipMemcpyDeviceToHost);
-        const char *path = getenv("SPLIT_TRACE_FILE");
-        if (FILE *f = fopen(path ? path : "/tmp/split_trace.bin", "wb")) {
-            fwrite(h, 1, sizeof(h), f);
-            fclose(f);
-        }
-    }
-#endif
-    *done = true;
-    return hipGetLastError();
-}
-
 // ---------------------------------------------------------------------------------------------
 // Default sweep: the single-wave sweep above with the LDS-DMA moved to a LOADER wave of the same workgroup.
 // Issuing the 24 `global_load_lds` pieces of a chunk from the sweeping wave itself cost it ~1/4 of its time (a piece takes
@@ -1594,7 +755,7 @@ template <int K, int G, int NB, bool BETA>
 __device__ void sweep_loader(const LossParams &p, float *bufs, const LdLink lk, const int b, const int lane) {
     constexpr int Up = 64 * K, chunkf = G * 2 * Up, n16 = chunkf / 4, pieces = n16 / 64;
     static_assert(n16 % 64 == 0 && pieces <= 63, "chunk must be whole wave-instructions within the vmcnt range");
-    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int Tb = length_T(p, b), Ub = length_U(p, b);
     const int nchunks = (Tb + Ub - 2) / G + 1;
     const float *Wb = p.W + (size_t)b * p.Nr * 2 * Up;
     for (int i = 0; i < nchunks; ++i) {
@@ -1614,7 +775,7 @@ __device__ void sweep_loader(const LossParams &p, float *bufs, const LdLink lk, 
 template <int K, int G, int NB>
 __device__ void alpha_sweep_ld(const LossParams &p, float *bufs, const LdLink lk, const int b, const int lane) {
     constexpr int Up = 64 * K, chunkf = G * 2 * Up;
-    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int Tb = length_T(p, b), Ub = length_U(p, b);
     const int Nb = Tb + Ub - 1;
     const RidgeLine ridge = make_ridge(Ub, Nb);
     float *out = p.A + (size_t)b * p.Nr * Up;
@@ -1635,7 +796,7 @@ __device__ void alpha_sweep_ld(const LossParams &p, float *bufs, const LdLink lk
     const int nchunks = last_row / G + 1;
 
     int have = 0;  // chunks known to have landed (the loader runs up to NB - 1 ahead: most chunks need no look at the counter)
-    bool timed_out = false;  // a bounded poll gave up: the result must not look valid
+    bool timed_out = lengths_invalid(p, b);  // a bounded poll gave up, or the caller's lengths were out of range: the result must not look valid
     for (int ck = 0; ck < nchunks; ++ck) {
         if (have < ck + 1) {
             have = lds_wait_ge(lk.landed, ck + 1);
@@ -1684,7 +845,7 @@ __device__ void alpha_sweep_ld(const LossParams &p, float *bufs, const LdLink lk
 template <int K, int G, int NB>
 __device__ void beta_sweep_ld(const LossParams &p, float *bufs, const LdLink lk, const int b, const int lane) {
     constexpr int Up = 64 * K, chunkf = G * 2 * Up;
-    const int Tb = p.input_lengths[b], Ub = p.label_lengths[b] + 1;
+    const int Tb = length_T(p, b), Ub = length_U(p, b);
     const int Nb = Tb + Ub - 1;
     const RidgeLine ridge = make_ridge(Ub, Nb);
     float *out = p.Bt + (size_t)b * p.Nr * Up;
@@ -1703,7 +864,7 @@ __device__ void beta_sweep_ld(const LossParams &p, float *bufs, const LdLink lk,
     st.row = out + (size_t)last * Up;
 
     int have = 0;
-    bool timed_out = false;
+    bool timed_out = lengths_invalid(p, b);
     for (int ck = ckl; ck >= 0; --ck) {
         const int i_ring = ckl - ck;  // the loader's chunk index
         if (have < i_ring + 1) {
@@ -1783,55 +944,18 @@ static hipError_t launch_sweep_ld(const LossParams &p, hipStream_t s) {
     return hipGetLastError();
 }
 
-bool overlap_path_ok(const LossParams &p, bool grad) {
-    // patch kernels on both sides and the single-wave sweep (the hand-off hooks live there)
-    return (p.V % 4) == 0 && tile_path_ok(p, false) && (!grad || tile_path_ok(p, true)) && sweep_mode() == 1 &&
-           sweep_K(p.U) != 0;
-}
-
-hipError_t launch_sweeps(const LossParams &p0, hipStream_t s, bool overlap) {
-    LossParams p = p0;
-    if (!overlap) p.flags = nullptr;  // the sweep kernels key the hand-off protocol on this pointer
-    if (sweep_mode() == 4 && !overlap) {
-        bool done = false;
-        hipError_t e = hipSuccess;
-        switch (sweep_K(p.U)) {  // two waves per direction (see sweep_split_kernel); G as large as the LDS allows
-            case 2: e = launch_sweep_split<1, 1, 16>(p, s, &done); break;
-            case 3: e = launch_sweep_split<2, 1, 16>(p, s, &done); break;
-            case 4: e = launch_sweep_split<2, 2, 8>(p, s, &done); break;
-            case 6: e = launch_sweep_split<3, 3, 8>(p, s, &done); break;
-            case 8: e = launch_sweep_split<4, 4, 4>(p, s, &done); break;
-            default: break;
-        }
-        if (e != hipSuccess || done) return e;
-    }
-    if (sweep_mode() == 1 && !overlap) {
-        switch (sweep_K(p.U)) {  // sweeping wave + loader wave (see sweep_ld_kernel); same chunk lengths as below
-            case 1: return launch_sweep_ld<1, 16>(p, s);
-            case 2: return launch_sweep_ld<2, 16>(p, s);
-#ifndef SWEEP_LD_G3
-#define SWEEP_LD_G3 16
-#endif
-            case 3: return launch_sweep_ld<3, SWEEP_LD_G3>(p, s);
-            case 4: return launch_sweep_ld<4, 16>(p, s);
-            case 6: return launch_sweep_ld<6, 8>(p, s);
-            case 8: return launch_sweep_ld<8, 8>(p, s);
-            case 12: return launch_sweep_ld<12, 4>(p, s);
-            case 16: return launch_sweep_ld<16, 4>(p, s);
-            default: return hipErrorInvalidValue;
-        }
-    }
-    switch (sweep_K(p.U)) {  // RNNT_SWEEP_MODE=5 (the sweeping wave issues its own LDS-DMA), 0, and the overlap mode
-        case 1: return launch_sweep_kg<1, 16>(p, s);
-        case 2: return launch_sweep_kg<2, 16>(p, s);
-        // chunk length G (diagonals per LDS-DMA batch / wait): the longest whose two buffers fit 64 KB (measured at C2:
-        // G = 16 beats 8 by 3 % of the step, 4 loses 5 %)
-        case 3: return launch_sweep_kg<3, 16>(p, s);
-        case 4: return launch_sweep_kg<4, 16>(p, s);
-        case 6: return launch_sweep_kg<6, 8>(p, s);
-        case 8: return launch_sweep_kg<8, 8>(p, s);
-        case 12: return launch_sweep_kg<12, 4>(p, s);
-        case 16: return launch_sweep_kg<16, 4>(p, s);
+// Chunk length G (diagonals per LDS-DMA batch): the longest whose ring fits the LDS (measured at C2: G = 16 beats 8 by
+// 3 % of the step, 4 loses 5 %).
+hipError_t launch_sweeps(const LossParams &p, hipStream_t s) {
+    switch (sweep_K(p.U)) {
+        case 1: return launch_sweep_ld<1, 16>(p, s);
+        case 2: return launch_sweep_ld<2, 16>(p, s);
+        case 3: return launch_sweep_ld<3, 16>(p, s);
+        case 4: return launch_sweep_ld<4, 16>(p, s);
+        case 6: return launch_sweep_ld<6, 8>(p, s);
+        case 8: return launch_sweep_ld<8, 8>(p, s);
+        case 12: return launch_sweep_ld<12, 4>(p, s);
+        case 16: return launch_sweep_ld<16, 4>(p, s);
         default: return hipErrorInvalidValue;  // maxU > 1024 is outside the register-resident sweep
     }
 }

@@ -94,8 +94,9 @@ def normalize_text(text: str) -> str:
 
 
 class CharEncoder:
-    """Character-level encoder over init_vocab() (utils/encoding.py: tf_vocab_encode + lookup table, default -1 for
-    unknown symbols)."""
+    """Character-level encoder over init_vocab() (utils/encoding.py:44-48 tf_vocab_encode = bytes_split + table lookup;
+    the reference builds that table with default_value=0, utils/encoding.py:66-67: every byte outside the vocabulary
+    -- digits, punctuation, each byte of a non-ASCII character -- becomes id 0, the blank)."""
 
     def __init__(self, vocab: Sequence[str] = None):
         self.vocab = list(vocab) if vocab is not None else init_vocab()
@@ -106,7 +107,8 @@ class CharEncoder:
         return len(self.vocab)
 
     def encode(self, text: str) -> List[int]:
-        return [self.index.get(c, -1) for c in text]
+        # bytes_split: one token per UTF-8 byte (a non-ASCII character yields several unknown bytes -> several zeros)
+        return [self.index.get(chr(b), 0) if b < 128 else 0 for b in text.encode("utf8")]
 
     def decode(self, ids) -> str:
         return "".join(self.vocab[int(i)] for i in ids if 0 <= int(i) < len(self.vocab))

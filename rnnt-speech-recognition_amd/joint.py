@@ -34,10 +34,15 @@ class _JointLossFunction(torch.autograd.Function):
         dev = enc_proj.device
         ep, pp, w2, bb = (x.detach().contiguous() for x in (enc_proj, pred_proj, W2, b2))
         labels = labels.to(device=dev, dtype=torch.int32).contiguous()
+        # the kernels index labels with row stride U-1: any other width would silently read the wrong labels
+        if U > 1 and tuple(labels.shape) != (B, U - 1):
+            raise ValueError(f"rnnt_joint_loss: labels must be [B, U-1] = [{B}, {U - 1}], got {tuple(labels.shape)}")
         if labels.numel() == 0:
             labels = torch.zeros((B, 1), dtype=torch.int32, device=dev)
         il = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
         ll = label_lengths.to(device=dev, dtype=torch.int32).contiguous()
+        if il.numel() != B or ll.numel() != B:
+            raise ValueError("rnnt_joint_loss: input_lengths and label_lengths must be [B]")
         with torch.cuda.device(dev):
             ws = torch.empty(_lib.joint_workspace_bytes(T, U, B, J, V), dtype=torch.uint8, device=dev)
             costs = torch.empty(B, dtype=torch.float32, device=dev)

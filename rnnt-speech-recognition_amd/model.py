@@ -10,7 +10,13 @@ Differences from the reference, all noted where they occur:
     reshape -- and then identical -- for f = 2, its default);
   * with `time_reduction_index` on the LAST encoder layer the reference's encoder output is f times wider than
     the prediction network's and the broadcast add at model.py:158-160 cannot work; this class raises;
-  * the joint is the fused engine (joint.py) in `loss()`; `logits()` is the unfused form for decoding/tests.
+  * the joint is the fused engine (joint.py) in `loss()`; `logits()` is the unfused form for decoding/tests;
+  * layer defaults follow Keras / TF1, not torch: BatchNormalization eps 1e-3, momentum 0.99 (torch momentum 0.01);
+    LayerNormalization eps 1e-3; tf.compat.v1 LSTMCell = glorot-uniform kernels, zero bias, forget_bias 1.0 (here folded
+    into the forget-gate slice of bias_ih; torch's second bias vector is zero), bias-free projection;
+  * torch's LSTM needs proj_size < hidden_size: for proj >= hidden (BASELINE configs 3/4: 320/320) the projection is
+    dropped, whereas TF1's num_proj always projects -- same widths, one matrix fewer per layer;
+  * `load_tf1_lstm_cell_` imports a TF1 LSTMCell's variables (gate order i, j, f, o; kernel [in + proj, 4 hidden]).
 """
 from __future__ import annotations
 
@@ -83,18 +89,77 @@ class _LSTMBlock(nn.Module):
         super().__init__()
         self.lstm = nn.LSTM(in_size, hidden, proj_size=proj if proj < hidden else 0, batch_first=True)
         self.drop = nn.Dropout(dropout)
-        self.norm = nn.LayerNorm(proj if proj < hidden else hidden)
+        self.norm = nn.LayerNorm(proj if proj < hidden else hidden, eps=1e-3)  # Keras LayerNormalization epsilon
+        init_lstm_like_tf1_(self.lstm)
 
     def forward(self, x):
         y, _ = self.lstm(x)
         return self.norm(self.drop(y))
 
 
+def _glorot_uniform_(w: torch.Tensor, fan_in: int, fan_out: int) -> None:
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    with torch.no_grad():
+        w.uniform_(-lim, lim)
+
+
+def init_lstm_like_tf1_(lstm: nn.LSTM, forget_bias: float = 1.0) -> None:
+    """tf.compat.v1.nn.rnn_cell.LSTMCell defaults (model.py:57-58, :101-102): ONE kernel [in + out, 4 hidden] drawn
+    glorot-uniform, zero bias, forget_bias added to the forget gate at run time, bias-free projection kernel."""
+    H = lstm.hidden_size
+    out = lstm.proj_size or H
+    for layer in range(lstm.num_layers):
+        w_ih, w_hh = getattr(lstm, f"weight_ih_l{layer}"), getattr(lstm, f"weight_hh_l{layer}")
+        fan_in = w_ih.shape[1] + out
+        _glorot_uniform_(w_ih, fan_in, 4 * H)
+        _glorot_uniform_(w_hh, fan_in, 4 * H)
+        with torch.no_grad():
+            getattr(lstm, f"bias_ih_l{layer}").zero_()
+            getattr(lstm, f"bias_hh_l{layer}").zero_()
+            getattr(lstm, f"bias_ih_l{layer}")[H:2 * H] = forget_bias  # torch gate order: i, f, g, o
+        if lstm.proj_size:
+            _glorot_uniform_(getattr(lstm, f"weight_hr_l{layer}"), H, lstm.proj_size)
+
+
+def load_tf1_lstm_cell_(lstm: nn.LSTM, kernel, bias, projection_kernel=None, forget_bias: float = 1.0,
+                        layer: int = 0) -> None:
+    """Import the variables of one tf.compat.v1.nn.rnn_cell.LSTMCell (what the reference's checkpoints hold for every
+    encoder / prediction-network layer, model.py:57-68, :101-109) into layer `layer` of a torch nn.LSTM.
+
+      kernel            [in + out, 4 hidden]   applied to concat([x_t, m_{t-1}]); gate columns in TF1 order i, j, f, o
+      bias              [4 hidden]             same order; forget_bias (1.0) is ADDED at run time, not stored
+      projection_kernel [hidden, proj] or None (bias-free)
+    torch: gates i, f, g, o (g = TF's j); weight_ih [4H, in], weight_hh [4H, out], two biases, weight_hr [proj, H]."""
+    kernel = torch.as_tensor(kernel, dtype=torch.float32)
+    bias = torch.as_tensor(bias, dtype=torch.float32)
+    H = lstm.hidden_size
+    w_ih, w_hh = getattr(lstm, f"weight_ih_l{layer}"), getattr(lstm, f"weight_hh_l{layer}")
+    n_in, n_out = w_ih.shape[1], w_hh.shape[1]
+    if tuple(kernel.shape) != (n_in + n_out, 4 * H) or tuple(bias.shape) != (4 * H,):
+        raise ValueError(f"LSTMCell kernel/bias shapes {tuple(kernel.shape)}/{tuple(bias.shape)} do not fit "
+                         f"[{n_in + n_out}, {4 * H}]/[{4 * H}]")
+    if (projection_kernel is None) != (lstm.proj_size == 0):
+        raise ValueError("projection kernel given for an LSTM without proj_size (or the reverse)")
+    order = torch.cat([torch.arange(0, H), torch.arange(2 * H, 3 * H), torch.arange(H, 2 * H),
+                       torch.arange(3 * H, 4 * H)])  # i, j, f, o -> i, f, j(=g), o
+    kt = kernel[:, order].t().contiguous()             # [4H, in + out]
+    b = bias[order].clone()
+    b[H:2 * H] += forget_bias
+    with torch.no_grad():
+        w_ih.copy_(kt[:, :n_in])
+        w_hh.copy_(kt[:, n_in:])
+        getattr(lstm, f"bias_ih_l{layer}").copy_(b)
+        getattr(lstm, f"bias_hh_l{layer}").zero_()
+        if projection_kernel is not None:
+            getattr(lstm, f"weight_hr_l{layer}").copy_(torch.as_tensor(projection_kernel, dtype=torch.float32).t())
+
+
 class Encoder(nn.Module):
     def __init__(self, hp: HParams):
         super().__init__()
         feat = hp.mel_bins * hp.downsample_factor  # model.py:124
-        self.input_norm = nn.BatchNorm1d(feat)     # model.py:55 (Keras BatchNormalization over the feature axis)
+        # model.py:55: Keras BatchNormalization over the feature axis, epsilon 1e-3, momentum 0.99 (= torch momentum 0.01)
+        self.input_norm = nn.BatchNorm1d(feat, eps=1e-3, momentum=0.01)
         self.blocks = nn.ModuleList()
         self.reduction_index = hp.time_reduction_index
         self.reduce = TimeReduction(hp.time_reduction_factor)

@@ -12,7 +12,7 @@ reproduced: its native op is float32-only and nothing casts the fp16 logits, so 
 from __future__ import annotations
 
 import time
-from typing import Dict, Sequence
+from typing import Callable, Dict, Iterable, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -27,6 +27,9 @@ class TrainStep:
         self.model = model
         self.global_batch = int(global_batch)
         self.group = group
+        # MirroredStrategy keeps every variable mirrored from creation (run_rnnt.py:119-122, :455-462): replicas must
+        # start from rank 0's weights and buffers, whatever seed each process happened to use.
+        sync_replicas_(model, group)
         self.params = [p for p in model.parameters() if p.requires_grad]
         lr = model.hp.learning_rate if learning_rate is None else learning_rate
         self.optimizer = torch.optim.SGD(self.params, lr=lr, momentum=momentum)
@@ -45,14 +48,74 @@ class TrainStep:
         return {"loss": float(logged), "step_time": time.time() - t0, "step": self.step_count}
 
     @torch.no_grad()
-    def evaluate(self, mel_specs, pred_inp, spec_lengths, label_lengths, labels) -> float:
-        """Eval loss of run_rnnt.py:392-424 (mean cost over the global batch); metrics/decoding are out of scope."""
+    def evaluate(self, mel_specs, pred_inp, spec_lengths, label_lengths, labels,
+                 metrics: Optional[Iterable[Callable]] = None) -> Tuple[float, Dict[str, float]]:
+        """One eval step of run_rnnt.py:392-424: (mean cost over the global batch, {metric name: value}).
+
+        `metrics` are the callables of metrics.build_accuracy_fn / build_wer_fn: each is called as
+        metric_fn(mel_specs, labels) (run_metrics, run_rnnt.py:223-230) on this rank's shard -- they decode its first
+        utterance -- and reduced with MEAN across replicas (:421-422).  BatchNorm running statistics are averaged across
+        replicas first so that every rank evaluates the same model."""
+        sync_buffers_(self.model, self.group)
         self.model.eval()
         costs = self.model.loss(mel_specs, pred_inp, spec_lengths, label_lengths, labels)
         s = costs.sum() / self.global_batch
-        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        multi = dist.is_initialized() and dist.get_world_size(self.group) > 1
+        if multi:
             dist.all_reduce(s, group=self.group)
-        return float(s)
+        results: Dict[str, float] = {}
+        for fn in (metrics or []):
+            v = torch.tensor(float(fn(mel_specs, labels)), dtype=torch.float64, device=costs.device)
+            if multi:
+                dist.all_reduce(v, group=self.group)
+                v = v / dist.get_world_size(self.group)
+            results[fn.__name__] = float(v)
+        return float(s), results
+
+    def save_checkpoint(self, path: str) -> None:
+        """Weights-only checkpoint (run_rnnt.py:326-329), written by rank 0 after the replicas' buffers are averaged."""
+        from .model import save_weights
+
+        sync_buffers_(self.model, self.group)
+        if not dist.is_initialized() or dist.get_rank(self.group) == 0:
+            save_weights(self.model, path)
+
+
+def _flat_collective_(tensors: Sequence[torch.Tensor], fn) -> None:
+    ts = [t for t in tensors if t is not None and t.numel() > 0]
+    if not ts:
+        return
+    for dtype in {t.dtype for t in ts}:
+        same = [t for t in ts if t.dtype == dtype]
+        flat = torch.cat([t.detach().reshape(-1) for t in same])
+        fn(flat)
+        off = 0
+        for t in same:
+            n = t.numel()
+            t.detach().copy_(flat[off:off + n].view_as(t))
+            off += n
+
+
+def sync_replicas_(model: torch.nn.Module, group=None, src: int = 0) -> None:
+    """Broadcast every parameter and buffer from rank `src` (one flat bucket per dtype).  No-op without a group."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    _flat_collective_(list(model.parameters()) + list(model.buffers()),
+                      lambda flat: dist.broadcast(flat, src=src, group=group))
+
+
+def sync_buffers_(model: torch.nn.Module, group=None) -> None:
+    """Average the floating-point buffers (BatchNorm running mean / variance) across replicas; integer buffers
+    (num_batches_tracked) are identical by construction.  No-op without a group."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    n = dist.get_world_size(group)
+
+    def mean_(flat):
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(n)
+
+    _flat_collective_([b for b in model.buffers() if b.is_floating_point()], mean_)
 
 
 def synthetic_batch(hp, batch: int, frames: int, max_labels: int, device, seed: int = 1234, ragged: bool = True):

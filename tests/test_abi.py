@@ -48,9 +48,37 @@ def test_workspace_size(lib):
     assert n >= 32 * 600 * 150 * 4 * 5
     assert _lib.workspace_bytes(600, 150, 64) > n
     bad = ctypes.c_size_t(0)
-    assert lib.get_workspace_size(0, 150, 32, 1, ctypes.byref(bad)) == 2
-    assert lib.get_workspace_size(600, 150, 32, 0, ctypes.byref(bad)) == 2  # CPU location not provided
-    assert lib.get_workspace_size(600, 150, 32, 1, None) == 2
+    assert lib.get_workspace_size(0, 150, 32, True, ctypes.byref(bad)) == 2
+    assert lib.get_workspace_size(600, 150, 32, False, ctypes.byref(bad)) == 2  # CPU location not provided
+    assert lib.get_workspace_size(600, 150, 32, True, None) == 2
+
+
+def test_options_struct_has_upstream_layout(lib):
+    """rnntOptions is passed BY VALUE: its layout must be upstream's (bool batch_first = 1 byte at offset 28, 32 bytes in
+    all), so that a caller compiled against upstream's rnnt.h can link against this library."""
+    O = _lib.rnntOptions
+    assert ctypes.sizeof(O) == 32
+    assert (O.loc.offset, O.u.offset, O.blank_label.offset, O.maxT.offset, O.maxU.offset) == (0, 8, 16, 20, 24)
+    assert (O.batch_first.offset, O.batch_first.size) == (28, 1)
+    header = open(os.path.join(ROOT, "include", "rnnt.h")).read()
+    assert "#include <stdbool.h>" in header and re.search(r"\bbool\s+batch_first\b", header)
+    assert re.search(r"get_workspace_size\(int maxT, int maxU, int minibatch, bool gpu", header)
+
+
+def test_padding_bytes_of_options_are_not_read(lib):
+    """A caller built against upstream's header leaves the three bytes behind `bool batch_first` uninitialised."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("passes validation and would enqueue on the fake pointers")
+    fake = ctypes.c_void_p(256)
+    o = _lib.make_options(0, 0, 10, 5)
+    raw = (ctypes.c_ubyte * 32).from_buffer(o)
+    raw[29] = raw[30] = raw[31] = 0xFF
+    ok_garbage = lib.compute_rnnt_loss(fake, None, fake, fake, fake, 28, 4, fake, fake, o)
+    assert ok_garbage != 2  # passed validation (then failed for lack of a device)
+    raw[28] = 0  # batch_first = false
+    assert lib.compute_rnnt_loss(fake, None, fake, fake, fake, 28, 4, fake, fake, o) == 2
 
 
 def test_argument_validation_needs_no_device(lib):

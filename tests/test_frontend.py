@@ -123,3 +123,15 @@ def test_accuracy_and_wer_builders():
     to_text = lambda ids: "".join(vocab[int(i)] for i in ids)
     w = metrics.build_wer_fn(dec, to_text)(mel, y_true)
     assert 0.0 <= w <= max(1.0, float(len(hyp)))
+
+
+def test_char_encoder_maps_unknown_bytes_to_zero_like_the_reference():
+    """utils/encoding.py:66-67: build_lookup_table(vocab, default_value=0); tf_vocab_encode splits BYTES (:44-48)."""
+    enc = pkg.features.CharEncoder()
+    ids = enc.encode("a1b!é c")
+    assert min(ids) >= 0
+    a, b, c, sp = (enc.index[ch] for ch in "abc ")
+    assert ids == [a, 0, b, 0, 0, 0, sp, c]  # digit, punctuation -> 0; 'é' is two UTF-8 bytes -> two zeros
+    hp = pkg.HParams(vocab_size=enc.vocab_size, mel_bins=8, downsample_factor=3)
+    rec = pkg.features.make_record(torch.randn(4000), 16000, "route 66, ok!", hp, enc)
+    assert int(rec[1].min()) >= 0 and int(rec[4].min()) >= 0  # pred_inp feeds an Embedding: never negative

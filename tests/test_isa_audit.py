@@ -80,7 +80,7 @@ def _find(d, *needles):
 def test_code_objects_are_gfx950_and_have_the_kernels(kernels):
     meta, asm = kernels
     assert len(meta) > 20
-    for needles in (("sweep_ld_kernel", "Li3ELi16E"), ("sweep_kernel", "Li3ELi16ELb1"), ("cell_tile_kernel", "Li32ELb1"), ("cell_tile_kernel", "Li32ELb0"),
+    for needles in (("sweep_ld_kernel", "Li3ELi16E"), ("cell_tile_kernel", "Li32ELb1"), ("cell_tile_kernel", "Li32ELb0"),
                     ("jh_logits_kernel", "Li40ELb0"), ("jh_logits_kernel", "Li40ELb1"), ("jh_dh_kernel",), ("jh_dw_kernel",),
                     ("joint_phase1_kernel",), ("joint_phase2_kernel",)):
         _find(meta, *needles)
@@ -88,8 +88,8 @@ def test_code_objects_are_gfx950_and_have_the_kernels(kernels):
 
 def test_hot_kernels_do_not_spill(kernels):
     meta, _ = kernels
-    hot = [("sweep_ld_kernel",), ("sweep_kernel", "Li3ELi16ELb1"), ("sweep_kernel", "Li6ELi8ELb1"), ("cell_tile_kernel", "Li32ELb1ELb0"),
-           ("cell_tile_kernel", "Li32ELb0ELb0"), ("jh_logits_kernel", "Li40ELb0"), ("jh_dh_kernel",), ("jh_dw_kernel",),
+    hot = [("sweep_ld_kernel",), ("cell_tile_kernel", "Li32ELb1ELb1"),
+           ("cell_tile_kernel", "Li32ELb0ELb1"), ("jh_logits_kernel", "Li40ELb0"), ("jh_dh_kernel",), ("jh_dw_kernel",),
            ("joint_phase1_kernel",), ("joint_phase2_kernel",), ("joint_dl_kernel",), ("joint_phase1s_kernel",),
            ("joint_phase2s_kernel",)]
     for needles in hot:
@@ -124,13 +124,10 @@ def test_instruction_selection(kernels):
     assert "ds_read_b64_tr_b16" in dw and "v_mfma_f32_32x32x16_f16" in dw and "v_dot2" in dw
     dh = asm[_find(asm, "jh_dh_kernel")[0]]
     assert "global_load_lds_dwordx4" in dh and dh.count("v_mfma_f32_32x32x16_f16") >= 16
-    sw = asm[_find(asm, "sweep_kernel", "Li3ELi16ELb1")[0]]
-    assert "global_load_lds_dwordx4" in sw and "v_exp_f32" in sw and "v_log_f32" in sw
-    assert "wave_shr:1" in sw or "wave_shl:1" in sw  # ONE whole-wave DPP shift per diagonal carries the neighbour column
-    assert "s_barrier" not in sw                      # single wave per lattice direction: no workgroup barrier at all
     ld = asm[_find(asm, "sweep_ld_kernel", "Li3ELi16E")[0]]  # the default sweep: sweeping wave + loader wave
     assert "global_load_lds_dwordx4" in ld and "global_store_dwordx3" in ld and "v_pk_add_f32" in ld
     assert ld.count("s_barrier") == 1                 # only the counter-initialisation barrier; the hand-off is two LDS counters
+    assert "wave_shr:1" in ld and "wave_shl:1" in ld  # ONE whole-wave DPP shift per diagonal carries the neighbour column
     assert ld.count("v_exp_f32") >= 96 and ld.count("v_log_f32") >= 96  # 2 directions x 16 unrolled diagonals x 3 columns
     p1 = asm[_find(asm, "joint_phase1_kernel")[0]]
     assert "v_mfma_f32_32x32x2_f32" in p1

@@ -48,6 +48,62 @@ def test_hparams_defaults_are_the_reference_ones(tmp_path):
     assert pkg.HParams.load(str(tmp_path)) == hp
 
 
+@pytest.mark.parametrize("proj", [None, 5])
+def test_tf1_lstm_cell_weights_import(proj):
+    """model.py:57-68: a reference checkpoint holds tf.compat.v1 LSTMCell variables (gate order i, j, f, o, forget_bias
+    added at run time, bias-free projection); imported into torch's nn.LSTM the layer must compute the same sequence."""
+    from oracle import lstm_oracle
+    from rnnt_speech_recognition_amd.model import load_tf1_lstm_cell_
+
+    rng = np.random.default_rng(5)
+    n_in, H = 7, 9
+    out = proj or H
+    kernel = rng.normal(size=(n_in + out, 4 * H)) * 0.4
+    bias = rng.normal(size=4 * H) * 0.3
+    pk = rng.normal(size=(H, proj)) * 0.5 if proj else None
+    x = rng.normal(size=(3, 11, n_in))
+    ref = lstm_oracle.tf1_lstm_cell_sequence(x, kernel, bias, pk)
+    lstm = torch.nn.LSTM(n_in, H, proj_size=proj or 0, batch_first=True).double()
+    load_tf1_lstm_cell_(lstm, kernel, bias, pk)
+    y, _ = lstm(torch.tensor(x))
+    np.testing.assert_allclose(y.detach().numpy(), ref, atol=1e-6, rtol=0)  # the importer stores float32 weights
+    with pytest.raises(ValueError):
+        load_tf1_lstm_cell_(lstm, kernel[:, :-4], bias, pk)
+
+
+def test_layer_defaults_follow_keras_and_tf1():
+    m = pkg.Transducer(small_hp())
+    bn = m.encoder.input_norm
+    assert (bn.eps, bn.momentum) == (1e-3, 0.01)  # Keras BatchNormalization: epsilon 1e-3, momentum 0.99
+    blk = m.encoder.blocks[0]
+    assert blk.norm.eps == 1e-3                    # Keras LayerNormalization epsilon
+    H = blk.lstm.hidden_size
+    b = blk.lstm.bias_ih_l0.detach()
+    assert torch.all(b[H:2 * H] == 1.0) and torch.all(b[:H] == 0) and torch.all(b[2 * H:] == 0)  # forget_bias = 1.0
+    assert torch.all(blk.lstm.bias_hh_l0 == 0)
+    lim = (6.0 / (blk.lstm.weight_ih_l0.shape[1] + blk.lstm.proj_size + 4 * H)) ** 0.5  # glorot over the ONE TF kernel
+    assert blk.lstm.weight_ih_l0.abs().max() <= lim and blk.lstm.weight_hh_l0.abs().max() <= lim
+
+
+def test_evaluate_runs_the_metric_builders(monkeypatch):
+    """run_rnnt.py:392-424: eval step = loss + run_metrics(mel_specs, labels).  The loss engine is HIP-only, so it is
+    stubbed here; what is checked is the wiring of build_accuracy_fn / build_wer_fn into TrainStep.evaluate."""
+    hp = small_hp()
+    m = pkg.Transducer(hp)
+    batch = pkg.synthetic_batch(hp, batch=3, frames=12, max_labels=4, device="cpu", seed=2)
+    monkeypatch.setattr(pkg.Transducer, "loss", lambda self, *a: torch.tensor([3.0, 6.0, 9.0]))
+    step = pkg.TrainStep(m, global_batch=3)
+    dec = pkg.greedy_decode_fn(m)
+    enc = pkg.features.CharEncoder()
+    acc = pkg.metrics.build_accuracy_fn(dec)
+    wer = pkg.metrics.build_wer_fn(dec, lambda ids: enc.decode(ids))
+    loss, res = step.evaluate(*batch, metrics=[acc, wer])
+    assert loss == pytest.approx(6.0)
+    assert set(res) == {"accuracy", "wer"} and all(0.0 <= v <= 1.0 or v >= 0 for v in res.values())
+    # the same numbers as calling the metric on its own (first utterance of the shard, run_rnnt.py:223-230)
+    assert res["accuracy"] == pytest.approx(acc(batch[0], batch[4]))
+
+
 @pytest.mark.gpu
 def test_train_step_reduces_loss_and_matches_unfused_loss():
     torch.manual_seed(0)
@@ -67,7 +123,7 @@ def test_train_step_reduces_loss_and_matches_unfused_loss():
     for _ in range(40):
         losses.append(step(*batch)["loss"])
     assert np.isfinite(losses).all() and losses[-1] < 0.9 * first, losses[::8]
-    assert abs(step.evaluate(*batch) - losses[-1]) < 0.5 * first
+    assert abs(step.evaluate(*batch)[0] - losses[-1]) < 0.5 * first
 
 
 @pytest.mark.gpu

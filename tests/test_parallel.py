@@ -86,6 +86,45 @@ def test_two_ranks_reproduce_full_batch_gradients():
     assert parallel.shard_bounds(5, 2, 0) == (0, 3) and parallel.shard_bounds(5, 2, 1) == (3, 5)
 
 
+def _sync_worker(rank, world, port, out):
+    """Every rank seeds differently (a user forgot torch.manual_seed): TrainStep must still start all replicas from rank
+    0's weights and buffers, and eval/checkpoints must see averaged BatchNorm statistics."""
+    import rnnt_speech_recognition_amd as pkg
+    from rnnt_speech_recognition_amd import train
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    hp = pkg.HParams(vocab_size=28, mel_bins=4, downsample_factor=2, embedding_size=8, encoder_layers=2, encoder_size=12,
+                     projection_size=8, time_reduction_index=0, pred_net_layers=1, pred_net_size=12, joint_net_size=64)
+    m = pkg.Transducer(hp)
+    before = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone()
+    pkg.TrainStep(m, global_batch=4)
+    after = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone()
+    # BatchNorm statistics drift apart per replica during training (each sees its own shard) ...
+    m.encoder.input_norm.running_mean.fill_(float(rank + 1))
+    m.encoder.input_norm.running_var.fill_(float(10 * (rank + 1)))
+    train.sync_buffers_(m)  # ... and are averaged before eval / checkpoints
+    out[rank] = (before.numpy(), after.numpy(), m.encoder.input_norm.running_mean.numpy().copy(),
+                 m.encoder.input_norm.running_var.numpy().copy(), int(m.encoder.input_norm.num_batches_tracked))
+    dist.destroy_process_group()
+
+
+def test_replicas_start_identical_and_buffers_are_averaged():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sync_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    b0, a0, mean0, var0, n0 = out[0]
+    b1, a1, mean1, var1, n1 = out[1]
+    assert not np.array_equal(b0, b1)                      # different seeds -> different initial weights ...
+    assert np.array_equal(a0, b0) and np.array_equal(a1, b0)  # ... all replaced by rank 0's
+    np.testing.assert_allclose(mean0, 1.5) and np.testing.assert_allclose(mean1, 1.5)
+    np.testing.assert_allclose(var0, 15.0) and np.testing.assert_allclose(var1, 15.0)
+    assert n0 == n1 == 0
+
+
 @pytest.mark.parametrize("gb,world", [(8, 8), (5, 2), (3, 4), (512, 8), (1, 1)])
 def test_shard_bounds_partition(gb, world):
     covered = []
