@@ -85,7 +85,7 @@ def _flat_collective_(tensors: Sequence[torch.Tensor], fn) -> None:
     ts = [t for t in tensors if t is not None and t.numel() > 0]
     if not ts:
         return
-    for dtype in {t.dtype for t in ts}:
+    for dtype in sorted({t.dtype for t in ts}, key=str):  # the same bucket order on every rank
         same = [t for t in ts if t.dtype == dtype]
         flat = torch.cat([t.detach().reshape(-1) for t in same])
         fn(flat)
