@@ -276,3 +276,87 @@ def joint_loss_and_grads_f16(enc, pred, W1, b1, W2, b2, labels, input_lengths, l
     dW1 = enc.reshape(-1, H).T @ d_a.reshape(-1, J) + pred.reshape(-1, H).T @ d_c.reshape(-1, J)
     return dict(costs=costs, d_enc=d_a @ W1.T, d_pred=d_c @ W1.T, dW1=dW1, db1=db1, dW2=dW2, db2=db2,
                 d_a=d_a, d_c=d_c, dlogits=gq)
+
+
+# --------------------------------------------------------------------------
+# One utterance of the fused path at ANY size, in row chunks (memory-light): used by the parity tests
+# that run at BASELINE.json's full configurations (C2 fused: T600 U150 J640 V28; C5: T1500 U300 J640 V1024),
+# where the [T, U, J] and [T, U, V] tensors of one utterance do not fit comfortably in float64.
+# Same mathematics as joint_loss_and_grads / joint_loss_and_grads_f16 (model.py:162-166 after the exact
+# factorisation of the first Dense layer into enc_proj + pred_proj, utils/loss.py:24-36, autodiff of both),
+# evaluated in two passes over the lattice rows: (1) log-probs of the blank/label edges -> alpha, beta;
+# (2) dlogits chunk by chunk -> dW2, db2, d enc_proj, d pred_proj.
+# --------------------------------------------------------------------------
+def joint_utterance_streamed(enc_proj, pred_proj, W2, b2, labels, blank=0, cost_scale=1.0, f16=False,
+                             dl_scale=None, rows_per_chunk=None, want_grads=True):
+    """enc_proj [T, J] (= enc @ W1 + b1), pred_proj [U, J] (= pred @ W1), W2 [J, V], b2 [V], labels [U-1], exact lengths.
+
+    f16=True states the operand roundings of the f16-MFMA joint (h, W2 and the scaled dlogits to binary16, see
+    joint_loss_and_grads_f16); dl_scale is that path's power-of-two dlogits scale (dl_scale_f16 of the WHOLE batch's
+    cost_scale).  Returns dict(cost, d_enc_proj [T,J], d_pred_proj [U,J], dW2, db2)."""
+    A = np.asarray(enc_proj, np.float64)
+    C = np.asarray(pred_proj, np.float64)
+    W = np.asarray(W2, np.float64)
+    bias = np.asarray(b2, np.float64)
+    T, J = A.shape
+    U = C.shape[0]
+    V = W.shape[1]
+    lab = np.asarray(labels, np.int64)[: U - 1]
+    Wq = _rne_half(W) if f16 else W
+    if rows_per_chunk is None:
+        rows_per_chunk = max(1, int(2.5e7 // (U * max(J, V))))  # ~200 MB per [rows, U, max(J, V)] float64 array
+
+    def rows(t0, t1):
+        h = np.tanh(A[t0:t1, None, :] + C[None, :, :])           # [r, U, J]
+        hq = _rne_half(h) if f16 else h
+        y = hq @ Wq + bias                                        # [r, U, V]
+        return h, hq, log_softmax(y)
+
+    lpb = np.empty((T, U))
+    lpl = np.empty((T, max(U - 1, 0)))
+    for t0 in range(0, T, rows_per_chunk):
+        t1 = min(T, t0 + rows_per_chunk)
+        _, _, lp = rows(t0, t1)
+        lpb[t0:t1] = lp[:, :, blank]
+        if U > 1:
+            lpl[t0:t1] = np.take_along_axis(lp[:, : U - 1, :], lab[None, :, None], axis=2)[:, :, 0]
+    a, ll = alphas(lpb, lpl)
+    if not want_grads:
+        return dict(cost=-ll)
+    b, _ = betas(lpb, lpl)
+    s = float(cost_scale)
+    S = float(dl_scale) if (f16 and dl_scale is not None) else 1.0
+    dW2 = np.zeros((J, V))
+    db2 = np.zeros(V)
+    d_a = np.zeros((T, J))
+    d_c = np.zeros((U, J))
+    uu = np.arange(max(U - 1, 0))
+    for t0 in range(0, T, rows_per_chunk):
+        t1 = min(T, t0 + rows_per_chunk)
+        h, hq, lp = rows(t0, t1)
+        r = t1 - t0
+        with np.errstate(invalid="ignore", over="ignore"):
+            occ = np.nan_to_num(np.exp(a[t0:t1] + b[t0:t1] - ll), nan=0.0)
+            g = occ[:, :, None] * np.exp(lp)
+            gb = np.zeros((r, U))
+            tt = np.arange(t0, t1)
+            inner = tt < T - 1
+            if inner.any():
+                gb[inner] = np.exp(a[tt[inner]] + lpb[tt[inner]] + b[tt[inner] + 1] - ll)
+            if t1 == T:
+                gb[r - 1, U - 1] = np.exp(a[T - 1, U - 1] + lpb[T - 1, U - 1] - ll)
+            gb = np.nan_to_num(gb, nan=0.0)
+            g[:, :, blank] -= gb
+            if U > 1:
+                gl = np.nan_to_num(np.exp(a[t0:t1, : U - 1] + lpl[t0:t1] + b[t0:t1, 1:] - ll), nan=0.0)
+                np.subtract.at(g, (np.arange(r)[:, None], uu[None, :], lab[None, :]), gl)
+        g *= s
+        if f16:
+            g = _rne_half(g * S) / S
+        g2 = g.reshape(-1, V)
+        dW2 += hq.reshape(-1, J).T @ g2
+        db2 += g2.sum(0)
+        dz = (g @ Wq.T) * (1.0 - h * h)
+        d_a[t0:t1] = dz.sum(axis=1)
+        d_c += dz.sum(axis=0)
+    return dict(cost=-ll, d_enc_proj=d_a, d_pred_proj=d_c, dW2=dW2, db2=db2)

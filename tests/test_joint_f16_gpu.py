@@ -9,8 +9,8 @@ the two backward products, and an f32 kernel value that differs from the f64 ora
 the other side of a rounding boundary for ~1 % of the elements; each such element then differs by a whole binary16
 step.  Measured: typically 5e-5 .. 4e-4, worst 6.1e-4 over 400 random cases (tests/tools/fuzz_parity.py); perturbing the
 oracle's own pre-rounding values by 3e-6 relative moves its gradients by 1.5e-4 (same mechanism).
-The distance to the UNROUNDED joint is bounded too (costs 5e-3 relative): that is the price of binary16 operands (the
-reference's mixed_float16 policy pays the same), not a kernel error."""
+The distance to the UNROUNDED joint is bounded too (costs 1e-4 relative, the north-star bar; measured <= 3e-5): that is
+the price of binary16 operands (the reference's mixed_float16 policy pays the same), not a kernel error."""
 import numpy as np
 import pytest
 import torch
@@ -73,7 +73,7 @@ def test_joint_f16_matches_oracle(B, T, U, H, J, V, ragged):
         tol = 1e-3 * max(1.0, np.abs(ref[key]).max())
         assert np.abs(g - ref[key]).max() <= tol, key
     exact = orc.joint_loss_and_grads(*case, cost_scale=scale)
-    np.testing.assert_allclose(costs, exact["costs"], rtol=5e-3)
+    np.testing.assert_allclose(costs, exact["costs"], rtol=1e-4)
     enc_g, pred_g = grads[0], grads[1]
     il, ll = case[7], case[8]
     for b in range(B):

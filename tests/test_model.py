@@ -142,9 +142,48 @@ def test_word_piece_sized_model_trains_through_the_f16_joint():
     m.eval()
     fused = m.loss(*batch)
     unfused = pkg.get_loss_fn(hp.time_reduction_factor)(labels, m.logits(mel, pred_inp), spec_len, lab_len)
-    np.testing.assert_allclose(fused.detach().cpu().numpy(), unfused.detach().cpu().numpy(), rtol=2e-3)
+    np.testing.assert_allclose(fused.detach().cpu().numpy(), unfused.detach().cpu().numpy(), rtol=1e-4)
     step = pkg.TrainStep(m, global_batch=4)
     losses = [step(*batch)["loss"] for _ in range(30)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses[::6]
     hyp = pkg.greedy_decode(m, mel, max_length=8)
     assert hyp.shape[0] == 1 and hyp.shape[1] <= 8 and int(hyp.min() if hyp.numel() else 1) > 0
+
+
+@pytest.mark.gpu
+def test_c3_end_to_end_step_at_baseline_size():
+    """BASELINE.json configs[2] at its own size: B=64, 600 frames x 240 features, encoder 2 x 320 (x2 time reduction
+    after layer 0), prediction network 1 x 320, joint 320, V=28.  The fused HIP loss and its gradients w.r.t. the joint
+    weights are checked against the float64 oracle on two utterances (fed with the model's own encoder / prediction
+    outputs), then three SGD steps run at full size."""
+    from oracle import rnnt_oracle as orc
+
+    torch.manual_seed(1234)
+    dev = torch.device("cuda:0")
+    hp = pkg.HParams(vocab_size=28, embedding_size=320, encoder_layers=2, encoder_size=320, projection_size=320,
+                     time_reduction_index=0, pred_net_layers=1, pred_net_size=320, joint_net_size=320)
+    m = pkg.Transducer(hp).to(dev)
+    batch = pkg.synthetic_batch(hp, batch=64, frames=600, max_labels=100, device=dev, seed=77)
+    mel, pred_inp, spec_len, lab_len, labels = batch
+    m.eval()
+    picks = [0, 17]
+    mask = torch.zeros(64, device=dev)
+    mask[picks] = 1.0
+    costs = m.loss(*batch)
+    (costs * mask).sum().backward()
+    enc, pred = m(mel, pred_inp)
+    assert enc.shape == (64, 300, 320) and pred.shape == (64, 101, 320)
+    t_len = pkg.reduced_lengths(spec_len, 2).cpu().numpy()
+    j = m.joint
+    n = lambda x: x.detach().cpu().numpy()
+    ref = orc.joint_loss_and_grads(n(enc)[picks], n(pred)[picks], n(j.W1), n(j.b1), n(j.W2), n(j.b2), n(labels)[picks],
+                                   t_len[picks], n(lab_len)[picks])
+    np.testing.assert_allclose(n(costs)[picks], ref["costs"], rtol=1e-4)
+    for got, key in ((j.W1.grad, "dW1"), (j.b1.grad, "db1"), (j.W2.grad, "dW2"), (j.b2.grad, "db2")):
+        assert np.abs(n(got) - ref[key]).max() <= 1e-4 * max(1.0, np.abs(ref[key]).max()), key
+    m.zero_grad()
+    step = pkg.TrainStep(m, global_batch=64, learning_rate=1e-3)
+    losses = [step(*batch)["loss"] for _ in range(3)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    ev, _ = step.evaluate(*batch)
+    assert np.isfinite(ev)

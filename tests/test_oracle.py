@@ -217,3 +217,28 @@ def test_f16_joint_oracle_stays_close_to_the_exact_joint():
     assert orc.dl_scale_f16(None, 3) == 2.0 ** 14
     assert orc.dl_scale_f16([0.25, -1.0], 2) == 2.0 ** 14 and orc.dl_scale_f16([3.0], 1) == 2.0 ** 12
     assert orc.dl_scale_f16([1.0 / 512], 1) == 2.0 ** 23
+
+
+@pytest.mark.parametrize("f16", [False, True])
+def test_streamed_utterance_oracle_equals_the_dense_oracles(f16):
+    """joint_utterance_streamed (used by the BASELINE-size GPU tests) against joint_loss_and_grads[_f16]."""
+    rng = np.random.default_rng(0)
+    B, T, U, H, J, V = 2, 13, 7, 5, 16, 11
+    enc, pred = rng.normal(size=(B, T, H)), rng.normal(size=(B, U, H))
+    W1, b1 = rng.normal(size=(H, J)) * 0.5, rng.normal(size=J) * 0.1
+    W2, b2 = rng.normal(size=(J, V)), rng.normal(size=V) * 0.1
+    labels = rng.integers(1, V, size=(B, U - 1))
+    il, ll, sc = np.array([13, 9]), np.array([6, 4]), np.array([0.7, 1.3])
+    ref = (orc.joint_loss_and_grads_f16 if f16 else orc.joint_loss_and_grads)(enc, pred, W1, b1, W2, b2, labels, il, ll,
+                                                                             cost_scale=sc)
+    S = orc.dl_scale_f16(sc, B)
+    dW2, db2 = 0.0, 0.0
+    for b in range(B):
+        Tb, Ub = il[b], ll[b] + 1
+        o = orc.joint_utterance_streamed(enc[b, :Tb] @ W1 + b1, pred[b, :Ub] @ W1, W2, b2, labels[b, : Ub - 1],
+                                         cost_scale=sc[b], f16=f16, dl_scale=S, rows_per_chunk=4)
+        assert abs(o["cost"] - ref["costs"][b]) < 1e-10
+        assert np.abs(o["d_enc_proj"] - ref["d_a"][b, :Tb]).max() < 1e-10
+        assert np.abs(o["d_pred_proj"] - ref["d_c"][b, :Ub]).max() < 1e-10
+        dW2, db2 = dW2 + o["dW2"], db2 + o["db2"]
+    assert np.abs(dW2 - ref["dW2"]).max() < 1e-10 and np.abs(db2 - ref["db2"]).max() < 1e-10
