@@ -165,7 +165,7 @@ def test_c3_end_to_end_step_at_baseline_size():
     m = pkg.Transducer(hp).to(dev)
     batch = pkg.synthetic_batch(hp, batch=64, frames=600, max_labels=100, device=dev, seed=77)
     mel, pred_inp, spec_len, lab_len, labels = batch
-    m.eval()
+    m.train()  # (the RNN backward needs training mode; dropout is 0, BatchNorm uses the batch statistics in both forwards)
     picks = [0, 17]
     mask = torch.zeros(64, device=dev)
     mask[picks] = 1.0
