@@ -459,6 +459,174 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1s_kernel(const Join
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward, resident-table form (default for J <= 640): the same outputs as joint_phase1s_kernel -- softmax denominators, lattice
+// edge weights, the parked logits tile -- from a kernel whose main loop has NO barrier and NO per-wave LDS staging:
+//   * persistent 16-wave workgroups, one per CU, striding over (row tile, utterance, u-tile) items;
+//   * LDS holds exactly two tables: the W2 hi/lo fragment image (128 J bytes, loaded once per workgroup) and the item's
+//     e^{2 pred_proj} tile Ct [32 u][J] (128 J bytes, rows XOR-swizzled by u so that a lane's two 16-byte reads per k-step
+//     are conflict-free), both brought in by LDS-DMA; 256 J bytes = all 160 KiB at J = 640;
+//   * the product is formed TRANSPOSED, logits^T = W2^T . h^T (A = W2 fragments, B = h): in the 32x32 C/D layout a LANE then
+//     owns one lattice cell and its 16 registers run over half of the vocabulary (the other half sits in lane ^ 32), so bias,
+//     log-softmax and the blank / label picks are register arithmetic plus two v_permlane32_swap -- no staging tile;
+//   * a wave carries TWO lattice rows at once (two accumulators): every Ct / W2 fragment read from LDS feeds both;
+//   * the e^{2 enc_proj} addends of a row are wave-uniform per half: plain 16-byte loads (L1-served), no LDS copy.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFwdWaves = 16;
+constexpr int kFwdRows = 64;  // lattice rows per item (two row pairs per wave)
+
+__device__ __forceinline__ float half_swap_max(const float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_swap_sum(const float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// lsm outputs + parked logits of one lattice row held in the transposed C/D layout (lane = cell u0 + l31, register r = symbol
+// cd_row(r, half)); `bias` carries b2 (and -1e30 for the pad symbols), `rsel_b` / `rsel_l` the register that holds this lane's
+// blank / label logit, or -1 when it lives in the other half (or there is no label edge).
+__device__ __forceinline__ void fwd_row_epilogue(const JointParams &jp, const f32x16 &acc, const float (&bias)[16],
+                                                 const int rsel_b, const int rsel_l, const int b, const int t,
+                                                 const int u, const int Tb, const int Ub, const int half) {
+    const LossParams &p = jp.lp;
+    float x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = acc[r] + bias[r];
+    float m = x[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, x[r]);
+    m = half_swap_max(m);
+    const float nml = -m * kLog2e;
+    float ssum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ssum += jex2(fmaf(x[r], kLog2e, nml));
+    ssum = half_swap_sum(ssum);
+    float xb = -INFINITY, xl = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        xb = (rsel_b == r) ? x[r] : xb;
+        xl = (rsel_l == r) ? x[r] : xl;
+    }
+    xb = half_swap_max(xb);
+    xl = half_swap_max(xl);
+    if (u < Ub) {
+        const size_t c = ((size_t)(b * p.T + t)) * p.U + u;
+        if (half == 0) {
+            const float lg2s = jlg2(ssum);
+            const bool blank_stays = (t < Tb - 1) || (u == Ub - 1);
+            const float ob = blank_stays ? fmaf(xb - m, kLog2e, -lg2s) : kNeg;
+            const float ol = (u < Ub - 1) ? fmaf(xl - m, kLog2e, -lg2s) : kNeg;
+            p.lse[c] = m + kLn2 * lg2s;
+            const size_t wi = ((size_t)b * p.Nr + (t + u)) * p.Up + u;
+            ((float2 *)p.W)[wi] = make_float2(ob, ol);
+        }
+        // park the logits (bias included): registers 4g .. 4g+3 are the four consecutive symbols 8g + 4 half + 0..3
+        float *dst = jp.dl + c * 32 + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *(float4 *)(dst + 8 * g) = make_float4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
+    }
+}
+
+__global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointParams jp) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const LossParams &p = jp.lp;
+    const int J = jp.J, V = p.V;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (jp.tflag[1] != 0.f) return;  // some |W2| outside the binary16 range: joint_phase1_kernel (plain f32 MFMAs) runs instead
+    const bool slow = jp.tflag[0] != 0.f;  // kernel-uniform
+    const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
+    char *Ct = (char *)lds;                 // [32 u][J] floats, 16-byte chunk c of row u stored at chunk c ^ (u & 15)
+    char *Wimg = Ct + (size_t)J * 128;      // [J/16][hi, lo][64 lanes][16 B]
+    const int cpr = J / 4;                  // 16-byte chunks per Ct row
+
+    for (int pc = wave; pc < J / 8; pc += kFwdWaves)  // W2 fragment image: J/8 pieces of 1 KB, once per workgroup
+        __builtin_amdgcn_global_load_lds((jglb_cvoid *)((const char *)jp.W2s + (size_t)pc * 1024 + lane * 16),
+                                         (lds_void *)(Wimg + pc * 1024), 16, 0, 0);
+    float bias[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int v = cd_row(r, half);
+        bias[r] = (v < V) ? jp.b2[v] : kNeg;
+    }
+    const int rsel_b = (((p.blank >> 2) & 1) == half) ? (p.blank & 3) + 4 * (p.blank >> 3) : -1;
+    const uint32_t ct_lane = (uint32_t)(l31 * cpr);          // this lane's Ct row, in chunks
+    const uint32_t ct_swz = (uint32_t)(l31 & 15);
+
+    const int n_tr = (p.T + kFwdRows - 1) / kFwdRows;
+    const int n_items = n_tr * p.B * jp.n_ut;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int tr = item / (p.B * jp.n_ut);
+        const int rem = item - tr * (p.B * jp.n_ut);
+        const int b = rem / jp.n_ut, ut = rem - b * jp.n_ut;
+        const int u0 = ut * 32;
+        const int Tb = length_T(p, b), Ub = length_U(p, b);
+        const int t_begin = tr * kFwdRows, t_end = min(min(t_begin + kFwdRows, p.T), Tb);
+        if (t_begin >= t_end || u0 >= Ub) continue;  // workgroup-uniform
+        __syncthreads();  // every wave is done with the previous item's Ct
+        for (int pc = wave; pc < J / 8; pc += kFwdWaves) {
+            const uint32_t q = (uint32_t)pc * 64u + (uint32_t)lane;  // LDS chunk this lane fills
+            const uint32_t u = q / (uint32_t)cpr, cpos = q - u * (uint32_t)cpr;
+            const uint32_t c = cpos ^ (u & 15u);                     // ... with this logical chunk of row u
+            const float *src = Ptab + ((size_t)b * p.U + min(u0 + (int)u, p.U - 1)) * J + c * 4u;
+            __builtin_amdgcn_global_load_lds((jglb_cvoid *)src, (lds_void *)(Ct + (size_t)pc * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        const int u = u0 + l31;
+        int rsel_l = -1;
+        if (u < Ub - 1) {
+            const int lab = min(max(p.labels[(size_t)b * (p.U - 1) + u], 0), V - 1);
+            rsel_l = (((lab >> 2) & 1) == half) ? (lab & 3) + 4 * (lab >> 3) : -1;
+        }
+        for (int t0 = t_begin + 2 * wave; t0 < t_end; t0 += 2 * kFwdWaves) {
+            const bool two = t0 + 1 < t_end;  // wave-uniform
+            const float *e0 = Etab + ((size_t)b * p.T + t0) * J + 8 * half;
+            const float *e1 = two ? e0 + J : e0;
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
+#pragma unroll 2
+            for (int ks = 0; ks < J / 16; ++ks) {
+                const float4 a00 = *(const float4 *)(e0 + 16 * ks), a01 = *(const float4 *)(e0 + 16 * ks + 4);
+                const float4 a10 = *(const float4 *)(e1 + 16 * ks), a11 = *(const float4 *)(e1 + 16 * ks + 4);
+                const uint32_t c0 = (uint32_t)(4 * ks + 2 * half);
+                const float4 c4a = *(const float4 *)(Ct + (size_t)(ct_lane + (c0 ^ ct_swz)) * 16);
+                const float4 c4b = *(const float4 *)(Ct + (size_t)(ct_lane + ((c0 + 1u) ^ ct_swz)) * 16);
+                const jh8 wh = *(const jh8 *)(Wimg + (size_t)(ks * 2 + 0) * 1024 + lane * 16);
+                const jh8 wl = *(const jh8 *)(Wimg + (size_t)(ks * 2 + 1) * 1024 + lane * 16);
+                const float ec[8] = {c4a.x, c4a.y, c4a.z, c4a.w, c4b.x, c4b.y, c4b.z, c4b.w};
+                const float ea0[8] = {a00.x, a00.y, a00.z, a00.w, a01.x, a01.y, a01.z, a01.w};
+                const float ea1[8] = {a10.x, a10.y, a10.z, a10.w, a11.x, a11.y, a11.z, a11.w};
+                float h0[8], h1[8];
+                if (!slow) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h0[e] = tanh_from_exp(ea0[e], ec[e]), h1[e] = tanh_from_exp(ea1[e], ec[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h0[e] = fast_tanh(ea0[e] + ec[e]), h1[e] = fast_tanh(ea1[e] + ec[e]);
+                }
+                jh8 hi0, lo0, hi1, lo1;
+                split_h8(h0, hi0, lo0);
+                split_h8(h1, hi1, lo1);
+                // logits^T += W2^T . h^T : A = W2 fragments (row = symbol), B = h (column = cell)
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hi0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hi1, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, lo0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, lo1, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hi0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hi1, acc1, 0, 0, 0);
+            }
+            fwd_row_epilogue(jp, acc0, bias, rsel_b, rsel_l, b, t0, u, Tb, Ub, half);
+            if (two) fwd_row_epilogue(jp, acc1, bias, rsel_b, rsel_l, b, t0 + 1, u, Tb, Ub, half);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward, step 1: dlogits from the parked logits tile (one lattice cell per lane, 128 B in / 128 B out, in place)
 // plus this workgroup's share of db2 = sum_cells dl.  Replaces a second run of phase 1.
 // ---------------------------------------------------------------------------------------------
@@ -1017,6 +1185,14 @@ bool fill_loss_params(LossParams &p, const float *acts, float *grads, const int 
                       const int *input_lengths, const float *cost_scale, int V, int B, float *costs, void *workspace,
                       int maxT, int maxU, int blank);
 
+// compute units of the current device (persistent kernels launch one workgroup per CU)
+static int device_cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+    return n;
+}
+
 template <typename K>
 static hipError_t set_lds(K kernel, size_t bytes) {
     if (bytes <= 65536) return hipSuccess;
@@ -1073,9 +1249,17 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
         if (hipMemsetAsync(jp.lp.W, kFillByte, L.w.A - L.w.W, s) != hipSuccess) return hipErrorUnknown;
         // Both forms are enqueued; the prep kernel's range flag (tflag[1], device data) decides which one works and which one
         // exits at once: split-precision f16 MFMAs whenever W2 fits binary16 hi + lo parts, plain f32 MFMAs otherwise.
-        const size_t shm1s = (size_t)J * 32 * sizeof(float) + 2 * 8192 + (kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
-        if ((e = set_lds(joint_phase1s_kernel, shm1s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(joint_phase1s_kernel, dim3(g1), dim3(kP1Waves * 64), shm1s, s, jp);
+        const size_t shm_fwd = (size_t)J * 256;  // Ct tile + W2 fragment image, both resident
+        if (shm_fwd <= 160 * 1024) {
+            if ((e = set_lds(joint_fwd_kernel, shm_fwd)) != hipSuccess) return e;
+            const int n_items = ((T + kFwdRows - 1) / kFwdRows) * B * L.n_ut;
+            const int ncu = device_cu_count();
+            hipLaunchKernelGGL(joint_fwd_kernel, dim3(n_items < ncu ? n_items : ncu), dim3(kFwdWaves * 64), shm_fwd, s, jp);
+        } else {  // J > 640: the two tables do not fit the LDS together; W2 streams through it in chunks instead
+            const size_t shm1s = (size_t)J * 32 * sizeof(float) + 2 * 8192 + (kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
+            if ((e = set_lds(joint_phase1s_kernel, shm1s)) != hipSuccess) return e;
+            hipLaunchKernelGGL(joint_phase1s_kernel, dim3(g1), dim3(kP1Waves * 64), shm1s, s, jp);
+        }
         hipLaunchKernelGGL(joint_phase1_kernel, dim3(g1), dim3(kP1Waves * 64), shm1, s, jp);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = launch_sweeps(jp.lp, s)) != hipSuccess) return e;
