@@ -71,7 +71,9 @@ __device__ __forceinline__ constexpr int cd_row(int reg, int half) { return (reg
 struct JointParams {
     LossParams lp;  // lattice workspace, labels, lengths, costs, cost_scale (acts/grads unused)
     const float *enc_proj, *pred_proj, *W2, *b2;
-    float *dl;      // [cells][32] dlogits of the backward pass
+    float *dl;      // [cells][32] parked logits (forward) / dlogits of the two-kernel backward
+    float4 *rec;    // [cells] per-cell gradient set-up of the single-kernel backward (joint_cellrec_kernel)
+    int *reclab;    // [cells] label of the cell, or -1
     float *dApart;  // [n_ut][B][T][J]
     float *dCpart;  // [n_ts][B][U][J]
     float *dWpart;  // [B*n_ut*n_ts][J][32]
@@ -86,6 +88,7 @@ struct JointParams {
     long long *trace;    // dev builds only: s_memtime stamps of one workgroup of phase 1 and one of phase 2
 #endif
     int J, n_ut, TR, n_tr, TS, n_ts;
+    int single_bwd;  // 1: joint_bwd_kernel does the backward; joint_dl_kernel only runs for the f32 fallback (tflag[1])
 };
 
 // tables for tanh_from_exp + the overflow flag (zeroed before the launch)
@@ -311,6 +314,10 @@ __device__ __forceinline__ void split_h8(const float (&x)[8], jh8 &hi, jh8 &lo) 
     }
 }
 __device__ __forceinline__ f32x16 mfma3(const jh8 ahi, const jh8 alo, const jh8 bhi, const jh8 blo, f32x16 acc) {
+#ifdef BWD_EXP_NOMFMA  // timing experiment (results wrong): no matrix work
+    acc[0] += (float)ahi[0] + (float)alo[0] + (float)bhi[0] + (float)blo[0];
+    return acc;
+#endif
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc, 0, 0, 0);
@@ -472,7 +479,55 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1s_kernel(const Join
 //   * the e^{2 enc_proj} addends of a row are wave-uniform per half: plain 16-byte loads (L1-served), no LDS copy.
 // ---------------------------------------------------------------------------------------------
 constexpr int kFwdWaves = 16;
-constexpr int kFwdRows = 64;  // lattice rows per item (two row pairs per wave)
+constexpr int kFwdRows = 2 * kFwdWaves;  // lattice rows per item: one row pair per wave
+
+// lane (16-lane row R, position i) <- lane (R, E): the enc-side addends of a k-step sit one per lane (see joint_fwd_kernel)
+template <int E>
+__device__ __forceinline__ float row_bcast(const float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + E /*row_newbcast:E*/, 0xf, 0xf, true));
+}
+template <int E, bool SLOW>
+__device__ __forceinline__ void fwd_h_pair(const float ea0, const float ea1, const float ec, float &h0, float &h1) {
+    const float a0 = row_bcast<E>(ea0), a1 = row_bcast<E>(ea1);
+    if (!SLOW) {
+        h0 = tanh_from_exp(a0, ec), h1 = tanh_from_exp(a1, ec);
+    } else {
+        h0 = fast_tanh(a0 + ec), h1 = fast_tanh(a1 + ec);
+    }
+}
+// The J-long product of one row pair: logits^T += W2^T . h^T, A = W2 fragments (row = symbol), B = h (column = cell).
+template <bool SLOW>
+__device__ __forceinline__ void fwd_row_pair(const int J, const float *e0, const float *e1, const char *ct_row, const uint32_t ct_swz,
+                                             const char *wlane, const int half, f32x16 &acc0, f32x16 &acc1) {
+    float ea0 = e0[0], ea1 = e1[0];
+    for (int ks = 0; ks < J / 16; ++ks) {
+        const float cur0 = ea0, cur1 = ea1;
+        if (ks + 1 < J / 16) ea0 = e0[16 * (ks + 1)], ea1 = e1[16 * (ks + 1)];  // next k-step's addends: one dword per lane
+        const uint32_t c0 = (uint32_t)(4 * ks + 2 * half);
+        const float4 c4a = *(const float4 *)(ct_row + (size_t)(c0 ^ ct_swz) * 16);
+        const float4 c4b = *(const float4 *)(ct_row + (size_t)((c0 + 1u) ^ ct_swz) * 16);
+        const jh8 wh = *(const jh8 *)(wlane + (size_t)(ks * 2 + 0) * 1024);
+        const jh8 wl = *(const jh8 *)(wlane + (size_t)(ks * 2 + 1) * 1024);
+        float h0[8], h1[8];
+        fwd_h_pair<0, SLOW>(cur0, cur1, c4a.x, h0[0], h1[0]);
+        fwd_h_pair<1, SLOW>(cur0, cur1, c4a.y, h0[1], h1[1]);
+        fwd_h_pair<2, SLOW>(cur0, cur1, c4a.z, h0[2], h1[2]);
+        fwd_h_pair<3, SLOW>(cur0, cur1, c4a.w, h0[3], h1[3]);
+        fwd_h_pair<4, SLOW>(cur0, cur1, c4b.x, h0[4], h1[4]);
+        fwd_h_pair<5, SLOW>(cur0, cur1, c4b.y, h0[5], h1[5]);
+        fwd_h_pair<6, SLOW>(cur0, cur1, c4b.z, h0[6], h1[6]);
+        fwd_h_pair<7, SLOW>(cur0, cur1, c4b.w, h0[7], h1[7]);
+        jh8 hi0, lo0, hi1, lo1;
+        split_h8(h0, hi0, lo0);
+        split_h8(h1, hi1, lo1);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hi0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hi1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, lo0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, lo1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hi0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hi1, acc1, 0, 0, 0);
+    }
+}
 
 __device__ __forceinline__ float half_swap_max(const float v) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -554,75 +609,59 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
     const int rsel_b = (((p.blank >> 2) & 1) == half) ? (p.blank & 3) + 4 * (p.blank >> 3) : -1;
     const uint32_t ct_lane = (uint32_t)(l31 * cpr);          // this lane's Ct row, in chunks
     const uint32_t ct_swz = (uint32_t)(l31 & 15);
+    // enc-side addends of a k-step (16 joint units), one per lane: positions 0..7 of every 16-lane row hold the 8 units of
+    // the lane's half (units 8 half + 0..7), so row_newbcast:e hands every lane "its" unit e
+    const int ea_off = ((lane & 15) + 8 * half) & 15;
 
+    // items = (utterance, u-tile, row tile) with the row tile fastest; every workgroup takes a CONTIGUOUS range of them, so
+    // that the 128 J-byte Ct tile is reloaded only when (utterance, u-tile) changes
     const int n_tr = (p.T + kFwdRows - 1) / kFwdRows;
     const int n_items = n_tr * p.B * jp.n_ut;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int tr = item / (p.B * jp.n_ut);
-        const int rem = item - tr * (p.B * jp.n_ut);
-        const int b = rem / jp.n_ut, ut = rem - b * jp.n_ut;
+    const int it_lo = (int)((long long)n_items * blockIdx.x / gridDim.x);
+    const int it_hi = (int)((long long)n_items * (blockIdx.x + 1) / gridDim.x);
+    int ct_owner = -1;
+    int rsel_l = -1;
+    for (int item = it_lo; item < it_hi; ++item) {
+        const int bu = item / n_tr, tr = item - bu * n_tr;
+        const int b = bu / jp.n_ut, ut = bu - b * jp.n_ut;
         const int u0 = ut * 32;
         const int Tb = length_T(p, b), Ub = length_U(p, b);
         const int t_begin = tr * kFwdRows, t_end = min(min(t_begin + kFwdRows, p.T), Tb);
         if (t_begin >= t_end || u0 >= Ub) continue;  // workgroup-uniform
-        __syncthreads();  // every wave is done with the previous item's Ct
-        for (int pc = wave; pc < J / 8; pc += kFwdWaves) {
-            const uint32_t q = (uint32_t)pc * 64u + (uint32_t)lane;  // LDS chunk this lane fills
-            const uint32_t u = q / (uint32_t)cpr, cpos = q - u * (uint32_t)cpr;
-            const uint32_t c = cpos ^ (u & 15u);                     // ... with this logical chunk of row u
-            const float *src = Ptab + ((size_t)b * p.U + min(u0 + (int)u, p.U - 1)) * J + c * 4u;
-            __builtin_amdgcn_global_load_lds((jglb_cvoid *)src, (lds_void *)(Ct + (size_t)pc * 1024), 16, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-
         const int u = u0 + l31;
-        int rsel_l = -1;
-        if (u < Ub - 1) {
-            const int lab = min(max(p.labels[(size_t)b * (p.U - 1) + u], 0), V - 1);
-            rsel_l = (((lab >> 2) & 1) == half) ? (lab & 3) + 4 * (lab >> 3) : -1;
-        }
-        for (int t0 = t_begin + 2 * wave; t0 < t_end; t0 += 2 * kFwdWaves) {
-            const bool two = t0 + 1 < t_end;  // wave-uniform
-            const float *e0 = Etab + ((size_t)b * p.T + t0) * J + 8 * half;
-            const float *e1 = two ? e0 + J : e0;
-            f32x16 acc0, acc1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
-#pragma unroll 2
-            for (int ks = 0; ks < J / 16; ++ks) {
-                const float4 a00 = *(const float4 *)(e0 + 16 * ks), a01 = *(const float4 *)(e0 + 16 * ks + 4);
-                const float4 a10 = *(const float4 *)(e1 + 16 * ks), a11 = *(const float4 *)(e1 + 16 * ks + 4);
-                const uint32_t c0 = (uint32_t)(4 * ks + 2 * half);
-                const float4 c4a = *(const float4 *)(Ct + (size_t)(ct_lane + (c0 ^ ct_swz)) * 16);
-                const float4 c4b = *(const float4 *)(Ct + (size_t)(ct_lane + ((c0 + 1u) ^ ct_swz)) * 16);
-                const jh8 wh = *(const jh8 *)(Wimg + (size_t)(ks * 2 + 0) * 1024 + lane * 16);
-                const jh8 wl = *(const jh8 *)(Wimg + (size_t)(ks * 2 + 1) * 1024 + lane * 16);
-                const float ec[8] = {c4a.x, c4a.y, c4a.z, c4a.w, c4b.x, c4b.y, c4b.z, c4b.w};
-                const float ea0[8] = {a00.x, a00.y, a00.z, a00.w, a01.x, a01.y, a01.z, a01.w};
-                const float ea1[8] = {a10.x, a10.y, a10.z, a10.w, a11.x, a11.y, a11.z, a11.w};
-                float h0[8], h1[8];
-                if (!slow) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) h0[e] = tanh_from_exp(ea0[e], ec[e]), h1[e] = tanh_from_exp(ea1[e], ec[e]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) h0[e] = fast_tanh(ea0[e] + ec[e]), h1[e] = fast_tanh(ea1[e] + ec[e]);
-                }
-                jh8 hi0, lo0, hi1, lo1;
-                split_h8(h0, hi0, lo0);
-                split_h8(h1, hi1, lo1);
-                // logits^T += W2^T . h^T : A = W2 fragments (row = symbol), B = h (column = cell)
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hi0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hi1, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, lo0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, lo1, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hi0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hi1, acc1, 0, 0, 0);
+        if (ct_owner != bu) {
+            ct_owner = bu;
+            __syncthreads();  // every wave is done with the previous Ct tile
+            for (int pc = wave; pc < J / 8; pc += kFwdWaves) {
+                const uint32_t q = (uint32_t)pc * 64u + (uint32_t)lane;  // LDS chunk this lane fills
+                const uint32_t ur = q / (uint32_t)cpr, cpos = q - ur * (uint32_t)cpr;
+                const uint32_t c = cpos ^ (ur & 15u);                    // ... with this logical chunk of row ur
+                const float *src = Ptab + ((size_t)b * p.U + min(u0 + (int)ur, p.U - 1)) * J + c * 4u;
+                __builtin_amdgcn_global_load_lds((jglb_cvoid *)src, (lds_void *)(Ct + (size_t)pc * 1024), 16, 0, 0);
             }
-            fwd_row_epilogue(jp, acc0, bias, rsel_b, rsel_l, b, t0, u, Tb, Ub, half);
-            if (two) fwd_row_epilogue(jp, acc1, bias, rsel_b, rsel_l, b, t0 + 1, u, Tb, Ub, half);
+            rsel_l = -1;
+            if (u < Ub - 1) {
+                const int lab = min(max(p.labels[(size_t)b * (p.U - 1) + u], 0), V - 1);
+                rsel_l = (((lab >> 2) & 1) == half) ? (lab & 3) + 4 * (lab >> 3) : -1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
+        const int t0 = t_begin + 2 * wave;
+        if (t0 >= t_end) continue;  // wave-uniform (no barrier below)
+        const bool two = t0 + 1 < t_end;  // wave-uniform
+        const float *e0 = Etab + ((size_t)b * p.T + t0) * J + ea_off;
+        const float *e1 = two ? e0 + J : e0;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
+        const char *ct_row = Ct + (size_t)ct_lane * 16, *wlane = Wimg + lane * 16;
+        if (!slow)
+            fwd_row_pair<false>(J, e0, e1, ct_row, ct_swz, wlane, half, acc0, acc1);
+        else
+            fwd_row_pair<true>(J, e0, e1, ct_row, ct_swz, wlane, half, acc0, acc1);
+        fwd_row_epilogue(jp, acc0, bias, rsel_b, rsel_l, b, t0, u, Tb, Ub, half);
+        if (two) fwd_row_epilogue(jp, acc1, bias, rsel_b, rsel_l, b, t0 + 1, u, Tb, Ub, half);
     }
 }
 
@@ -636,6 +675,7 @@ __global__ __launch_bounds__(256) void joint_dl_kernel(const JointParams jp) {
     __shared__ float red[256][33];
     const LossParams &p = jp.lp;
     const int V = p.V, tid = threadIdx.x;
+    if (jp.single_bwd && jp.tflag[1] == 0.f) return;  // joint_bwd_kernel forms dlogits itself
     float colsum[32];
 #pragma unroll
     for (int v = 0; v < 32; ++v) colsum[v] = 0.f;
@@ -1077,8 +1117,478 @@ __global__ __launch_bounds__(256, P2S_WG_PER_CU) void joint_phase2s_kernel(const
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward, single-kernel form (default for J <= 640): dlogits + the whole scatter through the joint in ONE persistent
+// launch, replacing joint_dl_kernel + joint_phase2s_kernel.  A workgroup = J/64 CONSUMER waves (one 64-unit J slab each,
+// all working on the same lattice row) + 2 PRODUCER waves.
+//   producers: per lattice row (32 cells of one u-tile) turn the parked logits into S.dlogits and publish them ONCE, already
+//              split into binary16 hi/lo parts and laid out as the MFMA fragments both products need (A of dh: lane = cell,
+//              k = symbol; B of dW2: lane = symbol, k-slots = the lattice columns of the C/D layout), 8 KB per row, into a
+//              ring of kBwdRing slots in LDS; they also accumulate db2.  (Before: every J slab re-read the f32 tile from L2,
+//              re-scaled, re-staged and re-split it: ~30 % of phase 2's VALU work, and a separate 0.25 ms kernel.)
+//   consumers: h tile in C/D layout from register-resident e^{2 pred_proj} factors (the 16 lattice columns x 2 j-tiles a
+//              lane needs never change within an (utterance, u-tile)), dh = dl.W2^T, dz = dh (1 - h^2), sum_u -> d enc_proj
+//              partial, running sum_t -> d pred_proj, dW2 += h^T.dl with the h registers as A fragments -- as in
+//              joint_phase2s_kernel; dW2 accumulators persist over ALL items of the workgroup (re-scaled by an exact power
+//              of two when the utterance, hence S, changes).
+//   hand-off:  per ring slot a sequence word (row + 1 once published) and a use counter (consumers that have read it);
+//              LDS operations of a wave complete in order, so "data, wait, flag" suffices; all polls are bounded and a
+//              timeout poisons the outputs with NaN instead of hanging.
+// Items = (utterance, u-tile, row tile of kBwdRows rows), row tile fastest; every workgroup takes a contiguous range.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBwdRing = 8;
+constexpr int kBwdSlotBytes = 8192 + 2048;  // fragment image + the row's enc-side addends for the group's joint units
+constexpr int kBwdRows = 32;
+constexpr int kBwdSlots = 3;  // d pred_proj partial slabs: an (utterance, u-tile) spans at most this many workgroups
+constexpr int kBwdMaxBlocks = 256;  // workgroups per group at most (sizes the dW2 / db2 partial buffers)
+
+struct BwdItem {
+    int b, ut, u0, Tb, Ub, t_begin, t_end, bu;
+    bool live;
+};
+__device__ __forceinline__ BwdItem bwd_item(const JointParams &jp, const int item, const int n_tr) {
+    const LossParams &p = jp.lp;
+    BwdItem it;
+    it.bu = item / n_tr;
+    const int tr = item - it.bu * n_tr;
+    it.b = it.bu / jp.n_ut, it.ut = it.bu - it.b * jp.n_ut;
+    it.u0 = it.ut * 32;
+    it.Tb = length_T(p, it.b), it.Ub = length_U(p, it.b);
+    it.t_begin = tr * kBwdRows;
+    it.t_end = min(min(it.t_begin + kBwdRows, p.T), it.Tb);
+    it.live = (it.t_begin < it.t_end) && (it.u0 < it.Ub);
+    return it;
+}
+// power-of-two dlogits scale of an utterance: |S dl| <= 2^14 (|dl| <= 2 |cost_scale|)
+__device__ __forceinline__ void bwd_scale(const LossParams &p, const int b, float &S, float &invS) {
+    S = 1.0f, invS = 1.0f;
+    const float cs = p.cost_scale ? fabsf(p.cost_scale[b]) : 1.0f;
+    if (cs > 0.f && cs < 3.0e38f) {
+        const int e = ilogbf(cs) + 1;
+        S = ldexpf(1.0f, 13 - e), invS = ldexpf(1.0f, e - 13);
+    }
+}
+__device__ __forceinline__ int lds_ld_i32(const uint32_t addr) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ bool lds_poll_ge(const uint32_t addr, const int need) {
+    for (int spin = 0; spin < (1 << 20); ++spin) {
+        if (lds_ld_i32(addr) >= need) return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+
+// one dlogits value (scaled by sS = cost_scale * S) of symbol v for a cell with the given set-up
+__device__ __forceinline__ float bwd_dl(const float x, const int v, const int V, const int blank, const float c0, const float sS,
+                                        const float corr_b, const float corr_l, const int lab) {
+    float d = (v < V) ? sS * jex2(fmaf(x, kLog2e, c0)) : 0.f;
+    d -= (v == blank) ? corr_b : 0.f;
+    d -= (v == lab) ? corr_l : 0.f;
+    return d;
+}
+
+template <bool SLOW>
+__device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t seq_a, const uint32_t use_a, const int cw,
+                             const int j0, const int blk, const int nblk, const int lane, const int it_lo, const int it_hi,
+                             const int n_tr) {
+    const LossParams &p = jp.lp;
+    const int J = jp.J, V = p.V;
+    const int half = lane >> 5, l31 = lane & 31;
+    const float *Ptab = SLOW ? jp.pred_proj : jp.expP;
+    // B fragments of dh = dl . W2^T for this wave's 32 joint units: lane (j = j0 + l31, half), k-step ks holds
+    // W2[j][16 ks + 8 half + 0..7] as binary16 hi + lo parts; row-independent, kept in registers
+    jh8 wf[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        float w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int v = 16 * ks + 8 * half + e;
+            w[e] = (v < V) ? jp.W2[(size_t)(j0 + l31) * V + v] : 0.f;
+        }
+        split_h8(w, wf[ks][0], wf[ks][1]);
+    }
+    // The consumers of one SIMD (waves w, w + 4, w + 8) run identical instruction streams on the same rows; a one-off
+    // stagger of about a third of a row keeps them from queueing for the same pipe at the same moment.
+    for (int i = 0; i < (cw >> 2); ++i) __builtin_amdgcn_s_sleep(4);
+
+    int rows_total = 0;  // rows this workgroup will process (all waves count alike)
+    for (int item = it_lo; item < it_hi; ++item) {
+        const BwdItem it = bwd_item(jp, item, n_tr);
+        if (it.live) rows_total += it.t_end - it.t_begin;
+    }
+
+    f32x16 accC, accW;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accC[r] = 0.f, accW[r] = 0.f;
+    float ec[16];
+    float S = 1.0f, invS = 1.0f;
+    int cur_bu = -1, cur_b = -1, cur_u0 = 0, cur_slot = 0;
+    int row = 0;
+    bool poisoned = false;
+
+    auto flush_C = [&]() {  // d pred_proj partial of (cur_b, u-tile) accumulated by this workgroup so far
+        if (cur_bu < 0) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int u = cur_u0 + cd_row(r, half);
+            if (u < p.U)
+                jp.dCpart[(((size_t)cur_slot * p.B + cur_b) * p.U + u) * J + j0 + l31] = poisoned ? NAN : accC[r] * invS;
+            accC[r] = 0.f;
+        }
+    };
+
+    // software pipeline, one row deep: the A fragments of dh for the NEXT row are polled for and read while the current
+    // row's products run, so that neither the sequence-word round trip nor the LDS latency sits in front of the MFMA chain
+#ifdef JH_TRACE
+    // dev builds: s_memtime stamps of consumers 0, 4, 8 (one SIMD) of workgroup 20, rows 40..71, 6 stamps per row
+    long long *trc = (blockIdx.x == 20 && (cw & 3) == 0 && cw < 12) ? jp.trace + (cw >> 2) * 256 : nullptr;
+#define BT(k)                                                                                          \
+    do {                                                                                               \
+        if (trc && lane == 0 && row >= 40 && row < 72) trc[(row - 40) * 6 + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define BT(k) do { } while (0)
+#endif
+    jh8 fa[2][2];
+    float aj_next = 0.f;  // e^{2 enc_proj} (or enc_proj) of the next row for this lane's joint unit, delivered with the image
+    if (rows_total > 0) {
+        if (!lds_poll_ge(seq_a, 1)) poisoned = true;
+        const jh8 *f0 = (const jh8 *)ring;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fa[ks][0] = f0[(ks * 2 + 0) * 64 + lane], fa[ks][1] = f0[(ks * 2 + 1) * 64 + lane];
+        aj_next = *(const float *)(ring + 8192 + (cw * 32 + l31) * 4);
+    }
+
+    for (int item = it_lo; item < it_hi; ++item) {
+        const BwdItem it = bwd_item(jp, item, n_tr);
+        if (!it.live) continue;
+        if (it.bu != cur_bu) {
+            flush_C();
+            cur_bu = it.bu, cur_u0 = it.u0;
+            {   // which of the (at most kBwdSlots) workgroups of my group that share this (utterance, u-tile) am I?
+                const long long first = (long long)it.bu * n_tr;  // first item of this (utterance, u-tile)
+                const int n_items = n_tr * p.B * jp.n_ut;
+                const int blk_first = (int)(((first + 1) * nblk - 1) / n_items);  // workgroup (of the group) that owns item `first`
+                cur_slot = blk - blk_first;
+            }
+            if (it.b != cur_b) {  // S changes: re-scale the dW2 accumulator (exact, powers of two)
+                float Sn, invSn;
+                bwd_scale(p, it.b, Sn, invSn);
+                const float f = Sn * invS;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accW[r] *= f;
+                S = Sn, invS = invSn, cur_b = it.b;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int u = min(it.u0 + cd_row(r, half), p.U - 1);
+                ec[r] = Ptab[((size_t)it.b * p.U + u) * J + j0 + l31];
+            }
+        }
+        for (int t = it.t_begin; t < it.t_end; ++t, ++row) {
+            const float aj = aj_next;
+            const int slot = row % kBwdRing;
+            const jh8 *frag = (const jh8 *)(ring + (size_t)slot * kBwdSlotBytes);
+            BT(0);
+            // B fragments of dW2 for this row: issued now, needed after the dh chain
+            jh8 fb[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fb[ks][0] = frag[(4 + ks * 2 + 0) * 64 + lane], fb[ks][1] = frag[(4 + ks * 2 + 1) * 64 + lane];
+            float h[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[r] = SLOW ? fast_tanh(aj + ec[r]) : tanh_from_exp(aj, ec[r]);
+#ifdef BWD_EXP_NOVALU  // timing experiment (results wrong): no tanh
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[r] = aj + ec[r];
+#endif
+            BT(1);
+            // S dh[u][j] = sum_v (S dl[u][v]) W2[j][v]
+            f32x16 dh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dh[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) dh = mfma3(fa[ks][0], fa[ks][1], wf[ks][0], wf[ks][1], dh);
+            BT(2);
+            // next row's A fragments (its sequence word first)
+            if (row + 1 < rows_total) {
+                const int nslot = (row + 1) % kBwdRing;
+                if (!lds_poll_ge(seq_a + 4u * nslot, row + 2)) poisoned = true;
+                const jh8 *fn = (const jh8 *)(ring + (size_t)nslot * kBwdSlotBytes);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fa[ks][0] = fn[(ks * 2 + 0) * 64 + lane], fa[ks][1] = fn[(ks * 2 + 1) * 64 + lane];
+                aj_next = *(const float *)((const char *)fn + 8192 + (cw * 32 + l31) * 4);
+            }
+            BT(3);
+            // S dW2[j][v] += sum_u h[u][j] (S dl[u][v]): k-slot (ks, half, e) <-> lattice column cd_row(8 ks + e, half)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const float hk[8] = {h[8 * ks], h[8 * ks + 1], h[8 * ks + 2], h[8 * ks + 3],
+                                     h[8 * ks + 4], h[8 * ks + 5], h[8 * ks + 6], h[8 * ks + 7]};
+                jh8 hhi, hlo;
+                split_h8(hk, hhi, hlo);
+                accW = mfma3(hhi, hlo, fb[ks][0], fb[ks][1], accW);
+            }
+            BT(4);
+            // every read of this row's slot has returned (fb above, fa one row earlier): hand it back to the loader
+            if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(use_a + 4u * slot), "v"(1) : "memory");
+            float colsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float dz = fmaf(-dh[r] * h[r], h[r], dh[r]);  // dh (1 - h^2)
+                accC[r] += dz;
+                colsum += dz;
+            }
+            colsum = half_swap_sum(colsum);
+            BT(5);
+#ifndef BWD_EXP_NOSTORE
+            if (lane < 32)
+                jp.dApart[(((size_t)it.ut * p.B + it.b) * p.T + t) * J + j0 + lane] = poisoned ? NAN : colsum * invS;
+#else
+            if (colsum == 12345.678f) jp.dApart[0] = colsum;
+#endif
+        }
+    }
+    flush_C();
+    // this workgroup's dW2 partial: accW is [j rows][v cols]
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        jp.dWpart[((size_t)blk * J + j0 + cd_row(r, half)) * 32 + l31] = poisoned ? NAN : accW[r] * invS;
+}
+
+// Per-cell gradient set-up, once per lattice cell, by the whole chip in parallel (a chain of dependent gathers from the
+// diagonal-major lattice arrays: latency-bound for a single wave, so it is NOT done by the backward kernel's producers):
+//   rec[c] = { c0 = alpha + beta - ll - lse (log2 domain; add x log2e), sS = cost_scale S_b,
+//              corr_b, corr_l = the blank / label corrections, already scaled by sS }    lab[c] = label of the cell or -1
+// The producers of joint_bwd_kernel turn a row of these plus the parked logits into the dlogits fragments.
+__global__ __launch_bounds__(256) void joint_cellrec_kernel(const JointParams jp) {
+    const LossParams &p = jp.lp;
+    if (jp.tflag[1] != 0.f) return;  // joint_dl_kernel + joint_phase2_kernel (plain f32 MFMAs) run instead
+    for (uint32_t c = blockIdx.x * 256u + threadIdx.x; c < p.cells; c += gridDim.x * 256u) {
+        const Cell cl = decode(p, c);
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        int lab = -1;
+        if (cl.valid) {
+            float S, invS;
+            bwd_scale(p, cl.b, S, invS);
+            const CellGrad g = cell_grad_setup(p, cl, c);
+            const float *xrow = jp.dl + (size_t)c * 32;
+            const float sS = g.scale * S;
+            r.x = g.c0, r.y = sS;
+            if (g.has_blank_corr) r.z = sS * jex2(fmaf(xrow[p.blank], kLog2e, g.nl) + g.cb);
+            if (g.has_label) lab = g.lab, r.w = sS * jex2(fmaf(xrow[g.lab], kLog2e, g.nl) + g.cl);
+        }
+        jp.rec[c] = r;
+        jp.reclab[c] = lab;
+    }
+}
+
+// dlogits fragments of one lattice row tile (32 cells x 32 symbols), 8 KB: pieces 0..3 = A fragments of dh ([ks][hi, lo],
+// lane = cell, k = symbol 16 ks + 8 half + e), pieces 4..7 = B fragments of dW2 ([ks][hi, lo], lane = symbol, k-slot
+// (ks, half, e) = lattice column cd_row(8 ks + e, half)); every value is S_b . dlogits split into binary16 hi + lo.
+// Built ONCE per row by a producer wave of the backward workgroup, straight into the LDS ring -- they never exist in HBM.
+// The two producers (alternating rows) sit on the two SIMDs that carry only two consumer waves.
+// walks the live rows of a workgroup's item range in order (the same sequence every wave of the workgroup sees)
+struct BwdRowIter {
+    int item, it_hi, n_tr, t;
+    BwdItem it;
+    bool valid;
+    __device__ __forceinline__ void settle(const JointParams &jp) {  // move to the first live row at or after (item, t)
+        while (item < it_hi) {
+            if (it.live && t < it.t_end) { valid = true; return; }
+            ++item;
+            if (item < it_hi) {
+                it = bwd_item(jp, item, n_tr);
+                t = it.t_begin;
+            }
+        }
+        valid = false;
+    }
+    __device__ __forceinline__ void init(const JointParams &jp, int lo, int hi, int ntr) {
+        item = lo, it_hi = hi, n_tr = ntr, valid = false;
+        if (item < it_hi) {
+            it = bwd_item(jp, item, n_tr);
+            t = it.t_begin;
+        }
+        settle(jp);
+    }
+    __device__ __forceinline__ void next(const JointParams &jp) {
+        ++t;
+        settle(jp);
+    }
+};
+
+// everything a producer needs from memory for one row; loaded one row (of its own) ahead
+struct BwdRowLoads {
+    float4 rc;        // per-cell set-up of this lane's cell
+    int lab;
+    float4 xa[2][2];  // this cell's logits for the A fragments
+    float xb[2][8];   // symbol l31 of the 16 lattice columns this lane's k-slots cover, for the B fragments
+    float av[5];      // enc-side addends of the group's joint units
+    int b, t, u0, Ub;
+};
+__device__ __forceinline__ void bwd_row_loads(const JointParams &jp, const BwdItem &it, const int t, const float *Etab,
+                                              const int n_cons, const int group, const int lane, BwdRowLoads &L) {
+    const LossParams &p = jp.lp;
+    const int half = lane >> 5, l31 = lane & 31;
+    const uint32_t cbase = ((uint32_t)(it.b * p.T + t)) * (uint32_t)p.U + (uint32_t)it.u0;
+    const uint32_t c = cbase + (uint32_t)min(l31, p.U - 1 - it.u0);
+    L.b = it.b, L.t = t, L.u0 = it.u0, L.Ub = it.Ub;
+    L.rc = jp.rec[c];
+    L.lab = jp.reclab[c];
+    const float *xrow = jp.dl + (size_t)c * 32;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+        L.xa[ks][0] = *(const float4 *)(xrow + 16 * ks + 8 * half), L.xa[ks][1] = *(const float4 *)(xrow + 16 * ks + 8 * half + 4);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            // every load of a row is unconditional (addresses clamped into the tensor, values masked at use): the number of
+            // loads in flight is then a compile-time constant and the wait for THIS row's data need not drain the next row's
+            const int uu = min(cd_row(8 * ks + e, half), p.U - 1 - it.u0);
+            L.xb[ks][e] = jp.dl[((size_t)cbase + uu) * 32 + l31];
+        }
+    const float *asrc = Etab + ((size_t)it.b * p.T + t) * jp.J + group * n_cons * 32;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) L.av[k] = asrc[min(lane + 64 * k, n_cons * 32 - 1)];
+}
+
+__device__ void bwd_producer(const JointParams &jp, char *ring, float *scratch, const uint32_t seq_a, const uint32_t use_a,
+                             const int pw, const int n_cons, const int group, const int blk, const bool want_db, const int lane,
+                             const int it_lo, const int it_hi, const int n_tr) {
+    const LossParams &p = jp.lp;
+    const int V = p.V;
+    const int half = lane >> 5, l31 = lane & 31;
+    const float *Etab = (jp.tflag[0] != 0.f) ? jp.enc_proj : jp.expE;
+    float dbacc = 0.f;  // db2[v = l31] over the cells this lane has seen (its half's k-slots)
+    float invS = 1.0f;
+    int cur_b = -1;
+    bool poisoned = false;
+    // the producers are the head of the pipeline and by far the lighter role: they win issue arbitration on their SIMD
+    __builtin_amdgcn_s_setprio(3);
+    // the two producers alternate rows: this one takes rows pw, pw + 2, ...
+    BwdRowIter iter;
+    iter.init(jp, it_lo, it_hi, n_tr);
+    if (pw == 1 && iter.valid) iter.next(jp);
+    int row = pw;
+    BwdRowLoads L;
+    if (iter.valid) bwd_row_loads(jp, iter.it, iter.t, Etab, n_cons, group, lane, L);
+    while (iter.valid) {
+        // ---- my next row's loads go out before this row's arithmetic: a producer never sits behind a memory round trip
+        iter.next(jp);
+        if (iter.valid) iter.next(jp);
+        BwdRowLoads Ln = L;
+        if (iter.valid) bwd_row_loads(jp, iter.it, iter.t, Etab, n_cons, group, lane, Ln);
+        if (L.b != cur_b) {
+            float S;
+            bwd_scale(p, L.b, S, invS);
+            cur_b = L.b;
+        }
+        const int slot = row % kBwdRing;
+        const bool valid = L.u0 + l31 < L.Ub;
+        // the other layout needs the per-cell set-up per lattice column: through this producer's scratch (lanes 0..31)
+        if (half == 0) {
+            *(float4 *)(scratch + l31 * 8) = L.rc;
+            scratch[l31 * 8 + 4] = __int_as_float(valid ? L.lab : -1);
+        }
+        // ---- the slot must be free: every consumer has finished the row that used it kBwdRing rows ago
+        if (row >= kBwdRing && !lds_poll_ge(use_a + 4u * slot, n_cons * (row / kBwdRing))) poisoned = true;
+        char *slotp = ring + (size_t)slot * kBwdSlotBytes;
+        jh8 *frag = (jh8 *)slotp;
+        // ---- A fragments of dh (row = this lane's cell, k = symbol 16 ks + 8 half + e)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float xs[8] = {L.xa[ks][0].x, L.xa[ks][0].y, L.xa[ks][0].z, L.xa[ks][0].w,
+                                 L.xa[ks][1].x, L.xa[ks][1].y, L.xa[ks][1].z, L.xa[ks][1].w};
+            float d[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                d[e] = valid ? bwd_dl(xs[e], 16 * ks + 8 * half + e, V, p.blank, L.rc.x, L.rc.y, L.rc.z, L.rc.w, L.lab) : 0.f;
+            if (poisoned) d[0] = NAN;
+            jh8 hi, lo;
+            split_h8(d, hi, lo);
+            frag[(ks * 2 + 0) * 64 + lane] = hi;
+            frag[(ks * 2 + 1) * 64 + lane] = lo;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            if (lane + 64 * k < n_cons * 32) *(float *)(slotp + 8192 + (lane + 64 * k) * 4) = L.av[k];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scratch written (a wave only reads its own scratch)
+        // ---- B fragments of dW2 (column = symbol l31, k-slot (ks, half, e) = lattice column cd_row(8 ks + e, half))
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float d[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int uu = cd_row(8 * ks + e, half);
+                const float4 q = *(const float4 *)(scratch + uu * 8);
+                const int labu = __float_as_int(scratch[uu * 8 + 4]);
+                d[e] = (L.u0 + uu < L.Ub) ? bwd_dl(L.xb[ks][e], l31, V, p.blank, q.x, q.y, q.z, q.w, labu) : 0.f;
+                dbacc = fmaf(d[e], invS, dbacc);
+            }
+            jh8 hi, lo;
+            split_h8(d, hi, lo);
+            frag[(4 + ks * 2 + 0) * 64 + lane] = hi;
+            frag[(4 + ks * 2 + 1) * 64 + lane] = lo;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the row's fragments and addends are in LDS
+        if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(seq_a + 4u * slot), "v"(row + 1) : "memory");
+        L = Ln;
+        row += 2;
+    }
+    dbacc = half_swap_sum(dbacc);
+    if (want_db && lane < 32) jp.dbpart[((size_t)blk * 2 + pw) * 32 + lane] = poisoned ? NAN : dbacc;
+}
+
+// Consumers own 32 joint units each; a workgroup holds at most kBwdMaxCons of them (register budget: 12 waves per CU), so
+// wider joints are covered by several GROUPS of workgroups, each group walking the whole item list for its share of J.
+constexpr int kBwdMaxCons = 10;
+inline int bwd_groups(int J) { return (J / 32 + kBwdMaxCons - 1) / kBwdMaxCons; }
+
+__global__ __launch_bounds__(768) void joint_bwd_kernel(const JointParams jp) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const LossParams &p = jp.lp;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_groups = (jp.J / 32 + kBwdMaxCons - 1) / kBwdMaxCons;
+    const int n_cons = jp.J / 32 / n_groups;
+    if (jp.tflag[1] != 0.f) return;  // joint_dl_kernel + joint_phase2_kernel (plain f32 MFMAs) run instead
+    const bool slow = jp.tflag[0] != 0.f;  // kernel-uniform
+    char *ring = (char *)lds;                                    // [kBwdRing][10 KB] dlogits fragments + enc addends of a row
+    float *scratch = (float *)(ring + kBwdRing * kBwdSlotBytes); // [2 producers][32 cells][8]
+    int *ctr = (int *)(scratch + 2 * 32 * 8);                    // seq[kBwdRing], use[kBwdRing]
+    if (tid < 2 * kBwdRing) ctr[tid] = 0;
+    __syncthreads();
+    const uint32_t seq_a = (uint32_t)(uintptr_t)((lds_void *)ctr), use_a = seq_a + 4u * kBwdRing;
+
+    // gridDim.x = n_groups * nblk: workgroup -> (group, index within the group); contiguous item range per workgroup
+    const int nblk = gridDim.x / n_groups;
+    const int group = blockIdx.x % n_groups, blk = blockIdx.x / n_groups;
+    const int n_tr = (p.T + kBwdRows - 1) / kBwdRows;
+    const int n_items = n_tr * p.B * jp.n_ut;
+    const int it_lo = (int)((long long)n_items * blk / nblk);
+    const int it_hi = (int)((long long)n_items * (blk + 1) / nblk);
+    if (wave < n_cons) {
+        const int j0 = (group * n_cons + wave) * 32;
+        if (!slow)
+            bwd_consumer<false>(jp, ring, seq_a, use_a, wave, j0, blk, nblk, lane, it_lo, it_hi, n_tr);
+        else
+            bwd_consumer<true>(jp, ring, seq_a, use_a, wave, j0, blk, nblk, lane, it_lo, it_hi, n_tr);
+    } else {
+        bwd_producer(jp, ring, scratch + (wave - n_cons) * 32 * 8, seq_a, use_a, wave - n_cons, n_cons, group, blk, group == 0, lane,
+                     it_lo, it_hi, n_tr);
+    }
+}
+
 // out[i] = sum_p in[p*n + i]  (fixed order)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(float *out, const float *in, int nparts, size_t n) {
+// `flag` (nullable): when flag[1] != 0 the fallback kernels produced the partials and there are `nparts_fb` of them
+__global__ __launch_bounds__(256) void reduce_partials_kernel(float *out, const float *in, int nparts, size_t n,
+                                                              const float *flag = nullptr, int nparts_fb = 0) {
+    if (flag && flag[1] != 0.f) nparts = nparts_fb;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float s = 0.f;
         for (int q = 0; q < nparts; ++q) s += in[(size_t)q * n + i];
@@ -1088,8 +1598,10 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(float *out, const 
 // Deterministic tree: out[i] = sum_p in[p*stride_p + map(i)], 256 threads = 32 outputs x 8 partial lanes.
 // Each partial lane sums its strided share in a fixed order, then the 8 lanes are combined in order.
 template <bool W2MAP>
-__global__ __launch_bounds__(256) void reduce_small_kernel(float *out, const float *in, int nparts, int n, int J, int V) {
+__global__ __launch_bounds__(256) void reduce_small_kernel(float *out, const float *in, int nparts, int n, int J, int V,
+                                                           const float *flag = nullptr, int nparts_fb = 0) {
     __shared__ float sm[8][33];
+    if (flag && flag[1] != 0.f) nparts = nparts_fb;
     const int o = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + o;
     float s = 0.f;
@@ -1119,8 +1631,8 @@ __global__ __launch_bounds__(256) void reduce_small_kernel(float *out, const flo
 // ---------------------------------------------------------------------------------------------
 struct JointLayout {
     WsLayout w;
-    size_t dl, dApart, dCpart, dWpart, dbpart, expE, expP, tflag, W2s, total;
-    int n_ut, TR, n_tr, TS, n_ts;
+    size_t dl, rec, reclab, dApart, dCpart, dWpart, dbpart, expE, expP, tflag, W2s, total;
+    int n_ut, TR, n_tr, TS, n_ts, nC, nW, nDb;
 };
 
 static JointLayout make_joint_layout(int T, int U, int B, int J) {
@@ -1139,10 +1651,18 @@ static JointLayout make_joint_layout(int T, int U, int B, int J) {
         return o;
     };
     L.dl = take((size_t)B * T * U * 32 * sizeof(float));
+    L.rec = take((size_t)B * T * U * sizeof(float4));
+    L.reclab = take((size_t)B * T * U * sizeof(int));
     L.dApart = take((size_t)L.n_ut * B * T * J * sizeof(float));
-    L.dCpart = take((size_t)L.n_ts * B * U * J * sizeof(float));
-    L.dWpart = take((size_t)B * L.n_ut * L.n_ts * J * 32 * sizeof(float));
-    L.dbpart = take(((size_t)B * T * U + 255) / 256 * 32 * sizeof(float));
+    // partial buffers are shared by the single-kernel backward and the two-kernel (f32 fallback / wide J) backward: sized for
+    // whichever needs more, zero-filled before every backward, and always reduced over the larger count
+    L.nC = L.n_ts > kBwdSlots ? L.n_ts : kBwdSlots;
+    L.nW = B * L.n_ut * L.n_ts > kBwdMaxBlocks ? B * L.n_ut * L.n_ts : kBwdMaxBlocks;
+    const size_t gdl = ((size_t)B * T * U + 256 * kDlChunks - 1) / (256 * kDlChunks);
+    L.nDb = (int)(gdl > 2 * (size_t)kBwdMaxBlocks ? gdl : 2 * (size_t)kBwdMaxBlocks);
+    L.dCpart = take((size_t)L.nC * B * U * J * sizeof(float));
+    L.dWpart = take((size_t)L.nW * J * 32 * sizeof(float));
+    L.dbpart = take((size_t)L.nDb * 32 * sizeof(float));
     L.expE = take((size_t)B * T * J * sizeof(float));
     L.expP = take((size_t)B * U * J * sizeof(float));
     L.tflag = take(256);
@@ -1167,7 +1687,7 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
 
 hipError_t launch_reduce_partials(float *out, const float *in, int nparts, size_t n, hipStream_t s) {
     const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, s, out, in, nparts, n);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, s, out, in, nparts, n, nullptr, 0);
     return hipGetLastError();
 }
 
@@ -1218,6 +1738,8 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     char *ws = (char *)workspace;
     jp.enc_proj = enc_proj, jp.pred_proj = pred_proj, jp.W2 = W2, jp.b2 = b2;
     jp.dl = (float *)(ws + L.dl);
+    jp.rec = (float4 *)(ws + L.rec);
+    jp.reclab = (int *)(ws + L.reclab);
     jp.dApart = (float *)(ws + L.dApart);
     jp.dCpart = (float *)(ws + L.dCpart);
     jp.dWpart = (float *)(ws + L.dWpart);
@@ -1266,24 +1788,44 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     }
     if (!(phases & 2) || !d_enc_proj) return hipSuccess;  // score only
 
-    // backward: dlogits tiles, then the scatter through the joint
+    // backward.  Partial buffers first: zero (rows / slots / workgroups a path does not write must read as zero)
+    if (hipMemsetAsync(jp.dApart, 0, (L.dbpart - L.dApart) + (size_t)L.nDb * 32 * sizeof(float), s) != hipSuccess) return hipErrorUnknown;
+    const int n_groups = bwd_groups(J);
+    const bool single = (J / 32) % n_groups == 0 && J <= 640;  // consumers per group must come out even; LDS / wave budget
+    jp.single_bwd = single ? 1 : 0;
     const unsigned gdl = (jp.lp.cells + 256u * kDlChunks - 1u) / (256u * kDlChunks);
-    hipLaunchKernelGGL(joint_dl_kernel, dim3(gdl), dim3(256), 0, s, jp);
+    hipLaunchKernelGGL(joint_dl_kernel, dim3(gdl), dim3(256), 0, s, jp);  // exits at once when joint_bwd_kernel does its work
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (hipMemsetAsync(jp.dApart, 0, L.dbpart - L.dApart, s) != hipSuccess) return hipErrorUnknown;  // dA/dC/dW partials
     const unsigned g2 = (unsigned)B * L.n_ut * (J / 64) * L.n_ts;
-    {
+    int bwd_nblk = 0;
+    if (single) {
+        const int n_cons = J / 32 / n_groups;
+        const int n_items = ((T + kBwdRows - 1) / kBwdRows) * B * L.n_ut;
+        int nblk = device_cu_count() / n_groups;
+        if (nblk > 2 * B * L.n_ut) nblk = 2 * B * L.n_ut;  // an (utterance, u-tile) then spans at most kBwdSlots workgroups
+        if (nblk > n_items) nblk = n_items;
+        if (nblk > kBwdMaxBlocks) nblk = kBwdMaxBlocks;
+        if (nblk < 1) nblk = 1;
+        bwd_nblk = nblk;
+        hipLaunchKernelGGL(joint_cellrec_kernel, dim3((jp.lp.cells + 255u) / 256u), dim3(256), 0, s, jp);
+        const size_t shm_bwd = (size_t)kBwdRing * kBwdSlotBytes + 2 * 32 * 8 * sizeof(float) + 2 * kBwdRing * sizeof(int);
+        if ((e = set_lds(joint_bwd_kernel, shm_bwd)) != hipSuccess) return e;
+        hipLaunchKernelGGL(joint_bwd_kernel, dim3(nblk * n_groups), dim3((n_cons + 2) * 64), shm_bwd, s, jp);
+    } else {
         const size_t shm2s = ((size_t)64 * 36 + 4 * 32 * 36 + 4 * 32 * kStagePad) * sizeof(float) + 8192;
         hipLaunchKernelGGL(joint_phase2s_kernel, dim3(g2), dim3(256), shm2s, s, jp);
-        hipLaunchKernelGGL(joint_phase2_kernel, dim3(g2), dim3(256), shm2, s, jp);  // exits at once unless tflag[1] is set
     }
+    hipLaunchKernelGGL(joint_phase2_kernel, dim3(g2), dim3(256), shm2, s, jp);  // exits at once unless tflag[1] is set
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const size_t nA = (size_t)B * T * J, nC = (size_t)B * U * J;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1024), dim3(256), 0, s, d_enc_proj, jp.dApart, L.n_ut, nA);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1024), dim3(256), 0, s, d_pred_proj, jp.dCpart, L.n_ts, nC);
-    hipLaunchKernelGGL((reduce_small_kernel<true>), dim3((J * V + 31) / 32), dim3(256), 0, s, dW2, jp.dWpart,
-                       B * L.n_ut * L.n_ts, J * V, J, V);
-    hipLaunchKernelGGL((reduce_small_kernel<false>), dim3(1), dim3(256), 0, s, db2, jp.dbpart, (int)gdl, V, J, V);
+    // partial counts: what the single-kernel backward wrote, or (flag set / wide J) what the two-kernel backward wrote
+    const int nC_fb = L.n_ts, nW_fb = B * L.n_ut * L.n_ts, nDb_fb = (int)gdl;
+    const int nC_s = single ? kBwdSlots : nC_fb, nW_s = single ? bwd_nblk : nW_fb, nDb_s = single ? 2 * bwd_nblk : nDb_fb;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1024), dim3(256), 0, s, d_enc_proj, jp.dApart, L.n_ut, nA, nullptr, 0);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1024), dim3(256), 0, s, d_pred_proj, jp.dCpart, nC_s, nC, jp.tflag, nC_fb);
+    hipLaunchKernelGGL((reduce_small_kernel<true>), dim3((J * V + 31) / 32), dim3(256), 0, s, dW2, jp.dWpart, nW_s, J * V, J, V,
+                       jp.tflag, nW_fb);
+    hipLaunchKernelGGL((reduce_small_kernel<false>), dim3(1), dim3(256), 0, s, db2, jp.dbpart, nDb_s, V, J, V, jp.tflag, nDb_fb);
 #ifdef JH_TRACE
     {
         (void)hipStreamSynchronize(s);
