@@ -100,7 +100,9 @@ rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool gpu, siz
 namespace {
 // fill + lsm + sweeps on the caller's stream (stream order is the only dependency between the stages)
 rnntStatus_t run_forward(LossParams &p, const WsLayout &w, hipStream_t s) {
-    if (hipMemsetAsync(p.W, kFillByte, w.A - w.W, s) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
+    // the patch kernels write the log-zero part of W themselves; the wave-per-cell kernels (large or unaligned vocabularies)
+    // rely on a pre-filled W
+    if (!tile_path_ok(p, false) && hipMemsetAsync(p.W, kFillByte, w.A - w.W, s) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
     hipError_t e = launch_lsm(p, s);
     if (e != hipSuccess) return from_hip(e);
     return from_hip(launch_sweeps(p, s));

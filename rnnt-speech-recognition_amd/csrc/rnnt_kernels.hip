@@ -120,6 +120,8 @@ __device__ __forceinline__ void cell_body(const LossParams &p, const Cell &cl, c
 // (a = start & 3, per row) into a 16-byte-aligned LDS row; cells read their logits with scalar LDS reads, and the gradient
 // rows go back with float4 stores for the aligned interior and single floats at the two ragged ends.  Needs B*T*U*V % 4 == 0
 // (then no aligned span reaches past the tensor).
+constexpr int kFillRows = 16;  // W diagonals per fill workgroup of the lsm launch
+
 template <int VP, bool GRAD, bool AL = true>
 __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -128,10 +130,29 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int V = p.V;
     const TileGeom &tg = p.tile;
+    // The lsm launch carries extra workgroups behind its patches that write "log zero" into the W positions no lattice cell
+    // writes (the sweeps read whole rows of the skewed array): kFillRows diagonals of one utterance each.  This replaces a
+    // 37 MB memset in front of the launch (7.5 us at C2) by ~14 MB of stores that overlap with the patches.
+    const uint32_t n_patch_wg = (uint32_t)p.nb * (uint32_t)tg.tiles_t * (uint32_t)tg.tiles_u;
+    if (!GRAD && blockIdx.x >= n_patch_wg) {
+        const uint32_t f = blockIdx.x - n_patch_wg, per = (uint32_t)p.Nr / kFillRows;
+        const int fb = p.b0 + (int)(f / per), chunk = (int)(f % per);
+        const int Tf = length_T(p, fb), Uf = length_U(p, fb);
+        const int Nf = Tf + Uf - 1;
+        float2 *Wb = (float2 *)p.W + (size_t)fb * p.Nr * p.Up;
+        const float2 z = make_float2(kNeg, kNeg);
+        for (int idx = tid; idx < kFillRows * p.Up; idx += 256) {
+            const int rr = idx / p.Up, u = idx - rr * p.Up;
+            const int n = chunk * kFillRows + rr;
+            // lattice cells of diagonal n: u in [lo, hi]; diagonals past the lattice are never read by the sweeps
+            if (n < Nf && (u < max(0, n - Tf + 1) || u > min(n, Uf - 1))) Wb[(size_t)n * p.Up + u] = z;
+        }
+        return;
+    }
     // XCD-aware remap: hand each XCD (blockIdx % 8) a contiguous range of patches (bijective form)
     uint32_t bid;
     {
-        const uint32_t nwg = gridDim.x, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+        const uint32_t nwg = n_patch_wg, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
         const uint32_t q = nwg >> 3, r = nwg & 7u;
         bid = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
         // The gradient pass walks each XCD's range backwards: the logits the lsm pass read LAST are the ones most
@@ -686,7 +707,8 @@ bool tile_path_ok(const LossParams &p, bool grad) {
 template <bool GRAD>
 static hipError_t launch_cell(const LossParams &p, hipStream_t s) {
     if (tile_path_ok(p, GRAD)) {
-        const unsigned blocks = (unsigned)p.nb * p.tile.tiles_t * p.tile.tiles_u;
+        // (the lsm launch fills the log-zero part of W itself: see cell_tile_kernel)
+        const unsigned blocks = (unsigned)p.nb * p.tile.tiles_t * p.tile.tiles_u + (GRAD ? 0u : (unsigned)p.nb * (unsigned)(p.Nr / kFillRows));
         const size_t shm = (size_t)256 * p.V * sizeof(float) + 64;
         if ((p.V % 4) != 0) {
             const size_t pitch = (size_t)((p.tile.UU * p.V + 3 + 3) & ~3);
