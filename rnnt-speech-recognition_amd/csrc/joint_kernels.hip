@@ -314,10 +314,6 @@ __device__ __forceinline__ void split_h8(const float (&x)[8], jh8 &hi, jh8 &lo) 
     }
 }
 __device__ __forceinline__ f32x16 mfma3(const jh8 ahi, const jh8 alo, const jh8 bhi, const jh8 blo, f32x16 acc) {
-#ifdef BWD_EXP_NOMFMA  // timing experiment (results wrong): no matrix work
-    acc[0] += (float)ahi[0] + (float)alo[0] + (float)bhi[0] + (float)blo[0];
-    return acc;
-#endif
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc, 0, 0, 0);
@@ -1301,10 +1297,6 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
             float h[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) h[r] = SLOW ? fast_tanh(aj + ec[r]) : tanh_from_exp(aj, ec[r]);
-#ifdef BWD_EXP_NOVALU  // timing experiment (results wrong): no tanh
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h[r] = aj + ec[r];
-#endif
             BT(1);
             // S dh[u][j] = sum_v (S dl[u][v]) W2[j][v]
             f32x16 dh;
@@ -1344,12 +1336,8 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
             }
             colsum = half_swap_sum(colsum);
             BT(5);
-#ifndef BWD_EXP_NOSTORE
             if (lane < 32)
                 jp.dApart[(((size_t)it.ut * p.B + it.b) * p.T + t) * J + j0 + lane] = poisoned ? NAN : colsum * invS;
-#else
-            if (colsum == 12345.678f) jp.dApart[0] = colsum;
-#endif
         }
     }
     flush_C();
