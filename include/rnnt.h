@@ -53,7 +53,7 @@ typedef struct rnntOptions {
     };
     int blank_label; /* reference never passes it -> op default 0 (utils/vocabulary.py:3-6) */
     int maxT;        /* acts.shape[1] */
-    int maxU;        /* acts.shape[2] = L_max + 1 (utils/preprocessing.py:177-183); at most 1024, see below */
+    int maxU;        /* acts.shape[2] = L_max + 1 (utils/preprocessing.py:177-183); at most 8192, see below */
     bool batch_first; /* must be true: acts is [B, maxT, maxU, V] row-major (1 byte, as upstream) */
 } rnntOptions;
 
@@ -69,9 +69,10 @@ rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool gpu, siz
 
 /* Deliberate limits of this library (upstream has none of them; all are reported as RNNT_STATUS_INVALID_VALUE at
  * enqueue time, never as wrong numbers):
- *   maxU <= 1024       the alpha/beta sweeps keep a whole anti-diagonal in the registers of ONE wavefront (64 lanes x
- *                      up to 16 lattice columns); longer label sequences would need a multi-wave sweep with a barrier
- *                      per diagonal, which is a different (slower) kernel that has not been written;
+ *   maxU <= 8192       up to 1024 the alpha/beta sweeps keep a whole anti-diagonal in the registers of ONE wavefront
+ *                      (64 lanes x up to 16 lattice columns); longer label sequences take a plain multi-wave sweep with
+ *                      the previous diagonal in LDS and a barrier per diagonal (same results, much slower per diagonal);
+ *                      the fused joint entry points stop at maxU = 1024;
  *   B*maxT*maxU < 2^31 cell indices are 32-bit;
  *   workspace 256-byte aligned.
  * Out-of-range per-utterance lengths (T_b < 1, T_b > maxT, L_b < 0, L_b > maxU-1) are device data and cannot be

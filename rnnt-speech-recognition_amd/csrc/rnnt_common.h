@@ -80,7 +80,8 @@ struct WsLayout {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// Lattice columns per lane in the sweeps (one of the instantiated widths); 0 = unsupported (U > 1024).
+constexpr int kMaxU = 8192;  // the wide sweep keeps two diagonals in LDS
+// Lattice columns per lane in the register-resident sweeps (one of the instantiated widths); 0 = U > 1024: wide sweep.
 inline int sweep_K(int U) {
     const int k = (U + 63) / 64;
     const int avail[] = {1, 2, 3, 4, 6, 8, 12, 16};
@@ -95,7 +96,8 @@ inline WsLayout make_layout(int T, int U, int B) {
     WsLayout w;
     w.N = T + U - 1;
     w.Nr = (int)align_up((size_t)w.N, 16);  // multiple of every sweep chunk length G
-    w.Up = 64 * sweep_K(U);  // row stride of the skewed arrays = 64 lanes x K columns
+    // row stride of the skewed arrays = 64 lanes x K columns (U <= 1024), else U rounded up to 64
+    w.Up = sweep_K(U) ? 64 * sweep_K(U) : (int)align_up((size_t)U, 64);
     w.NC = w.Nr / kRebase + 1;
     w.NG = w.Up / 64;
     size_t off = 0;

@@ -23,7 +23,7 @@ static rnntStatus_t check_options(const rnntOptions &o) {
     if (o.loc != RNNT_GPU) return RNNT_STATUS_INVALID_VALUE;  // device-only library: no CPU fallback
     if (!o.batch_first) return RNNT_STATUS_INVALID_VALUE;
     if (o.maxT <= 0 || o.maxU <= 0 || o.blank_label < 0) return RNNT_STATUS_INVALID_VALUE;
-    if (o.maxU > 1024) return RNNT_STATUS_INVALID_VALUE;  // register-resident sweep limit
+    if (o.maxU > kMaxU) return RNNT_STATUS_INVALID_VALUE;  // the wide sweep keeps two diagonals in LDS (include/rnnt.h)
     return RNNT_STATUS_SUCCESS;
 }
 
@@ -200,6 +200,7 @@ static rnntStatus_t joint_call(const float *enc_proj, const float *pred_proj, co
     rnntStatus_t st = check_options(options);
     if (st != RNNT_STATUS_SUCCESS) return st;
     if (options.blank_label >= alphabet_size) return RNNT_STATUS_INVALID_VALUE;
+    if (options.maxU > 1024) return RNNT_STATUS_INVALID_VALUE;  // the fused joint paths are built on the register-resident sweeps
     const bool any_grad = d_enc_proj || d_pred_proj || dW2 || db2;
     if (any_grad && !(d_enc_proj && d_pred_proj && dW2 && db2)) return RNNT_STATUS_INVALID_VALUE;
     if ((phases & 2) && !(phases & 1) && !any_grad) return RNNT_STATUS_INVALID_VALUE;

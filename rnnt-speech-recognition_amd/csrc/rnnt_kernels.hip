@@ -966,6 +966,105 @@ static hipError_t launch_sweep_ld(const LossParams &p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wide sweep (1024 < maxU <= 8192; upstream has no such limit, label sequences this long are rare): one workgroup of 1024
+// threads per (utterance, direction), the previous diagonal in LDS, one barrier per diagonal -- the plain formulation, an
+// order of magnitude slower per diagonal than the register-resident sweeps, with the SAME arithmetic (log2 domain, finite
+// log zero, integer re-basing against the straight-line ridge cell every kRebase diagonals; one offset per block, copied to
+// every 64-column group of the offset tables) and the same outputs, so the gradient pass does not know which sweep ran.
+// ---------------------------------------------------------------------------------------------
+template <bool BETA>
+__global__ __launch_bounds__(1024) void sweep_wide_kernel(const LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int b = p.b0 + (int)blockIdx.x;
+    const int Up = p.Up;
+    const int Tb = length_T(p, b), Ub = length_U(p, b);
+    const int Nb = Tb + Ub - 1, last = Nb - 1;
+    const RidgeLine ridge = make_ridge(Ub, Nb);
+    const float2 *Wb = (const float2 *)p.W + (size_t)b * p.Nr * Up;
+    float *out = (BETA ? p.Bt : p.A) + (size_t)b * p.Nr * Up;
+    float *offs = (BETA ? p.offB : p.offA) + (size_t)b * p.NC * p.NG;
+    float *cur = lds, *nxt = lds + Up;
+    float off = 0.f;  // cumulative integer offset (every thread tracks the same value)
+    const bool bad = lengths_invalid(p, b);
+    auto record = [&](const int kc) {
+        for (int g = tid; g < p.NG; g += 1024) offs[(size_t)kc * p.NG + g] = off;
+    };
+    auto rebase_row = [&](float *row, const int n) {  // row is complete and visible; afterwards so is the re-based row
+        const float mi = rintf(row[ridge.u_at(n)]);
+        __syncthreads();
+        for (int u = tid; u < Up; u += 1024) row[u] -= mi;
+        off += mi;
+        __syncthreads();
+    };
+    if (!BETA) {
+        for (int u = tid; u < Up; u += 1024) {
+            cur[u] = (u == 0) ? 0.f : kNeg;
+            out[u] = cur[u];
+        }
+        record(0);
+        __syncthreads();
+        for (int n = 1; n <= last; ++n) {  // diagonal n from diagonal n - 1 and the edge weights leaving diagonal n - 1
+            const float2 *wrow = Wb + (size_t)(n - 1) * Up;
+            for (int u = tid; u < Up; u += 1024) {
+                const float stay = cur[u] + wrow[u].x;                             // blank: (t-1, u) -> (t, u)
+                const float emit = (u > 0) ? cur[u - 1] + wrow[u - 1].y : kNeg;    // label: (t, u-1) -> (t, u)
+                nxt[u] = lse2(stay, emit);
+            }
+            __syncthreads();
+            if ((n & (kRebase - 1)) == 0) {
+                rebase_row(nxt, n);
+                record(n / kRebase);
+            }
+            for (int u = tid; u < Up; u += 1024) out[(size_t)n * Up + u] = nxt[u];
+            float *t = cur;
+            cur = nxt, nxt = t;
+        }
+        if (tid == 0) {
+            const double ll2 = bad ? (double)NAN : (double)off + (double)cur[Ub - 1] + (double)Wb[(size_t)last * Up + Ub - 1].x;
+            p.ll[2 * b] = ll2;
+            p.costs[b] = (float)(-ll2 * 0.6931471805599453);
+        }
+    } else {
+        for (int u = tid; u < Up; u += 1024) cur[u] = (u == Ub - 1) ? 0.f : kNeg;  // the virtual terminal node (T_b, U_b - 1)
+        __syncthreads();
+        for (int n = last; n >= 0; --n) {  // diagonal n from diagonal n + 1 and the edge weights leaving diagonal n
+            const float2 *wrow = Wb + (size_t)n * Up;
+            for (int u = tid; u < Up; u += 1024) {
+                const float stay = cur[u] + wrow[u].x;
+                const float emit = ((u + 1 < Up) ? cur[u + 1] : kNeg) + wrow[u].y;
+                nxt[u] = lse2(stay, emit);
+            }
+            __syncthreads();
+            if ((n & (kRebase - 1)) == kRebase - 1 || n == last) {
+                rebase_row(nxt, n);
+                record(n / kRebase);
+            }
+            for (int u = tid; u < Up; u += 1024) out[(size_t)n * Up + u] = nxt[u];
+            float *t = cur;
+            cur = nxt, nxt = t;
+        }
+        if (tid == 0) {
+            p.ll[2 * b + 1] = bad ? (double)NAN : (double)off + (double)cur[0];
+            if (bad) p.costs[b] = NAN;
+        }
+    }
+}
+
+static hipError_t launch_sweep_wide(const LossParams &p, hipStream_t s) {
+    const size_t shm = (size_t)2 * p.Up * sizeof(float);
+    hipError_t e;
+    if (shm > 64 * 1024) {
+        if ((e = hipFuncSetAttribute((const void *)sweep_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void *)sweep_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)) != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((sweep_wide_kernel<false>), dim3(p.nb), dim3(1024), shm, s, p);
+    hipLaunchKernelGGL((sweep_wide_kernel<true>), dim3(p.nb), dim3(1024), shm, s, p);  // (the gradient pass needs both; the
+    // alpha launch is not a dependency of the beta launch, but one stream keeps the caller's ordering contract simple)
+    return hipGetLastError();
+}
+
 // Chunk length G (diagonals per LDS-DMA batch): the longest whose ring fits the LDS (measured at C2: G = 16 beats 8 by
 // 3 % of the step, 4 loses 5 %).
 hipError_t launch_sweeps(const LossParams &p, hipStream_t s) {
@@ -978,7 +1077,7 @@ hipError_t launch_sweeps(const LossParams &p, hipStream_t s) {
         case 8: return launch_sweep_ld<8, 8>(p, s);
         case 12: return launch_sweep_ld<12, 4>(p, s);
         case 16: return launch_sweep_ld<16, 4>(p, s);
-        default: return hipErrorInvalidValue;  // maxU > 1024 is outside the register-resident sweep
+        default: return (p.U <= kMaxU) ? launch_sweep_wide(p, s) : hipErrorInvalidValue;  // 1024 < maxU <= 8192
     }
 }
 

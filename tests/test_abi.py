@@ -88,8 +88,10 @@ def test_argument_validation_needs_no_device(lib):
     fake = ctypes.c_void_p(256)  # never dereferenced: rejected before any launch
     cpu = _lib.make_options(0, 0, 10, 5, loc=_lib.RNNT_CPU)
     assert lib.compute_rnnt_loss(fake, None, fake, fake, fake, 28, 4, fake, fake, cpu) == 2  # no CPU fallback
-    big = _lib.make_options(0, 0, 10, 2000)
-    assert lib.compute_rnnt_loss(fake, None, fake, fake, fake, 28, 4, fake, fake, big) == 2  # maxU > 1024
+    big = _lib.make_options(0, 0, 10, 9000)
+    assert lib.compute_rnnt_loss(fake, None, fake, fake, fake, 28, 4, fake, fake, big) == 2  # maxU > 8192
+    n1, n2 = _lib.workspace_bytes(10, 1024, 2), _lib.workspace_bytes(10, 1100, 2)  # the wide-sweep layout (row stride U rounded to 64)
+    assert n2 > n1
     blank_oob = _lib.make_options(0, 28, 10, 5)
     assert lib.compute_rnnt_loss(fake, None, fake, fake, fake, 28, 4, fake, fake, blank_oob) == 2
     assert lib.compute_rnnt_loss(fake, None, fake, fake, fake, 0, 4, fake, fake, o) == 2

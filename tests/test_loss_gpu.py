@@ -213,6 +213,15 @@ def test_widest_and_longest_lattices(shape):
     check(acts, labels, il, ll)
 
 
+@pytest.mark.parametrize("shape", [(2, 20, 1100, 4), (1, 9, 2049, 8), (2, 300, 1030, 4)])
+def test_label_sequences_beyond_1024_take_the_wide_sweep(shape):
+    """1024 < maxU <= 8192: the multi-wave sweep (previous diagonal in LDS, a barrier per diagonal) behind the same
+    lsm / gradient kernels; upstream has no limit on U, this is what keeps the boundary a drop-in there."""
+    B, T, U, V = shape
+    acts, labels, il, ll = make_case(B, T, U, V, True, seed=T + U)
+    check(acts, labels, il, ll)
+
+
 def test_back_to_back_calls_on_one_stream():
     """Several calls in flight on one stream, different workspaces/inputs: stream order is the only dependency."""
     dev = torch.device("cuda:0")
