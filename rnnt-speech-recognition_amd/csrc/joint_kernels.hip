@@ -54,6 +54,10 @@ __device__ __forceinline__ float fast_tanh(float x) {
 __device__ __forceinline__ float tanh_from_exp(float ea, float ec) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(fmaf(ea, ec, 1.0f));
 }
+// r = (1 - tanh(a + c)) / 2 = 1 / (1 + e^{2(a + c)}), the quantity joint_fwd_kernel puts on the matrix units (same tables, same
+// saturation behaviour: 0 for an overflowing product, 1 for an underflowing one)
+__device__ __forceinline__ float r_from_exp(float ea, float ec) { return __builtin_amdgcn_rcpf(fmaf(ea, ec, 1.0f)); }
+__device__ __forceinline__ float fast_r(float x) { return __builtin_amdgcn_rcpf(1.0f + jex2(x * 2.8853900817779268f)); }
 constexpr float kExpTabLimit = 43.0f;
 constexpr float kSplitLimit = 60000.0f;  // |W2| beyond this leaves binary16's range (65504): no hi/lo split
 // row of the 32x32 MFMA C/D tile held in register `reg` of a lane in half `half` (= lane >> 5)
@@ -84,6 +88,7 @@ struct JointParams {
                          // [1] != 0: some |W2| is outside the binary16 range: the plain f32 MFMA kernels run instead of the
                          //           split-precision ones (both are enqueued; the one the flag does not select exits at once)
     jf16 *W2s;           // [J/16][2 (hi, lo)][64 lanes][8]: W2 as binary16 hi + lo parts in MFMA B-fragment order (phase 1s)
+    float *b2s;          // [2][32]: b2[v] + sum_j W2[j][v] as an f32 hi + lo pair (-1e30 / 0 beyond V), for joint_fwd_kernel
 #ifdef JH_TRACE
     long long *trace;    // dev builds only: s_memtime stamps of one workgroup of phase 1 and one of phase 2
 #endif
@@ -104,6 +109,21 @@ __global__ __launch_bounds__(256) void joint_prep_kernel(const JointParams jp) {
         else jp.expP[i - nE] = ex;
     }
     if (__any(big) && (threadIdx.x & 63) == 0) jp.tflag[0] = 1.0f;
+    if (blockIdx.x == 0) {  // joint_fwd_kernel accumulates r = (1 - h) / 2: logits = (b2 + sum_j W2) - 2 W2^T r
+        __shared__ double part[8][32];
+        const int v = threadIdx.x & 31, q = threadIdx.x >> 5;
+        double sum = 0.0;
+        if (v < p.V)
+            for (int j = q; j < jp.J; j += 8) sum += (double)jp.W2[(size_t)j * p.V + v];
+        part[q][v] = sum;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            sum = (v < p.V) ? (double)jp.b2[v] : -1.0e30;
+            for (int k = 0; k < 8; ++k) sum += part[k][v];
+            const float hi = (float)sum;
+            jp.b2s[v] = hi, jp.b2s[32 + v] = (v < p.V) ? (float)(sum - (double)hi) : 0.f;
+        }
+    }
     // W2 = hi + lo with both parts binary16 (22 significand bits together), laid out as the B fragments of
     // v_mfma_f32_32x32x16_f16: lane l of k-step ks holds W2[16 ks + 8 (l >> 5) + 0..7][l & 31] (zero beyond V)
     const int nfrag = (jp.J / 16) * 64;
@@ -297,7 +317,20 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
 typedef _Float16 jh2 __attribute__((ext_vector_type(2)));
 // x -> binary16 hi (round to nearest even) and lo = binary16(x - hi).  The residual is one v_fma_mix_f32 per value: it reads
 // the binary16 operand straight out of the packed register (no v_cvt_f32_f16), hi * -1 + x is exact in f32.
+// (v_fma_mixlo_f16 / v_fma_mixhi_f16 would also do the final rounding, but they issue at half rate on gfx950 -- 8.2 against
+// 4.3 cycles, profiles/r02_probe_rates.txt -- and lose to v_fma_mix_f32 + half a v_cvt_pk_f16_f32.)
+// NOTE on hazards: the compiler does not see into inline asm, so it cannot insert the wait state gfx950 needs between a
+// transcendental (v_rcp_f32, v_exp_f32 ...) and a VALU instruction that reads its result.  Both forms leave the hi conversion
+// to the compiler, which therefore always sits between a reciprocal and the asm residuals (they depend on it); the _trans
+// name marks the call sites whose inputs come straight out of v_rcp_f32.
 __device__ __forceinline__ void split_pair(const float x0, const float x1, jh2 &hi, jh2 &lo) {
+    hi[0] = (jf16)x0, hi[1] = (jf16)x1;
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(x1));
+    lo[0] = (jf16)l0, lo[1] = (jf16)l1;
+}
+__device__ __forceinline__ void split_pair_trans(const float x0, const float x1, jh2 &hi, jh2 &lo) {
     hi[0] = (jf16)x0, hi[1] = (jf16)x1;
     float l0, l1;
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(x0));
@@ -485,43 +518,61 @@ __device__ __forceinline__ float row_bcast(const float x) {
 template <int E, bool SLOW>
 __device__ __forceinline__ void fwd_h_pair(const float ea0, const float ea1, const float ec, float &h0, float &h1) {
     const float a0 = row_bcast<E>(ea0), a1 = row_bcast<E>(ea1);
-    if (!SLOW) {
-        h0 = tanh_from_exp(a0, ec), h1 = tanh_from_exp(a1, ec);
+    if (!SLOW) {  // r = (1 - h) / 2, see fwd_row_epilogue
+        h0 = r_from_exp(a0, ec), h1 = r_from_exp(a1, ec);
     } else {
-        h0 = fast_tanh(a0 + ec), h1 = fast_tanh(a1 + ec);
+        h0 = fast_r(a0 + ec), h1 = fast_r(a1 + ec);
     }
 }
-// The J-long product of one row pair: logits^T += W2^T . h^T, A = W2 fragments (row = symbol), B = h (column = cell).
+// The J-long product of one row pair: acc += W2^T . r^T, A = W2 fragments (row = symbol), B = r (column = cell), with
+// r = (1 - h) / 2 = 1 / (1 + e^{2(a + c)}) (see fwd_row_epilogue).  Measured alternatives (profiles/r02_notes.md): building
+// step ks + 1's fragments between the MFMAs of step ks (one MFMA per ~13 VALU instructions, pinned with sched_barrier) is
+// slower (621 vs 605 us): the MFMAs do not hide behind freshly written operands the way they do in an operand-invariant probe.
+struct FwdFrags {
+    jh8 hi0, lo0, hi1, lo1;  // B fragments of the two rows, binary16 hi + lo parts
+};
+// units E, E + 1 (already evaluated: row 0 in x0, row 1 in x1) -> one packed hi / lo dword per row
+template <int E>
+__device__ __forceinline__ void fwd_split_quad(const float (&x0)[2], const float (&x1)[2], FwdFrags &f) {
+    jh2 h, l;
+    split_pair_trans(x0[0], x0[1], h, l);
+    f.hi0[E] = h[0], f.hi0[E + 1] = h[1], f.lo0[E] = l[0], f.lo0[E + 1] = l[1];
+    split_pair_trans(x1[0], x1[1], h, l);
+    f.hi1[E] = h[0], f.hi1[E + 1] = h[1], f.lo1[E] = l[0], f.lo1[E + 1] = l[1];
+}
 template <bool SLOW>
 __device__ __forceinline__ void fwd_row_pair(const int J, const float *e0, const float *e1, const char *ct_row, const uint32_t ct_swz,
                                              const char *wlane, const int half, f32x16 &acc0, f32x16 &acc1) {
+    const int n = J / 16;
     float ea0 = e0[0], ea1 = e1[0];
-    for (int ks = 0; ks < J / 16; ++ks) {
-        const float cur0 = ea0, cur1 = ea1;
-        if (ks + 1 < J / 16) ea0 = e0[16 * (ks + 1)], ea1 = e1[16 * (ks + 1)];  // next k-step's addends: one dword per lane
+    for (int ks = 0; ks < n; ++ks) {
+        const float a0 = ea0, a1 = ea1;
+        if (ks + 1 < n) ea0 = e0[16 * (ks + 1)], ea1 = e1[16 * (ks + 1)];  // next k-step's addends: one dword per lane
         const uint32_t c0 = (uint32_t)(4 * ks + 2 * half);
         const float4 c4a = *(const float4 *)(ct_row + (size_t)(c0 ^ ct_swz) * 16);
         const float4 c4b = *(const float4 *)(ct_row + (size_t)((c0 + 1u) ^ ct_swz) * 16);
         const jh8 wh = *(const jh8 *)(wlane + (size_t)(ks * 2 + 0) * 1024);
         const jh8 wl = *(const jh8 *)(wlane + (size_t)(ks * 2 + 1) * 1024);
-        float h0[8], h1[8];
-        fwd_h_pair<0, SLOW>(cur0, cur1, c4a.x, h0[0], h1[0]);
-        fwd_h_pair<1, SLOW>(cur0, cur1, c4a.y, h0[1], h1[1]);
-        fwd_h_pair<2, SLOW>(cur0, cur1, c4a.z, h0[2], h1[2]);
-        fwd_h_pair<3, SLOW>(cur0, cur1, c4a.w, h0[3], h1[3]);
-        fwd_h_pair<4, SLOW>(cur0, cur1, c4b.x, h0[4], h1[4]);
-        fwd_h_pair<5, SLOW>(cur0, cur1, c4b.y, h0[5], h1[5]);
-        fwd_h_pair<6, SLOW>(cur0, cur1, c4b.z, h0[6], h1[6]);
-        fwd_h_pair<7, SLOW>(cur0, cur1, c4b.w, h0[7], h1[7]);
-        jh8 hi0, lo0, hi1, lo1;
-        split_h8(h0, hi0, lo0);
-        split_h8(h1, hi1, lo1);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hi0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hi1, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, lo0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, lo1, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hi0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hi1, acc1, 0, 0, 0);
+        FwdFrags f;
+        float x0[2], x1[2];
+        fwd_h_pair<0, SLOW>(a0, a1, c4a.x, x0[0], x1[0]);
+        fwd_h_pair<1, SLOW>(a0, a1, c4a.y, x0[1], x1[1]);
+        fwd_split_quad<0>(x0, x1, f);
+        fwd_h_pair<2, SLOW>(a0, a1, c4a.z, x0[0], x1[0]);
+        fwd_h_pair<3, SLOW>(a0, a1, c4a.w, x0[1], x1[1]);
+        fwd_split_quad<2>(x0, x1, f);
+        fwd_h_pair<4, SLOW>(a0, a1, c4b.x, x0[0], x1[0]);
+        fwd_h_pair<5, SLOW>(a0, a1, c4b.y, x0[1], x1[1]);
+        fwd_split_quad<4>(x0, x1, f);
+        fwd_h_pair<6, SLOW>(a0, a1, c4b.z, x0[0], x1[0]);
+        fwd_h_pair<7, SLOW>(a0, a1, c4b.w, x0[1], x1[1]);
+        fwd_split_quad<6>(x0, x1, f);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, f.hi0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, f.hi1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, f.lo0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, f.lo1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, f.hi0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, f.hi1, acc1, 0, 0, 0);
     }
 }
 
@@ -535,15 +586,24 @@ __device__ __forceinline__ float half_swap_sum(const float v) {
 }
 
 // lsm outputs + parked logits of one lattice row held in the transposed C/D layout (lane = cell u0 + l31, register r = symbol
-// cd_row(r, half)); `bias` carries b2 (and -1e30 for the pad symbols), `rsel_b` / `rsel_l` the register that holds this lane's
-// blank / label logit, or -1 when it lives in the other half (or there is no label edge).
-__device__ __forceinline__ void fwd_row_epilogue(const JointParams &jp, const f32x16 &acc, const float (&bias)[16],
+// cd_row(r, half)).  `acc` holds W2^T r with r = (1 - h) / 2 = 1 / (1 + e^{2(a + c)}): the main loop saves the multiply-add that
+// turns the reciprocal into tanh, and logits = (b2 + sum_j W2[j]) - 2 acc with the first term tabulated by joint_prep_kernel as an
+// f32 hi + lo pair (-1e30 for the pad symbols).  Rounding: the split products bound the error of acc by ~2^-22 sum_j |W2[j][v]| r_j
+// -- at most twice the bound of the h form, and of the order of an f32 matrix product's.  `rsel_b` / `rsel_l`: the register
+// that holds this lane's blank / label logit, or -1 when it lives in the other half (or there is no label edge).
+__device__ __forceinline__ void fwd_row_epilogue(const JointParams &jp, const f32x16 &acc,
                                                  const int rsel_b, const int rsel_l, const int b, const int t,
                                                  const int u, const int Tb, const int Ub, const int half) {
     const LossParams &p = jp.lp;
     float x[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = acc[r] + bias[r];
+    for (int g = 0; g < 4; ++g) {  // registers 4g .. 4g+3 are the four consecutive symbols 8g + 4 half + 0..3
+        const float4 bh = *(const float4 *)(jp.b2s + 8 * g + 4 * half), bl = *(const float4 *)(jp.b2s + 32 + 8 * g + 4 * half);
+        x[4 * g + 0] = fmaf(acc[4 * g + 0], -2.0f, bh.x) + bl.x;
+        x[4 * g + 1] = fmaf(acc[4 * g + 1], -2.0f, bh.y) + bl.y;
+        x[4 * g + 2] = fmaf(acc[4 * g + 2], -2.0f, bh.z) + bl.z;
+        x[4 * g + 3] = fmaf(acc[4 * g + 3], -2.0f, bh.w) + bl.w;
+    }
     float m = x[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fmaxf(m, x[r]);
@@ -596,12 +656,6 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
     for (int pc = wave; pc < J / 8; pc += kFwdWaves)  // W2 fragment image: J/8 pieces of 1 KB, once per workgroup
         __builtin_amdgcn_global_load_lds((jglb_cvoid *)((const char *)jp.W2s + (size_t)pc * 1024 + lane * 16),
                                          (lds_void *)(Wimg + pc * 1024), 16, 0, 0);
-    float bias[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int v = cd_row(r, half);
-        bias[r] = (v < V) ? jp.b2[v] : kNeg;
-    }
     const int rsel_b = (((p.blank >> 2) & 1) == half) ? (p.blank & 3) + 4 * (p.blank >> 3) : -1;
     const uint32_t ct_lane = (uint32_t)(l31 * cpr);          // this lane's Ct row, in chunks
     const uint32_t ct_swz = (uint32_t)(l31 & 15);
@@ -656,8 +710,8 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
             fwd_row_pair<false>(J, e0, e1, ct_row, ct_swz, wlane, half, acc0, acc1);
         else
             fwd_row_pair<true>(J, e0, e1, ct_row, ct_swz, wlane, half, acc0, acc1);
-        fwd_row_epilogue(jp, acc0, bias, rsel_b, rsel_l, b, t0, u, Tb, Ub, half);
-        if (two) fwd_row_epilogue(jp, acc1, bias, rsel_b, rsel_l, b, t0 + 1, u, Tb, Ub, half);
+        fwd_row_epilogue(jp, acc0, rsel_b, rsel_l, b, t0, u, Tb, Ub, half);
+        if (two) fwd_row_epilogue(jp, acc1, rsel_b, rsel_l, b, t0 + 1, u, Tb, Ub, half);
     }
 }
 
@@ -1653,7 +1707,7 @@ static JointLayout make_joint_layout(int T, int U, int B, int J) {
     L.dbpart = take((size_t)L.nDb * 32 * sizeof(float));
     L.expE = take((size_t)B * T * J * sizeof(float));
     L.expP = take((size_t)B * U * J * sizeof(float));
-    L.tflag = take(256);
+    L.tflag = take(512);  // flags (zeroed per call) + the b2s table
     L.W2s = take((size_t)J * 32 * 2 * sizeof(jf16));
     L.total = off;
     return L;
@@ -1734,6 +1788,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     jp.dbpart = (float *)(ws + L.dbpart);
     jp.d_enc_proj = d_enc_proj, jp.d_pred_proj = d_pred_proj, jp.dW2 = dW2, jp.db2 = db2;
     jp.expE = (float *)(ws + L.expE), jp.expP = (float *)(ws + L.expP), jp.tflag = (float *)(ws + L.tflag);
+    jp.b2s = jp.tflag + 64;
     jp.W2s = (jf16 *)(ws + L.W2s);
 #ifdef JH_TRACE
     static long long *trace_dev = nullptr;
