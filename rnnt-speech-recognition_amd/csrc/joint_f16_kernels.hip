@@ -528,7 +528,7 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
     for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accC[q][r] = 0.f;
-    const float invS = jp.scal[1];
+    const float c4 = 4.0f * jp.scal[1];  // 4 / S: (1 - h^2) is formed as 4 r (1 - r), S is the dlogits scale
     const int NK = V >> 6;
 
     // DMA descriptors of this wave: wave-instructions i = wave + 8 k (k = 0..5) of the 48 that fill one stage.  i < 32 are
@@ -672,22 +672,39 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
                     const int j = j0 + wn * 64 + ni * 32 + n;
                     const float ej = ejv[mi][ni];
                     float colsum = 0.f;
-                    float hh[16];
+                    // q = (1 - h^2) / 4 = r (1 - r) with r = 1 / (1 + e^{2(a + c)}): multiply-add, reciprocal, multiply-add;
+                    // the factor 4 / S is applied once per output (column sums here, accC after the row loop)
+                    float q[16];
                     if (!slow) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) hh[r] = htanh2(ej, pr[ni][r]);
+                        for (int r = 0; r < 16; ++r) {
+                            const float rr = __builtin_amdgcn_rcpf(fmaf(ej, pr[ni][r], 1.0f));
+                            q[r] = fmaf(-rr, rr, rr);
+                        }
                     } else {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) hh[r] = htanh(ej + pr[ni][r]);
+                        for (int r = 0; r < 16; ++r) {
+                            const float h = htanh(ej + pr[ni][r]);
+                            q[r] = 0.25f * fmaf(-h, h, 1.0f);
+                        }
                     }
+                    if (u0 + 32 <= Ub) {  // workgroup-uniform: every column of the tile is a real cell
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float h = hh[r];
-                        float dz = acc[mi][ni][r] * invS * (1.0f - h * h);
-                        dz = ((vmask >> r) & 1u) ? dz : 0.f;
-                        accC[ni][r] += dz;
-                        colsum += dz;
+                        for (int r = 0; r < 16; ++r) {
+                            const float dz = acc[mi][ni][r] * q[r];
+                            accC[ni][r] += dz;
+                            colsum += dz;
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float dz = acc[mi][ni][r] * q[r];
+                            dz = ((vmask >> r) & 1u) ? dz : 0.f;
+                            accC[ni][r] += dz;
+                            colsum += dz;
+                        }
                     }
+                    colsum *= c4;
                     colsum += __shfl_xor(colsum, 32);
                     if (lane < 32) jp.dApart[(((size_t)ut * p.B + b) * p.T + t) * J + j] = colsum;
                 }
@@ -700,7 +717,7 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[(((wm * 2 + wn) * 2 + ni) * 32 + cdrow(r, half)) * 33 + n] = accC[ni][r];
+        for (int r = 0; r < 16; ++r) red[(((wm * 2 + wn) * 2 + ni) * 32 + cdrow(r, half)) * 33 + n] = accC[ni][r] * c4;
     __syncthreads();
     for (int e = tid; e < 32 * 128; e += 512) {
         const int uu = e >> 7, jj = e & 127, wn2 = jj >> 6, ni = (jj >> 5) & 1, nn = jj & 31;
