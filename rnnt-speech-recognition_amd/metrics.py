@@ -59,17 +59,17 @@ def token_error_rate(y_true, decoded, tok_fn: Callable[[str], list], idx_to_text
 
 def build_accuracy_fn(decode_fn):
     """utils/metrics.py:62-77: Accuracy(inputs, y_true) on the first utterance."""
-    def accuracy(inputs, y_true) -> float:
+    def Accuracy(inputs, y_true) -> float:  # the name is the key of the results dict (run_rnnt.py:323-324, :366)
         first = _as_list(y_true[0])
         decoded = decode_fn(inputs, max_length=len(first))
         return 1.0 - error_rate(first, decoded)
-    return accuracy
+    return Accuracy
 
 
 def build_wer_fn(decode_fn, idx_to_text: Callable):
     """utils/metrics.py:80-92: WER(inputs, y_true) on the first utterance, tokens = space-separated words."""
-    def wer(inputs, y_true) -> float:
+    def WER(inputs, y_true) -> float:
         first = _as_list(y_true[0])
         decoded = _as_list(decode_fn(inputs, max_length=len(first)))
         return token_error_rate(first, decoded, tok_fn=lambda t: t.split(" "), idx_to_text=idx_to_text)
-    return wer
+    return WER

@@ -81,6 +81,91 @@ class TrainStep:
             save_weights(self.model, path)
 
 
+class _Mean:
+    """tf.keras.metrics.Mean: running average of the values it is called with."""
+    def __init__(self):
+        self.total, self.count = 0.0, 0
+
+    def __call__(self, value):
+        self.total += float(value)
+        self.count += 1
+
+    def result(self) -> float:
+        return self.total / self.count if self.count else 0.0
+
+
+def run_evaluate(step: "TrainStep", eval_batches: Iterable, metrics: Optional[Iterable[Callable]] = None,
+                 to_device=None) -> Tuple[float, Dict[str, float]]:
+    """run_rnnt.py:380-452: the mean over the evaluation batches of (loss, every metric).  `eval_batches` yields this
+    rank's 5-tuples (features.padded_batch / records.batches); `to_device` moves one to the model's device."""
+    metrics = list(metrics or [])
+    loss_object = _Mean()
+    metric_objects = {fn.__name__: _Mean() for fn in metrics}
+    for inputs in eval_batches:
+        if to_device is not None:
+            inputs = to_device(inputs)
+        loss, results = step.evaluate(*inputs, metrics=metrics)
+        loss_object(loss)
+        for name, value in results.items():
+            metric_objects[name](value)
+    return loss_object.result(), {name: obj.result() for name, obj in metric_objects.items()}
+
+
+def run_training(step: "TrainStep", train_batches: Callable[[], Iterable], n_epochs: int, steps_per_log: int = 1,
+                 steps_per_checkpoint: int = 1000, eval_batches: Optional[Callable[[], Iterable]] = None,
+                 eval_metrics: Optional[Iterable[Callable]] = None, checkpoint_template: Optional[str] = None,
+                 to_device=None, log: Callable[[str], None] = print) -> Dict[str, float]:
+    """The reference's training loop around the step (run_rnnt.py:300-377), line for line in behaviour:
+
+      * `train_batches()` / `eval_batches()` return a fresh iterator per epoch / per evaluation (a tf.data dataset is
+        re-iterable; a generator is not);
+      * evaluation + checkpoint BEFORE every step whose global index is a multiple of `steps_per_checkpoint` -- hence also
+        before the first step -- when an evaluation set is given (:347-349), and once more after the last epoch (:377);
+      * every `steps_per_log` steps one line with the epoch's running mean loss and the step time (:360-365), one
+        'EPOCH RESULTS' line per epoch (:372-375), one 'VALIDATION RESULTS' line per evaluation (:314-318);
+      * checkpoints are weights only, named `checkpoint_template.format(step=..., val_loss=...)` (:326-329).
+    TensorBoard summaries (:320-325, :367-370) are not written.  Returns the last epoch's mean loss and the last
+    validation results."""
+    is_rank0 = not dist.is_initialized() or dist.get_rank(step.group) == 0
+    say = log if is_rank0 else (lambda _msg: None)
+    last: Dict[str, float] = {}
+
+    def checkpoint_model(global_step: int) -> None:
+        t0 = time.time()
+        eval_loss, results = run_evaluate(step, eval_batches(), eval_metrics, to_device)
+        line = "VALIDATION RESULTS: Time: {:.4f}, Loss: {:.4f}".format(time.time() - t0, eval_loss)
+        for name, value in results.items():
+            line += ", {}: {:.4f}".format(name, value)
+        say(line)
+        last.update({"val_loss": eval_loss, **{"val_" + k: v for k, v in results.items()}})
+        if checkpoint_template is not None:
+            path = checkpoint_template.format(step=global_step, val_loss=eval_loss)
+            say("Saving checkpoint {}".format(path))
+            step.save_checkpoint(path)
+
+    say("Starting training.")
+    global_step = 0
+    for epoch in range(n_epochs):
+        loss_object = _Mean()
+        for batch, inputs in enumerate(train_batches()):
+            if global_step % steps_per_checkpoint == 0 and eval_batches is not None:
+                checkpoint_model(global_step)
+            if to_device is not None:
+                inputs = to_device(inputs)
+            out = step(*inputs)
+            loss_object(out["loss"])
+            if global_step % steps_per_log == 0:
+                say("Epoch: {}, Batch: {}, Global Step: {}, Step Time: {:.4f}, Loss: {:.4f}".format(
+                    epoch, batch, global_step, out["step_time"], loss_object.result()))
+            global_step += 1
+        say("EPOCH RESULTS: Loss: {:.4f}".format(loss_object.result()))
+        last["loss"] = loss_object.result()
+    if eval_batches is not None:
+        checkpoint_model(global_step)
+    last["steps"] = float(global_step)
+    return last
+
+
 def _flat_collective_(tensors: Sequence[torch.Tensor], fn) -> None:
     ts = [t for t in tensors if t is not None and t.numel() > 0]
     if not ts:

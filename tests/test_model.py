@@ -1,4 +1,6 @@
 """The callers of the hot path: model surface on CPU, train step on GPU."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -99,9 +101,9 @@ def test_evaluate_runs_the_metric_builders(monkeypatch):
     wer = pkg.metrics.build_wer_fn(dec, lambda ids: enc.decode(ids))
     loss, res = step.evaluate(*batch, metrics=[acc, wer])
     assert loss == pytest.approx(6.0)
-    assert set(res) == {"accuracy", "wer"} and all(0.0 <= v <= 1.0 or v >= 0 for v in res.values())
+    assert set(res) == {"Accuracy", "WER"} and all(0.0 <= v <= 1.0 or v >= 0 for v in res.values())
     # the same numbers as calling the metric on its own (first utterance of the shard, run_rnnt.py:223-230)
-    assert res["accuracy"] == pytest.approx(acc(batch[0], batch[4]))
+    assert res["Accuracy"] == pytest.approx(acc(batch[0], batch[4]))
 
 
 @pytest.mark.gpu
@@ -187,3 +189,80 @@ def test_c3_end_to_end_step_at_baseline_size():
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
     ev, _ = step.evaluate(*batch)
     assert np.isfinite(ev)
+
+
+def test_training_loop_follows_the_reference_schedule(tmp_path):
+    """run_rnnt.py:300-377 with a stand-in step (the loop itself needs no GPU): evaluation + checkpoint before every
+    steps_per_checkpoint-th step (also before step 0) and once after the last epoch; log lines; epoch means."""
+    from rnnt_speech_recognition_amd import train as tr
+
+    class FakeStep:
+        group = None
+
+        def __init__(self):
+            self.n, self.saved, self.evals = 0, [], 0
+
+        def __call__(self, *inputs):
+            self.n += 1
+            return {"loss": float(inputs[0]), "step_time": 0.001, "step": self.n}
+
+        def evaluate(self, *inputs, metrics=None):
+            self.evals += 1
+            return float(inputs[0]) * 2, {fn.__name__: fn(None, None) for fn in (metrics or [])}
+
+        def save_checkpoint(self, path):
+            self.saved.append(path)
+
+    def Accuracy(_x, _y):
+        return 0.25
+
+    step, lines = FakeStep(), []
+    batches = lambda: iter([(1.0, 0, 0, 0, 0), (2.0, 0, 0, 0, 0), (6.0, 0, 0, 0, 0)])
+    evals = lambda: iter([(5.0, 0, 0, 0, 0), (7.0, 0, 0, 0, 0)])
+    out = tr.run_training(step, batches, n_epochs=2, steps_per_log=2, steps_per_checkpoint=4, eval_batches=evals,
+                          eval_metrics=[Accuracy], checkpoint_template=str(tmp_path / "ck_{step}_{val_loss:.1f}.pt"),
+                          log=lines.append)
+    assert step.n == 6 and out["steps"] == 6 and out["loss"] == pytest.approx(3.0)
+    # checkpoints before global steps 0 and 4 and after the last epoch: 3 evaluations of 2 batches each
+    assert step.evals == 6 and [p.split("ck_")[1] for p in step.saved] == ["0_12.0.pt", "4_12.0.pt", "6_12.0.pt"]
+    assert out["val_loss"] == pytest.approx(12.0) and out["val_Accuracy"] == pytest.approx(0.25)
+    assert lines[0] == "Starting training." and lines[1].startswith("VALIDATION RESULTS: Time: ")
+    assert "Loss: 12.0000, Accuracy: 0.2500" in lines[1] and lines[2].startswith("Saving checkpoint ")
+    logs = [l for l in lines if l.startswith("Epoch: ")]
+    assert [l.split(", Step Time")[0] for l in logs] == ["Epoch: 0, Batch: 0, Global Step: 0", "Epoch: 0, Batch: 2, Global Step: 2",
+                                                        "Epoch: 1, Batch: 1, Global Step: 4"]
+    assert logs[1].endswith("Loss: 3.0000")  # running mean of 1, 2, 6 within the epoch
+    assert [l for l in lines if l.startswith("EPOCH RESULTS")] == ["EPOCH RESULTS: Loss: 3.0000"] * 2
+    loss, res = tr.run_evaluate(step, evals(), [Accuracy])
+    assert loss == pytest.approx(12.0) and res == {"Accuracy": 0.25}
+
+
+@pytest.mark.gpu
+def test_training_loop_from_tfrecords_on_gpu(tmp_path):
+    """The callers either side of the path, end to end: reference-format TFRecord files -> padded batches -> train steps
+    through the fused HIP joint + loss -> evaluation with the decode metrics -> weights-only checkpoint."""
+    import rnnt_speech_recognition_amd as pkg
+    from rnnt_speech_recognition_amd import decoding, features, metrics, records
+
+    torch.manual_seed(0)
+    enc = features.CharEncoder()
+    hp = pkg.HParams(vocab_size=enc.vocab_size, mel_bins=8, downsample_factor=3, embedding_size=16, encoder_layers=2,
+                     encoder_size=32, projection_size=16, time_reduction_index=0, pred_net_layers=1, pred_net_size=32,
+                     joint_net_size=64)
+    texts = ["hello world", "ok", "the cat", "a b c d", "yes", "no way"]
+    recs = [features.make_record(torch.randn(6000 + 900 * i), 16000, t, hp, enc) for i, t in enumerate(texts)]
+    records.write_dataset(recs[:4], str(tmp_path / "train.tfrecord"))
+    records.write_dataset(recs[4:], str(tmp_path / "dev.tfrecord"))
+    dev = torch.device("cuda:0")
+    model = pkg.Transducer(hp).to(dev)
+    step = pkg.TrainStep(model, global_batch=2)
+    to_dev = lambda t5: tuple(x.to(dev) if torch.is_tensor(x) else x for x in t5)
+    dec = decoding.greedy_decode_fn(model)
+    lines = []
+    out = pkg.run_training(
+        step, lambda: records.batches(records.load_dataset(str(tmp_path), "train"), 2), n_epochs=2, steps_per_log=1,
+        steps_per_checkpoint=2, eval_batches=lambda: records.batches(records.load_dataset(str(tmp_path), "dev"), 2),
+        eval_metrics=[metrics.build_accuracy_fn(dec)], checkpoint_template=str(tmp_path / "model_{step}_{val_loss:.2f}.pt"),
+        to_device=to_dev, log=lines.append)
+    assert out["steps"] == 4 and math.isfinite(out["loss"]) and math.isfinite(out["val_loss"]) and "val_Accuracy" in out
+    assert len(list(tmp_path.glob("model_*.pt"))) >= 2 and sum(l.startswith("Epoch: ") for l in lines) == 4
