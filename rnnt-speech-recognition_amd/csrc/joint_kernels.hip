@@ -78,6 +78,7 @@ struct JointParams {
     float *dl;      // [cells][32] parked logits (forward) / dlogits of the two-kernel backward
     float4 *rec;    // [cells] per-cell gradient set-up of the single-kernel backward (joint_cellrec_kernel)
     int *reclab;    // [cells] label of the cell, or -1
+    float2 *xbl;    // [cells] blank / label logits of the cell, written by joint_fwd_kernel for joint_cellrec_kernel
     float *dApart;  // [n_ut][B][T][J]
     float *dCpart;  // [n_ts][B][U][J]
     float *dWpart;  // [B*n_ut*n_ts][J][32]
@@ -631,6 +632,7 @@ __device__ __forceinline__ void fwd_row_epilogue(const JointParams &jp, const f3
             p.lse[c] = m + kLn2 * lg2s;
             const size_t wi = ((size_t)b * p.Nr + (t + u)) * p.Up + u;
             ((float2 *)p.W)[wi] = make_float2(ob, ol);
+            jp.xbl[c] = make_float2(xb, xl);  // what the backward's per-cell records need of the logits tile (8 of its 128 bytes)
         }
         // park the logits (bias included): registers 4g .. 4g+3 are the four consecutive symbols 8g + 4 half + 0..3
         float *dst = jp.dl + c * 32 + 4 * half;
@@ -1406,26 +1408,59 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
 //   rec[c] = { c0 = alpha + beta - ll - lse (log2 domain; add x log2e), sS = cost_scale S_b,
 //              corr_b, corr_l = the blank / label corrections, already scaled by sS }    lab[c] = label of the cell or -1
 // The producers of joint_bwd_kernel turn a row of these plus the parked logits into the dlogits fragments.
+// Workgroup = a patch of 8 lattice rows x 32 columns.  The lattice state is diagonal-major (row n = t + u of the skewed
+// arrays): the patch touches 40 diagonals and, on each, a window of at most 10 consecutive columns -- staged through LDS with
+// window-contiguous loads (a lane-per-cell gather touches a different 64-byte sector for every lane: 4 x 64 sectors per wave).
+constexpr int kRecRows = 8, kRecDiags = kRecRows + 32, kRecWin = 10;
 __global__ __launch_bounds__(256) void joint_cellrec_kernel(const JointParams jp) {
+    __shared__ float As[kRecDiags][kRecWin], Bs[kRecDiags][kRecWin];
     const LossParams &p = jp.lp;
     if (jp.tflag[1] != 0.f) return;  // joint_dl_kernel + joint_phase2_kernel (plain f32 MFMAs) run instead
-    for (uint32_t c = blockIdx.x * 256u + threadIdx.x; c < p.cells; c += gridDim.x * 256u) {
-        const Cell cl = decode(p, c);
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        int lab = -1;
-        if (cl.valid) {
-            float S, invS;
-            bwd_scale(p, cl.b, S, invS);
-            const CellGrad g = cell_grad_setup(p, cl, c);
-            const float *xrow = jp.dl + (size_t)c * 32;
-            const float sS = g.scale * S;
-            r.x = g.c0, r.y = sS;
-            if (g.has_blank_corr) r.z = sS * jex2(fmaf(xrow[p.blank], kLog2e, g.nl) + g.cb);
-            if (g.has_label) lab = g.lab, r.w = sS * jex2(fmaf(xrow[g.lab], kLog2e, g.nl) + g.cl);
+    const int tid = threadIdx.x;
+    const int n_tt = (p.T + kRecRows - 1) / kRecRows;
+    int bid = blockIdx.x;
+    const int ut = bid % jp.n_ut;
+    bid /= jp.n_ut;
+    const int tt = bid % n_tt;
+    const int b = bid / n_tt;
+    const int t0 = tt * kRecRows, u0 = ut * 32;
+    const int Tb = length_T(p, b), Ub = length_U(p, b);
+    const bool live = (t0 < Tb) && (u0 < Ub);  // workgroup-uniform
+    if (live) {
+        const size_t base = (size_t)b * p.Nr;
+        for (int e = tid; e < 2 * kRecDiags * kRecWin; e += 256) {
+            const int arr = e / (kRecDiags * kRecWin), q = e - arr * (kRecDiags * kRecWin);
+            const int n = q / kRecWin, k = q - n * kRecWin;
+            const int col = min(u0 + max(0, n - kRecRows) + k, p.Up - 1);  // clamped entries are never used
+            const size_t idx = (base + min(t0 + u0 + n, p.Nr - 1)) * p.Up + col;
+            (arr ? Bs : As)[n][k] = (arr ? p.Bt : p.A)[idx];
         }
-        jp.rec[c] = r;
-        jp.reclab[c] = lab;
     }
+    __syncthreads();
+    const int r = tid >> 5, cu = tid & 31;
+    const int t = t0 + r, u = u0 + cu;
+    if (t >= p.T || u >= p.U) return;
+    const uint32_t c = ((uint32_t)(b * p.T + t)) * (uint32_t)p.U + (uint32_t)u;
+    float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+    int lab = -1;
+    if (live && t < Tb && u < Ub) {
+        Cell cl;
+        cl.b = b, cl.t = t, cl.u = u, cl.Tb = Tb, cl.Ub = Ub, cl.valid = true;
+        const int n = r + cu, n1 = n + 1;
+        const int w0 = max(0, n - kRecRows), w1 = max(0, n1 - kRecRows);
+        float S, invS;
+        bwd_scale(p, b, S, invS);
+        const CellGrad g = cell_grad_from(p, cl, c, As[n][cu - w0], Bs[n][cu - w0], Bs[n1][cu - w1], Bs[n1][cu + 1 - w1]);
+        // blank / label logits from the forward kernel's compact copy (gathering them out of the parked tiles read two
+        // sectors of every cell's 128-byte row: the whole 369 MB at C2 for 23 MB of payload)
+        const float2 xx = jp.xbl[c];
+        const float sS = g.scale * S;
+        rec.x = g.c0, rec.y = sS;
+        if (g.has_blank_corr) rec.z = sS * jex2(fmaf(xx.x, kLog2e, g.nl) + g.cb);
+        if (g.has_label) lab = g.lab, rec.w = sS * jex2(fmaf(xx.y, kLog2e, g.nl) + g.cl);
+    }
+    jp.rec[c] = rec;
+    jp.reclab[c] = lab;
 }
 
 // dlogits fragments of one lattice row tile (32 cells x 32 symbols), 8 KB: pieces 0..3 = A fragments of dh ([ks][hi, lo],
@@ -1673,7 +1708,7 @@ __global__ __launch_bounds__(256) void reduce_small_kernel(float *out, const flo
 // ---------------------------------------------------------------------------------------------
 struct JointLayout {
     WsLayout w;
-    size_t dl, rec, reclab, dApart, dCpart, dWpart, dbpart, expE, expP, tflag, W2s, total;
+    size_t dl, rec, reclab, xbl, dApart, dCpart, dWpart, dbpart, expE, expP, tflag, W2s, total;
     int n_ut, TR, n_tr, TS, n_ts, nC, nW, nDb;
 };
 
@@ -1695,6 +1730,7 @@ static JointLayout make_joint_layout(int T, int U, int B, int J) {
     L.dl = take((size_t)B * T * U * 32 * sizeof(float));
     L.rec = take((size_t)B * T * U * sizeof(float4));
     L.reclab = take((size_t)B * T * U * sizeof(int));
+    L.xbl = take((size_t)B * T * U * sizeof(float2));
     L.dApart = take((size_t)L.n_ut * B * T * J * sizeof(float));
     // partial buffers are shared by the single-kernel backward and the two-kernel (f32 fallback / wide J) backward: sized for
     // whichever needs more, zero-filled before every backward, and always reduced over the larger count
@@ -1782,6 +1818,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     jp.dl = (float *)(ws + L.dl);
     jp.rec = (float4 *)(ws + L.rec);
     jp.reclab = (int *)(ws + L.reclab);
+    jp.xbl = (float2 *)(ws + L.xbl);
     jp.dApart = (float *)(ws + L.dApart);
     jp.dCpart = (float *)(ws + L.dCpart);
     jp.dWpart = (float *)(ws + L.dWpart);
@@ -1850,7 +1887,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
         if (nblk > kBwdMaxBlocks) nblk = kBwdMaxBlocks;
         if (nblk < 1) nblk = 1;
         bwd_nblk = nblk;
-        hipLaunchKernelGGL(joint_cellrec_kernel, dim3((jp.lp.cells + 255u) / 256u), dim3(256), 0, s, jp);
+        hipLaunchKernelGGL(joint_cellrec_kernel, dim3((unsigned)B * L.n_ut * ((T + kRecRows - 1) / kRecRows)), dim3(256), 0, s, jp);
         const size_t shm_bwd = (size_t)kBwdRing * kBwdSlotBytes + 2 * 32 * 8 * sizeof(float) + 2 * kBwdRing * sizeof(int);
         if ((e = set_lds(joint_bwd_kernel, shm_bwd)) != hipSuccess) return e;
         hipLaunchKernelGGL(joint_bwd_kernel, dim3(nblk * n_groups), dim3((n_cons + 2) * 64), shm_bwd, s, jp);

@@ -84,13 +84,13 @@ struct CellGrad {
     float scale;
 };
 
+// The set-up from the cell's lattice values: a = alpha~(t,u), bt = beta~(t,u), b_t1 = beta~(t+1,u), b_u1 = beta~(t,u+1) (the
+// last two are only looked at where that neighbour exists), all relative to the offset tables.
 template <bool SC1 = false>
-__device__ __forceinline__ CellGrad cell_grad_setup(const LossParams &p, const Cell &cl, uint32_t c) {
+__device__ __forceinline__ CellGrad cell_grad_from(const LossParams &p, const Cell &cl, uint32_t c, const float a, const float bt,
+                                                   const float b_t1, const float b_u1) {
     CellGrad g;
     const int n = cl.t + cl.u;
-    const size_t sk = ((size_t)cl.b * p.Nr + n) * p.Up + cl.u;
-    const float a = ld_f32<SC1>(p.A + sk);
-    const float bt = ld_f32<SC1>(p.Bt + sk);
     // offsets are kept per (block of kRebase diagonals, group of 64 lattice columns)
     const int kc = n / kRebase, kc1 = (n + 1) / kRebase;
     const int g0 = cl.u >> 6, g1 = (cl.u + 1) >> 6;
@@ -103,7 +103,7 @@ __device__ __forceinline__ CellGrad cell_grad_setup(const LossParams &p, const C
     g.c0 = (a + bt) + E0 + g.nl;
     g.has_blank_corr = true;
     if (cl.t < cl.Tb - 1)
-        g.cb = a + ld_f32<SC1>(p.Bt + sk + p.Up) + (float)(oa + (double)ld_f32<SC1>(p.offB + ob + (size_t)kc1 * p.NG + g0) - ll2);
+        g.cb = a + b_t1 + (float)(oa + (double)ld_f32<SC1>(p.offB + ob + (size_t)kc1 * p.NG + g0) - ll2);
     else if (cl.u == cl.Ub - 1)
         g.cb = a + (float)(oa - ll2);
     else {
@@ -115,9 +115,20 @@ __device__ __forceinline__ CellGrad cell_grad_setup(const LossParams &p, const C
     g.cl = 0.f;
     if (g.has_label) {
         g.lab = clamp_label(p.labels[(size_t)cl.b * (p.U - 1) + cl.u], p.V);
-        g.cl = a + ld_f32<SC1>(p.Bt + sk + p.Up + 1) + (float)(oa + (double)ld_f32<SC1>(p.offB + ob + (size_t)kc1 * p.NG + g1) - ll2);
+        g.cl = a + b_u1 + (float)(oa + (double)ld_f32<SC1>(p.offB + ob + (size_t)kc1 * p.NG + g1) - ll2);
     }
     return g;
+}
+
+template <bool SC1 = false>
+__device__ __forceinline__ CellGrad cell_grad_setup(const LossParams &p, const Cell &cl, uint32_t c) {
+    const int n = cl.t + cl.u;
+    const size_t sk = ((size_t)cl.b * p.Nr + n) * p.Up + cl.u;
+    const float a = ld_f32<SC1>(p.A + sk);
+    const float bt = ld_f32<SC1>(p.Bt + sk);
+    const float b_t1 = (cl.t < cl.Tb - 1) ? ld_f32<SC1>(p.Bt + sk + p.Up) : 0.f;
+    const float b_u1 = (cl.u < cl.Ub - 1) ? ld_f32<SC1>(p.Bt + sk + p.Up + 1) : 0.f;
+    return cell_grad_from<SC1>(p, cl, c, a, bt, b_t1, b_u1);
 }
 
 }  // namespace rnnt
