@@ -114,8 +114,15 @@ __global__ __launch_bounds__(256) void joint_prep_kernel(const JointParams jp) {
         __shared__ double part[8][32];
         const int v = threadIdx.x & 31, q = threadIdx.x >> 5;
         double sum = 0.0;
-        if (v < p.V)
-            for (int j = q; j < jp.J; j += 8) sum += (double)jp.W2[(size_t)j * p.V + v];
+        if (v < p.V) {  // eight loads in flight per thread: the block is alone on its CU and would otherwise wait out every load
+            float w[8];
+            for (int j0 = q; j0 < jp.J; j0 += 64) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) w[k] = (j0 + 8 * k < jp.J) ? jp.W2[(size_t)(j0 + 8 * k) * p.V + v] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sum += (double)w[k];
+            }
+        }
         part[q][v] = sum;
         __syncthreads();
         if (threadIdx.x < 32) {

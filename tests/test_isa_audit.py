@@ -137,3 +137,31 @@ def test_instruction_selection(kernels):
         assert ks.count("v_mfma_f32_32x32x16_f16") >= 12 and "v_cvt_pk" in ks and "v_mfma_f32_32x32x2_f32" not in ks
     for name, text in asm.items():
         assert "v_mfma_f32_32x32x8" not in text  # no CDNA3-shaped f16 MFMAs: gfx950 forms only
+
+
+def test_no_transcendental_result_is_read_by_the_next_instruction(kernels):
+    """gfx950 needs one wait state between a transcendental (v_rcp / v_exp / v_log / v_rsq / v_sqrt / v_sin / v_cos) and a
+    VALU instruction that reads its result.  The compiler inserts it for the instructions it can see -- not for inline asm
+    (a v_cvt_pk_f16_f32 written in asm once read the stale 1 + e^x instead of its reciprocal: inf -> NaN costs).  Every
+    kernel of the library is scanned: the destination of a transcendental must not be a source of the next instruction."""
+    _, asm = kernels
+    trans = re.compile(r"^\s*(v_(?:rcp|exp|log|rsq|sqrt|sin|cos)_(?:f32|f16|legacy_f32|iflag_f32))\S*\s+(v\d+)\b")
+    bad = []
+    for name, text in asm.items():
+        ins = [l.split("//")[0].rstrip() for l in text.splitlines() if re.match(r"^\s+[a-z]", l)]
+        for cur, nxt in zip(ins, ins[1:]):
+            m = trans.match(cur)
+            if not m or not re.match(r"^\s*v_", nxt):
+                continue
+            dst = int(m.group(2)[1:])
+            ops = nxt.split(None, 1)[1] if len(nxt.split(None, 1)) > 1 else ""
+            srcs = ops.split(",", 1)[1] if "," in ops else ""
+            if nxt.lstrip().startswith(("v_fma_mixhi", "v_fma_mixlo", "v_fmac", "v_mac", "v_dot2c", "v_mfma")):
+                srcs = ops  # these read their destination too
+            regs = set()
+            for lo, hi in re.findall(r"v\[(\d+):(\d+)\]", srcs):
+                regs.update(range(int(lo), int(hi) + 1))
+            regs.update(int(r) for r in re.findall(r"\bv(\d+)\b", re.sub(r"v\[\d+:\d+\]", "", srcs)))
+            if dst in regs:
+                bad.append((name[:60], cur.strip(), nxt.strip()))
+    assert not bad, bad[:5]
