@@ -548,14 +548,29 @@ __device__ __forceinline__ void fwd_split_quad(const float (&x0)[2], const float
     split_pair_trans(x1[0], x1[1], h, l);
     f.hi1[E] = h[0], f.hi1[E + 1] = h[1], f.lo1[E] = l[0], f.lo1[E + 1] = l[1];
 }
+// The enc-side addends of FOUR k-steps arrive with ONE coalesced dword load per lane (lane (row R, position i) <- unit
+// 16 (4 q + R) + i: 256 contiguous bytes) instead of one load per k-step (the knock-out of those loads: -11 % of the kernel).
+// Every 16-lane row must then hold "its" k-step's 16 units -- rows 2, 3 (half 1) rotated by 8, see joint_fwd_kernel -- for
+// row_newbcast to pick from: x -> (row_ror:8 copy) -> v_permlane32_swap -> 2 x v_permlane16_swap gives the four registers.
+struct FwdAddends {
+    float y[4];
+};
+__device__ __forceinline__ FwdAddends fwd_spread(const float x) {
+    const uint32_t xi = __float_as_uint(x);
+    const uint32_t xr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xi, 0x128 /*row_ror:8*/, 0xf, 0xf, false);
+    const auto pq = __builtin_amdgcn_permlane32_swap(xi, xr, false, false);  // p = [x0 x1 x'0 x'1], q = [x2 x3 x'2 x'3] (rows)
+    const auto y01 = __builtin_amdgcn_permlane16_swap(pq[0], pq[0], false, false);
+    const auto y23 = __builtin_amdgcn_permlane16_swap(pq[1], pq[1], false, false);
+    FwdAddends f;
+    f.y[0] = __uint_as_float(y01[0]), f.y[1] = __uint_as_float(y01[1]);
+    f.y[2] = __uint_as_float(y23[0]), f.y[3] = __uint_as_float(y23[1]);
+    return f;
+}
 template <bool SLOW>
 __device__ __forceinline__ void fwd_row_pair(const int J, const float *e0, const float *e1, const char *ct_row, const uint32_t ct_swz,
-                                             const char *wlane, const int half, f32x16 &acc0, f32x16 &acc1) {
+                                             const char *wlane, const int half, const int lane, f32x16 &acc0, f32x16 &acc1) {
     const int n = J / 16;
-    float ea0 = e0[0], ea1 = e1[0];
-    for (int ks = 0; ks < n; ++ks) {
-        const float a0 = ea0, a1 = ea1;
-        if (ks + 1 < n) ea0 = e0[16 * (ks + 1)], ea1 = e1[16 * (ks + 1)];  // next k-step's addends: one dword per lane
+    auto kstep = [&](const int ks, const float a0, const float a1) __attribute__((always_inline)) {
         const uint32_t c0 = (uint32_t)(4 * ks + 2 * half);
         const float4 c4a = *(const float4 *)(ct_row + (size_t)(c0 ^ ct_swz) * 16);
         const float4 c4b = *(const float4 *)(ct_row + (size_t)((c0 + 1u) ^ ct_swz) * 16);
@@ -581,6 +596,19 @@ __device__ __forceinline__ void fwd_row_pair(const int J, const float *e0, const
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, f.lo1, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, f.hi0, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, f.hi1, acc1, 0, 0, 0);
+    };
+    // this lane's unit within the group of 64 (the ea_off rotation of the one-k-step form lives in fwd_spread now)
+    const int ngroups = (n + 3) >> 2;
+    float xa = e0[min(lane, J - 1)], xb = e1[min(lane, J - 1)];
+    for (int q = 0; q < ngroups; ++q) {
+        const FwdAddends ya = fwd_spread(xa), yb = fwd_spread(xb);
+        if (q + 1 < ngroups) {  // next group's addends: in flight during the four k-steps below
+            const int idx = min(64 * (q + 1) + lane, J - 1);
+            xa = e0[idx], xb = e1[idx];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * q + r < n) kstep(4 * q + r, ya.y[r], yb.y[r]);
     }
 }
 
@@ -669,8 +697,7 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
     const uint32_t ct_lane = (uint32_t)(l31 * cpr);          // this lane's Ct row, in chunks
     const uint32_t ct_swz = (uint32_t)(l31 & 15);
     // enc-side addends of a k-step (16 joint units), one per lane: positions 0..7 of every 16-lane row hold the 8 units of
-    // the lane's half (units 8 half + 0..7), so row_newbcast:e hands every lane "its" unit e
-    const int ea_off = ((lane & 15) + 8 * half) & 15;
+    // the lane's half (units 8 half + 0..7), so row_newbcast:e hands every lane "its" unit e (fwd_spread builds those rows)
 
     // items = (utterance, u-tile, row tile) with the row tile fastest; every workgroup takes a CONTIGUOUS range of them, so
     // that the 128 J-byte Ct tile is reloaded only when (utterance, u-tile) changes
@@ -709,16 +736,16 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
         const int t0 = t_begin + 2 * wave;
         if (t0 >= t_end) continue;  // wave-uniform (no barrier below)
         const bool two = t0 + 1 < t_end;  // wave-uniform
-        const float *e0 = Etab + ((size_t)b * p.T + t0) * J + ea_off;
+        const float *e0 = Etab + ((size_t)b * p.T + t0) * J;
         const float *e1 = two ? e0 + J : e0;
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
         const char *ct_row = Ct + (size_t)ct_lane * 16, *wlane = Wimg + lane * 16;
         if (!slow)
-            fwd_row_pair<false>(J, e0, e1, ct_row, ct_swz, wlane, half, acc0, acc1);
+            fwd_row_pair<false>(J, e0, e1, ct_row, ct_swz, wlane, half, lane, acc0, acc1);
         else
-            fwd_row_pair<true>(J, e0, e1, ct_row, ct_swz, wlane, half, acc0, acc1);
+            fwd_row_pair<true>(J, e0, e1, ct_row, ct_swz, wlane, half, lane, acc0, acc1);
         fwd_row_epilogue(jp, acc0, rsel_b, rsel_l, b, t0, u, Tb, Ub, half);
         if (two) fwd_row_epilogue(jp, acc1, rsel_b, rsel_l, b, t0 + 1, u, Tb, Ub, half);
     }
@@ -1673,6 +1700,27 @@ __global__ __launch_bounds__(768) void joint_bwd_kernel(const JointParams jp) {
 __global__ __launch_bounds__(256) void reduce_partials_kernel(float *out, const float *in, int nparts, size_t n,
                                                               const float *flag = nullptr, int nparts_fb = 0) {
     if (flag && flag[1] != 0.f) nparts = nparts_fb;
+    // fixed order q = 0, 1, ... for every element (deterministic); 16-byte accesses, up to four partials in flight per thread
+    if ((n & 3) == 0 && (((uintptr_t)out | (uintptr_t)in) & 15) == 0) {
+        const size_t n4 = n >> 2;
+        const float4 *in4 = (const float4 *)in;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            int q = 0;
+            for (; q + 4 <= nparts; q += 4) {
+                const float4 a = in4[(size_t)q * n4 + i], b = in4[(size_t)(q + 1) * n4 + i];
+                const float4 c = in4[(size_t)(q + 2) * n4 + i], d = in4[(size_t)(q + 3) * n4 + i];
+                s.x = (((s.x + a.x) + b.x) + c.x) + d.x, s.y = (((s.y + a.y) + b.y) + c.y) + d.y;
+                s.z = (((s.z + a.z) + b.z) + c.z) + d.z, s.w = (((s.w + a.w) + b.w) + c.w) + d.w;
+            }
+            for (; q < nparts; ++q) {
+                const float4 a = in4[(size_t)q * n4 + i];
+                s.x += a.x, s.y += a.y, s.z += a.z, s.w += a.w;
+            }
+            ((float4 *)out)[i] = s;
+        }
+        return;
+    }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float s = 0.f;
         for (int q = 0; q < nparts; ++q) s += in[(size_t)q * n + i];
