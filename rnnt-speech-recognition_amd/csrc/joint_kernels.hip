@@ -102,12 +102,24 @@ __global__ __launch_bounds__(256) void joint_prep_kernel(const JointParams jp) {
     const LossParams &p = jp.lp;
     const size_t nE = (size_t)p.B * p.T * jp.J, nP = (size_t)p.B * p.U * jp.J;
     bool big = false;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nE + nP; i += (size_t)gridDim.x * 256) {
-        const float x = (i < nE) ? jp.enc_proj[i] : jp.pred_proj[i - nE];
+    auto one = [&](const float x) {
         big |= !(fabsf(x) <= kExpTabLimit);  // also catches NaN
-        const float ex = jex2(x * 2.8853900817779268f);
-        if (i < nE) jp.expE[i] = ex;
-        else jp.expP[i - nE] = ex;
+        return jex2(x * 2.8853900817779268f);
+    };
+    if (((nE | nP) & 3) == 0 && ((((uintptr_t)jp.enc_proj | (uintptr_t)jp.pred_proj) & 15) == 0)) {  // 16-byte accesses (J % 4 == 0)
+        const size_t nE4 = nE >> 2, n4 = (nE + nP) >> 2;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            const float4 x = (i < nE4) ? ((const float4 *)jp.enc_proj)[i] : ((const float4 *)jp.pred_proj)[i - nE4];
+            const float4 ex = make_float4(one(x.x), one(x.y), one(x.z), one(x.w));
+            if (i < nE4) ((float4 *)jp.expE)[i] = ex;
+            else ((float4 *)jp.expP)[i - nE4] = ex;
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nE + nP; i += (size_t)gridDim.x * 256) {
+            const float ex = one((i < nE) ? jp.enc_proj[i] : jp.pred_proj[i - nE]);
+            if (i < nE) jp.expE[i] = ex;
+            else jp.expP[i - nE] = ex;
+        }
     }
     if (__any(big) && (threadIdx.x & 63) == 0) jp.tflag[0] = 1.0f;
     if (blockIdx.x == 0) {  // joint_fwd_kernel accumulates r = (1 - h) / 2: logits = (b2 + sum_j W2) - 2 W2^T r
