@@ -1739,6 +1739,32 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(float *out, const 
         out[i] = s;
     }
 }
+// d enc_proj[b][t][:] = sum over the u-tiles of their partial rows, in u-tile order.  Every backward kernel writes the row
+// (ut, b, t) exactly when the u-tile starts inside the utterance's label range and t < T_b, and never otherwise: the reduction
+// reads only those rows (and writes zeros for t >= T_b), so the 4 n_ut B T J bytes of partials need no zero-fill.
+__global__ __launch_bounds__(256) void reduce_enc_kernel(float *out, const float *in, int n_ut, const LossParams p, int J) {
+    const uint32_t J4 = (uint32_t)J >> 2, n4 = (uint32_t)p.B * (uint32_t)p.T * J4;
+    const float4 *in4 = (const float4 *)in;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+        const uint32_t row = i / J4, b = row / (uint32_t)p.T, t = row - b * (uint32_t)p.T;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((int)t < length_T(p, (int)b)) {
+            const int nv = min(n_ut, (length_U(p, (int)b) + 31) >> 5);
+            int q = 0;
+            for (; q + 4 <= nv; q += 4) {
+                const float4 a = in4[(size_t)q * n4 + i], bb = in4[(size_t)(q + 1) * n4 + i];
+                const float4 c = in4[(size_t)(q + 2) * n4 + i], d = in4[(size_t)(q + 3) * n4 + i];
+                s.x = (((s.x + a.x) + bb.x) + c.x) + d.x, s.y = (((s.y + a.y) + bb.y) + c.y) + d.y;
+                s.z = (((s.z + a.z) + bb.z) + c.z) + d.z, s.w = (((s.w + a.w) + bb.w) + c.w) + d.w;
+            }
+            for (; q < nv; ++q) {
+                const float4 a = in4[(size_t)q * n4 + i];
+                s.x += a.x, s.y += a.y, s.z += a.z, s.w += a.w;
+            }
+        }
+        ((float4 *)out)[i] = s;
+    }
+}
 // Deterministic tree: out[i] = sum_p in[p*stride_p + map(i)], 256 threads = 32 outputs x 8 partial lanes.
 // Each partial lane sums its strided share in a fixed order, then the 8 lanes are combined in order.
 template <bool W2MAP>
@@ -1936,7 +1962,8 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     if (!(phases & 2) || !d_enc_proj) return hipSuccess;  // score only
 
     // backward.  Partial buffers first: zero (rows / slots / workgroups a path does not write must read as zero)
-    if (hipMemsetAsync(jp.dApart, 0, (L.dbpart - L.dApart) + (size_t)L.nDb * 32 * sizeof(float), s) != hipSuccess) return hipErrorUnknown;
+    // (the d enc_proj partials need none: reduce_enc_kernel knows which of their rows exist)
+    if (hipMemsetAsync(jp.dCpart, 0, (L.dbpart - L.dCpart) + (size_t)L.nDb * 32 * sizeof(float), s) != hipSuccess) return hipErrorUnknown;
     const int n_groups = bwd_groups(J);
     const bool single = (J / 32) % n_groups == 0 && J <= 640;  // consumers per group must come out even; LDS / wave budget
     jp.single_bwd = single ? 1 : 0;
@@ -1964,11 +1991,11 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     }
     hipLaunchKernelGGL(joint_phase2_kernel, dim3(g2), dim3(256), shm2, s, jp);  // exits at once unless tflag[1] is set
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    const size_t nA = (size_t)B * T * J, nC = (size_t)B * U * J;
+    const size_t nC = (size_t)B * U * J;
     // partial counts: what the single-kernel backward wrote, or (flag set / wide J) what the two-kernel backward wrote
     const int nC_fb = L.n_ts, nW_fb = B * L.n_ut * L.n_ts, nDb_fb = (int)gdl;
     const int nC_s = single ? kBwdSlots : nC_fb, nW_s = single ? bwd_nblk : nW_fb, nDb_s = single ? 2 * bwd_nblk : nDb_fb;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1024), dim3(256), 0, s, d_enc_proj, jp.dApart, L.n_ut, nA, nullptr, 0);
+    hipLaunchKernelGGL(reduce_enc_kernel, dim3(1024), dim3(256), 0, s, d_enc_proj, jp.dApart, L.n_ut, jp.lp, J);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1024), dim3(256), 0, s, d_pred_proj, jp.dCpart, nC_s, nC, jp.tflag, nC_fb);
     hipLaunchKernelGGL((reduce_small_kernel<true>), dim3((J * V + 31) / 32), dim3(256), 0, s, dW2, jp.dWpart, nW_s, J * V, J, V,
                        jp.tflag, nW_fb);
