@@ -1009,6 +1009,7 @@ bool fill_loss_params(LossParams &p, const float *acts, float *grads, const int 
                       const int *input_lengths, const float *cost_scale, int V, int B, float *costs, void *workspace,
                       int maxT, int maxU, int blank);
 hipError_t launch_reduce_partials(float *out, const float *in, int nparts, size_t n, hipStream_t s);
+hipError_t launch_reduce_enc(float *out, const float *in, int n_ut, const LossParams &lp, int J, hipStream_t s);
 
 template <typename K>
 static hipError_t set_lds_f16(K kernel, size_t bytes) {
@@ -1104,7 +1105,8 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     if (!(phases & 2) || !d_enc_proj) return hipSuccess;
 
     if ((e = logits(true)) != hipSuccess) return e;
-    if (hipMemsetAsync(jp.dApart, 0, L.dWpart - L.dApart, s) != hipSuccess) return hipErrorUnknown;  // dA / dC partials, zero row
+    // dC partials + the zero row (the dA partials need no zero-fill: launch_reduce_enc reads only the rows K3 writes)
+    if (hipMemsetAsync(jp.dCpart, 0, L.dWpart - L.dCpart, s) != hipSuccess) return hipErrorUnknown;
     {
         const size_t shm = 3 * (size_t)(256 + 128) * 128;
         if ((e = set_lds_f16(jh_dh_kernel, shm)) != hipSuccess) return e;
@@ -1119,7 +1121,7 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
         hipLaunchKernelGGL(jh_dw_kernel, dim3(grid), dim3(512), shm, s, jp);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if ((e = launch_reduce_partials(d_enc_proj, jp.dApart, L.n_ut, (size_t)B * T * J, s)) != hipSuccess) return e;
+    if ((e = launch_reduce_enc(d_enc_proj, jp.dApart, L.n_ut, jp.lp, J, s)) != hipSuccess) return e;
     if ((e = launch_reduce_partials(d_pred_proj, jp.dCpart, L.n_ts, (size_t)B * U * J, s)) != hipSuccess) return e;
     if ((e = launch_reduce_partials(dW2, jp.dWpart, L.n_ranges, (size_t)J * V, s)) != hipSuccess) return e;
     e = launch_reduce_partials(db2, jp.dbpart, L.n_ranges, (size_t)V, s);

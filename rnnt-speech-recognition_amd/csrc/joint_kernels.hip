@@ -1856,6 +1856,12 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
                                  float *d_enc_proj, float *d_pred_proj, float *dW2, float *db2, int phases,
                                  void *workspace, hipStream_t s);
 
+// d enc_proj from its [n_ut][B][T][J] partial rows (reduce_enc_kernel); shared with the f16 joint
+hipError_t launch_reduce_enc(float *out, const float *in, int n_ut, const LossParams &lp, int J, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_enc_kernel, dim3(1024), dim3(256), 0, s, out, in, n_ut, lp, J);
+    return hipGetLastError();
+}
+
 hipError_t launch_reduce_partials(float *out, const float *in, int nparts, size_t n, hipStream_t s) {
     const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, s, out, in, nparts, n, nullptr, 0);
