@@ -301,3 +301,42 @@ def test_module_and_input_checks():
     with pytest.raises(ValueError):
         pkg.rnnt_loss(torch.tensor(acts, device=dev), torch.tensor(labels[:, :1], device=dev),
                       torch.tensor(il, device=dev), torch.tensor(ll, device=dev))
+
+
+def test_calls_can_be_captured_in_a_hip_graph():
+    """The library allocates nothing, never synchronises and enqueues everything on the caller's stream: a whole
+    loss + gradient call (and the fused joint) records into a HIP graph and replays with new inputs in the same buffers."""
+    from rnnt_speech_recognition_amd import _lib
+
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    B, T, U, V = 3, 37, 21, 28
+    acts = torch.zeros(B, T, U, V, device=dev)
+    labels = torch.tensor(rng.integers(1, V, size=(B, U - 1)), dtype=torch.int32, device=dev)
+    il = torch.tensor([T, T - 5, T - 11], dtype=torch.int32, device=dev)
+    ll = torch.tensor([U - 1, U - 4, U - 2], dtype=torch.int32, device=dev)
+    costs = torch.empty(B, device=dev)
+    grads = torch.empty_like(acts)
+    ws = torch.empty(_lib.workspace_bytes(T, U, B), dtype=torch.uint8, device=dev)
+
+    def call(stream):
+        opts = _lib.make_options(stream.cuda_stream, 0, T, U)
+        _lib.check(lib.compute_rnnt_loss(acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), ll.data_ptr(), il.data_ptr(),
+                                         V, B, costs.data_ptr(), ws.data_ptr(), opts), "compute_rnnt_loss")
+
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):  # warm-up outside the capture (first-use function attributes)
+        call(side)
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call(torch.cuda.current_stream())
+    for seed in (1, 2):
+        x = np.random.default_rng(seed).normal(size=(B, T, U, V)).astype(np.float32)
+        acts.copy_(torch.from_numpy(x))
+        graph.replay()
+        torch.cuda.synchronize()
+        cr, gr = orc.rnnt_loss_and_grad(x, labels.cpu().numpy(), il.cpu().numpy(), ll.cpu().numpy())
+        assert np.abs(costs.cpu().numpy() - cr).max() <= CTOL * max(1.0, np.abs(cr).max())
+        assert np.abs(grads.cpu().numpy() - gr).max() <= GTOL
