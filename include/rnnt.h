@@ -148,7 +148,7 @@ rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, const int *fl
  *                                0 = f32-grade products (operands split into binary16 hi + lo parts, three f16 MFMAs per product, f32
  *                                    accumulation; |W2| must stay below 65504, the binary16 range; RNNT_JOINT_P1/P2=f32 select the
  *                                    plain f32 MFMA kernels, which have no such limit), small vocabularies: alphabet_size <= 32 (the reference's
- *                                    character set), joint_size a multiple of 64 (<= 768).
+ *                                    character set), joint_size a multiple of 64 (<= 704).
  *                                1 = f16 MFMA, large vocabularies: alphabet_size a multiple of 512 (<= 8192),
  *                                    joint_size in {128, 256, 512, 640}.  h = tanh(.) and W2 are rounded to binary16
  *                                    (round-to-nearest-even) before the products, accumulation is f32; the loss gradient

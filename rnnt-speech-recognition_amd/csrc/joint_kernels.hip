@@ -1843,8 +1843,9 @@ static JointLayout make_joint_layout(int T, int U, int B, int J) {
 }
 
 static bool joint_supported(int J, int V) {
-    // J <= 768: the phase-1 workgroup keeps the whole C^T tile (128*J B) plus 8 rows of enc_proj in LDS
-    return V >= 1 && V <= 32 && J >= 64 && (J % 64) == 0 && J <= 768;
+    // J <= 704: the streaming forward (640 < J) keeps the whole C^T tile (128 J bytes), a row of enc_proj per wave (32 J) and
+    // 50 KB of staging in LDS: 162,816 of the 163,840 bytes at J = 704
+    return V >= 1 && V <= 32 && J >= 64 && (J % 64) == 0 && J <= 704;
 }
 
 // joint_f16_kernels.hip (large vocabularies on the f16 MFMA units)

@@ -123,8 +123,8 @@ def padded_joint_shape(J: int, V: int, joint_dtype: str):
         if V > 32:
             raise ValueError("rnnt_joint_loss: the f32 joint takes vocabularies of at most 32 symbols; use joint_dtype='f16'")
         Jp = (J + 63) // 64 * 64
-        if Jp > 768:
-            raise ValueError("rnnt_joint_loss: the f32 joint takes joint sizes of at most 768")
+        if Jp > 704:
+            raise ValueError("rnnt_joint_loss: the f32 joint takes joint sizes of at most 704")
         return Jp, V
     Jp = next((j for j in _F16_J if j >= J), None)
     if Jp is None:

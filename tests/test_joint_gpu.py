@@ -50,6 +50,8 @@ SHAPES = [
     (2, 50, 33, 32, 192, 31),   # u-tile boundary at 32/33, V = 31 (reference vocabulary)
     (1, 7, 70, 8, 64, 32),      # three u-tiles, V = 32 exactly
     (2, 300, 20, 16, 64, 5),    # row splits (T >= 256)
+    (2, 40, 37, 16, 704, 28),   # 640 < J <= 704: W2 streams through the LDS (joint_phase1s_kernel), two-kernel backward
+    (1, 33, 70, 8, 704, 31),    # widest joint of the f32 path, three u-tiles, V = 31
 ]
 
 
@@ -112,9 +114,9 @@ def test_joint_is_deterministic():
 def test_joint_limits_are_reported():
     dev = torch.device("cuda:0")
     enc, pred = torch.zeros(1, 4, 8, device=dev), torch.zeros(1, 3, 8, device=dev)
-    W1, b1 = torch.zeros(8, 832, device=dev), torch.zeros(832, device=dev)  # J = 832 > 768: beyond the f32 joint
+    W1, b1 = torch.zeros(8, 832, device=dev), torch.zeros(832, device=dev)  # J = 832 > 704: beyond the f32 joint
     W2, b2 = torch.zeros(832, 5, device=dev), torch.zeros(5, device=dev)
-    with pytest.raises(ValueError, match="at most 768"):
+    with pytest.raises(ValueError, match="at most 704"):
         pkg.rnnt_joint_loss(enc, pred, W1, b1, W2, b2, torch.ones(1, 2, dtype=torch.int32, device=dev),
                             torch.tensor([4], device=dev), torch.tensor([2], device=dev))
     from rnnt_speech_recognition_amd import _lib
