@@ -1,0 +1,57 @@
+"""Shape extremes of the fused joint entry points (limits of include/rnnt.h) against the float64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+import rnnt_speech_recognition_amd as pkg
+from oracle import rnnt_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def run(B, T, U, H, J, V, dtype, seed=0):
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.tensor(x, device=dev)
+    rng = np.random.default_rng(seed)
+    enc, pred = rng.normal(size=(B, T, H)).astype(np.float32), rng.normal(size=(B, U, H)).astype(np.float32)
+    W1, b1 = (rng.normal(size=(H, J)) * 0.3).astype(np.float32), (rng.normal(size=J) * 0.1).astype(np.float32)
+    W2, b2 = (rng.normal(size=(J, V)) * 0.1).astype(np.float32), (rng.normal(size=V) * 0.1).astype(np.float32)
+    labels = rng.integers(1, V, size=(B, U - 1)).astype(np.int32)
+    il = np.full(B, T, np.int32)
+    ll = np.full(B, U - 1, np.int32)
+    if B > 1:
+        il[1], ll[1] = max(1, T // 2), (U - 1) // 2
+    params = [t(x).requires_grad_(True) for x in (enc, pred, W1, b1, W2, b2)]
+    costs = pkg.rnnt_joint_loss(*params, t(labels), t(il), t(ll), joint_dtype=dtype)
+    costs.sum().backward()
+    torch.cuda.synchronize()
+    f = orc.joint_loss_and_grads_f16 if dtype == "f16" else orc.joint_loss_and_grads
+    ref = f(*(x.astype(np.float64) for x in (enc, pred, W1, b1, W2, b2)), labels, il, ll)
+    dc = np.abs(costs.detach().cpu().numpy() - ref["costs"]).max() / max(1.0, np.abs(ref["costs"]).max())
+    out = {"cost": dc}
+    for name, p in zip(("d_enc", "d_pred", "dW1", "db1", "dW2", "db2"), params):
+        g, r = p.grad.cpu().numpy(), ref[name]
+        out[name] = float(np.abs(g - r).max() / max(1e-30, np.abs(r).max()))
+    return out
+
+
+CASES = [
+    (1, 3, 1024, 8, 64, 8, "f32"),      # fused joint's widest lattice (maxU = 1024)
+    (2, 5, 1000, 8, 128, 28, "f32"),
+    (1, 2000, 3, 8, 64, 28, "f32"),     # long and narrow
+    (2, 11, 40, 8, 704, 32, "f32"),     # widest f32 joint, full 32-symbol tile
+    (2, 6, 5, 8, 640, 8192, "f16"),     # largest vocabulary, widest native joint
+    (1, 4, 3, 8, 128, 8192, "f16"),
+    (1, 3, 1024, 8, 128, 512, "f16"),
+    (2, 7, 9, 8, 100, 1000, "f16"),     # padded J and V
+    (1, 1, 1, 8, 64, 5, "f32"),         # degenerate lattice
+    (1, 1, 1, 8, 128, 512, "f16"),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_fused_joint_at_its_limits(case):
+    pkg.build()
+    out = run(*case)
+    tol = 2e-3 if case[-1] == "f16" else 1e-4  # relative to max |reference| per tensor; f16: binary16 dlogits (test_joint_f16_gpu.py)
+    assert all(v <= tol for v in out.values()), out
