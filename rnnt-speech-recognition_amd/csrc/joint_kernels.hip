@@ -1745,6 +1745,19 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(float *out, const 
 __global__ __launch_bounds__(256) void reduce_enc_kernel(float *out, const float *in, int n_ut, const LossParams p, int J) {
     const uint32_t J4 = (uint32_t)J >> 2, n4 = (uint32_t)p.B * (uint32_t)p.T * J4;
     const float4 *in4 = (const float4 *)in;
+    if (((uintptr_t)out & 15) != 0) {  // a caller's gradient buffer off the 16-byte grid (the partials are workspace: aligned)
+        const uint32_t n = n4 * 4u;
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+            const uint32_t row = i / (uint32_t)J, b = row / (uint32_t)p.T, t = row - b * (uint32_t)p.T;
+            float s = 0.f;
+            if ((int)t < length_T(p, (int)b)) {
+                const int nv = min(n_ut, (length_U(p, (int)b) + 31) >> 5);
+                for (int q = 0; q < nv; ++q) s += in[(size_t)q * n + i];
+            }
+            out[i] = s;
+        }
+        return;
+    }
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
         const uint32_t row = i / J4, b = row / (uint32_t)p.T, t = row - b * (uint32_t)p.T;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
