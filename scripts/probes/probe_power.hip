@@ -1,7 +1,7 @@
 // Hardware probe (dev tool): what the chip sustains on v_mfma_f32_32x32x16_f16 once it is power-limited.
 // 256 workgroups x 8 waves (2 per SIMD), every wave a stream of MFMAs on four accumulators for ~60 ms per variant:
 //   operands: zeros | random binary16;   beside every MFMA: nothing | one ds_read_b128 | one ds_read_b128 + four v_fma_f32
-// Prints TFLOP/s (wall clock, HIP events), the effective shader clock (s_memtime ticks / wall time) and cycles per MFMA.
+// Prints TFLOP/s (wall clock, HIP events).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -60,8 +60,8 @@ static void run(const char *what, const h8 *src, long long *cyc, float *sink) {
     long long c = 0;
     (void)hipMemcpy(&c, cyc + 100, sizeof(c), hipMemcpyDeviceToHost);
     const double mfmas = (double)blocks * 8 * iters * 8;
-    printf("%-44s %7.1f ms  %7.1f TFLOP/s  clock %.2f GHz  %.1f cycles per MFMA per SIMD\n", what, ms, mfmas * 32768.0 / (ms * 1e-3) / 1e12,
-           (double)c / (ms * 1e-3) / 1e9, (double)c / (iters * 8.0 * 2.0));
+    (void)c;  // (s_memtime ticks at a fixed rate on this part: no clock estimate from it)
+    printf("%-44s %7.1f ms  %7.1f TFLOP/s\n", what, ms, mfmas * 32768.0 / (ms * 1e-3) / 1e12);
 }
 
 int main() {
