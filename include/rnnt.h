@@ -23,6 +23,13 @@
 #include <stdbool.h>
 #include <stddef.h>
 
+/* The library is built with -fvisibility=hidden: only the entry points declared here are exported. */
+#if defined(__GNUC__)
+#define RNNT_API __attribute__((visibility("default")))
+#else
+#define RNNT_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -58,14 +65,14 @@ typedef struct rnntOptions {
 } rnntOptions;
 
 /* Replaces upstream get_warprnnt_version(). */
-int get_warprnnt_version(void);
+RNNT_API int get_warprnnt_version(void);
 
 /* Replaces upstream rnntGetStatusString(). */
-const char *rnntGetStatusString(rnntStatus_t status);
+RNNT_API const char *rnntGetStatusString(rnntStatus_t status);
 
 /* Replaces upstream get_workspace_size(maxT, maxU, minibatch, gpu, &size_bytes).
  * `gpu` must be true.  The size depends on (maxT, maxU, minibatch) only. */
-rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool gpu, size_t *size_bytes);
+RNNT_API rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool gpu, size_t *size_bytes);
 
 /* Deliberate limits of this library (upstream has none of them; all are reported as RNNT_STATUS_INVALID_VALUE at
  * enqueue time, never as wrong numbers):
@@ -96,7 +103,7 @@ rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool gpu, siz
  *
  * Returns immediately after enqueueing; errors detected at enqueue time are returned, device
  * faults surface on the caller's next stream synchronisation. */
-rnntStatus_t compute_rnnt_loss(const float *acts, float *grads, const int *flat_labels,
+RNNT_API rnntStatus_t compute_rnnt_loss(const float *acts, float *grads, const int *flat_labels,
                                const int *label_lengths, const int *input_lengths,
                                int alphabet_size, int minibatch, float *costs, void *workspace,
                                rnntOptions options);
@@ -109,20 +116,19 @@ rnntStatus_t compute_rnnt_loss(const float *acts, float *grads, const int *flat_
  *   compute_rnnt_loss_bwd  = grads[b] = cost_scale[b] * d cost_b / d acts  (cost_scale NULL = 1),
  *                            from the SAME acts and the workspace left by _fwd.
  * compute_rnnt_loss(acts, grads, ...) == _fwd followed by _bwd(cost_scale = NULL).
- *   compute_rnnt_loss_ex   = compute_rnnt_loss with cost_scale folded into grads, in ONE call; this
- *                            form pipelines utterance groups across internal streams (the gradient
- *                            pass of one group overlaps the alpha/beta sweeps of the next). */
-rnntStatus_t compute_rnnt_loss_fwd(const float *acts, const int *flat_labels,
+ *   compute_rnnt_loss_ex   = compute_rnnt_loss with cost_scale folded into grads, in ONE call
+ *                            (_fwd followed by _bwd on the caller's stream; nothing else differs). */
+RNNT_API rnntStatus_t compute_rnnt_loss_fwd(const float *acts, const int *flat_labels,
                                    const int *label_lengths, const int *input_lengths,
                                    int alphabet_size, int minibatch, float *costs, void *workspace,
                                    rnntOptions options);
 
-rnntStatus_t compute_rnnt_loss_bwd(const float *acts, float *grads, const int *flat_labels,
+RNNT_API rnntStatus_t compute_rnnt_loss_bwd(const float *acts, float *grads, const int *flat_labels,
                                    const int *label_lengths, const int *input_lengths,
                                    const float *cost_scale, int alphabet_size, int minibatch,
                                    void *workspace, rnntOptions options);
 
-rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, const int *flat_labels,
+RNNT_API rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, const int *flat_labels,
                                   const int *label_lengths, const int *input_lengths,
                                   const float *cost_scale, int alphabet_size, int minibatch,
                                   float *costs, void *workspace, rnntOptions options);
@@ -146,9 +152,9 @@ rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, const int *fl
  *                                Fully overwritten.  May all be NULL for score-only.
  *   joint_dtype                  arithmetic of the J x V products.
  *                                0 = f32-grade products (operands split into binary16 hi + lo parts, three f16 MFMAs per product, f32
- *                                    accumulation; |W2| must stay below 65504, the binary16 range; RNNT_JOINT_P1/P2=f32 select the
- *                                    plain f32 MFMA kernels, which have no such limit), small vocabularies: alphabet_size <= 32 (the reference's
- *                                    character set), joint_size a multiple of 64 (<= 704).
+ *                                    accumulation; when some |W2| leaves the binary16 range the library switches, on the device, to
+ *                                    plain f32 MFMA kernels with no such limit), small vocabularies: alphabet_size <= 32 (the
+ *                                    reference's character set), joint_size a multiple of 64 (<= 704).
  *                                1 = f16 MFMA, large vocabularies: alphabet_size a multiple of 512 (<= 8192),
  *                                    joint_size in {128, 256, 512, 640}.  h = tanh(.) and W2 are rounded to binary16
  *                                    (round-to-nearest-even) before the products, accumulation is f32; the loss gradient
@@ -164,10 +170,10 @@ rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, const int *fl
  * compute_rnnt_joint_loss_bwd  = the gradients, from the same inputs and that workspace (autograd split,
  *                                as compute_rnnt_loss_fwd/_bwd)
  */
-rnntStatus_t get_joint_workspace_size(int maxT, int maxU, int minibatch, int joint_size,
+RNNT_API rnntStatus_t get_joint_workspace_size(int maxT, int maxU, int minibatch, int joint_size,
                                       int alphabet_size, size_t *size_bytes);
 
-rnntStatus_t compute_rnnt_joint_loss(const float *enc_proj, const float *pred_proj,
+RNNT_API rnntStatus_t compute_rnnt_joint_loss(const float *enc_proj, const float *pred_proj,
                                      const float *W2, const float *b2, const int *flat_labels,
                                      const int *label_lengths, const int *input_lengths,
                                      const float *cost_scale, int joint_size, int alphabet_size,
@@ -175,14 +181,14 @@ rnntStatus_t compute_rnnt_joint_loss(const float *enc_proj, const float *pred_pr
                                      float *d_pred_proj, float *dW2, float *db2, int joint_dtype,
                                      void *workspace, rnntOptions options);
 
-rnntStatus_t compute_rnnt_joint_loss_fwd(const float *enc_proj, const float *pred_proj,
+RNNT_API rnntStatus_t compute_rnnt_joint_loss_fwd(const float *enc_proj, const float *pred_proj,
                                          const float *W2, const float *b2, const int *flat_labels,
                                          const int *label_lengths, const int *input_lengths,
                                          int joint_size, int alphabet_size, int minibatch,
                                          float *costs, int joint_dtype, void *workspace,
                                          rnntOptions options);
 
-rnntStatus_t compute_rnnt_joint_loss_bwd(const float *enc_proj, const float *pred_proj,
+RNNT_API rnntStatus_t compute_rnnt_joint_loss_bwd(const float *enc_proj, const float *pred_proj,
                                          const float *W2, const float *b2, const int *flat_labels,
                                          const int *label_lengths, const int *input_lengths,
                                          const float *cost_scale, int joint_size, int alphabet_size,

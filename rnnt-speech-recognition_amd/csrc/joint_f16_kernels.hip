@@ -1047,6 +1047,7 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
                                  void *workspace, hipStream_t s) {
     if (!joint_f16_supported(J, V)) return hipErrorInvalidValue;
     if (((uintptr_t)enc_proj & 15) || ((uintptr_t)pred_proj & 15) || ((uintptr_t)b2 & 15)) return hipErrorInvalidValue;
+    if ((unsigned long long)B * T * J >= (1ull << 32) || (unsigned long long)B * U * J >= (1ull << 32)) return hipErrorInvalidValue;  // 32-bit indices in the reductions
     const JhLayout L = make_jh_layout(T, U, B, J, V);
     JhParams jp;
     if (!fill_loss_params(jp.lp, nullptr, nullptr, labels, label_lengths, input_lengths, cost_scale, V, B, costs,

@@ -1872,6 +1872,7 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
 
 // d enc_proj from its [n_ut][B][T][J] partial rows (reduce_enc_kernel); shared with the f16 joint
 hipError_t launch_reduce_enc(float *out, const float *in, int n_ut, const LossParams &lp, int J, hipStream_t s) {
+    if ((unsigned long long)lp.B * lp.T * J >= (1ull << 32)) return hipErrorInvalidValue;  // 32-bit element indices in the kernel
     hipLaunchKernelGGL(reduce_enc_kernel, dim3(1024), dim3(256), 0, s, out, in, n_ut, lp, J);
     return hipGetLastError();
 }
@@ -1921,6 +1922,8 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
                                      B, T, U, blank, costs, d_enc_proj, d_pred_proj, dW2, db2, phases, workspace, s);
     if (!joint_supported(J, V) || joint_dtype != 0) return hipErrorInvalidValue;
     if (((uintptr_t)enc_proj & 15) || ((uintptr_t)pred_proj & 15)) return hipErrorInvalidValue;
+    // the reductions over the [B][T][J] / [B][U][J] arrays index with 32 bits (B*T*U < 2^31 alone does not bound B*T*J)
+    if ((unsigned long long)B * T * J >= (1ull << 32) || (unsigned long long)B * U * J >= (1ull << 32)) return hipErrorInvalidValue;
     const JointLayout L = make_joint_layout(T, U, B, J);
     JointParams jp;
     if (!fill_loss_params(jp.lp, nullptr, nullptr, labels, label_lengths, input_lengths, cost_scale, V, B, costs,

@@ -39,9 +39,8 @@ __device__ __forceinline__ Cell decode(const LossParams &p, uint32_t c) {
 
 __device__ __forceinline__ int clamp_label(int lab, int V) { return min(max(lab, 0), V - 1); }
 
-// ---- cross-workgroup hand-off helpers (overlap mode; MI355X guide G16) ----
-// Payload is stored write-through (sc1) and read with sc1 loads (L2-served, never a stale L1 line);
-// flags are relaxed agent-scope counters.  No fences: every storing wave drains vmcnt before the flag.
+// ---- write-through (sc1) stores / L2-served (sc1) loads (MI355X guide G16) ----
+// The sweeps store the lattice state write-through: nothing on their XCD re-reads it, and the gradient pass runs on all XCDs.
 template <bool SC1>
 __device__ __forceinline__ float ld_f32(const float *q) {
     return SC1 ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
@@ -56,23 +55,6 @@ __device__ __forceinline__ void st_f32_wt(float *q, float v) {
 __device__ __forceinline__ void st_f64_wt(double *q, double v) {
     __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// XCD (accelerator complex die) this wave runs on, 0..7.  Used ONLY to decide whether a hand-off may take
-// the "same L2" fast path; correctness never depends on where the dispatcher placed a workgroup.
-__device__ __forceinline__ int my_xcd() {
-    unsigned x;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
-    return (int)(x & 7u);
-}
-// Bounded poll: ~1 s worst case, then flag the failure instead of hanging the device.
-__device__ __forceinline__ bool spin_until_ge(const int *flag, const int need, int *err) {
-    for (int it = 0; it < (1 << 22); ++it) {
-        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
-        __builtin_amdgcn_s_sleep(8);
-    }
-    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return false;
-}
-
 // What one valid cell needs from the lattice to form its gradient (all log2 domain).
 struct CellGrad {
     float c0;     // alpha + beta - ll - lse*log2e  (add x*log2e -> log2 of softmax*occupancy)

@@ -97,9 +97,8 @@ rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool gpu, siz
     return RNNT_STATUS_SUCCESS;
 }
 
-namespace {
 // fill + lsm + sweeps on the caller's stream (stream order is the only dependency between the stages)
-rnntStatus_t run_forward(LossParams &p, const WsLayout &w, hipStream_t s) {
+static rnntStatus_t run_forward(LossParams &p, const WsLayout &w, hipStream_t s) {
     // the patch kernels write the log-zero part of W themselves; the wave-per-cell kernels (large or unaligned vocabularies)
     // rely on a pre-filled W
     if (!tile_path_ok(p, false) && hipMemsetAsync(p.W, kFillByte, w.A - w.W, s) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
@@ -108,7 +107,7 @@ rnntStatus_t run_forward(LossParams &p, const WsLayout &w, hipStream_t s) {
     return from_hip(launch_sweeps(p, s));
 }
 
-rnntStatus_t validate(const void *acts, const void *labels, const void *ll, const void *il, const void *ws,
+static rnntStatus_t validate(const void *acts, const void *labels, const void *ll, const void *il, const void *ws,
                       int V, int B, const rnntOptions &o) {
     if (!acts || !labels || !ll || !il || !ws) return RNNT_STATUS_INVALID_VALUE;
     if (V <= 0 || B <= 0) return RNNT_STATUS_INVALID_VALUE;
@@ -117,7 +116,6 @@ rnntStatus_t validate(const void *acts, const void *labels, const void *ll, cons
     if (o.blank_label >= V) return RNNT_STATUS_INVALID_VALUE;
     return RNNT_STATUS_SUCCESS;
 }
-}  // namespace
 
 // Build-only split of compute_rnnt_loss so that an autograd caller can delay the gradient pass
 // until the upstream gradient (run_rnnt.py:278: 1/global_batch) is known, and fold it in for free.

@@ -1,9 +1,9 @@
 // rnnt_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the transducer loss.
 //
 // Replaces the three GPU stages of the reference's native op:
-//   a-6  log-softmax denominator            -> cell_*_kernel<GRAD=false>   ("lsm" pass)
-//   a-7/a-8 alpha / beta lattice recurrences -> sweep_kernel
-//   a-9  fused-softmax gradient              -> cell_*_kernel<GRAD=true>    ("grad" pass)
+//   a-6  log-softmax denominator            -> cell_tile_kernel / cell_wave_kernel <GRAD=false>   ("lsm" pass)
+//   a-7/a-8 alpha / beta lattice recurrences -> sweep_ld_kernel (U <= 1024), sweep_wide_kernel (U <= 8192)
+//   a-9  fused-softmax gradient              -> cell_tile_kernel / cell_wave_kernel <GRAD=true>    ("grad" pass)
 // Call site in the reference: utils/loss.py:34-35 (rnnt_loss) via run_rnnt.py:272.
 //
 // Design (DESIGN.md has the full account):
@@ -14,8 +14,9 @@
 //  * the sweeps run one wave64 per (utterance, direction): the live anti-diagonal stays in
 //    VGPRs (K consecutive u per lane), the only cross-lane traffic per step is ONE DPP
 //    wave-shift, no LDS exchange and no s_barrier; edge weights stream HBM -> LDS by
-//    LDS-DMA in double-buffered chunks of G diagonals.  alpha~/beta~ are re-based every 4
-//    diagonals (f64 offsets kept aside) so f32 log-space values stay O(100) instead of O(T+U).
+//    LDS-DMA (issued by a loader wave of the same workgroup) through a ring of chunks of G
+//    diagonals.  alpha~/beta~ are re-based every kRebase = 8 diagonals by INTEGER amounts (exact in
+//    f32; the offsets are kept aside) so f32 log-space values stay O(10) instead of O(T+U).
 //  * grad pass re-reads the logits once, forms all V gradients of a cell in one lane from
 //    alpha~, beta~, lse, applies the blank/label corrections, and stores through LDS so the
 //    HBM writes are full 16-B coalesced lines.

@@ -7,8 +7,9 @@ definitions (tf.signal.stft: periodic Hann window, fft_length = next power of tw
 tf.signal.linear_to_mel_weight_matrix: HTK mel scale, triangles in the mel domain, DC bin excluded).
 TensorFlow is not available in this image, so these are checked against the NumPy restatement in
 oracle/features_oracle.py and against closed-form properties, not against TF outputs (parity unpinned, as for the loss).
-TFRecord files are not read here (that needs TF's protobuf schema); `make_record` / `padded_batch` produce the same
-five tensors from raw audio + text.
+`make_record` / `padded_batch` produce the five tensors from raw audio + text; the reference's `<name>.tfrecord` files of
+those records are read and written by records.py (TFRecord framing, tf.train.Example and TensorProto wire formats,
+utils/preprocessing.py:97-161), without TensorFlow.
 
 Runs on whatever device the audio tensor lives on (cuFFT's ROCm counterpart through torch.fft on an MI355X)."""
 from __future__ import annotations

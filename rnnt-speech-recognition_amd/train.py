@@ -49,20 +49,26 @@ class TrainStep:
 
     @torch.no_grad()
     def evaluate(self, mel_specs, pred_inp, spec_lengths, label_lengths, labels,
-                 metrics: Optional[Iterable[Callable]] = None) -> Tuple[float, Dict[str, float]]:
-        """One eval step of run_rnnt.py:392-424: (mean cost over the global batch, {metric name: value}).
+                 metrics: Optional[Iterable[Callable]] = None, sync_buffers: bool = True) -> Tuple[float, Dict[str, float]]:
+        """One eval step of run_rnnt.py:392-424: (mean cost over the examples of this global batch, {metric name: value}).
 
         `metrics` are the callables of metrics.build_accuracy_fn / build_wer_fn: each is called as
         metric_fn(mel_specs, labels) (run_metrics, run_rnnt.py:223-230) on this rank's shard -- they decode its first
         utterance -- and reduced with MEAN across replicas (:421-422).  BatchNorm running statistics are averaged across
-        replicas first so that every rank evaluates the same model."""
-        sync_buffers_(self.model, self.group)
+        replicas first so that every rank evaluates the same model (`sync_buffers=False`: the caller has done that once for
+        the whole evaluation, as run_evaluate does)."""
+        if sync_buffers:
+            sync_buffers_(self.model, self.group)
         self.model.eval()
         costs = self.model.loss(mel_specs, pred_inp, spec_lengths, label_lengths, labels)
-        s = costs.sum() / self.global_batch
+        # strategy.reduce(MEAN, loss, axis=0) (run_rnnt.py:417-418): the mean over the examples actually present on all
+        # replicas -- a short final batch (records.batches(drop_remainder=False)) is divided by its own size
+        sc = torch.stack([costs.sum().to(torch.float64), torch.tensor(float(costs.numel()), dtype=torch.float64,
+                                                                      device=costs.device)])
         multi = dist.is_initialized() and dist.get_world_size(self.group) > 1
         if multi:
-            dist.all_reduce(s, group=self.group)
+            dist.all_reduce(sc, group=self.group)
+        s = sc[0] / sc[1].clamp_min(1.0)
         results: Dict[str, float] = {}
         for fn in (metrics or []):
             v = torch.tensor(float(fn(mel_specs, labels)), dtype=torch.float64, device=costs.device)
@@ -101,10 +107,11 @@ def run_evaluate(step: "TrainStep", eval_batches: Iterable, metrics: Optional[It
     metrics = list(metrics or [])
     loss_object = _Mean()
     metric_objects = {fn.__name__: _Mean() for fn in metrics}
+    sync_buffers_(step.model, step.group)  # once per evaluation: nothing trains in between
     for inputs in eval_batches:
         if to_device is not None:
             inputs = to_device(inputs)
-        loss, results = step.evaluate(*inputs, metrics=metrics)
+        loss, results = step.evaluate(*inputs, metrics=metrics, sync_buffers=False)
         loss_object(loss)
         for name, value in results.items():
             metric_objects[name](value)
@@ -182,11 +189,13 @@ def _flat_collective_(tensors: Sequence[torch.Tensor], fn) -> None:
 
 
 def sync_replicas_(model: torch.nn.Module, group=None, src: int = 0) -> None:
-    """Broadcast every parameter and buffer from rank `src` (one flat bucket per dtype).  No-op without a group."""
+    """Broadcast every parameter and buffer from the group's rank `src` (one flat bucket per dtype).  No-op without a group."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
+    # dist.broadcast takes a GLOBAL rank: translate the group-local source (a sub-group need not contain global rank 0)
+    gsrc = dist.get_global_rank(group, src) if group is not None else src
     _flat_collective_(list(model.parameters()) + list(model.buffers()),
-                      lambda flat: dist.broadcast(flat, src=src, group=group))
+                      lambda flat: dist.broadcast(flat, src=gsrc, group=group))
 
 
 def sync_buffers_(model: torch.nn.Module, group=None) -> None:

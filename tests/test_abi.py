@@ -34,6 +34,26 @@ def test_exports_every_declared_symbol(lib):
         assert ctypes.cast(getattr(lib, name), ctypes.c_void_p).value
 
 
+def test_dynamic_symbol_table_is_the_abi_and_nothing_else(lib):
+    """The library is built with -fvisibility=hidden: its dynamic symbol table holds the entry points of include/rnnt.h and,
+    besides them, only what the HIP toolchain itself emits for device code -- the kernel handles (mangled, inside namespace
+    rnnt) and the __hip_cuid_* translation-unit tags.  No host-side helper (validate, run_forward, rnnt::launch_* ...) is
+    exported, so nothing of this library can be interposed in a TensorFlow / PyTorch process."""
+    import shutil
+    import subprocess
+
+    nm = shutil.which("nm")
+    if nm is None:
+        pytest.skip("binutils nm not available")
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    plain = sorted(n for n in names if not n.startswith("_Z") and not n.startswith("__hip_cuid_"))
+    assert plain == sorted(_lib.SYMBOLS)
+    for n in names:
+        if n.startswith("_Z"):
+            assert n.startswith("_ZN4rnnt") and "kernel" in n and "launch" not in n and "device_stub" not in n, n
+
+
 def test_version_and_status_strings(lib):
     assert lib.get_warprnnt_version() >= 1
     assert _lib.status_string(0) == "no error"

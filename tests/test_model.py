@@ -106,6 +106,20 @@ def test_evaluate_runs_the_metric_builders(monkeypatch):
     assert res["Accuracy"] == pytest.approx(acc(batch[0], batch[4]))
 
 
+def test_evaluate_is_the_mean_over_the_examples_present(monkeypatch):
+    """strategy.reduce(MEAN, loss, axis=0) (run_rnnt.py:417-418): a short final evaluation batch is divided by ITS size,
+    not by the configured global batch (records.batches(drop_remainder=False) yields one)."""
+    hp = small_hp()
+    m = pkg.Transducer(hp)
+    step = pkg.TrainStep(m, global_batch=8)
+    batch = pkg.synthetic_batch(hp, batch=3, frames=12, max_labels=4, device="cpu", seed=2)
+    monkeypatch.setattr(pkg.Transducer, "loss", lambda self, *a: torch.tensor([3.0, 6.0, 9.0]))
+    assert step.evaluate(*batch)[0] == pytest.approx(6.0)
+    full = [batch, batch]
+    from rnnt_speech_recognition_amd import train as tr
+    assert tr.run_evaluate(step, iter(full))[0] == pytest.approx(6.0)
+
+
 @pytest.mark.gpu
 def test_train_step_reduces_loss_and_matches_unfused_loss():
     torch.manual_seed(0)
@@ -198,6 +212,7 @@ def test_training_loop_follows_the_reference_schedule(tmp_path):
 
     class FakeStep:
         group = None
+        model = torch.nn.Linear(1, 1)  # run_evaluate averages its buffers once per evaluation (no group here: no-op)
 
         def __init__(self):
             self.n, self.saved, self.evals = 0, [], 0
@@ -206,7 +221,8 @@ def test_training_loop_follows_the_reference_schedule(tmp_path):
             self.n += 1
             return {"loss": float(inputs[0]), "step_time": 0.001, "step": self.n}
 
-        def evaluate(self, *inputs, metrics=None):
+        def evaluate(self, *inputs, metrics=None, sync_buffers=True):
+            assert sync_buffers is False  # run_evaluate synchronised once, up front
             self.evals += 1
             return float(inputs[0]) * 2, {fn.__name__: fn(None, None) for fn in (metrics or [])}
 
