@@ -55,8 +55,10 @@ def parse(argv=None):
     ap.add_argument("--fused-only", type=str, default="",
                     help="B,T,U,V: time only the fused joint+loss on this shape (e.g. 16,1500,300,1024 = BASELINE "
                          "config 5) and print its JSON object")
-    ap.add_argument("--e2e", action="store_true",
-                    help="also time BASELINE configs[2]: end-to-end train step, 2x320 LSTM encoder / 1x320 decoder, B=64")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip BASELINE configs[2] (end-to-end train step, 2x320 LSTM encoder / 1x320 decoder, B=64 per GPU)")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skip the two BASELINE configs[4] legs (f16 fused joint and the op on materialised logits; N=1 only)")
     ap.add_argument("--cpu-reps", type=int, default=10)
     ap.add_argument("--engine", choices=["hip", "stub"], default="hip",
                     help="stub = CPU/gloo stand-in with no kernels: exercises the launch / sharding / collective / reporting "
@@ -212,6 +214,7 @@ def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
     if f16:
         return {"workload": f"joint+loss+grads from enc_proj/pred_proj, B={B} T={T} U={U} V={V} J={J}, "
                             "f16 MFMA joint / f32 lattice",
+                "dtype": "f16 products (binary16 operands, f32 accumulation), f32 lattice",
                 "ms_per_step": dt * 1e3, "cells_per_s": cells / dt,
                 "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F16_PEAK_TFLOPS,
@@ -227,6 +230,7 @@ def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
     split_peak = MFMA_F16_PEAK_TFLOPS / 3.0
     return {"workload": f"joint+loss+grads from enc_proj/pred_proj, B={B} T={T} U={U} V={V} J={J}, "
                         "f32-grade products on split-precision f16 MFMAs",
+            "dtype": "f16x3-split (binary16 hi+lo operands, three f16 MFMAs per product, f32 accumulation), f32 lattice",
             "ms_per_step": dt * 1e3, "cells_per_s": cells / dt,
             "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": split_peak,
                          "unit": "TFLOP/s", "frac": flops / dt / 1e12 / split_peak,
@@ -237,6 +241,64 @@ def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
                                  "uses the 8*J*V convention (its backward recompute is not executed: the V<=32 logits tile "
                                  "is parked); executed_mfma_tflops counts the products actually issued (V padded to 32)"},
             "workspace_GB": ws.numel() / 1e9}
+
+
+def bench_fused_full(dev, B, T, U, V, J, reps):
+    """The complete fused step as a training graph sees it (model.py:158-166 + run_rnnt.py:269-288): enc [B,T,H], pred [B,U,H]
+    -> W1 projections (two hipBLASLt GEMMs, bias folded) -> libwarprnnt.so joint + loss + gradient scatter -> autograd back
+    to dW1, db1, d enc, d pred.  Everything the timed region of `fused_joint` leaves out (it starts from enc_proj / pred_proj)
+    is inside this one.  H = J (hparams.py:18,23)."""
+    import rnnt_speech_recognition_amd as pkg
+
+    torch.manual_seed(99)
+    joint = pkg.JointLoss(J, J, V).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    enc = torch.randn(B, T, J, generator=g).to(dev).requires_grad_(True)
+    pred = torch.randn(B, U, J, generator=g).to(dev).requires_grad_(True)
+    labels = torch.randint(1, V, (B, U - 1), generator=g, dtype=torch.int32).to(dev)
+    il = torch.full((B,), T, dtype=torch.int32, device=dev)
+    ll = torch.full((B,), U - 1, dtype=torch.int32, device=dev)
+    leaves = list(joint.parameters()) + [enc, pred]
+
+    def step():
+        for x in leaves:
+            x.grad = None
+        costs = joint(enc, pred, labels, il, ll)
+        (costs.sum() * (1.0 / B)).backward()  # run_rnnt.py:278
+
+    def w1_only():  # the part of the step that is NOT behind the C ABI: the two projections and their backward
+        for x in leaves:
+            x.grad = None
+        ep = torch.matmul(enc, joint.W1) + joint.b1
+        pp = torch.matmul(pred, joint.W1)
+        torch.autograd.backward([ep, pp], [g_ep, g_pp])
+
+    def timeit(fn, n):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    g_ep = torch.randn(B, T, J, device=dev)
+    g_pp = torch.randn(B, U, J, device=dev)
+    dt = timeit(step, reps)
+    dt_w1 = timeit(w1_only, reps)
+    cells = B * T * U
+    flops = 8.0 * J * V * cells + 6.0 * B * (T + U) * J * J  # SURVEY.md 8(d): joint products + the factored first layer
+    split_peak = MFMA_F16_PEAK_TFLOPS / 3.0
+    return {"workload": f"fused step from enc/pred: W1 GEMMs + joint + loss + gradients (dW1, db1, dW2, db2, d enc, d pred), "
+                        f"B={B} T={T} U={U} V={V} H=J={J}",
+            "dtype": "f32 W1 GEMMs (hipBLASLt) + f16x3-split joint products, f32 lattice",
+            "ms_per_step": dt * 1e3, "cells_per_s": cells / dt,
+            "w1_gemms_fwd_bwd_ms": dt_w1 * 1e3,
+            "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": split_peak, "unit": "TFLOP/s",
+                         "frac": flops / dt / 1e12 / split_peak, "algorithmic_flops_per_step": flops,
+                         "note": "8*J*V per cell + 6*B*(T+U)*H*J; peak = dense f16 MFMA peak / 3 as for fused_joint (the W1 "
+                                 "GEMMs run on f32 MFMAs, 157.3 TFLOP/s peak: 12.5 % of these flops)"}}
 
 
 def bench_fused_dp_step(dev, world, rank, B, T, U, V, J, reps, sync):
@@ -304,6 +366,46 @@ def bench_e2e(dev, world, rank, steps=8):
     return {"workload": "configs[2]: B=64/GPU, 600 frames x 240 feats, enc 2x320 (x2 time reduction), pred 1x320, "
                         "J=320, V=28, SGD(1e-4, 0.9); synthetic features",
             "ms_per_step": dt * 1e3, "utterances_per_s": 64 * world / dt, "loss": log["loss"]}
+
+
+def bench_op_shape(lib, _lib, dev, B, T, U, V, stream, reps):
+    """P1 (the warp-transducer op contract: loss + gradient on MATERIALISED f32 logits) at another shape -- BASELINE
+    configs[4] B=16 T=1500 U=300 V=1024: 29.5 GB of logits in, 29.5 GB of gradients out, generated on the device."""
+    gd = torch.Generator(device=dev).manual_seed(4321)
+    acts = torch.randn(B, T, U, V, generator=gd, dtype=torch.float32, device=dev)
+    grads = torch.empty_like(acts)
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    labels = torch.randint(1, V, (B, U - 1), generator=g, dtype=torch.int32).to(dev)
+    il = torch.full((B,), T, dtype=torch.int32, device=dev)
+    ll = torch.full((B,), U - 1, dtype=torch.int32, device=dev)
+    scale = torch.full((B,), 1.0 / B, dtype=torch.float32, device=dev)
+    costs = torch.empty(B, dtype=torch.float32, device=dev)
+    ws = torch.empty(_lib.workspace_bytes(T, U, B), dtype=torch.uint8, device=dev)
+    opts = _lib.make_options(stream.cuda_stream, 0, T, U)
+
+    def step():
+        _lib.check(lib.compute_rnnt_loss_ex(acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), ll.data_ptr(),
+                                            il.data_ptr(), scale.data_ptr(), V, B, costs.data_ptr(), ws.data_ptr(), opts),
+                   "compute_rnnt_loss_ex")
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    cells = B * T * U
+    alg = 8.0 * V * cells
+    finite = bool(torch.isfinite(costs).all())
+    del acts, grads, ws
+    torch.cuda.empty_cache()
+    return {"workload": f"transducer loss+grad on given f32 logits, B={B} T={T} U={U} V={V}, full lengths, acts~N(0,1)",
+            "dtype": "f32", "ms_per_step": dt * 1e3, "cells_per_s": cells / dt, "costs_finite": finite,
+            "roofline": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / dt / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg,
+                         "note": "whole op (lsm + sweeps + gradient pass), 8*V bytes per cell"}}
 
 
 def joint_bucket_floats(H, J, V):
@@ -532,24 +634,53 @@ def main():
                   "lengths": "T_b ~ U{T/2..T}, L_b ~ U{(U-1)/2..U-1}, one full-length utterance (SURVEY.md 8d)"}
 
     # ---- fused joint + loss (SURVEY.md 8d "P2"): reported beside the headline, not as `value` ----
-    fused = None
-    fused_c5 = None
-    fused_dp = None
+    fused = fused_full = fused_c5 = op_c5 = fused_dp = None
+    headline_shape = (B, T, U, V) == (32, 600, 150, 28)
     if not a.no_fused:
+        nf = max(3, min(a.steps, 10))
         if rank == 0:
-            fused = bench_fused_joint(lib, _lib, dev, B, T, U, V, a.joint_size, stream, max(3, min(a.steps, 10)))
-        if world > 1 and V <= 32:
-            fused_dp = bench_fused_dp_step(dev, world, rank, B, T, U, V, a.joint_size, max(3, min(a.steps, 10)), sync)
-        if rank == 0 and world == 1 and (B, T, U, V) == (32, 600, 150, 28):
-            # BASELINE configs[4] (large-vocabulary stress, f16 MFMA joint / f32 lattice): a parity-test case, timed here
-            # too because it is the path's MFMA-bound corner (3 steps, ~16 GB of workspace)
+            fused = bench_fused_joint(lib, _lib, dev, B, T, U, V, a.joint_size, stream, nf)
+        if rank == 0 and V <= 32:
+            try:
+                fused_full = bench_fused_full(dev, B, T, U, V, a.joint_size, nf)
+            except Exception as e:  # a leg must not take the headline line down with it
+                fused_full = {"error": repr(e)}
+        if V <= 32:
+            # the complete data-parallel step of the fused engine through parallel.dp_loss_step and RCCL.  At N = 1 this is a
+            # ONE-rank RCCL group (the collective degenerates to a copy): the point is that the driver's single-GPU run
+            # executes exactly the code the N > 1 runs execute.
+            own_group = False
+            try:
+                if world == 1 and not dist.is_initialized():
+                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                    os.environ.setdefault("MASTER_PORT", str(_free_port()))
+                    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                    own_group = True
+                fused_dp = bench_fused_dp_step(dev, world, rank, B, T, U, V, a.joint_size, nf, sync)
+            except Exception as e:
+                fused_dp = {"error": repr(e)}
+            finally:
+                if own_group and dist.is_initialized():
+                    dist.destroy_process_group()
+        if rank == 0 and world == 1 and headline_shape and not a.no_config5:
+            # BASELINE configs[4] (large-vocabulary stress): parity-test cases, timed here too because they are the path's
+            # MFMA-bound corner (fused f16 joint, ~16 GB of workspace) and its largest HBM-bound one (op on 29.5 GB of logits)
             del acts_ring[1:]
             torch.cuda.empty_cache()
             fused_c5 = bench_fused_joint(lib, _lib, dev, 16, 1500, 300, 1024, 640, stream, 3)
+            torch.cuda.empty_cache()
+            try:
+                op_c5 = bench_op_shape(lib, _lib, dev, 16, 1500, 300, 1024, stream, 3)
+            except Exception as e:
+                op_c5 = {"error": repr(e)}
 
     e2e = None
-    if a.e2e:
-        e2e = bench_e2e(dev, world, rank)
+    if not a.no_e2e and headline_shape:
+        try:
+            e2e = bench_e2e(dev, world, rank)
+        except Exception as e:
+            e2e = {"error": repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -571,13 +702,15 @@ def main():
             "warm_value": world * cells * a.steps / dt_warm,
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "roofline": roof, "cpu_baseline": cpu, "ragged_batch": ragged, "fused_joint": fused,
-            "fused_joint_config5": fused_c5, "fused_dp_step": fused_dp,
+            "fused_joint_full": fused_full, "fused_joint_config5": fused_c5, "op_config5": op_c5,
+            "fused_dp_step": fused_dp, "e2e_train_step": e2e,
         }
         if world > 1:
             out["collective"] = {"op": "all_reduce SUM (RCCL)", "bytes": bucket.numel() * 4, "per_step": 1,
-                                 "inside_timed_region": True}
-        if e2e is not None:
-            out["e2e_train_step"] = e2e
+                                 "inside_timed_region": True,
+                                 "note": "latency probe: the op-level step produces no parameter gradients, so the bucket it "
+                                         "reduces has the SIZE of the reference joint's (W1, b1, W2, b2) but carries zeros; "
+                                         "fused_dp_step reduces the real dW1, db1, dW2, db2"}
         if cpu:
             out["gpu_over_cpu"] = value / cpu["value"]
         print(json.dumps(out))

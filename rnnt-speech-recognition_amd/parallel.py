@@ -66,7 +66,7 @@ def flat_all_reduce_(tensors: Iterable[torch.Tensor], group=None) -> None:
     """SUM-all-reduce a list of tensors as ONE flat bucket (in place).  The bucket takes the tensors' dtype
     (fp32 for every product parameter; mixed lists are promoted to the widest)."""
     ts = [t for t in tensors if t is not None]
-    if not ts or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not ts or not dist.is_initialized():  # a one-rank group still runs the collective: the same code path at every N
         return
     dtype = ts[0].dtype
     for t in ts[1:]:
@@ -97,6 +97,6 @@ def dp_loss_step(costs_fn: Callable[[], torch.Tensor], params: Sequence[torch.Te
             p.grad = torch.zeros_like(p)
     flat_all_reduce_([p.grad for p in params], group)  # run_rnnt.py:288 -- replicas' gradients are summed
     logged = local.detach().clone()
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():
         dist.all_reduce(logged, op=dist.ReduceOp.SUM, group=group)  # run_rnnt.py:293-294
     return logged

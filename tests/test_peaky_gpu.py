@@ -1,0 +1,148 @@
+"""GPU parity under PEAKED posteriors at BASELINE.json configs[1] size (B=32 T=600 U=150 V=28) -- what a trained model
+produces, as opposed to the N(0,1) logits of the headline bench.  Through the C ABI, against the float64 oracle on 8 of the
+32 utterances per case.
+
+  sigma4 / sigma8   logits = 4 / 8 * N(0,1): incoherent peaks (no dominant alignment), costs of 4,000 / 7,500 nats
+  trained           one dominant symbol per cell along a monotone alignment (bonus 10 nats on blank before the cell's label
+                    is due, on the label afterwards); half of the utterances emit all labels in the last 40 % of the frames
+                    (alignments far from the lattice's straight diagonal), costs of a few nats
+  fused x5 / x10    the f32-grade fused joint with glorot W2 scaled by 5 / 10 (logit spread ~4 / ~8)
+
+Bars (north_star "within 1e-4 fp32"): costs |d| <= 1e-4 max(1, |cost|); gradients max|d| <= 1e-4 (P1: absolute, gradients
+live in [-1, 1]; fused: relative to max(1, max|ref|)).  The measured maxima are written to gpurun_out/r03_accuracy.json
+(copied to profiles/ by hand)."""
+import json
+import math
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+import torch
+
+import rnnt_speech_recognition_amd as pkg
+from oracle import rnnt_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B, T, U, V = 32, 600, 150, 28
+PICKS = list(range(0, B, 4))  # 8 utterances
+GTOL = CTOL = 1e-4
+_report = {}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _setup():
+    assert torch.cuda.is_available(), "these tests need a real MI355X"
+    pkg.build()
+    yield
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "r03_accuracy.json"), "w") as f:
+        json.dump(_report, f, indent=1, sort_keys=True)
+
+
+def _pool():
+    # threads, not processes: the float64 oracle spends its time in NumPy kernels that release the GIL, and a worker process
+    # that fails to start must not be able to hang a GPU box
+    return ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1))
+
+
+def make_logits(kind, seed):
+    rng = np.random.default_rng(seed)
+    labels = rng.integers(1, V, size=(B, U - 1)).astype(np.int32)
+    x = rng.normal(size=(B, T, U, V)).astype(np.float32)
+    if kind.startswith("sigma"):
+        x *= np.float32(kind[5:])
+    else:
+        bonus = np.float32(10.0)
+        for b in range(B):
+            lo = int(0.6 * T) if b % 2 else 0  # odd utterances: every label is emitted late
+            emit = np.sort(rng.integers(lo, T, size=U - 1))
+            for u in range(U):
+                te = emit[u] if u < U - 1 else T
+                x[b, :te, u, 0] += bonus
+                if u < U - 1:
+                    x[b, te:, u, labels[b, u]] += bonus
+    il = np.full(B, T, np.int32)
+    ll = np.full(B, U - 1, np.int32)
+    return x, labels, il, ll
+
+
+def _p1_oracle(args):
+    x, lab = args
+    c, g, _, _, _ = orc.utterance_cost_and_grad(x, lab)
+    return c, g.astype(np.float32), float(np.abs(g).max())
+
+
+@pytest.mark.parametrize("kind", ["sigma4", "sigma8", "trained"])
+def test_p1_peaked_logits_at_c2_size(kind):
+    x, labels, il, ll = make_logits(kind, seed={"sigma4": 41, "sigma8": 81, "trained": 7}[kind])
+    dev = torch.device("cuda:0")
+    costs, grads = pkg.rnnt_loss_and_grad(torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev),
+                                          torch.from_numpy(il).to(dev), torch.from_numpy(ll).to(dev))
+    torch.cuda.synchronize()
+    c = costs.cpu().numpy().astype(np.float64)
+    assert np.isfinite(c).all() and bool(torch.isfinite(grads).all())
+    with _pool() as ex:
+        refs = list(ex.map(_p1_oracle, [(x[b], labels[b]) for b in PICKS]))
+    dc, dg = [], []
+    for b, (c_ref, g_ref, _) in zip(PICKS, refs):
+        dc.append(abs(c[b] - c_ref) / max(1.0, abs(c_ref)))
+        dg.append(float(np.abs(grads[b].cpu().numpy() - g_ref).max()))
+    _report[f"p1_{kind}"] = {"utterances": PICKS, "max_rel_dcost": max(dc), "max_abs_dgrad": max(dg),
+                             "cost_range_nats": [float(min(r[0] for r in refs)), float(max(r[0] for r in refs))]}
+    assert max(dc) <= CTOL, (kind, dc)
+    assert max(dg) <= GTOL, (kind, dg)
+
+
+def _fused_oracle(args):
+    ep, pp, W2, b2, lab, cs = args
+    o = orc.joint_utterance_streamed(ep, pp, W2, b2, lab, cost_scale=cs, f16=False, dl_scale=1.0)
+    return {k: o[k] for k in ("cost", "d_enc_proj", "d_pred_proj", "dW2", "db2")}
+
+
+@pytest.mark.parametrize("gain", [5.0, 10.0])
+def test_fused_f32_joint_peaked_at_c2_size(gain):
+    from rnnt_speech_recognition_amd.joint import JOINT_DTYPES, _JointLossFunction
+
+    J = 640
+    g = torch.Generator().manual_seed(1000 + int(gain))
+    ep = torch.randn(B, T, J, generator=g)
+    pp = torch.randn(B, U, J, generator=g)
+    W2 = (torch.rand(J, V, generator=g) * 2 - 1) * (math.sqrt(6.0 / (J + V)) * gain)
+    b2 = 0.1 * torch.randn(V, generator=g)
+    labels = torch.randint(1, V, (B, U - 1), generator=g, dtype=torch.int32)
+    il = torch.full((B,), T, dtype=torch.int32)
+    ll = torch.full((B,), U - 1, dtype=torch.int32)
+    scale = torch.full((B,), 1.0 / B)
+    dev = torch.device("cuda:0")
+
+    def run(sc):
+        ps = [x.clone().to(dev).requires_grad_(True) for x in (ep, pp, W2, b2)]
+        costs = _JointLossFunction.apply(*ps, labels.to(dev), il.to(dev), ll.to(dev), 0, JOINT_DTYPES["f32"])
+        (costs * sc.to(dev)).sum().backward()
+        torch.cuda.synchronize()
+        return costs.detach().cpu().numpy().astype(np.float64), [p.grad.cpu().numpy() for p in ps]
+
+    costs, grads = run(scale)
+    picks = PICKS if gain >= 10 else PICKS[::2]  # 7 s of float64 oracle per utterance
+    mask = torch.zeros(B)
+    mask[picks] = 1.0
+    _, gm = run(scale * mask)  # dW2 / db2 of the picked utterances only
+    epn, ppn, W2n, b2n, labn = (x.numpy() for x in (ep, pp, W2, b2, labels))
+    with _pool() as ex:
+        refs = list(ex.map(_fused_oracle, [(epn[b], ppn[b], W2n, b2n, labn[b], float(scale[b])) for b in picks]))
+    dc, dg = [], []
+    dW2_ref = sum(r["dW2"] for r in refs)
+    db2_ref = sum(r["db2"] for r in refs)
+    for b, r in zip(picks, refs):
+        dc.append(abs(costs[b] - r["cost"]) / max(1.0, abs(r["cost"])))
+        for got, ref in ((grads[0][b], r["d_enc_proj"]), (grads[1][b], r["d_pred_proj"])):
+            dg.append(float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max())))
+    for got, ref in ((gm[2], dW2_ref), (gm[3], db2_ref)):
+        dg.append(float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max())))
+    _report[f"fused_f32_w2x{gain:g}"] = {"utterances": picks, "max_rel_dcost": max(dc), "max_rel_dgrad": max(dg),
+                                         "cost_range_nats": [float(min(r["cost"] for r in refs)), float(max(r["cost"] for r in refs))]}
+    assert max(dc) <= CTOL, dc
+    assert max(dg) <= GTOL, dg
