@@ -196,6 +196,20 @@ RNNT_API rnntStatus_t compute_rnnt_joint_loss_bwd(const float *enc_proj, const f
                                          float *dW2, float *db2, int joint_dtype, void *workspace,
                                          rnntOptions options);
 
+/* Build-only extension: the joint network alone, for decoding.  Replaces `joint(model, f, g)` of the reference's greedy
+ * decoder (utils/decoding.py:6-18: dense_1 (tanh) and dense_2 on f + g for one lattice cell per step; called at :63-69):
+ *   logits[b,t,u,:] = tanh(enc_proj[b,t,:] + pred_proj[b,u,:]) @ W2 + b2        device f32 [minibatch, maxT, maxU, alphabet_size]
+ * with enc_proj / pred_proj as for compute_rnnt_joint_loss (the first Dense layer factored, bias folded into enc_proj).
+ * It runs the forward kernels of compute_rnnt_joint_loss with joint_dtype 0 -- the same f32-grade split-precision products
+ * and the same device-side switch to plain f32 MFMAs -- on a lattice whose every cell is live, so a decoder sees bit for bit
+ * the logits the loss was trained on.  Shapes: alphabet_size <= 32, joint_size a multiple of 64 (<= 704), maxU <= 1024;
+ * a greedy decoder calls it with maxT = maxU = 1 and minibatch = the number of hypotheses.
+ * workspace: get_joint_workspace_size(maxT, maxU, minibatch, joint_size, alphabet_size) bytes, 256-byte aligned. */
+RNNT_API rnntStatus_t compute_rnnt_joint_logits(const float *enc_proj, const float *pred_proj,
+                                                const float *W2, const float *b2, int joint_size,
+                                                int alphabet_size, int minibatch, float *logits,
+                                                void *workspace, rnntOptions options);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,7 @@ SYMBOLS = [
     "compute_rnnt_joint_loss",
     "compute_rnnt_joint_loss_fwd",
     "compute_rnnt_joint_loss_bwd",
+    "compute_rnnt_joint_logits",
 ]
 
 
@@ -89,6 +90,8 @@ def load():
     lib.compute_rnnt_joint_loss_fwd.argtypes = [vp] * 7 + [ci, ci, ci, vp, ci, vp, rnntOptions]
     lib.compute_rnnt_joint_loss_bwd.restype = ci
     lib.compute_rnnt_joint_loss_bwd.argtypes = [vp] * 8 + [ci, ci, ci] + [vp] * 4 + [ci, vp, rnntOptions]
+    lib.compute_rnnt_joint_logits.restype = ci
+    lib.compute_rnnt_joint_logits.argtypes = [vp] * 4 + [ci, ci, ci, vp, vp, rnntOptions]
     _lib = lib
     return lib
 

@@ -94,6 +94,7 @@ struct JointParams {
     long long *trace;    // dev builds only: s_memtime stamps of one workgroup of phase 1 and one of phase 2
 #endif
     int J, n_ut, TR, n_tr, TS, n_ts;
+    int logits_only;  // compute_rnnt_joint_logits: full lengths written by the prep kernel, only the parked logits are kept
     int single_bwd;  // 1: joint_bwd_kernel does the backward; joint_dl_kernel only runs for the f32 fallback (tflag[1])
 };
 
@@ -122,6 +123,11 @@ __global__ __launch_bounds__(256) void joint_prep_kernel(const JointParams jp) {
         }
     }
     if (__any(big) && (threadIdx.x & 63) == 0) jp.tflag[0] = 1.0f;
+    if (jp.logits_only && blockIdx.x == 1)  // every lattice cell is wanted: full lengths (the arrays live in the workspace)
+        for (int b = threadIdx.x; b < p.B; b += 256) {
+            const_cast<int *>(p.input_lengths)[b] = p.T;
+            const_cast<int *>(p.label_lengths)[b] = p.U - 1;
+        }
     if (blockIdx.x == 0) {  // joint_fwd_kernel accumulates r = (1 - h) / 2: logits = (b2 + sum_j W2) - 2 W2^T r
         __shared__ double part[8][32];
         const int v = threadIdx.x & 31, q = threadIdx.x >> 5;
@@ -1911,6 +1917,71 @@ static hipError_t set_lds(K kernel, size_t bytes) {
     return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// logits[c][0..V) <- the parked tile dl[c][0..32) (bias included)
+__global__ __launch_bounds__(256) void joint_logits_copy_kernel(float *out, const float *dl, const uint32_t cells, const int V) {
+    const size_t n = (size_t)cells * (size_t)V;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t c = i / (size_t)V;
+        out[i] = dl[c * 32 + (i - c * (size_t)V)];
+    }
+}
+
+// Joint logits only (decoding: utils/decoding.py:6-18): the forward kernels of launch_joint_loss -- the same tables, the same
+// split-precision products, the same device-side choice between them -- with every lattice cell live; what they park in the
+// workspace is copied out as [B, T, U, V].
+hipError_t launch_joint_logits(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2, int J, int V,
+                               int B, int T, int U, float *logits, void *workspace, hipStream_t s) {
+    if (!joint_supported(J, V) || sweep_K(U) == 0) return hipErrorInvalidValue;
+    if (((uintptr_t)enc_proj & 15) || ((uintptr_t)pred_proj & 15)) return hipErrorInvalidValue;
+    if ((unsigned long long)B * T * J >= (1ull << 32) || (unsigned long long)B * U * J >= (1ull << 32)) return hipErrorInvalidValue;
+    const JointLayout L = make_joint_layout(T, U, B, J);
+    char *ws = (char *)workspace;
+    // lengths and labels of the "everything is live" lattice sit in workspace regions the forward kernels do not touch
+    int *il = (int *)(ws + L.rec), *ll = il + B, *labels = (int *)(ws + L.reclab);
+    JointParams jp;
+    if (!fill_loss_params(jp.lp, nullptr, nullptr, labels, ll, il, nullptr, V, B, nullptr, workspace, T, U, 0))
+        return hipErrorInvalidValue;
+    jp.enc_proj = enc_proj, jp.pred_proj = pred_proj, jp.W2 = W2, jp.b2 = b2;
+    jp.dl = (float *)(ws + L.dl);
+    jp.rec = nullptr, jp.reclab = nullptr;
+    jp.xbl = (float2 *)(ws + L.xbl);
+    jp.dApart = jp.dCpart = jp.dWpart = jp.dbpart = nullptr;
+    jp.d_enc_proj = jp.d_pred_proj = jp.dW2 = jp.db2 = nullptr;
+    jp.expE = (float *)(ws + L.expE), jp.expP = (float *)(ws + L.expP), jp.tflag = (float *)(ws + L.tflag);
+    jp.b2s = jp.tflag + 64;
+    jp.W2s = (jf16 *)(ws + L.W2s);
+#ifdef JH_TRACE
+    jp.trace = nullptr;
+#endif
+    jp.J = J, jp.n_ut = L.n_ut, jp.TR = L.TR, jp.n_tr = L.n_tr, jp.TS = L.TS, jp.n_ts = L.n_ts;
+    jp.logits_only = 1, jp.single_bwd = 0;
+    hipError_t e;
+    if (hipMemsetAsync(jp.tflag, 0, 256, s) != hipSuccess) return hipErrorUnknown;
+    if (U > 1 && hipMemsetAsync(labels, 0, (size_t)B * (U - 1) * sizeof(int), s) != hipSuccess) return hipErrorUnknown;
+    hipLaunchKernelGGL(joint_prep_kernel, dim3(1024), dim3(256), 0, s, jp);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    const unsigned g1 = (unsigned)B * L.n_ut * L.n_tr;
+    const size_t shm_fwd = (size_t)J * 256;
+    if (shm_fwd <= 160 * 1024) {
+        if ((e = set_lds(joint_fwd_kernel, shm_fwd)) != hipSuccess) return e;
+        const int n_items = ((T + kFwdRows - 1) / kFwdRows) * B * L.n_ut;
+        const int ncu = device_cu_count();
+        hipLaunchKernelGGL(joint_fwd_kernel, dim3(n_items < ncu ? n_items : ncu), dim3(kFwdWaves * 64), shm_fwd, s, jp);
+    } else {
+        const size_t shm1s = (size_t)J * 32 * sizeof(float) + 2 * 8192 + (kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
+        if ((e = set_lds(joint_phase1s_kernel, shm1s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(joint_phase1s_kernel, dim3(g1), dim3(kP1Waves * 64), shm1s, s, jp);
+    }
+    const size_t shm1 = ((size_t)J * 32 + 2 * 1024 + kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
+    if ((e = set_lds(joint_phase1_kernel, shm1)) != hipSuccess) return e;
+    hipLaunchKernelGGL(joint_phase1_kernel, dim3(g1), dim3(kP1Waves * 64), shm1, s, jp);  // exits at once unless W2 left binary16
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    const size_t n = (size_t)jp.lp.cells * V;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(joint_logits_copy_kernel, dim3(grid), dim3(256), 0, s, logits, jp.dl, jp.lp.cells, V);
+    return hipGetLastError();
+}
+
 hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2,
                              const int *labels, const int *label_lengths, const int *input_lengths,
                              const float *cost_scale, int J, int V, int B, int T, int U, int blank, float *costs,
@@ -1951,6 +2022,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     jp.trace = trace_dev;
 #endif
     jp.J = J, jp.n_ut = L.n_ut, jp.TR = L.TR, jp.n_tr = L.n_tr, jp.TS = L.TS, jp.n_ts = L.n_ts;
+    jp.logits_only = 0;
 
     const size_t shm1 = ((size_t)J * 32 + 2 * 1024 + kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
     const size_t shm2 = ((size_t)64 * 36 + 64 * kStagePad + 2 * 4 * 32 * kStagePad) * sizeof(float);

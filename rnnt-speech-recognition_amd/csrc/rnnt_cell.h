@@ -73,21 +73,21 @@ __device__ __forceinline__ CellGrad cell_grad_from(const LossParams &p, const Ce
                                                    const float b_t1, const float b_u1) {
     CellGrad g;
     const int n = cl.t + cl.u;
-    // offsets are kept per (block of kRebase diagonals, group of 64 lattice columns)
+    // offsets are kept per (block of kRebase diagonals, group of OG lattice columns: one sweep lane)
     const int kc = n / kRebase, kc1 = (n + 1) / kRebase;
-    const int g0 = cl.u >> 6, g1 = (cl.u + 1) >> 6;
+    const int g0 = (int)fdiv((uint32_t)cl.u, p.divOG), g1 = (int)fdiv((uint32_t)cl.u + 1u, p.divOG);
     const size_t ob = (size_t)cl.b * p.NC * p.NG;
     const double oa = (double)ld_f32<SC1>(p.offA + ob + (size_t)kc * p.NG + g0);
     const double ll2 = ld_f64<SC1>(p.ll + 2 * cl.b);
-    const float E0 = (float)(oa + (double)ld_f32<SC1>(p.offB + ob + (size_t)kc * p.NG + g0) - ll2);
+    const double da = (double)a + (oa - ll2);  // alpha(t,u) - ll: residue + offset, formed in f64 and rounded ONCE below
     g.scale = p.cost_scale ? p.cost_scale[cl.b] : 1.0f;
     g.nl = -p.lse[c] * kLog2e;
-    g.c0 = (a + bt) + E0 + g.nl;
+    g.c0 = (float)(da + ((double)bt + (double)ld_f32<SC1>(p.offB + ob + (size_t)kc * p.NG + g0))) + g.nl;
     g.has_blank_corr = true;
     if (cl.t < cl.Tb - 1)
-        g.cb = a + b_t1 + (float)(oa + (double)ld_f32<SC1>(p.offB + ob + (size_t)kc1 * p.NG + g0) - ll2);
+        g.cb = (float)(da + ((double)b_t1 + (double)ld_f32<SC1>(p.offB + ob + (size_t)kc1 * p.NG + g0)));
     else if (cl.u == cl.Ub - 1)
-        g.cb = a + (float)(oa - ll2);
+        g.cb = (float)da;
     else {
         g.cb = 0.f;
         g.has_blank_corr = false;
@@ -97,7 +97,7 @@ __device__ __forceinline__ CellGrad cell_grad_from(const LossParams &p, const Ce
     g.cl = 0.f;
     if (g.has_label) {
         g.lab = clamp_label(p.labels[(size_t)cl.b * (p.U - 1) + cl.u], p.V);
-        g.cl = a + b_u1 + (float)(oa + (double)ld_f32<SC1>(p.offB + ob + (size_t)kc1 * p.NG + g1) - ll2);
+        g.cl = (float)(da + ((double)b_u1 + (double)ld_f32<SC1>(p.offB + ob + (size_t)kc1 * p.NG + g1)));
     }
     return g;
 }

@@ -8,8 +8,9 @@
 //                                              W[b][n][u][1] = log2 p(y_{u+1} | t=n-u, u)
 //   A, Bt          f32 [B][Nr][Up]             alpha~/beta~ lattices, log2 domain, skewed,
 //                                              stored relative to a per-block offset (kRebase diagonals)
-//   offA, offB     f32 [B][NC][NG]             the offsets (integer-valued; per block of kRebase diagonals and
-//                                              group of 64 columns)
+//   offA, offB     f32 [B][NC][NG]             the offsets (integer-valued; per block of kRebase diagonals and group of OG
+//                                              lattice columns: OG = K, the columns of one sweep lane, NG = 64 for the
+//                                              register-resident sweeps; OG = 64, NG = Up/64 for the wide sweep)
 //   ll             f64 [B][2]                  log2-likelihood from the alpha side / beta side
 // with N = T+U-1 diagonals, Nr = N rounded up to 16 (a multiple of every chunk length), Up = 64*K (K = lattice columns per sweep lane).
 #pragma once
@@ -67,15 +68,15 @@ struct LossParams {
     double *ll;
     int B, T, U, V, blank;
     int b0, nb;  // this launch covers utterances [b0, b0+nb)
-    int N, Nr, Up, NC, NG;  // NG = Up/64 column groups (offset tables are [NC][NG])
+    int N, Nr, Up, NC, NG;  // NG = Up/OG offset groups (offset tables are [NC][NG])
     uint32_t cells;  // B*T*U
-    FastDiv divU, divT, divV;
+    FastDiv divU, divT, divV, divOG;  // divOG: lattice column -> offset group
     TileGeom tile;
 };
 
 struct WsLayout {
     size_t lse, W, A, Bt, offA, offB, ll, total;
-    int N, Nr, Up, NC, NG;
+    int N, Nr, Up, NC, NG, OG;
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -99,7 +100,8 @@ inline WsLayout make_layout(int T, int U, int B) {
     // row stride of the skewed arrays = 64 lanes x K columns (U <= 1024), else U rounded up to 64
     w.Up = sweep_K(U) ? 64 * sweep_K(U) : (int)align_up((size_t)U, 64);
     w.NC = w.Nr / kRebase + 1;
-    w.NG = w.Up / 64;
+    w.OG = sweep_K(U) ? sweep_K(U) : 64;  // columns per offset group: one sweep lane, or 64 columns of the wide sweep
+    w.NG = w.Up / w.OG;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         size_t o = off;

@@ -17,6 +17,8 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
                              const float *cost_scale, int J, int V, int B, int T, int U, int blank, float *costs,
                              float *d_enc_proj, float *d_pred_proj, float *dW2, float *db2, int joint_dtype,
                              int phases, void *workspace, hipStream_t s);
+hipError_t launch_joint_logits(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2, int J, int V,
+                               int B, int T, int U, float *logits, void *workspace, hipStream_t s);
 }  // namespace rnnt
 
 static rnntStatus_t check_options(const rnntOptions &o) {
@@ -57,6 +59,7 @@ static bool fill_params(LossParams &p, const float *acts, float *grads, const in
     p.divU = make_fastdiv((uint32_t)o.maxU);
     p.divT = make_fastdiv((uint32_t)o.maxT);
     p.divV = make_fastdiv((uint32_t)V);
+    p.divOG = make_fastdiv((uint32_t)w.OG);
     return true;
 }
 
@@ -238,6 +241,20 @@ rnntStatus_t compute_rnnt_joint_loss_bwd(const float *enc_proj, const float *pre
     return joint_call(enc_proj, pred_proj, W2, b2, flat_labels, label_lengths, input_lengths, cost_scale, joint_size,
                       alphabet_size, minibatch, nullptr, d_enc_proj, d_pred_proj, dW2, db2, joint_dtype, 2, workspace,
                       options);
+}
+
+// The joint alone, for decoding (utils/decoding.py:6-18 evaluates dense_1 / dense_2 on one lattice cell per step).
+rnntStatus_t compute_rnnt_joint_logits(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2,
+                                       int joint_size, int alphabet_size, int minibatch, float *logits, void *workspace,
+                                       rnntOptions options) {
+    if (!enc_proj || !pred_proj || !W2 || !b2 || !logits || !workspace) return RNNT_STATUS_INVALID_VALUE;
+    if (joint_size <= 0 || alphabet_size <= 0 || minibatch <= 0) return RNNT_STATUS_INVALID_VALUE;
+    rnntStatus_t st = check_options(options);
+    if (st != RNNT_STATUS_SUCCESS) return st;
+    if (options.maxU > 1024) return RNNT_STATUS_INVALID_VALUE;
+    if (((uintptr_t)workspace & 255) != 0) return RNNT_STATUS_INVALID_VALUE;
+    return from_hip(launch_joint_logits(enc_proj, pred_proj, W2, b2, joint_size, alphabet_size, minibatch, options.maxT,
+                                        options.maxU, logits, workspace, (hipStream_t)options.stream));
 }
 
 }  // extern "C"

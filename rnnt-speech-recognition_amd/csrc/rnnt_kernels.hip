@@ -400,11 +400,9 @@ __device__ __forceinline__ void dma_rows(const float *g, float *l, int n16, int 
     }
 }
 
-// Precision control.  alpha~/beta~ are stored relative to a per-block offset (kept in f64 on the
-// side) so that the f32 values that carry probability mass stay O(10) instead of O(T+U).  The
-// reference value is the lattice cell on the straight line (0,0)->(T_b-1,U_b-1) -- NOT the wave
-// maximum: for near-uniform posteriors the alpha-maximum of a diagonal sits at the binomial centre,
-// ~e^(0.19 n) above the cells that matter, which would leave those at magnitude ~100.
+// Re-basing reference of the WIDE sweep (1024 < U <= 8192; the register-resident sweeps re-base per lane, see rebase_lane):
+// the lattice cell on the straight line (0,0)->(T_b-1,U_b-1) -- NOT the row maximum: for near-uniform posteriors the
+// alpha-maximum of a diagonal sits at the binomial centre, ~e^(0.19 n) above the cells that matter.
 struct RidgeLine {
     uint32_t slope_fx;  // (U_b-1)/(N_b-1) in 16.16 fixed point
     __device__ __forceinline__ int u_at(int n) const { return (int)(((uint32_t)n * slope_fx + 32768u) >> 16); }
@@ -415,48 +413,48 @@ __device__ __forceinline__ RidgeLine make_ridge(int Ub, int Nb) {
     return r;
 }
 
-// Returns the INTEGER amount subtracted (exact in f32, so offsets accumulate exactly in f32 too).  The ridge cell
-// (n - u_ref, u_ref) is a lattice node for every diagonal of a well-formed utterance, hence never log zero.
-template <int K>
-__device__ __forceinline__ float rebase(float (&v)[K], const int u_ref) {
-    const int src_lane = u_ref / K, src_j = u_ref - src_lane * K;  // wave-uniform
-    float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[0]), src_lane));
+// ---------------------------------------------------------------------------------------------
+// Precision control, per LANE.  Every lane keeps its own cumulative INTEGER offset (exact in f32) for the K lattice columns
+// it owns: true value = stored value + off[lane].  Every kRebase diagonals a lane re-bases against its own maximum, so the
+// f32 values that carry probability mass stay O(K x edge weight) whatever the logits look like -- one offset per diagonal
+// (the previous scheme, against the straight-line "ridge" cell) left the mass-carrying cells at |value| ~ 10^2..10^3 whenever
+// the posterior strays from the straight line: 2e-4 cost error for trained-like late alignments, 2-3e-4 gradient error for
+// 8 x N(0,1) logits (tests/tools/emulate_sweep.py; now 1e-6 / <1e-4).
+// The only values that cross a lane boundary are the label-edge terms of a lane's last column; the (integer) offset
+// difference of the two lanes is folded into that edge WEIGHT (`dlt`, off the dependent chain), so the step itself is unchanged.
+// A lane that holds no lattice node yet copies the offset of the neighbour the mass will arrive from (R rounds: up to
+// ceil(kRebase / K) lanes wake up within one block), so a first arrival is never rounded at the magnitude of the total offset.
+// The offsets go to the table [block of kRebase diagonals][64 lanes] (one coalesced 256-byte store per block).
+// ---------------------------------------------------------------------------------------------
+struct SweepState {
+    float off;       // this lane's cumulative (integer-valued) offset
+    float dlt;       // alpha: off - off[lane + 1], beta: off[lane + 1] - off -- added to the label-edge weight of column K - 1
+    float *tab;      // this utterance's offset table [NC][64], already advanced by `lane`
+    float *row;      // wave-uniform base of the output row of the NEXT diagonal to be stored
+    float edge;      // what DPP shifted in last (edge lane: log zero, see alpha_step_c)
+};
+
+template <int K, bool BETA>
+__device__ __forceinline__ void rebase_lane(float (&v)[K], SweepState &st, const int kc) {
+    float m = v[0];
 #pragma unroll
-    for (int j = 1; j < K; ++j) {
-        const float mj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[j]), src_lane));
-        m = (src_j == j) ? mj : m;
-    }
-    const float mi = rintf(m);
+    for (int j = 1; j < K; ++j) m = fmaxf(m, v[j]);
+    const bool fin = m > kNegTest;
+    const float mi = fin ? rintf(m) : 0.f;
 #pragma unroll
     for (int j = 0; j < K; ++j) v[j] -= mi;  // log zeros stay log zeros: |mi| << 1e30
-    return mi;
+    float off = st.off + mi;
+    constexpr int R = (kRebase + K - 1) / K;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float nb = BETA ? dpp_from_upper_lane(off, off) : dpp_from_lower_lane(off, off);  // edge lanes see themselves
+        off = fin ? off : nb;
+    }
+    st.off = off;
+    const float nr = dpp_from_upper_lane(off, off);
+    st.dlt = BETA ? nr - off : off - nr;
+    st_f32_wt(st.tab + (size_t)kc * 64, off);
 }
-
-// Log of the offsets, one per block of kRebase diagonals.  Lane (kc & 63) of `hist` holds the offset of block kc;
-// every 64 blocks (and at the end) the register is flushed to the table with one coalesced store per column group.
-struct OffsetLog {
-    float *table;  // this utterance's [NC][NG] floats
-    int ng;        // NG (row length of the table)
-    int g0, gn;    // column groups this wave writes: [g0, g0 + gn)
-    float hist;
-    int lo, hi;    // block range recorded since the last flush (lo > hi: empty)
-    __device__ __forceinline__ void init(float *t, int ng_) { init(t, ng_, 0, ng_); }
-    __device__ __forceinline__ void init(float *t, int ng_, int g0_, int gn_) {
-        table = t, ng = ng_, g0 = g0_, gn = gn_, hist = 0.f, lo = 1 << 30, hi = -1;
-    }
-    __device__ __forceinline__ void flush(const int lane) {
-        if (lo > hi) return;
-        const int kc = (lo & ~63) + lane;
-        if (kc >= lo && kc <= hi)
-            for (int g = g0; g < g0 + gn; ++g) st_f32_wt(table + (size_t)kc * ng + g, hist);
-        lo = 1 << 30, hi = -1;
-    }
-    __device__ __forceinline__ void record(const int kc, const float off, const int lane) {
-        if (lo <= hi && (kc >> 6) != (lo >> 6)) flush(lane);
-        hist = (lane == (kc & 63)) ? off : hist;
-        lo = min(lo, kc), hi = max(hi, kc);
-    }
-};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -532,13 +530,14 @@ __device__ __forceinline__ void lds_wait() {
 // One alpha step: diagonal r -> r+1 using the outgoing edge weights `w` of diagonal r.
 // {d_j, e_j} = {a_j, a_j} + {blank_j, label_j} is ONE packed add per column.
 template <int K>
-__device__ __forceinline__ void alpha_step(float (&a)[K], const f32x2 (&w)[K]) {
+__device__ __forceinline__ void alpha_step(float (&a)[K], const f32x2 (&w)[K], const float dlt) {
     f32x2 de[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const f32x2 aa = {a[j], a[j]};
         de[j] = aa + w[j];  // .x blank: (t-1,u) -> (t,u);  .y label: (t,u) -> (t,u+1)
     }
+    de[K - 1][1] += dlt;  // into the next lane's frame (integer offset difference)
     const float from_left = dpp_from_lower_lane(de[K - 1][1], kNeg);
 #pragma unroll
     for (int j = 0; j < K; ++j) a[j] = lse2(de[j][0], (j == 0) ? from_left : de[j - 1][1]);
@@ -581,13 +580,17 @@ __device__ __forceinline__ void lse2_staged(float (&out)[K], const float (&u)[K]
     SWEEP_FENCE();
 }
 template <int K>
-__device__ __forceinline__ void alpha_step_c(float (&a)[K], const f32x2 (&w)[K], float &edge) {
+__device__ __forceinline__ void alpha_step_c(float (&a)[K], const f32x2 (&w)[K], float &edge, const float dlt) {
     f32x2 de[K];
+    // the value that leaves this lane goes into the next lane's frame: the integer offset difference rides on the edge
+    // weight (an add that depends on the LDS read only, not on the previous diagonal)
+    f32x2 wl = w[K - 1];
+    wl[1] += dlt;
     SWEEP_FENCE();
 #pragma unroll
     for (int j = K - 1; j >= 0; --j) {  // last column first: the DPP move waits for it
         const f32x2 aa = {a[j], a[j]};
-        de[j] = aa + w[j];
+        de[j] = aa + ((j == K - 1) ? wl : w[j]);
     }
     SWEEP_FENCE();
     edge = dpp_from_lower_lane(de[K - 1][1], edge);
@@ -598,14 +601,16 @@ __device__ __forceinline__ void alpha_step_c(float (&a)[K], const f32x2 (&w)[K],
     lse2_staged<K>(a, u, l);
 }
 template <int K>
-__device__ __forceinline__ void beta_step_c(float (&bv)[K], const f32x2 (&w)[K], float &edge) {
+__device__ __forceinline__ void beta_step_c(float (&bv)[K], const f32x2 (&w)[K], float &edge, const float dlt) {
+    f32x2 wl = w[K - 1];
+    wl[1] += dlt;  // the value arriving from the next lane is in THAT lane's frame
     SWEEP_FENCE();
     edge = dpp_from_upper_lane(bv[0], edge);
     f32x2 s2[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) {  // last column last: it waits for the DPP move
         const f32x2 br = {bv[j], (j == K - 1) ? edge : bv[j + 1]};
-        s2[j] = br + w[j];
+        s2[j] = br + ((j == K - 1) ? wl : w[j]);
     }
     SWEEP_FENCE();
     float u[K], l[K];
@@ -619,12 +624,12 @@ __device__ __forceinline__ void beta_step_c(float (&bv)[K], const f32x2 (&w)[K],
 
 // One beta step: diagonal n+1 -> n using the outgoing edge weights `w` of diagonal n.
 template <int K>
-__device__ __forceinline__ void beta_step(float (&bv)[K], const f32x2 (&w)[K]) {
+__device__ __forceinline__ void beta_step(float (&bv)[K], const f32x2 (&w)[K], const float dlt) {
     const float from_right = dpp_from_upper_lane(bv[0], kNeg);
     float nv[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        const f32x2 br = {bv[j], (j == K - 1) ? from_right : bv[j + 1]};
+        const f32x2 br = {bv[j], (j == K - 1) ? from_right + dlt : bv[j + 1]};
         const f32x2 s2 = br + w[j];
         nv[j] = lse2(s2[0], s2[1]);
     }
@@ -632,19 +637,11 @@ __device__ __forceinline__ void beta_step(float (&bv)[K], const f32x2 (&w)[K]) {
     for (int j = 0; j < K; ++j) bv[j] = nv[j];
 }
 
-// State a sweep carries from step to step besides the diagonal itself.
-struct SweepState {
-    float off;       // cumulative (integer-valued) offset: true value = stored value + off
-    OffsetLog log;
-    float *row;      // wave-uniform base of the output row of the NEXT diagonal to be stored
-    float edge;      // what DPP shifted in last (edge lane: log zero, see alpha_step_c)
-};
-
 // Fully unrolled, explicitly pipelined steps of one chunk (compile-time recursion over the step index
 // II so that every LDS offset is an immediate and the two weight register sets ping-pong by name).
 template <int K, int G, int II>
 __device__ __forceinline__ void alpha_fast_steps(float (&a)[K], f32x2 (&wq)[2][K], const uint32_t abase, SweepState &st,
-                                                 const int voff, const int lane, const int r0, const RidgeLine &ridge) {
+                                                 const int voff, const int lane, const int r0) {
     if constexpr (II < G) {
         constexpr int cur = II & 1, nxt = cur ^ 1;
         if constexpr (II + 1 < G) {
@@ -654,21 +651,18 @@ __device__ __forceinline__ void alpha_fast_steps(float (&a)[K], f32x2 (&wq)[2][K
             lds_wait<0>();
         }
         const int n = r0 + II + 1;
-        alpha_step_c<K>(a, wq[cur], st.edge);
-        if ((n & (kRebase - 1)) == 0) {
-            st.off += rebase<K>(a, ridge.u_at(n));
-            st.log.record(n / kRebase, st.off, lane);
-        }
+        alpha_step_c<K>(a, wq[cur], st.edge, st.dlt);
+        if ((n & (kRebase - 1)) == 0) rebase_lane<K, false>(a, st, n / kRebase);
         constexpr int R = rows_per_base(K);
         store_diag<K, true, (II % R) * 64 * K * 4>(st.row, voff, lane, a);
         if constexpr (II % R == R - 1 || II == G - 1) st.row += (II % R + 1) * 64 * K;
-        alpha_fast_steps<K, G, II + 1>(a, wq, abase, st, voff, lane, r0, ridge);
+        alpha_fast_steps<K, G, II + 1>(a, wq, abase, st, voff, lane, r0);
     }
 }
 
 template <int K, int G, int II>
 __device__ __forceinline__ void beta_fast_steps(float (&bv)[K], f32x2 (&wq)[2][K], const uint32_t abase, SweepState &st,
-                                                const int voff, const int lane, const int r0, const RidgeLine &ridge) {
+                                                const int voff, const int lane, const int r0) {
     if constexpr (II < G) {
         constexpr int cur = II & 1, nxt = cur ^ 1;
         constexpr int i = G - 1 - II;  // row inside the chunk (descending)
@@ -679,15 +673,12 @@ __device__ __forceinline__ void beta_fast_steps(float (&bv)[K], f32x2 (&wq)[2][K
             lds_wait<0>();
         }
         const int n = r0 + i;
-        beta_step_c<K>(bv, wq[cur], st.edge);
-        if ((n & (kRebase - 1)) == kRebase - 1) {
-            st.off += rebase<K>(bv, ridge.u_at(n));
-            st.log.record(n / kRebase, st.off, lane);
-        }
+        beta_step_c<K>(bv, wq[cur], st.edge, st.dlt);
+        if ((n & (kRebase - 1)) == kRebase - 1) rebase_lane<K, true>(bv, st, n / kRebase);
         constexpr int R = rows_per_base(K);
         store_diag<K, true, -(II % R) * 64 * K * 4>(st.row, voff, lane, bv);
         if constexpr (II % R == R - 1 || II == G - 1) st.row -= (II % R + 1) * 64 * K;
-        beta_fast_steps<K, G, II + 1>(bv, wq, abase, st, voff, lane, r0, ridge);
+        beta_fast_steps<K, G, II + 1>(bv, wq, abase, st, voff, lane, r0);
     }
 }
 
@@ -800,7 +791,6 @@ __device__ void alpha_sweep_ld(const LossParams &p, float *bufs, const LdLink lk
     constexpr int Up = 64 * K, chunkf = G * 2 * Up;
     const int Tb = length_T(p, b), Ub = length_U(p, b);
     const int Nb = Tb + Ub - 1;
-    const RidgeLine ridge = make_ridge(Ub, Nb);
     float *out = p.A + (size_t)b * p.Nr * Up;
     const int voff = lane * K * 4;
     const int u0 = lane * K;
@@ -810,10 +800,10 @@ __device__ void alpha_sweep_ld(const LossParams &p, float *bufs, const LdLink lk
     for (int j = 0; j < K; ++j) a[j] = (u0 + j == 0) ? 0.f : kNeg;
     store_diag<K, false>(out, voff, lane, a);
     SweepState st;
-    st.off = 0.f;
+    st.off = 0.f, st.dlt = 0.f;
     st.edge = kNeg;
-    st.log.init(p.offA + (size_t)b * p.NC * p.NG, p.NG);
-    st.log.record(0, 0.f, lane);
+    st.tab = p.offA + (size_t)b * p.NC * p.NG + lane;  // NG = 64 for the register-resident sweeps
+    st_f32_wt(st.tab, 0.f);  // block 0
     st.row = out + Up;
     const int last_row = Nb - 1;
     const int nchunks = last_row / G + 1;
@@ -831,18 +821,15 @@ __device__ void alpha_sweep_ld(const LossParams &p, float *bufs, const LdLink lk
             const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
             f32x2 wq[2][K];
             lds_issue_row<K, 0>(wq[0], abase);
-            alpha_fast_steps<K, G, 0>(a, wq, abase, st, voff, lane, r0, ridge);
+            alpha_fast_steps<K, G, 0>(a, wq, abase, st, voff, lane, r0);
         } else {
             for (int i = 0; i < G; ++i) {
                 const int n = r0 + i + 1;
                 if (n > last_row) break;
                 f32x2 wc[K];
                 load_w<K>(wc, cur + i * 2 * Up);
-                alpha_step<K>(a, wc);
-                if ((n & (kRebase - 1)) == 0) {
-                    st.off += rebase<K>(a, ridge.u_at(n));
-                    st.log.record(n / kRebase, st.off, lane);
-                }
+                alpha_step<K>(a, wc, st.dlt);
+                if ((n & (kRebase - 1)) == 0) rebase_lane<K, false>(a, st, n / kRebase);
                 store_diag<K, false>(st.row, voff, lane, a);
                 st.row += Up;
             }
@@ -852,7 +839,6 @@ __device__ void alpha_sweep_ld(const LossParams &p, float *bufs, const LdLink lk
             if (lane == 0) lds_post(lk.consumed, ck + 1);
         }
     }
-    st.log.flush(lane);
     {
         const float *wrow = bufs + ((nchunks - 1) % NB) * chunkf + (last_row % G) * 2 * Up + 2 * u0;
 #pragma unroll
@@ -870,7 +856,6 @@ __device__ void beta_sweep_ld(const LossParams &p, float *bufs, const LdLink lk,
     constexpr int Up = 64 * K, chunkf = G * 2 * Up;
     const int Tb = length_T(p, b), Ub = length_U(p, b);
     const int Nb = Tb + Ub - 1;
-    const RidgeLine ridge = make_ridge(Ub, Nb);
     float *out = p.Bt + (size_t)b * p.Nr * Up;
     const int voff = lane * K * 4;
     const int u0 = lane * K;
@@ -881,9 +866,9 @@ __device__ void beta_sweep_ld(const LossParams &p, float *bufs, const LdLink lk,
     const int last = Nb - 1;
     const int ckl = last / G;
     SweepState st;
-    st.off = 0.f;
+    st.off = 0.f, st.dlt = 0.f;
     st.edge = kNeg;
-    st.log.init(p.offB + (size_t)b * p.NC * p.NG, p.NG);
+    st.tab = p.offB + (size_t)b * p.NC * p.NG + lane;
     st.row = out + (size_t)last * Up;
 
     int have = 0;
@@ -900,7 +885,7 @@ __device__ void beta_sweep_ld(const LossParams &p, float *bufs, const LdLink lk,
             const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
             f32x2 wq[2][K];
             lds_issue_row<K, G - 1>(wq[0], abase);
-            beta_fast_steps<K, G, 0>(bv, wq, abase, st, voff, lane, r0, ridge);
+            beta_fast_steps<K, G, 0>(bv, wq, abase, st, voff, lane, r0);
         } else {
             for (int ii = 0; ii < G; ++ii) {
                 const int i = G - 1 - ii;
@@ -908,11 +893,8 @@ __device__ void beta_sweep_ld(const LossParams &p, float *bufs, const LdLink lk,
                 if (n > last) continue;
                 f32x2 wc[K];
                 load_w<K>(wc, cur + i * 2 * Up);
-                beta_step<K>(bv, wc);
-                if (((n & (kRebase - 1)) == kRebase - 1) || n == last) {
-                    st.off += rebase<K>(bv, ridge.u_at(n));
-                    st.log.record(n / kRebase, st.off, lane);
-                }
+                beta_step<K>(bv, wc, st.dlt);
+                if (((n & (kRebase - 1)) == kRebase - 1) || n == last) rebase_lane<K, true>(bv, st, n / kRebase);
                 store_diag<K, false>(st.row, voff, lane, bv);
                 st.row -= Up;
             }
@@ -922,7 +904,6 @@ __device__ void beta_sweep_ld(const LossParams &p, float *bufs, const LdLink lk,
             if (lane == 0) lds_post(lk.consumed, i_ring + 1);
         }
     }
-    st.log.flush(lane);
     if (lane == 0) st_f64_wt(p.ll + 2 * b + 1, timed_out ? (double)NAN : (double)st.off + (double)bv[0]);
     if (timed_out && lane == 0) st_f32_wt(p.costs + b, NAN);  // the alpha side may have finished normally
 }

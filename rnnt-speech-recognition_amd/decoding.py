@@ -10,9 +10,9 @@ The reference re-runs the prediction network over the whole hypothesis for every
 causal LSTM stack, so carrying its state forward gives the same outputs at O(1) per symbol.  `stateless=True` keeps
 the reference's formulation (used by the tests as the cross-check).
 
-The joint is evaluated for ONE lattice cell at a time here (T = U = 1): a J-long tanh and a J x V mat-vec.  That is
-launch-latency work, not bandwidth work -- it goes through torch (hipBLASLt gemv) via JointLoss.logits rather than the
-fused loss kernels."""
+The joint is evaluated for ONE lattice cell at a time (T = U = 1), as the reference does (`joint`, utils/decoding.py:6-18).
+On the device it goes through the engine's logits-only entry point (compute_rnnt_joint_logits via JointLoss.cell_logits):
+the forward kernels of the fused loss, so the decoder sees the logits the loss was trained on."""
 from __future__ import annotations
 
 from typing import List, Optional
@@ -53,7 +53,7 @@ def greedy_decode(model, mel_specs: torch.Tensor, max_length: Optional[int] = No
                 break
             f = enc[:, i : i + 1, :]
             while True:
-                logits = joint.logits(f, g)[0, 0, 0]  # [V]
+                logits = joint.cell_logits(f, g)[0, 0, 0]  # [V]
                 k = int(torch.argmax(torch.log_softmax(logits, dim=-1)).item())
                 if k == joint.blank_label:
                     break

@@ -113,6 +113,40 @@ def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_leng
                                     JOINT_DTYPES[joint_dtype])
 
 
+@torch.no_grad()
+def joint_logits(enc, pred, W1, b1, W2, b2):
+    """logits [B, T, U, V] of the joint network through libwarprnnt.so's compute_rnnt_joint_logits (no autograd): the decoding
+    twin of the joint (utils/decoding.py:6-18).  Same factorisation, tables and split-precision products as the fused loss, so
+    a decoder sees the logits the loss was trained on.  V <= 32 (the f32-grade joint); joint sizes are padded to a multiple of
+    64 with zero units, exactly."""
+    lib = _lib.load()
+    for name, x in (("enc", enc), ("pred", pred), ("W1", W1), ("W2", W2)):
+        if not x.is_cuda:
+            raise RuntimeError(f"joint_logits: {name} must live on an MI355X (cuda/HIP) device; no CPU path")
+    B, T, _ = enc.shape
+    U = pred.shape[1]
+    J, V = W2.shape
+    if V > 32:
+        raise ValueError("joint_logits: the engine's logits-only entry takes vocabularies of at most 32 symbols")
+    enc_proj = torch.matmul(enc.float(), W1) + b1
+    pred_proj = torch.matmul(pred.float(), W1)
+    Jp, _ = padded_joint_shape(J, V, "f32")
+    if Jp != J:
+        enc_proj = torch.nn.functional.pad(enc_proj, (0, Jp - J))
+        pred_proj = torch.nn.functional.pad(pred_proj, (0, Jp - J))
+        W2 = torch.nn.functional.pad(W2, (0, 0, 0, Jp - J))
+    ep, pp, w2, bb = (x.detach().contiguous().float() for x in (enc_proj, pred_proj, W2, b2))
+    dev = ep.device
+    with torch.cuda.device(dev):
+        ws = torch.empty(_lib.joint_workspace_bytes(T, U, B, Jp, V), dtype=torch.uint8, device=dev)
+        out = torch.empty(B, T, U, V, dtype=torch.float32, device=dev)
+        opts = _lib.make_options(torch.cuda.current_stream().cuda_stream, 0, T, U)
+        st = lib.compute_rnnt_joint_logits(ep.data_ptr(), pp.data_ptr(), w2.data_ptr(), bb.data_ptr(), Jp, V, B,
+                                           out.data_ptr(), ws.data_ptr(), opts)
+    _lib.check(st, "compute_rnnt_joint_logits")
+    return out
+
+
 _PAD_BIAS = -1.0e4
 _F16_J = (128, 256, 512, 640)
 
@@ -155,6 +189,14 @@ class JointLoss(torch.nn.Module):
                                label_lengths, self.blank_label)
 
     def logits(self, enc, pred):
-        """Unfused reference form (materialises [B,T,U,V]); for decoding single cells and for tests."""
+        """Unfused reference form (materialises [B,T,U,J] and [B,T,U,V] in torch); for tests and host-logic checks on CPU."""
         z = enc.unsqueeze(2) + pred.unsqueeze(1)
         return torch.tanh(z @ self.W1 + self.b1) @ self.W2 + self.b2
+
+    def cell_logits(self, enc, pred):
+        """Joint logits [B, T, U, V] for decoding (utils/decoding.py:6-18).  On an MI355X this is the ENGINE
+        (compute_rnnt_joint_logits: the fused loss's own forward kernels); CPU tensors -- the host-logic tests -- and
+        vocabularies beyond the f32-grade joint's 32 symbols take the torch composition."""
+        if enc.is_cuda and self.W2.shape[1] <= 32:
+            return joint_logits(enc, pred, self.W1, self.b1, self.W2, self.b2)
+        return self.logits(enc, pred)

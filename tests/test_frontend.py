@@ -218,6 +218,114 @@ def test_tfrecord_round_trip_and_corruption(tmp_path):
 
 
 @pytest.mark.gpu
+def test_record_pipeline_on_the_device_matches_the_numpy_front_end(tmp_path):
+    """f-3 where the product runs: raw audio ON cuda:0 -> features.make_record (log-mel through rocFFT) -> TFRecord file ->
+    records.load_dataset / batches -> device batch -> Transducer.loss.  The log-mel tensors that reach the loss are compared
+    with oracle/features_oracle.py (NumPy float64 restatement of utils/preprocessing.py:48-94), paddings and lengths with
+    utils/preprocessing.py:177-183 / run_rnnt.py:78-83, and the loss the batch yields is finite."""
+    from rnnt_speech_recognition_amd import records
+
+    dev = torch.device("cuda:0")
+    enc = features.CharEncoder()
+    hp = pkg.HParams(vocab_size=enc.vocab_size, encoder_layers=2, encoder_size=32, projection_size=16, pred_net_layers=1,
+                     pred_net_size=32, embedding_size=16, joint_net_size=64, time_reduction_index=0)
+    rng = np.random.default_rng(11)
+    sr = 16000
+    items = []
+    for n, text in [(16000, "hello world"), (9000, "ok"), (20000, "a longer sentence")]:
+        t = np.arange(n) / sr
+        audio = (0.3 * np.sin(2 * np.pi * (300 + 40 * len(text)) * t) + 0.1 * rng.normal(size=n)).astype(np.float32)
+        items.append((audio, text))
+    recs = [features.make_record(torch.tensor(a, device=dev), sr, text, hp, enc) for a, text in items]
+    assert all(r[0].is_cuda for r in recs)
+    records.write_dataset(recs, str(tmp_path / "train.tfrecord"))
+    (batch,) = list(records.batches(records.load_dataset(str(tmp_path), "train", verify_payload=True), batch_size=3))
+    mel, pred_inp, spec_len, label_len, labels = (x.to(dev) for x in batch)
+    for b, (audio, text) in enumerate(items):
+        ref = fo.downsample(fo.log_mel(audio, sr), hp.downsample_factor)
+        Tb = int(spec_len[b])
+        assert Tb == ref.shape[0] and int(label_len[b]) == len(text)
+        assert np.abs(mel[b, :Tb].cpu().numpy() - ref).max() < 2e-3  # f32 FFT + log of small mel energies
+        assert not bool(mel[b, Tb:].any())  # zero padding (run_rnnt.py:78-83)
+        ids = enc.encode(text)
+        assert labels[b, : len(ids)].tolist() == ids and pred_inp[b, : len(ids) + 1].tolist() == [0] + ids
+    torch.manual_seed(0)
+    model = pkg.Transducer(hp).to(dev).eval()
+    costs = model.loss(mel, pred_inp, spec_len, label_len, labels)
+    assert costs.shape == (3,) and bool(torch.isfinite(costs).all()) and bool((costs > 0).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(6, 1, 1, 24, 64), (3, 7, 5, 40, 128), (2, 33, 70, 16, 192)])
+def test_joint_logits_entry_matches_oracle(shape):
+    """compute_rnnt_joint_logits (the decoder's joint, utils/decoding.py:6-18) against oracle.joint_forward in float64:
+    hypothesis-batched single cells (T = U = 1) and small lattices; f32-grade bar, plus the device-side switch to plain
+    f32 MFMAs when W2 leaves the binary16 range."""
+    from oracle import rnnt_oracle as orc
+
+    B, T, U, H, J = shape
+    V = 28
+    rng = np.random.default_rng(B * 100 + T)
+    enc, pred = rng.normal(size=(B, T, H)).astype(np.float32), rng.normal(size=(B, U, H)).astype(np.float32)
+    W1 = (rng.uniform(-1, 1, size=(H, J)) * np.sqrt(6.0 / (H + J))).astype(np.float32)
+    b1 = (0.1 * rng.normal(size=J)).astype(np.float32)
+    b2 = (0.1 * rng.normal(size=V)).astype(np.float32)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.tensor(x, device=dev)
+    for gain in (1.0, 8.0, 1.0e6):  # 1e6: |W2| beyond binary16 -> the plain f32 MFMA forward runs instead
+        W2 = (rng.uniform(-1, 1, size=(J, V)) * np.sqrt(6.0 / (J + V)) * gain).astype(np.float32)
+        got = pkg.joint_logits(t(enc), t(pred), t(W1), t(b1), t(W2), t(b2)).cpu().numpy()
+        ref, _ = orc.joint_forward(enc, pred, W1, b1, W2, b2)
+        assert got.shape == (B, T, U, V)
+        assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (gain, np.abs(got - ref).max(), np.abs(ref).max())
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        pkg.joint_logits(torch.tensor(enc), t(pred), t(W1), t(b1), t(W2), t(b2))
+
+
+@pytest.mark.gpu
+def test_greedy_decode_through_the_engine_matches_a_float64_restatement():
+    """f-4 on the device: the decoder's joint is the ENGINE (JointLoss.cell_logits -> compute_rnnt_joint_logits).  The
+    check is a test-side restatement of utils/decoding.py:22-108 whose joint is the float64 oracle (encoder / prediction
+    network outputs taken from the same torch modules): same hypothesis, and no decision was closer than the f32-grade
+    error of the engine's logits."""
+    from oracle import rnnt_oracle as orc
+
+    model = small_model(3)
+    with torch.no_grad():
+        model.joint.b2[0] -= 0.4
+    mel = torch.randn(2, 30, 8)
+    dev = torch.device("cuda:0")
+    model = model.to(dev).eval()
+    got = decoding.greedy_decode(model, mel.to(dev), 40).tolist()[0]
+    jn = model.joint
+    W1, b1, W2, b2 = (x.detach().cpu().numpy() for x in (jn.W1, jn.b1, jn.W2, jn.b2))
+    with torch.no_grad():
+        enc = model.encoder(mel[:1].to(dev))
+        hyp, min_gap = [0], np.inf
+        for i in range(enc.shape[1]):
+            while True:
+                g = model.prediction(torch.tensor([hyp], device=dev))[:, -1:, :]
+                y, _ = orc.joint_forward(enc[:, i : i + 1].cpu().numpy(), g.cpu().numpy(), W1, b1, W2, b2)
+                y = y[0, 0, 0]
+                top = np.sort(y)[::-1]
+                min_gap = min(min_gap, float(top[0] - top[1]))
+                k = int(np.argmax(y))
+                if k == 0:
+                    break
+                hyp.append(k)
+                if len(hyp) >= 41:
+                    break
+            if len(hyp) >= 41:
+                break
+    assert min_gap > 1e-5, "a near-tie on this seed: pick another seed"
+    assert got == hyp[1:], (got, hyp[1:])
+    # and the engine really is what the decoder called: its logits differ from the torch composition in the last bits only
+    f, g = enc[:, :1], model.prediction(torch.tensor([[0]], device=dev))[:, -1:, :]
+    a, b = jn.cell_logits(f, g), jn.logits(f, g)
+    assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-5
+
+
+@pytest.mark.gpu
 def test_greedy_decode_on_gpu_matches_cpu():
     """The decode loop on cuda:0 (incremental and stateless forms) emits what the CPU run of the same weights emits."""
     model = small_model(3)

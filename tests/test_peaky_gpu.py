@@ -84,13 +84,15 @@ def test_p1_peaked_logits_at_c2_size(kind):
     torch.cuda.synchronize()
     c = costs.cpu().numpy().astype(np.float64)
     assert np.isfinite(c).all() and bool(torch.isfinite(grads).all())
+    # trained: odd utterances are the late-alignment ones -- take four of each kind
+    picks = [0, 1, 8, 9, 16, 17, 24, 25] if kind == "trained" else PICKS
     with _pool() as ex:
-        refs = list(ex.map(_p1_oracle, [(x[b], labels[b]) for b in PICKS]))
+        refs = list(ex.map(_p1_oracle, [(x[b], labels[b]) for b in picks]))
     dc, dg = [], []
-    for b, (c_ref, g_ref, _) in zip(PICKS, refs):
+    for b, (c_ref, g_ref, _) in zip(picks, refs):
         dc.append(abs(c[b] - c_ref) / max(1.0, abs(c_ref)))
         dg.append(float(np.abs(grads[b].cpu().numpy() - g_ref).max()))
-    _report[f"p1_{kind}"] = {"utterances": PICKS, "max_rel_dcost": max(dc), "max_abs_dgrad": max(dg),
+    _report[f"p1_{kind}"] = {"utterances": picks, "max_rel_dcost": max(dc), "max_abs_dgrad": max(dg),
                              "cost_range_nats": [float(min(r[0] for r in refs)), float(max(r[0] for r in refs))]}
     assert max(dc) <= CTOL, (kind, dc)
     assert max(dg) <= GTOL, (kind, dg)
