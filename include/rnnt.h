@@ -82,6 +82,12 @@ RNNT_API rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool
  *                      the fused joint entry points stop at maxU = 1024;
  *   B*maxT*maxU < 2^31 cell indices are 32-bit;
  *   workspace 256-byte aligned.
+ * Numerics (the lattice is float32, log2 domain, with exact integer re-basing per sweep lane; float64 only where offsets
+ * are combined).  Against a float64 evaluation of the same logits: costs within 1e-4 max(1, |cost|); gradients within 1e-4
+ * absolute for N(0,1) ... 4 x N(0,1) logits and for trained-like posteriors (one dominant symbol per cell along any monotone
+ * alignment), measured 1e-6 ... 9e-5 at B=32 T=600 U=150 V=28; within 2.5e-4 for 8 x N(0,1) logits (costs of ~7,500 nats),
+ * where the float32 representation of the log-probabilities themselves limits the result (profiles/r03_accuracy.json,
+ * tests/test_peaky_gpu.py).
  * Out-of-range per-utterance lengths (T_b < 1, T_b > maxT, L_b < 0, L_b > maxU-1) are device data and cannot be
  * checked at enqueue time: the kernels clamp them into the tensor (no out-of-bounds access) and report that
  * utterance with a NaN cost and NaN gradients.  Labels outside [0, alphabet_size) are clamped into range. */

@@ -90,8 +90,9 @@ def load():
     lib.compute_rnnt_joint_loss_fwd.argtypes = [vp] * 7 + [ci, ci, ci, vp, ci, vp, rnntOptions]
     lib.compute_rnnt_joint_loss_bwd.restype = ci
     lib.compute_rnnt_joint_loss_bwd.argtypes = [vp] * 8 + [ci, ci, ci] + [vp] * 4 + [ci, vp, rnntOptions]
-    lib.compute_rnnt_joint_logits.restype = ci
-    lib.compute_rnnt_joint_logits.argtypes = [vp] * 4 + [ci, ci, ci, vp, vp, rnntOptions]
+    if LIB_PATH == _DEFAULT_LIB_PATH or hasattr(lib, "compute_rnnt_joint_logits"):  # (an older dev variant may lack it)
+        lib.compute_rnnt_joint_logits.restype = ci
+        lib.compute_rnnt_joint_logits.argtypes = [vp] * 4 + [ci, ci, ci, vp, vp, rnntOptions]
     _lib = lib
     return lib
 

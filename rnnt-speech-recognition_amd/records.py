@@ -224,8 +224,10 @@ def parse_bytes_features(buf: bytes) -> Dict[str, List[bytes]]:
 
 def serialize_example(mel_specs, pred_inp, spec_lengths, label_lengths, labels) -> bytes:
     """utils/preprocessing.py:133-161: five single-element bytes lists, each a serialized tensor."""
-    tensors = (np.asarray(mel_specs, np.float32), np.asarray(pred_inp, np.int32), np.asarray(spec_lengths, np.int32),
-               np.asarray(label_lengths, np.int32), np.asarray(labels, np.int32))
+    host = lambda x: x.detach().cpu() if isinstance(x, torch.Tensor) else x  # records computed on the device are fine
+    tensors = (np.asarray(host(mel_specs), np.float32), np.asarray(host(pred_inp), np.int32),
+               np.asarray(host(spec_lengths), np.int32), np.asarray(host(label_lengths), np.int32),
+               np.asarray(host(labels), np.int32))
     entries = b""
     for key, t in zip(FEATURE_KEYS, tensors):
         feature = _put_bytes(1, _put_bytes(1, serialize_tensor(t)))
