@@ -202,6 +202,47 @@ RNNT_API rnntStatus_t compute_rnnt_joint_loss_bwd(const float *enc_proj, const f
                                          float *dW2, float *db2, int joint_dtype, void *workspace,
                                          rnntOptions options);
 
+/* Build-only extension: the WHOLE joint network of model.py:158-166 fused with the loss -- the first Dense layer
+ * (model.py:162-163) and its backward run inside the library too, on the matrix cores, f32-grade:
+ *   enc   device f32 [B, maxT, H]  encoder output        pred  device f32 [B, maxU, H]  prediction-network output
+ *   W1 [H, J], b1 [J]   (Keras Dense kernel / bias, model.py:162-163)          W2 [J, V], b2 [V]  (model.py:165-166)
+ *   logits[b,t,u,:] = tanh((enc[b,t,:] + pred[b,u,:]) @ W1 + b1) @ W2 + b2, never materialised; the layer is factored exactly
+ *   as (enc @ W1 + b1) + pred @ W1 (three GEMMs over B (maxT + maxU) rows with their operands split into binary16 hi + lo
+ *   parts, as for joint_dtype 0: csrc/dense_kernels.hip) and the rest is compute_rnnt_joint_loss on those projections.
+ *   d_enc [B,maxT,H], d_pred [B,maxU,H], dW1 [H,J], db1 [J], dW2 [J,V], db2 [V]: gradients of sum_b cost_scale[b] * cost_b
+ *   (all six or none; fully overwritten; padded frames / label positions get exact zeros in d_enc / d_pred).
+ * hidden_size a multiple of 32, joint_size a multiple of 64 (both <= 4096), then the (joint_size, alphabet_size, joint_dtype)
+ * rules of compute_rnnt_joint_loss; enc, pred, W1 16-byte aligned.  workspace: get_joint_net_workspace_size() bytes, 256-byte
+ * aligned; _bwd needs the workspace left by _fwd of the same inputs (projections and operand images live there). */
+RNNT_API rnntStatus_t get_joint_net_workspace_size(int maxT, int maxU, int minibatch, int hidden_size,
+                                                   int joint_size, int alphabet_size, size_t *size_bytes);
+
+RNNT_API rnntStatus_t compute_rnnt_joint_net_loss(const float *enc, const float *pred, const float *W1,
+                                                  const float *b1, const float *W2, const float *b2,
+                                                  const int *flat_labels, const int *label_lengths,
+                                                  const int *input_lengths, const float *cost_scale,
+                                                  int hidden_size, int joint_size, int alphabet_size,
+                                                  int minibatch, float *costs, float *d_enc, float *d_pred,
+                                                  float *dW1, float *db1, float *dW2, float *db2,
+                                                  int joint_dtype, void *workspace, rnntOptions options);
+
+RNNT_API rnntStatus_t compute_rnnt_joint_net_loss_fwd(const float *enc, const float *pred, const float *W1,
+                                                      const float *b1, const float *W2, const float *b2,
+                                                      const int *flat_labels, const int *label_lengths,
+                                                      const int *input_lengths, int hidden_size,
+                                                      int joint_size, int alphabet_size, int minibatch,
+                                                      float *costs, int joint_dtype, void *workspace,
+                                                      rnntOptions options);
+
+RNNT_API rnntStatus_t compute_rnnt_joint_net_loss_bwd(const float *enc, const float *pred, const float *W1,
+                                                      const float *b1, const float *W2, const float *b2,
+                                                      const int *flat_labels, const int *label_lengths,
+                                                      const int *input_lengths, const float *cost_scale,
+                                                      int hidden_size, int joint_size, int alphabet_size,
+                                                      int minibatch, float *d_enc, float *d_pred, float *dW1,
+                                                      float *db1, float *dW2, float *db2, int joint_dtype,
+                                                      void *workspace, rnntOptions options);
+
 /* Build-only extension: the joint network alone, for decoding.  Replaces `joint(model, f, g)` of the reference's greedy
  * decoder (utils/decoding.py:6-18: dense_1 (tanh) and dense_2 on f + g for one lattice cell per step; called at :63-69):
  *   logits[b,t,u,:] = tanh(enc_proj[b,t,:] + pred_proj[b,u,:]) @ W2 + b2        device f32 [minibatch, maxT, maxU, alphabet_size]

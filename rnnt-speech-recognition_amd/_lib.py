@@ -28,6 +28,10 @@ SYMBOLS = [
     "compute_rnnt_joint_loss_fwd",
     "compute_rnnt_joint_loss_bwd",
     "compute_rnnt_joint_logits",
+    "get_joint_net_workspace_size",
+    "compute_rnnt_joint_net_loss",
+    "compute_rnnt_joint_net_loss_fwd",
+    "compute_rnnt_joint_net_loss_bwd",
 ]
 
 
@@ -93,6 +97,15 @@ def load():
     if LIB_PATH == _DEFAULT_LIB_PATH or hasattr(lib, "compute_rnnt_joint_logits"):  # (an older dev variant may lack it)
         lib.compute_rnnt_joint_logits.restype = ci
         lib.compute_rnnt_joint_logits.argtypes = [vp] * 4 + [ci, ci, ci, vp, vp, rnntOptions]
+    if LIB_PATH == _DEFAULT_LIB_PATH or hasattr(lib, "compute_rnnt_joint_net_loss"):
+        lib.get_joint_net_workspace_size.restype = ci
+        lib.get_joint_net_workspace_size.argtypes = [ci] * 6 + [ctypes.POINTER(ctypes.c_size_t)]
+        lib.compute_rnnt_joint_net_loss.restype = ci
+        lib.compute_rnnt_joint_net_loss.argtypes = [vp] * 10 + [ci] * 4 + [vp] * 7 + [ci, vp, rnntOptions]
+        lib.compute_rnnt_joint_net_loss_fwd.restype = ci
+        lib.compute_rnnt_joint_net_loss_fwd.argtypes = [vp] * 9 + [ci] * 4 + [vp, ci, vp, rnntOptions]
+        lib.compute_rnnt_joint_net_loss_bwd.restype = ci
+        lib.compute_rnnt_joint_net_loss_bwd.argtypes = [vp] * 10 + [ci] * 4 + [vp] * 6 + [ci, vp, rnntOptions]
     _lib = lib
     return lib
 
@@ -121,6 +134,13 @@ def joint_workspace_bytes(maxT: int, maxU: int, minibatch: int, joint_size: int,
     n = ctypes.c_size_t(0)
     check(load().get_joint_workspace_size(maxT, maxU, minibatch, joint_size, alphabet_size, ctypes.byref(n)),
           "get_joint_workspace_size")
+    return int(n.value)
+
+
+def joint_net_workspace_bytes(maxT: int, maxU: int, minibatch: int, hidden_size: int, joint_size: int, alphabet_size: int) -> int:
+    n = ctypes.c_size_t(0)
+    check(load().get_joint_net_workspace_size(maxT, maxU, minibatch, hidden_size, joint_size, alphabet_size, ctypes.byref(n)),
+          "get_joint_net_workspace_size")
     return int(n.value)
 
 

@@ -17,6 +17,15 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
                              const float *cost_scale, int J, int V, int B, int T, int U, int blank, float *costs,
                              float *d_enc_proj, float *d_pred_proj, float *dW2, float *db2, int joint_dtype,
                              int phases, void *workspace, hipStream_t s);
+// dense_kernels.hip (the joint's first Dense layer)
+bool dense_supported(int H, int J);
+hipError_t dense_workspace_bytes(int B, int T, int U, int H, int J, size_t base, size_t *bytes);
+void dense_proj_pointers(void *workspace, int B, int T, int U, int H, int J, size_t base, float **enc_proj, float **pred_proj,
+                         float **d_enc_proj, float **d_pred_proj);
+hipError_t launch_dense_fwd(const float *enc, const float *pred, const float *W1, const float *b1, int B, int T, int U, int H, int J,
+                            void *workspace, size_t base, hipStream_t s);
+hipError_t launch_dense_bwd(int B, int T, int U, int H, int J, float *d_enc, float *d_pred, float *dW1, float *db1, void *workspace,
+                            size_t base, hipStream_t s);
 hipError_t launch_joint_logits(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2, int J, int V,
                                int B, int T, int U, float *logits, void *workspace, hipStream_t s);
 }  // namespace rnnt
@@ -241,6 +250,78 @@ rnntStatus_t compute_rnnt_joint_loss_bwd(const float *enc_proj, const float *pre
     return joint_call(enc_proj, pred_proj, W2, b2, flat_labels, label_lengths, input_lengths, cost_scale, joint_size,
                       alphabet_size, minibatch, nullptr, d_enc_proj, d_pred_proj, dW2, db2, joint_dtype, 2, workspace,
                       options);
+}
+
+// ---- the whole joint network (first Dense layer included) fused with the loss ----
+rnntStatus_t get_joint_net_workspace_size(int maxT, int maxU, int minibatch, int hidden_size, int joint_size, int alphabet_size,
+                                          size_t *size_bytes) {
+    if (!size_bytes || maxT <= 0 || maxU <= 0 || minibatch <= 0 || hidden_size <= 0 || joint_size <= 0 || alphabet_size <= 0)
+        return RNNT_STATUS_INVALID_VALUE;
+    size_t base = 0;
+    hipError_t e = joint_workspace_bytes(maxT, maxU, minibatch, joint_size, alphabet_size, &base);
+    if (e != hipSuccess) return from_hip(e);
+    return from_hip(dense_workspace_bytes(minibatch, maxT, maxU, hidden_size, joint_size, base, size_bytes));
+}
+
+static rnntStatus_t joint_net_call(const float *enc, const float *pred, const float *W1, const float *b1, const float *W2,
+                                   const float *b2, const int *flat_labels, const int *label_lengths, const int *input_lengths,
+                                   const float *cost_scale, int hidden_size, int joint_size, int alphabet_size, int minibatch,
+                                   float *costs, float *d_enc, float *d_pred, float *dW1, float *db1, float *dW2, float *db2,
+                                   int joint_dtype, int phases, void *workspace, const rnntOptions &options) {
+    if (!enc || !pred || !W1 || !b1 || !W2 || !b2 || !flat_labels || !label_lengths || !input_lengths || !workspace)
+        return RNNT_STATUS_INVALID_VALUE;
+    if ((phases & 1) && !costs) return RNNT_STATUS_INVALID_VALUE;
+    if (hidden_size <= 0 || joint_size <= 0 || alphabet_size <= 0 || minibatch <= 0) return RNNT_STATUS_INVALID_VALUE;
+    rnntStatus_t st = check_options(options);
+    if (st != RNNT_STATUS_SUCCESS) return st;
+    if (options.blank_label >= alphabet_size || options.maxU > 1024) return RNNT_STATUS_INVALID_VALUE;
+    if (((uintptr_t)workspace & 255) != 0 || !dense_supported(hidden_size, joint_size)) return RNNT_STATUS_INVALID_VALUE;
+    const bool any_grad = d_enc || d_pred || dW1 || db1 || dW2 || db2;
+    if (any_grad && !(d_enc && d_pred && dW1 && db1 && dW2 && db2)) return RNNT_STATUS_INVALID_VALUE;
+    if ((phases & 2) && !(phases & 1) && !any_grad) return RNNT_STATUS_INVALID_VALUE;
+    const int B = minibatch, T = options.maxT, U = options.maxU;
+    hipStream_t s = (hipStream_t)options.stream;
+    size_t base = 0;
+    hipError_t e = joint_workspace_bytes(T, U, B, joint_size, alphabet_size, &base);
+    if (e != hipSuccess) return from_hip(e);
+    if ((phases & 1) && (e = launch_dense_fwd(enc, pred, W1, b1, B, T, U, hidden_size, joint_size, workspace, base, s)) != hipSuccess)
+        return from_hip(e);
+    float *ep, *pp, *dep, *dpp;
+    dense_proj_pointers(workspace, B, T, U, hidden_size, joint_size, base, &ep, &pp, &dep, &dpp);
+    const bool bwd = (phases & 2) && any_grad;
+    e = launch_joint_loss(ep, pp, W2, b2, flat_labels, label_lengths, input_lengths, cost_scale, joint_size, alphabet_size, B, T, U,
+                          options.blank_label, costs, bwd ? dep : nullptr, bwd ? dpp : nullptr, bwd ? dW2 : nullptr,
+                          bwd ? db2 : nullptr, joint_dtype, phases, workspace, s);
+    if (e != hipSuccess || !bwd) return from_hip(e);
+    return from_hip(launch_dense_bwd(B, T, U, hidden_size, joint_size, d_enc, d_pred, dW1, db1, workspace, base, s));
+}
+
+rnntStatus_t compute_rnnt_joint_net_loss(const float *enc, const float *pred, const float *W1, const float *b1, const float *W2,
+                                         const float *b2, const int *flat_labels, const int *label_lengths,
+                                         const int *input_lengths, const float *cost_scale, int hidden_size, int joint_size,
+                                         int alphabet_size, int minibatch, float *costs, float *d_enc, float *d_pred, float *dW1,
+                                         float *db1, float *dW2, float *db2, int joint_dtype, void *workspace, rnntOptions options) {
+    return joint_net_call(enc, pred, W1, b1, W2, b2, flat_labels, label_lengths, input_lengths, cost_scale, hidden_size, joint_size,
+                          alphabet_size, minibatch, costs, d_enc, d_pred, dW1, db1, dW2, db2, joint_dtype, 3, workspace, options);
+}
+
+rnntStatus_t compute_rnnt_joint_net_loss_fwd(const float *enc, const float *pred, const float *W1, const float *b1, const float *W2,
+                                             const float *b2, const int *flat_labels, const int *label_lengths,
+                                             const int *input_lengths, int hidden_size, int joint_size, int alphabet_size,
+                                             int minibatch, float *costs, int joint_dtype, void *workspace, rnntOptions options) {
+    return joint_net_call(enc, pred, W1, b1, W2, b2, flat_labels, label_lengths, input_lengths, nullptr, hidden_size, joint_size,
+                          alphabet_size, minibatch, costs, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, joint_dtype, 1,
+                          workspace, options);
+}
+
+rnntStatus_t compute_rnnt_joint_net_loss_bwd(const float *enc, const float *pred, const float *W1, const float *b1, const float *W2,
+                                             const float *b2, const int *flat_labels, const int *label_lengths,
+                                             const int *input_lengths, const float *cost_scale, int hidden_size, int joint_size,
+                                             int alphabet_size, int minibatch, float *d_enc, float *d_pred, float *dW1, float *db1,
+                                             float *dW2, float *db2, int joint_dtype, void *workspace, rnntOptions options) {
+    if (!d_enc) return RNNT_STATUS_INVALID_VALUE;
+    return joint_net_call(enc, pred, W1, b1, W2, b2, flat_labels, label_lengths, input_lengths, cost_scale, hidden_size, joint_size,
+                          alphabet_size, minibatch, nullptr, d_enc, d_pred, dW1, db1, dW2, db2, joint_dtype, 2, workspace, options);
 }
 
 // The joint alone, for decoding (utils/decoding.py:6-18 evaluates dense_1 / dense_2 on one lattice cell per step).

@@ -75,11 +75,72 @@ class _JointLossFunction(torch.autograd.Function):
         return d_ep, d_pp, d_w2, d_b2, None, None, None, None, None
 
 
+class _JointNetLossFunction(torch.autograd.Function):
+    """The whole joint network + loss behind the C ABI (compute_rnnt_joint_net_loss_fwd / _bwd): the first Dense layer and its
+    backward run in the library too (csrc/dense_kernels.hip), not in torch."""
+
+    @staticmethod
+    def forward(ctx, enc, pred, W1, b1, W2, b2, labels, input_lengths, label_lengths, blank_label, joint_dtype):
+        lib = _lib.load()
+        for name, x in (("enc", enc), ("pred", pred), ("W1", W1), ("b1", b1), ("W2", W2), ("b2", b2)):
+            if not x.is_cuda:
+                raise RuntimeError(f"rnnt_joint_loss: {name} must live on an MI355X (cuda/HIP) device; no CPU path")
+            if x.dtype != torch.float32:
+                raise TypeError(f"rnnt_joint_loss: {name} must be float32")
+        B, T, H = enc.shape
+        U = pred.shape[1]
+        J, V = W2.shape
+        if pred.shape != (B, U, H) or W1.shape != (H, J) or b1.shape != (J,) or b2.shape != (V,):
+            raise ValueError("rnnt_joint_loss: inconsistent shapes")
+        dev = enc.device
+        e, p, w1, bb1, w2, bb2 = (x.detach().contiguous() for x in (enc, pred, W1, b1, W2, b2))
+        labels = labels.to(device=dev, dtype=torch.int32).contiguous()
+        if U > 1 and tuple(labels.shape) != (B, U - 1):
+            raise ValueError(f"rnnt_joint_loss: labels must be [B, U-1] = [{B}, {U - 1}], got {tuple(labels.shape)}")
+        if labels.numel() == 0:
+            labels = torch.zeros((B, 1), dtype=torch.int32, device=dev)
+        il = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
+        ll = label_lengths.to(device=dev, dtype=torch.int32).contiguous()
+        if il.numel() != B or ll.numel() != B:
+            raise ValueError("rnnt_joint_loss: input_lengths and label_lengths must be [B]")
+        with torch.cuda.device(dev):
+            ws = torch.empty(_lib.joint_net_workspace_bytes(T, U, B, H, J, V), dtype=torch.uint8, device=dev)
+            costs = torch.empty(B, dtype=torch.float32, device=dev)
+            opts = _lib.make_options(torch.cuda.current_stream().cuda_stream, int(blank_label), T, U)
+            st = lib.compute_rnnt_joint_net_loss_fwd(e.data_ptr(), p.data_ptr(), w1.data_ptr(), bb1.data_ptr(), w2.data_ptr(),
+                                                     bb2.data_ptr(), labels.data_ptr(), ll.data_ptr(), il.data_ptr(), H, J, V, B,
+                                                     costs.data_ptr(), int(joint_dtype), ws.data_ptr(), opts)
+        _lib.check(st, "compute_rnnt_joint_net_loss_fwd")
+        ctx.save_for_backward(e, p, w1, bb1, w2, bb2, labels, il, ll, ws)
+        ctx.blank = int(blank_label)
+        ctx.joint_dtype = int(joint_dtype)
+        return costs
+
+    @staticmethod
+    def backward(ctx, grad_costs):
+        e, p, w1, bb1, w2, bb2, labels, il, ll, ws = ctx.saved_tensors
+        lib = _lib.load()
+        B, T, H = e.shape
+        U = p.shape[1]
+        J, V = w2.shape
+        dev = e.device
+        scale = grad_costs.to(device=dev, dtype=torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            grads = [torch.empty_like(x) for x in (e, p, w1, bb1, w2, bb2)]
+            opts = _lib.make_options(torch.cuda.current_stream().cuda_stream, ctx.blank, T, U)
+            st = lib.compute_rnnt_joint_net_loss_bwd(e.data_ptr(), p.data_ptr(), w1.data_ptr(), bb1.data_ptr(), w2.data_ptr(),
+                                                     bb2.data_ptr(), labels.data_ptr(), ll.data_ptr(), il.data_ptr(),
+                                                     scale.data_ptr(), H, J, V, B, *(g.data_ptr() for g in grads),
+                                                     ctx.joint_dtype, ws.data_ptr(), opts)
+        _lib.check(st, "compute_rnnt_joint_net_loss_bwd")
+        return (*grads, None, None, None, None, None)
+
+
 JOINT_DTYPES = {"f32": 0, "f16": 1}
 
 
 def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_lengths, blank_label: int = 0,
-                    joint_dtype: str = "auto"):
+                    joint_dtype: str = "auto", first_layer: str = "auto"):
     """costs[b] = transducer NLL of  logits = tanh((enc[:,:,None]+pred[:,None]) @ W1 + b1) @ W2 + b2.
 
     enc [B,T,H] (encoder output), pred [B,U,H] (prediction-network output), W1 [H,J], b1 [J],
@@ -89,26 +150,41 @@ def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_leng
     character set).  "f16": operands rounded to binary16, f32 accumulation, for large vocabularies -- the counterpart
     of the reference's `mixed_float16` policy (run_rnnt.py:96-99); the lattice stays f32 either way.  "auto" picks by V.
     Shapes the kernels do not take natively (f16: V a multiple of 512, J in {128, 256, 512, 640}; f32: J a multiple of
-    64) are padded up exactly (zero units / zero-probability symbols)."""
+    64) are padded up exactly (zero units / zero-probability symbols).
+
+    first_layer: where the first Dense layer (enc @ W1 + b1, pred @ W1, and dW1 / db1 / d enc / d pred) runs.  "engine": inside
+    libwarprnnt.so (compute_rnnt_joint_net_loss_*: split-precision MFMA GEMMs, csrc/dense_kernels.hip; hidden size a multiple
+    of 32).  "torch": torch.matmul + autograd around compute_rnnt_joint_loss_*.  "auto": the engine whenever it takes the shape."""
     if joint_dtype == "auto":
         joint_dtype = "f32" if W2.shape[1] <= 32 else "f16"
     if joint_dtype not in JOINT_DTYPES:
         raise ValueError(f"rnnt_joint_loss: joint_dtype must be one of {sorted(JOINT_DTYPES)} or 'auto'")
-    enc_proj = torch.matmul(enc, W1) + b1
-    pred_proj = torch.matmul(pred, W1)
     # The kernels take a fixed set of (J, V) shapes; anything else is padded up here, exactly:
-    #   joint units  -- extra units get zero projections and zero W2 rows: h = tanh(0) = 0 contributes nothing;
+    #   joint units  -- extra units get zero W1 columns / b1 entries (projections 0) and zero W2 rows: h = tanh(0) = 0 contributes nothing;
     #   vocabulary   -- extra columns get zero weights and a bias of -1e4: their softmax mass is exp(-1e4) = 0 in f32.
     # Autograd slices the gradients back through the pads.
     J, V = W2.shape
+    H = W1.shape[0]
     Jp, Vp = padded_joint_shape(J, V, joint_dtype)
     if Jp != J:
-        enc_proj = torch.nn.functional.pad(enc_proj, (0, Jp - J))
-        pred_proj = torch.nn.functional.pad(pred_proj, (0, Jp - J))
+        W1 = torch.nn.functional.pad(W1, (0, Jp - J))
+        b1 = torch.nn.functional.pad(b1, (0, Jp - J))
         W2 = torch.nn.functional.pad(W2, (0, 0, 0, Jp - J))
     if Vp != V:
         W2 = torch.nn.functional.pad(W2, (0, Vp - V))
         b2 = torch.nn.functional.pad(b2, (0, Vp - V), value=_PAD_BIAS)
+    if first_layer == "auto":
+        first_layer = "engine" if (H % 32 == 0 and Jp % 64 == 0 and max(H, Jp) <= 4096) else "torch"
+    if first_layer == "engine":
+        # the whole joint network behind the C ABI: W1 GEMMs, their backward, tanh, W2, the lattice (include/rnnt.h)
+        return _JointNetLossFunction.apply(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_lengths, blank_label,
+                                           JOINT_DTYPES[joint_dtype])
+    if first_layer != "torch":
+        raise ValueError("rnnt_joint_loss: first_layer must be 'auto', 'engine' or 'torch'")
+    # hidden sizes the library's dense kernels do not take (not a multiple of 32): the first layer through torch.matmul
+    # (hipBLASLt) and autograd, the rest through compute_rnnt_joint_loss
+    enc_proj = torch.matmul(enc, W1) + b1
+    pred_proj = torch.matmul(pred, W1)
     return _JointLossFunction.apply(enc_proj, pred_proj, W2, b2, labels, input_lengths, label_lengths, blank_label,
                                     JOINT_DTYPES[joint_dtype])
 

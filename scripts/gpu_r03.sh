@@ -35,6 +35,15 @@ if has profj; then
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/profj -o j -- python $R/bench.py --fused-only 32,600,150,28 --steps 5 > $R/$OUT/rocprofj.log 2>&1); echo "rocprof rc=$?"
   python scripts/summarize_trace.py stats $OUT/profj $OUT/joint_kernel_stats.json $OUT/joint_kernel_stats.csv
 fi
+if has proff; then
+  echo "== rocprof kernel trace of the bench WITH the fused legs (dense + joint kernels)"
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/proff -o f -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-ragged --no-e2e --no-config5 > $R/$OUT/rocproff.log 2>&1); echo "rocprof rc=$?"
+  python scripts/summarize_trace.py stats $OUT/proff $OUT/fused_kernel_stats.json $OUT/fused_kernel_stats.csv
+fi
+if has dense; then
+  echo "== dense-layer tests"
+  timeout 600 python -m pytest tests/test_dense_gpu.py -m gpu -q -x > $OUT/pytest_dense.log 2>&1; echo "dense rc=$?"; tail -15 $OUT/pytest_dense.log
+fi
 if has pmc; then
   for c in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/pmc/$c -o pmc -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fused --no-ragged --no-e2e --no-config5 > $R/$OUT/pmc_$c.log 2>&1); echo "pmc $c rc=$?"
