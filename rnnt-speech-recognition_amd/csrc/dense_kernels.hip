@@ -37,24 +37,67 @@ typedef __attribute__((address_space(1))) const void dglb_cvoid;
 typedef __attribute__((address_space(3))) ds4 dlds_s4;
 
 __device__ __forceinline__ constexpr int dcd_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+// XCD-aware bijective remap: workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8); give every XCD a CONTIGUOUS range
+// of logical work items, so that items which share operand tiles (neighbours in logical order) share one L2
+__device__ __forceinline__ uint32_t dxcd_remap(uint32_t bid, uint32_t nwg) {
+    const uint32_t xcd = bid & 7u, idx = bid >> 3, q = nwg >> 3, r = nwg & 7u;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
+}
 
 constexpr int kDenseScaleLog2 = 14;  // max |S x| < 2^14 before the binary16 rounding (headroom for the f16 range: 65504)
 
 // ---------------------------------------------------------------------------------------------
 // abs-max of a tensor (bit pattern of the non-negative float: unsigned order = float order), NaN / inf propagate as "huge"
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dense_absmax_kernel(const float *x, size_t n, unsigned *out) {
-    unsigned m = 0u;
-    const size_t n4 = ((((uintptr_t)x) & 15) == 0) ? (n >> 2) : 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const uint4 q = ((const uint4 *)x)[i];
-        m = max(max(m, q.x & 0x7fffffffu), max(q.y & 0x7fffffffu, max(q.z & 0x7fffffffu, q.w & 0x7fffffffu)));
+constexpr int kAbsBlocks = 512;  // grid of the abs-max pass = entries per tensor it leaves for the split kernels
+struct AbsmaxJob {
+    const float *x[3];
+    size_t n[3];
+    unsigned *out[3];  // [kAbsBlocks] per tensor: every block stores its own maximum (no atomics, no zero-fill)
+    int count;
+};
+__global__ __launch_bounds__(256) void dense_absmax_kernel(const AbsmaxJob job) {
+    __shared__ unsigned red[4];
+    for (int t = 0; t < job.count; ++t) {
+        const float *x = job.x[t];
+        const size_t n = job.n[t];
+        unsigned m = 0u;
+        const size_t n4 = ((((uintptr_t)x) & 15) == 0) ? (n >> 2) : 0;
+        const size_t stride = (size_t)gridDim.x * 256;
+        size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+        for (; i + 3 * stride < n4; i += 4 * stride) {  // four 16-byte loads in flight
+            const uint4 a = ((const uint4 *)x)[i], b = ((const uint4 *)x)[i + stride], c = ((const uint4 *)x)[i + 2 * stride],
+                        d = ((const uint4 *)x)[i + 3 * stride];
+            m = max(m, max(max(max(a.x & 0x7fffffffu, a.y & 0x7fffffffu), max(a.z & 0x7fffffffu, a.w & 0x7fffffffu)),
+                           max(max(b.x & 0x7fffffffu, b.y & 0x7fffffffu), max(b.z & 0x7fffffffu, b.w & 0x7fffffffu))));
+            m = max(m, max(max(max(c.x & 0x7fffffffu, c.y & 0x7fffffffu), max(c.z & 0x7fffffffu, c.w & 0x7fffffffu)),
+                           max(max(d.x & 0x7fffffffu, d.y & 0x7fffffffu), max(d.z & 0x7fffffffu, d.w & 0x7fffffffu))));
+        }
+        for (; i < n4; i += stride) {
+            const uint4 q = ((const uint4 *)x)[i];
+            m = max(max(m, q.x & 0x7fffffffu), max(q.y & 0x7fffffffu, max(q.z & 0x7fffffffu, q.w & 0x7fffffffu)));
+        }
+        for (size_t k = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += stride)
+            m = max(m, __float_as_uint(x[k]) & 0x7fffffffu);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) job.out[t][blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
     }
-    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+}
+
+// the tensor's maximum from its per-block entries (every block of a consumer kernel redoes this small reduction)
+__device__ __forceinline__ unsigned dense_max_of(const unsigned *arr, const int count) {
+    __shared__ unsigned red2[4];
+    unsigned m = 0u;
+    for (int i = threadIdx.x; i < count; i += 256) m = max(m, arr[i]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0) red2[threadIdx.x >> 6] = m;
+    __syncthreads();
+    return max(max(red2[0], red2[1]), max(red2[2], red2[3]));
 }
 
 // S = 2^(14 - e) with max|x| < 2^e (1 for an all-zero or non-finite tensor: the products then carry the inf / NaN through)
@@ -78,8 +121,8 @@ __device__ __forceinline__ void dense_split4(const float4 v, const float S, dh4 
 // x [rows][cols] f32 (row-major, contiguous) -> hi / lo images at rows [row_off, row_off + rows) of [*][cols] binary16 arrays,
 // scaled by the tensor's power of two; scal[slot] receives S.  Flat, 16-byte loads / 8-byte stores.
 __global__ __launch_bounds__(256) void dense_split_kernel(const float *__restrict__ x, df16 *__restrict__ hi, df16 *__restrict__ lo,
-                                                          size_t n, size_t elem_off, const unsigned *maxbits, float *scal, int slot) {
-    const float S = dense_scale_from_bits(maxbits[slot]);
+                                                          size_t n, size_t elem_off, const unsigned *maxarr, int maxcount, float *scal, int slot) {
+    const float S = dense_scale_from_bits(dense_max_of(maxarr, maxcount));
     if (blockIdx.x == 0 && threadIdx.x == 0) scal[slot] = S;
     const size_t n4 = n >> 2;  // cols % 8 == 0 (checked by the launcher): n % 4 == 0 and the images are 8-byte aligned
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -95,9 +138,9 @@ __global__ __launch_bounds__(256) void dense_split_kernel(const float *__restric
 // colpart[block][cols] and summed in a fixed order afterwards.  A block owns kDbRows rows; a thread owns 4 columns.
 constexpr int kDbRows = 16;
 __global__ __launch_bounds__(256) void dense_split_colsum_kernel(const float *__restrict__ x, df16 *__restrict__ hi, df16 *__restrict__ lo,
-                                                                 int rows, int cols, const unsigned *maxbits, float *scal, int slot,
+                                                                 int rows, int cols, const unsigned *maxarr, int maxcount, float *scal, int slot,
                                                                  float *__restrict__ colpart) {
-    const float S = dense_scale_from_bits(maxbits[slot]);
+    const float S = dense_scale_from_bits(dense_max_of(maxarr, maxcount));
     if (blockIdx.x == 0 && threadIdx.x == 0) scal[slot] = S;
     const int c4 = cols >> 2;
     const int r0 = blockIdx.x * kDbRows, nr = min(kDbRows, rows - r0);
@@ -131,8 +174,8 @@ __global__ __launch_bounds__(256) void dense_zero_rows_kernel(df16 *hi, df16 *lo
 
 // W [H][J] f32 -> split images of W ([H][J], for dX = dproj . W^T) and of W^T ([J][H], for proj = X . W); tiny (H J <= 0.5 M)
 __global__ __launch_bounds__(256) void dense_split_w_kernel(const float *W, df16 *whi, df16 *wlo, df16 *thi, df16 *tlo, int H, int J,
-                                                            const unsigned *maxbits, float *scal, int slot) {
-    const float S = dense_scale_from_bits(maxbits[slot]);
+                                                            const unsigned *maxarr, int maxcount, float *scal, int slot) {
+    const float S = dense_scale_from_bits(dense_max_of(maxarr, maxcount));
     if (blockIdx.x == 0 && threadIdx.x == 0) scal[slot] = S;
     const size_t n = (size_t)H * J;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -152,6 +195,8 @@ __global__ __launch_bounds__(256) void dense_split_w_kernel(const float *W, df16
 struct DenseNT {
     const df16 *Ahi, *Alo, *Bhi, *Blo;
     float *C0, *C1;
+    float *E0, *E1;    // nullable: e^{2 C} tables next to C0 / C1 (what the fused joint's prep kernel would compute from C)
+    float *tflag;      // with E0: tflag[0] is raised when some |C| exceeds the tables' range (joint_kernels.hip kExpTabLimit)
     const float *bias;
     const float *scal;
     int sa0, sa1, sb;  // slots of the scales in `scal`: A segment 0, A segment 1, B
@@ -169,8 +214,9 @@ __global__ __launch_bounds__(512) void dense_gemm_nt_kernel(const DenseNT g) {
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, n31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;
-    // the N tiles of one M tile are neighbours in dispatch order: the A rows are fetched from HBM once
-    const int nt = (int)(blockIdx.x % (unsigned)g.tiles_n), mt = (int)(blockIdx.x / (unsigned)g.tiles_n);
+    // the N tiles of one M tile are neighbours in ONE XCD's queue: the A rows are fetched from HBM once and shared through that L2
+    const uint32_t lid = dxcd_remap(blockIdx.x, gridDim.x);
+    const int nt = (int)(lid % (unsigned)g.tiles_n), mt = (int)(lid / (unsigned)g.tiles_n);
     const int m0 = mt * kNtM, n0 = nt * kNtN;
     const int K = g.K;
 
@@ -225,17 +271,22 @@ __global__ __launch_bounds__(512) void dense_gemm_nt_kernel(const DenseNT g) {
         const char *S = dsm + sc * kNtStage;
         const bool pf = kc + 2 < nK;
         const int sp = (sc + 2) % kNtStages;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            dh8 ah[2], al[2], bh[2], bl[2];
+        // fragments of k-step ks in [ks & 1]: read one k-step ahead of their MFMAs
+        dh8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+        auto rd = [&](const int ks, dh8 (&a_h)[2], dh8 (&a_l)[2], dh8 (&b_h)[2], dh8 (&b_l)[2]) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int pa = ((ks * 2 + half) ^ ((arow[q] >> 2) & 3)) * 16, pb = ((ks * 2 + half) ^ ((brow[q] >> 2) & 3)) * 16;
-                ah[q] = *(const dh8 *)(S + arow[q] * 64 + pa);
-                al[q] = *(const dh8 *)(S + kNtPartA + arow[q] * 64 + pa);
-                bh[q] = *(const dh8 *)(S + 2 * kNtPartA + brow[q] * 64 + pb);
-                bl[q] = *(const dh8 *)(S + 2 * kNtPartA + kNtPartB + brow[q] * 64 + pb);
+                a_h[q] = *(const dh8 *)(S + arow[q] * 64 + pa);
+                a_l[q] = *(const dh8 *)(S + kNtPartA + arow[q] * 64 + pa);
+                b_h[q] = *(const dh8 *)(S + 2 * kNtPartA + brow[q] * 64 + pb);
+                b_l[q] = *(const dh8 *)(S + 2 * kNtPartA + kNtPartB + brow[q] * 64 + pb);
             }
+        };
+        rd(0, ah[0], al[0], bh[0], bl[0]);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks == 0) rd(1, ah[1], al[1], bh[1], bl[1]);
             __builtin_amdgcn_sched_barrier(0);
             if (pf) {  // three of the six pieces of stage kc + 2 per k-step, between the MFMA groups
                 dma_piece(3 * ks + 0, kc + 2, sp);
@@ -246,9 +297,9 @@ __global__ __launch_bounds__(512) void dense_gemm_nt_kernel(const DenseNT g) {
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][mi], bh[ks][ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][mi], bh[ks][ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][mi], bl[ks][ni], acc[mi][ni], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -256,6 +307,8 @@ __global__ __launch_bounds__(512) void dense_gemm_nt_kernel(const DenseNT g) {
     }
     // epilogue: exact power-of-two rescale, bias, row segment
     const float inv0 = 1.0f / (g.scal[g.sa0] * g.scal[g.sb]), inv1 = 1.0f / (g.scal[g.sa1] * g.scal[g.sb]);
+    const bool tables = g.E0 != nullptr;
+    bool big = false;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int col = n0 + wn * 64 + ni * 32 + n31;
@@ -266,10 +319,20 @@ __global__ __launch_bounds__(512) void dense_gemm_nt_kernel(const DenseNT g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + mi * 32 + dcd_row(r, half);
-                if (row < g.R0) g.C0[(size_t)row * g.ldc + col] = fmaf(acc[mi][ni][r], inv0, bv);
-                else if (row >= g.R0p && row < g.R0p + g.R1) g.C1[(size_t)(row - g.R0p) * g.ldc + col] = acc[mi][ni][r] * inv1;
+                float v;
+                size_t o;
+                float *C, *E;
+                if (row < g.R0) v = fmaf(acc[mi][ni][r], inv0, bv), o = (size_t)row * g.ldc + col, C = g.C0, E = g.E0;
+                else if (row >= g.R0p && row < g.R0p + g.R1) v = acc[mi][ni][r] * inv1, o = (size_t)(row - g.R0p) * g.ldc + col, C = g.C1, E = g.E1;
+                else continue;
+                C[o] = v;
+                if (tables) {
+                    big |= !(fabsf(v) <= 43.0f);  // kExpTabLimit; also catches NaN
+                    E[o] = __builtin_amdgcn_exp2f(v * 2.8853900817779268f);
+                }
             }
     }
+    if (tables && __any(big) && lane == 0) g.tflag[0] = 1.0f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -297,9 +360,11 @@ __global__ __launch_bounds__(256) void dense_gemm_tn_kernel(const DenseTN g) {
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, n31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
-    int bid = blockIdx.x;
-    const int split = bid % g.nsplit;
-    bid /= g.nsplit;
+    // all tiles of one K split are neighbours in one XCD's queue: they share the split's rows of both operands through that L2
+    int bid = (int)dxcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int split = bid / ntile;
+    bid -= split * ntile;
     const int nt = bid % g.tiles_n, mt = bid / g.tiles_n;
     const int m0 = mt * kTnT, n0 = nt * kTnT;
     const bool first = split < g.ns0;
@@ -413,11 +478,46 @@ __global__ __launch_bounds__(256) void dense_gemm_tn_kernel(const DenseTN g) {
     }
 }
 
+// out[i] = sum_q P[q][i] in a FIXED association (deterministic): G lanes share an output float4, lane g sums partials g, g + G,
+// g + 2G, ... in order (four loads in flight), then a binary tree over the G lanes.  n % 4 == 0.
+template <int G>
+__global__ __launch_bounds__(256) void dense_reduce_kernel(float *out, const float *P, int nparts, size_t n) {
+    const size_t n4 = n >> 2;
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) / G;
+    const int grp = threadIdx.x & (G - 1);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+        const float4 *p4 = (const float4 *)P + i;
+        int q = grp;
+        for (; q + 3 * G < nparts; q += 4 * G) {
+            const float4 a = p4[(size_t)q * n4], b = p4[(size_t)(q + G) * n4], c = p4[(size_t)(q + 2 * G) * n4], d = p4[(size_t)(q + 3 * G) * n4];
+            s.x = (((s.x + a.x) + b.x) + c.x) + d.x, s.y = (((s.y + a.y) + b.y) + c.y) + d.y;
+            s.z = (((s.z + a.z) + b.z) + c.z) + d.z, s.w = (((s.w + a.w) + b.w) + c.w) + d.w;
+        }
+        for (; q < nparts; q += G) {
+            const float4 a = p4[(size_t)q * n4];
+            s.x += a.x, s.y += a.y, s.z += a.z, s.w += a.w;
+        }
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+        s.x += __shfl_down(s.x, off, G), s.y += __shfl_down(s.y, off, G);
+        s.z += __shfl_down(s.z, off, G), s.w += __shfl_down(s.w, off, G);
+    }
+    if (i < n4 && grp == 0) ((float4 *)out)[i] = s;
+}
+
+template <int G>
+static hipError_t dense_reduce(float *out, const float *P, int nparts, size_t n, hipStream_t s) {
+    if ((n & 3) != 0 || ((uintptr_t)out & 15) != 0) return hipErrorInvalidValue;
+    const size_t threads = (n >> 2) * G;
+    hipLaunchKernelGGL((dense_reduce_kernel<G>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, out, P, nparts, n);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_reduce_partials(float *out, const float *in, int nparts, size_t n, hipStream_t s);  // joint_kernels.hip
-
 struct DenseLayout {
     size_t proj_e, proj_p, dproj_e, dproj_p, Xhi, Xlo, Dhi, Dlo, Whi, Wlo, WThi, WTlo, dWpart, dbpart, scal, total;
     int R0, R0p, R1, Rp, nsplit, ns0, db_blocks;
@@ -462,7 +562,7 @@ static DenseLayout make_dense_layout(int B, int T, int U, int H, int J, size_t b
     L.WTlo = take((size_t)H * J * sizeof(df16));
     L.dWpart = take((size_t)L.nsplit * H * J * sizeof(float));
     L.dbpart = take((size_t)L.db_blocks * J * sizeof(float));
-    L.scal = take(256);
+    L.scal = take(256 + (size_t)(3 * kAbsBlocks + 2 * kHookBlocks) * sizeof(unsigned));  // scales + the per-block abs-max entries
     L.total = off;
     return L;
 }
@@ -482,13 +582,22 @@ void dense_proj_pointers(void *workspace, int B, int T, int U, int H, int J, siz
     *d_enc_proj = (float *)(ws + L.dproj_e), *d_pred_proj = (float *)(ws + L.dproj_p);
 }
 
-enum { kSlotXe = 0, kSlotXp = 1, kSlotW = 2, kSlotDe = 3, kSlotDp = 4 };  // scal[slot] = S; the abs-max bit patterns at scal + 32
+enum { kSlotXe = 0, kSlotXp = 1, kSlotW = 2, kSlotDe = 3, kSlotDp = 4 };  // scal[slot] = S
+// per-block abs-max entries behind the scales: X enc, X pred, W1 (kAbsBlocks each), then d enc_proj, d pred_proj (kHookBlocks each)
+static unsigned *dense_maxarr(float *scal, int slot) {
+    unsigned *base = (unsigned *)(scal + 64);
+    return slot < 3 ? base + slot * kAbsBlocks : base + 3 * kAbsBlocks + (slot - 3) * kHookBlocks;
+}
+void dense_hook_pointers(void *workspace, int B, int T, int U, int H, int J, size_t base, unsigned **dmax_enc, unsigned **dmax_pred) {
+    const DenseLayout L = make_dense_layout(B, T, U, H, J, base);
+    float *scal = (float *)((char *)workspace + L.scal);
+    *dmax_enc = dense_maxarr(scal, kSlotDe), *dmax_pred = dense_maxarr(scal, kSlotDp);
+}
 
 static unsigned dense_flat_grid(size_t n4) { return (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048); }
 
-static void dense_absmax(const float *x, size_t n, unsigned *slot, hipStream_t s) {
-    const unsigned gm = dense_flat_grid(n / 4);
-    hipLaunchKernelGGL(dense_absmax_kernel, dim3(gm ? gm : 1), dim3(256), 0, s, x, n, slot);
+static void dense_absmax(const AbsmaxJob &job, hipStream_t s) {
+    hipLaunchKernelGGL(dense_absmax_kernel, dim3(kAbsBlocks), dim3(256), 0, s, job);
 }
 
 static void dense_zero_pad(df16 *hi, df16 *lo, const DenseLayout &L, int cols, hipStream_t s) {
@@ -506,32 +615,38 @@ static hipError_t dense_nt_launch(DenseNT &g, hipStream_t s) {
 }
 
 // proj = [enc; pred] . W1 (+ b1 on the enc rows), into the workspace; the split image of X stays there for the backward
+// expE / expP / tflag: nullable; when given (joint_dtype 0) the GEMM's epilogue also writes the fused joint's e^{2x} tables
 hipError_t launch_dense_fwd(const float *enc, const float *pred, const float *W1, const float *b1, int B, int T, int U, int H, int J,
-                            void *workspace, size_t base, hipStream_t s) {
+                            void *workspace, size_t base, float *expE, float *expP, float *tflag, hipStream_t s) {
     if (!dense_supported(H, J)) return hipErrorInvalidValue;
     if ((((uintptr_t)enc | (uintptr_t)pred | (uintptr_t)W1) & 15) != 0) return hipErrorInvalidValue;
     const DenseLayout L = make_dense_layout(B, T, U, H, J, base);
     char *ws = (char *)workspace;
     float *scal = (float *)(ws + L.scal);
-    unsigned *maxbits = (unsigned *)(scal + 32);
-    if (hipMemsetAsync(scal, 0, 256, s) != hipSuccess) return hipErrorUnknown;
     df16 *Xhi = (df16 *)(ws + L.Xhi), *Xlo = (df16 *)(ws + L.Xlo);
     const size_t ne = (size_t)L.R0 * H, np = (size_t)L.R1 * H, nw = (size_t)H * J;
-    dense_absmax(enc, ne, maxbits + kSlotXe, s);
-    dense_absmax(pred, np, maxbits + kSlotXp, s);
-    dense_absmax(W1, nw, maxbits + kSlotW, s);
+    {
+        AbsmaxJob job;
+        job.x[0] = enc, job.n[0] = ne, job.out[0] = dense_maxarr(scal, kSlotXe);
+        job.x[1] = pred, job.n[1] = np, job.out[1] = dense_maxarr(scal, kSlotXp);
+        job.x[2] = W1, job.n[2] = nw, job.out[2] = dense_maxarr(scal, kSlotW);
+        job.count = 3;
+        dense_absmax(job, s);
+    }
     hipLaunchKernelGGL(dense_split_kernel, dim3(dense_flat_grid(ne / 4)), dim3(256), 0, s, enc, Xhi, Xlo, ne, (size_t)0,
-                       (const unsigned *)maxbits, scal, (int)kSlotXe);
+                       (const unsigned *)dense_maxarr(scal, kSlotXe), (int)kAbsBlocks, scal, (int)kSlotXe);
     hipLaunchKernelGGL(dense_split_kernel, dim3(dense_flat_grid(np / 4)), dim3(256), 0, s, pred, Xhi, Xlo, np, (size_t)L.R0p * H,
-                       (const unsigned *)maxbits, scal, (int)kSlotXp);
+                       (const unsigned *)dense_maxarr(scal, kSlotXp), (int)kAbsBlocks, scal, (int)kSlotXp);
     dense_zero_pad(Xhi, Xlo, L, H, s);
     hipLaunchKernelGGL(dense_split_w_kernel, dim3(512), dim3(256), 0, s, W1, (df16 *)(ws + L.Whi), (df16 *)(ws + L.Wlo),
-                       (df16 *)(ws + L.WThi), (df16 *)(ws + L.WTlo), H, J, (const unsigned *)maxbits, scal, (int)kSlotW);
+                       (df16 *)(ws + L.WThi), (df16 *)(ws + L.WTlo), H, J, (const unsigned *)dense_maxarr(scal, kSlotW), (int)kAbsBlocks,
+                       scal, (int)kSlotW);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     DenseNT g;
     g.Ahi = Xhi, g.Alo = Xlo, g.Bhi = (const df16 *)(ws + L.WThi), g.Blo = (const df16 *)(ws + L.WTlo);
     g.C0 = (float *)(ws + L.proj_e), g.C1 = (float *)(ws + L.proj_p), g.bias = b1, g.scal = scal;
+    g.E0 = expE, g.E1 = expP, g.tflag = tflag;
     g.sa0 = kSlotXe, g.sa1 = kSlotXp, g.sb = kSlotW;
     g.M = L.R0p + L.R1, g.N = J, g.K = H, g.R0 = L.R0, g.R0p = L.R0p, g.R1 = L.R1, g.ldc = J;
     return dense_nt_launch(g, s);
@@ -546,18 +661,15 @@ hipError_t launch_dense_bwd(int B, int T, int U, int H, int J, float *d_enc, flo
     const DenseLayout L = make_dense_layout(B, T, U, H, J, base);
     char *ws = (char *)workspace;
     float *scal = (float *)(ws + L.scal);
-    unsigned *maxbits = (unsigned *)(scal + 32);
     hipError_t e;
     df16 *Dhi = (df16 *)(ws + L.Dhi), *Dlo = (df16 *)(ws + L.Dlo);
     const float *de = (const float *)(ws + L.dproj_e), *dp = (const float *)(ws + L.dproj_p);
     const size_t ne = (size_t)L.R0 * J, np = (size_t)L.R1 * J;
-    if (hipMemsetAsync(maxbits + kSlotDe, 0, 2 * sizeof(unsigned), s) != hipSuccess) return hipErrorUnknown;
-    dense_absmax(de, ne, maxbits + kSlotDe, s);
-    dense_absmax(dp, np, maxbits + kSlotDp, s);
-    hipLaunchKernelGGL(dense_split_colsum_kernel, dim3(L.db_blocks), dim3(256), 0, s, de, Dhi, Dlo, L.R0, J, (const unsigned *)maxbits, scal,
-                       (int)kSlotDe, (float *)(ws + L.dbpart));
+    // (the abs-max entries of d enc_proj / d pred_proj were left by the fused joint's reductions: JointHooks)
+    hipLaunchKernelGGL(dense_split_colsum_kernel, dim3(L.db_blocks), dim3(256), 0, s, de, Dhi, Dlo, L.R0, J,
+                       (const unsigned *)dense_maxarr(scal, kSlotDe), (int)kHookBlocks, scal, (int)kSlotDe, (float *)(ws + L.dbpart));
     hipLaunchKernelGGL(dense_split_kernel, dim3(dense_flat_grid(np / 4)), dim3(256), 0, s, dp, Dhi, Dlo, np, (size_t)L.R0p * J,
-                       (const unsigned *)maxbits, scal, (int)kSlotDp);
+                       (const unsigned *)dense_maxarr(scal, kSlotDp), (int)kHookBlocks, scal, (int)kSlotDp);
     dense_zero_pad(Dhi, Dlo, L, J, s);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // dX = dproj . W1^T  (NT: A = dproj rows, B = W1 rows [H][J], K = J)
@@ -565,6 +677,7 @@ hipError_t launch_dense_bwd(int B, int T, int U, int H, int J, float *d_enc, flo
         DenseNT g;
         g.Ahi = Dhi, g.Alo = Dlo, g.Bhi = (const df16 *)(ws + L.Whi), g.Blo = (const df16 *)(ws + L.Wlo);
         g.C0 = d_enc, g.C1 = d_pred, g.bias = nullptr, g.scal = scal, g.sa0 = kSlotDe, g.sa1 = kSlotDp, g.sb = kSlotW;
+        g.E0 = g.E1 = g.tflag = nullptr;
         g.M = L.R0p + L.R1, g.N = H, g.K = J, g.R0 = L.R0, g.R0p = L.R0p, g.R1 = L.R1, g.ldc = H;
         if ((e = dense_nt_launch(g, s)) != hipSuccess) return e;
     }
@@ -579,9 +692,9 @@ hipError_t launch_dense_bwd(int B, int T, int U, int H, int J, float *d_enc, flo
         g.tiles_m = (H + kTnT - 1) / kTnT, g.tiles_n = (J + kTnT - 1) / kTnT, g.nsplit = L.nsplit, g.ns0 = L.ns0;
         hipLaunchKernelGGL(dense_gemm_tn_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n * g.nsplit)), dim3(256), shm, s, g);
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        if ((e = launch_reduce_partials(dW1, g.P, L.nsplit, (size_t)H * J, s)) != hipSuccess) return e;
+        if ((e = dense_reduce<4>(dW1, g.P, L.nsplit, (size_t)H * J, s)) != hipSuccess) return e;
     }
-    return launch_reduce_partials(db1, (const float *)(ws + L.dbpart), L.db_blocks, (size_t)J, s);
+    return dense_reduce<64>(db1, (const float *)(ws + L.dbpart), L.db_blocks, (size_t)J, s);
 }
 
 }  // namespace rnnt

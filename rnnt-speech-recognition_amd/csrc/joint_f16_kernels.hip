@@ -1008,8 +1008,8 @@ hipError_t joint_f16_workspace_bytes(int T, int U, int B, int J, int V, size_t *
 bool fill_loss_params(LossParams &p, const float *acts, float *grads, const int *labels, const int *label_lengths,
                       const int *input_lengths, const float *cost_scale, int V, int B, float *costs, void *workspace,
                       int maxT, int maxU, int blank);
-hipError_t launch_reduce_partials(float *out, const float *in, int nparts, size_t n, hipStream_t s);
-hipError_t launch_reduce_enc(float *out, const float *in, int n_ut, const LossParams &lp, int J, hipStream_t s);
+hipError_t launch_reduce_partials(float *out, const float *in, int nparts, size_t n, hipStream_t s, unsigned *blockmax);
+hipError_t launch_reduce_enc(float *out, const float *in, int n_ut, const LossParams &lp, int J, hipStream_t s, unsigned *blockmax);
 
 template <typename K>
 static hipError_t set_lds_f16(K kernel, size_t bytes) {
@@ -1044,7 +1044,7 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
                                  const int *labels, const int *label_lengths, const int *input_lengths,
                                  const float *cost_scale, int J, int V, int B, int T, int U, int blank, float *costs,
                                  float *d_enc_proj, float *d_pred_proj, float *dW2, float *db2, int phases,
-                                 void *workspace, hipStream_t s) {
+                                 void *workspace, hipStream_t s, const JointHooks *hooks) {
     if (!joint_f16_supported(J, V)) return hipErrorInvalidValue;
     if (((uintptr_t)enc_proj & 15) || ((uintptr_t)pred_proj & 15) || ((uintptr_t)b2 & 15)) return hipErrorInvalidValue;
     if ((unsigned long long)B * T * J >= (1ull << 32) || (unsigned long long)B * U * J >= (1ull << 32)) return hipErrorInvalidValue;  // 32-bit indices in the reductions
@@ -1122,10 +1122,10 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
         hipLaunchKernelGGL(jh_dw_kernel, dim3(grid), dim3(512), shm, s, jp);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if ((e = launch_reduce_enc(d_enc_proj, jp.dApart, L.n_ut, jp.lp, J, s)) != hipSuccess) return e;
-    if ((e = launch_reduce_partials(d_pred_proj, jp.dCpart, L.n_ts, (size_t)B * U * J, s)) != hipSuccess) return e;
-    if ((e = launch_reduce_partials(dW2, jp.dWpart, L.n_ranges, (size_t)J * V, s)) != hipSuccess) return e;
-    e = launch_reduce_partials(db2, jp.dbpart, L.n_ranges, (size_t)V, s);
+    if ((e = launch_reduce_enc(d_enc_proj, jp.dApart, L.n_ut, jp.lp, J, s, hooks ? hooks->dmax_enc : nullptr)) != hipSuccess) return e;
+    if ((e = launch_reduce_partials(d_pred_proj, jp.dCpart, L.n_ts, (size_t)B * U * J, s, hooks ? hooks->dmax_pred : nullptr)) != hipSuccess) return e;
+    if ((e = launch_reduce_partials(dW2, jp.dWpart, L.n_ranges, (size_t)J * V, s, nullptr)) != hipSuccess) return e;
+    e = launch_reduce_partials(db2, jp.dbpart, L.n_ranges, (size_t)V, s, nullptr);
 #ifdef JH_TRACE
     {
         hipStreamSynchronize(s);

@@ -94,6 +94,7 @@ struct JointParams {
     long long *trace;    // dev builds only: s_memtime stamps of one workgroup of phase 1 and one of phase 2
 #endif
     int J, n_ut, TR, n_tr, TS, n_ts;
+    int tables_ready; // the e^{2x} tables and tflag[0] were written by the caller (the dense layer's epilogue): prep does W2 only
     int logits_only;  // compute_rnnt_joint_logits: full lengths written by the prep kernel, only the parked logits are kept
     int single_bwd;  // 1: joint_bwd_kernel does the backward; joint_dl_kernel only runs for the f32 fallback (tflag[1])
 };
@@ -107,7 +108,9 @@ __global__ __launch_bounds__(256) void joint_prep_kernel(const JointParams jp) {
         big |= !(fabsf(x) <= kExpTabLimit);  // also catches NaN
         return jex2(x * 2.8853900817779268f);
     };
-    if (((nE | nP) & 3) == 0 && ((((uintptr_t)jp.enc_proj | (uintptr_t)jp.pred_proj) & 15) == 0)) {  // 16-byte accesses (J % 4 == 0)
+    if (jp.tables_ready) {
+        // nothing to tabulate
+    } else if (((nE | nP) & 3) == 0 && ((((uintptr_t)jp.enc_proj | (uintptr_t)jp.pred_proj) & 15) == 0)) {  // 16-byte accesses (J % 4 == 0)
         const size_t nE4 = nE >> 2, n4 = (nE + nP) >> 2;
         for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
             const float4 x = (i < nE4) ? ((const float4 *)jp.enc_proj)[i] : ((const float4 *)jp.pred_proj)[i - nE4];
@@ -1713,11 +1716,29 @@ __global__ __launch_bounds__(768) void joint_bwd_kernel(const JointParams jp) {
     }
 }
 
+// abs-max (as the bit pattern of |x|) of what a block wrote, for the consumer of the output (dense_kernels.hip): every block
+// stores its own entry -- no atomics, no zero-fill
+__device__ __forceinline__ unsigned absbits4(const float4 v) {
+    return max(max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu),
+               max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu));
+}
+__device__ __forceinline__ void store_block_max(unsigned m, unsigned *blockmax) {
+    __shared__ unsigned red[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) blockmax[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
+}
+
 // out[i] = sum_p in[p*n + i]  (fixed order)
 // `flag` (nullable): when flag[1] != 0 the fallback kernels produced the partials and there are `nparts_fb` of them
+// `blockmax` (nullable): [gridDim.x] abs-max bit patterns of the block's outputs
 __global__ __launch_bounds__(256) void reduce_partials_kernel(float *out, const float *in, int nparts, size_t n,
-                                                              const float *flag = nullptr, int nparts_fb = 0) {
+                                                              const float *flag = nullptr, int nparts_fb = 0,
+                                                              unsigned *blockmax = nullptr) {
     if (flag && flag[1] != 0.f) nparts = nparts_fb;
+    unsigned bm = 0u;
     // fixed order q = 0, 1, ... for every element (deterministic); 16-byte accesses, up to four partials in flight per thread
     if ((n & 3) == 0 && (((uintptr_t)out | (uintptr_t)in) & 15) == 0) {
         const size_t n4 = n >> 2;
@@ -1736,21 +1757,27 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(float *out, const 
                 s.x += a.x, s.y += a.y, s.z += a.z, s.w += a.w;
             }
             ((float4 *)out)[i] = s;
+            bm = max(bm, absbits4(s));
         }
+        if (blockmax) store_block_max(bm, blockmax);
         return;
     }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float s = 0.f;
         for (int q = 0; q < nparts; ++q) s += in[(size_t)q * n + i];
         out[i] = s;
+        bm = max(bm, __float_as_uint(s) & 0x7fffffffu);
     }
+    if (blockmax) store_block_max(bm, blockmax);
 }
 // d enc_proj[b][t][:] = sum over the u-tiles of their partial rows, in u-tile order.  Every backward kernel writes the row
 // (ut, b, t) exactly when the u-tile starts inside the utterance's label range and t < T_b, and never otherwise: the reduction
 // reads only those rows (and writes zeros for t >= T_b), so the 4 n_ut B T J bytes of partials need no zero-fill.
-__global__ __launch_bounds__(256) void reduce_enc_kernel(float *out, const float *in, int n_ut, const LossParams p, int J) {
+__global__ __launch_bounds__(256) void reduce_enc_kernel(float *out, const float *in, int n_ut, const LossParams p, int J,
+                                                         unsigned *blockmax = nullptr) {
     const uint32_t J4 = (uint32_t)J >> 2, n4 = (uint32_t)p.B * (uint32_t)p.T * J4;
     const float4 *in4 = (const float4 *)in;
+    unsigned bm = 0u;
     if (((uintptr_t)out & 15) != 0) {  // a caller's gradient buffer off the 16-byte grid (the partials are workspace: aligned)
         const uint32_t n = n4 * 4u;
         for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
@@ -1761,7 +1788,9 @@ __global__ __launch_bounds__(256) void reduce_enc_kernel(float *out, const float
                 for (int q = 0; q < nv; ++q) s += in[(size_t)q * n + i];
             }
             out[i] = s;
+            bm = max(bm, __float_as_uint(s) & 0x7fffffffu);
         }
+        if (blockmax) store_block_max(bm, blockmax);
         return;
     }
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
@@ -1782,7 +1811,9 @@ __global__ __launch_bounds__(256) void reduce_enc_kernel(float *out, const float
             }
         }
         ((float4 *)out)[i] = s;
+        bm = max(bm, absbits4(s));
     }
+    if (blockmax) store_block_max(bm, blockmax);
 }
 // Deterministic tree: out[i] = sum_p in[p*stride_p + map(i)], 256 threads = 32 outputs x 8 partial lanes.
 // Each partial lane sums its strided share in a fixed order, then the 8 lanes are combined in order.
@@ -1874,19 +1905,29 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
                                  const int *labels, const int *label_lengths, const int *input_lengths,
                                  const float *cost_scale, int J, int V, int B, int T, int U, int blank, float *costs,
                                  float *d_enc_proj, float *d_pred_proj, float *dW2, float *db2, int phases,
-                                 void *workspace, hipStream_t s);
+                                 void *workspace, hipStream_t s, const JointHooks *hooks);
 
 // d enc_proj from its [n_ut][B][T][J] partial rows (reduce_enc_kernel); shared with the f16 joint
-hipError_t launch_reduce_enc(float *out, const float *in, int n_ut, const LossParams &lp, int J, hipStream_t s) {
+hipError_t launch_reduce_enc(float *out, const float *in, int n_ut, const LossParams &lp, int J, hipStream_t s, unsigned *blockmax) {
     if ((unsigned long long)lp.B * lp.T * J >= (1ull << 32)) return hipErrorInvalidValue;  // 32-bit element indices in the kernel
-    hipLaunchKernelGGL(reduce_enc_kernel, dim3(1024), dim3(256), 0, s, out, in, n_ut, lp, J);
+    hipLaunchKernelGGL(reduce_enc_kernel, dim3(kHookBlocks), dim3(256), 0, s, out, in, n_ut, lp, J, blockmax);
     return hipGetLastError();
 }
 
-hipError_t launch_reduce_partials(float *out, const float *in, int nparts, size_t n, hipStream_t s) {
-    const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, s, out, in, nparts, n, nullptr, 0);
+hipError_t launch_reduce_partials(float *out, const float *in, int nparts, size_t n, hipStream_t s, unsigned *blockmax) {
+    // (a consumer of `blockmax` reads kHookBlocks entries: the grid is then exactly that, whatever n is)
+    const unsigned grid = blockmax ? (unsigned)kHookBlocks : (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, s, out, in, nparts, n, nullptr, 0, blockmax);
     return hipGetLastError();
+}
+
+// where the fused joint (joint_dtype 0) keeps the e^{2x} tables and its flags: for a caller that fills them itself (JointHooks)
+hipError_t joint_aux_pointers(void *workspace, int T, int U, int B, int J, int V, float **expE, float **expP, float **tflag) {
+    if (!joint_supported(J, V) || sweep_K(U) == 0) return hipErrorInvalidValue;
+    const JointLayout L = make_joint_layout(T, U, B, J);
+    char *ws = (char *)workspace;
+    *expE = (float *)(ws + L.expE), *expP = (float *)(ws + L.expP), *tflag = (float *)(ws + L.tflag);
+    return hipSuccess;
 }
 
 hipError_t joint_workspace_bytes(int T, int U, int B, int J, int V, size_t *bytes) {
@@ -1954,7 +1995,7 @@ hipError_t launch_joint_logits(const float *enc_proj, const float *pred_proj, co
     jp.trace = nullptr;
 #endif
     jp.J = J, jp.n_ut = L.n_ut, jp.TR = L.TR, jp.n_tr = L.n_tr, jp.TS = L.TS, jp.n_ts = L.n_ts;
-    jp.logits_only = 1, jp.single_bwd = 0;
+    jp.logits_only = 1, jp.single_bwd = 0, jp.tables_ready = 0;
     hipError_t e;
     if (hipMemsetAsync(jp.tflag, 0, 256, s) != hipSuccess) return hipErrorUnknown;
     if (U > 1 && hipMemsetAsync(labels, 0, (size_t)B * (U - 1) * sizeof(int), s) != hipSuccess) return hipErrorUnknown;
@@ -1986,11 +2027,11 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
                              const int *labels, const int *label_lengths, const int *input_lengths,
                              const float *cost_scale, int J, int V, int B, int T, int U, int blank, float *costs,
                              float *d_enc_proj, float *d_pred_proj, float *dW2, float *db2, int joint_dtype,
-                             int phases, void *workspace, hipStream_t s) {
+                             int phases, void *workspace, hipStream_t s, const JointHooks *hooks) {
     // phases: bit 0 = forward (costs + lattice state in the workspace), bit 1 = backward (needs that state)
     if (joint_dtype == 1)
         return launch_joint_loss_f16(enc_proj, pred_proj, W2, b2, labels, label_lengths, input_lengths, cost_scale, J, V,
-                                     B, T, U, blank, costs, d_enc_proj, d_pred_proj, dW2, db2, phases, workspace, s);
+                                     B, T, U, blank, costs, d_enc_proj, d_pred_proj, dW2, db2, phases, workspace, s, hooks);
     if (!joint_supported(J, V) || joint_dtype != 0) return hipErrorInvalidValue;
     if (((uintptr_t)enc_proj & 15) || ((uintptr_t)pred_proj & 15)) return hipErrorInvalidValue;
     // the reductions over the [B][T][J] / [B][U][J] arrays index with 32 bits (B*T*U < 2^31 alone does not bound B*T*J)
@@ -2023,6 +2064,8 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
 #endif
     jp.J = J, jp.n_ut = L.n_ut, jp.TR = L.TR, jp.n_tr = L.n_tr, jp.TS = L.TS, jp.n_ts = L.n_ts;
     jp.logits_only = 0;
+    const int prep_mode = hooks ? hooks->prep_mode : 0;
+    jp.tables_ready = prep_mode == 1;
 
     const size_t shm1 = ((size_t)J * 32 + 2 * 1024 + kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
     const size_t shm2 = ((size_t)64 * 36 + 64 * kStagePad + 2 * 4 * 32 * kStagePad) * sizeof(float);
@@ -2030,9 +2073,10 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     if ((e = set_lds(joint_phase1_kernel, shm1)) != hipSuccess) return e;
 
     const unsigned g1 = (unsigned)B * L.n_ut * L.n_tr;
-    // tanh tables (rebuilt by whichever phase runs: a few microseconds, and the projections may have changed)
-    if (hipMemsetAsync(jp.tflag, 0, 256, s) != hipSuccess) return hipErrorUnknown;
-    hipLaunchKernelGGL(joint_prep_kernel, dim3(1024), dim3(256), 0, s, jp);
+    // tanh tables + W2 images (rebuilt by whichever phase runs: the projections may have changed -- unless the caller vouches
+    // for the workspace, JointHooks::prep_mode)
+    if (prep_mode == 0 && hipMemsetAsync(jp.tflag, 0, 256, s) != hipSuccess) return hipErrorUnknown;
+    if (prep_mode != 2) hipLaunchKernelGGL(joint_prep_kernel, dim3(jp.tables_ready ? 64 : 1024), dim3(256), 0, s, jp);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (phases & 1) {
         // forward: edge weights (W pre-filled with log zero) -> sweeps -> costs
@@ -2090,8 +2134,10 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     // partial counts: what the single-kernel backward wrote, or (flag set / wide J) what the two-kernel backward wrote
     const int nC_fb = L.n_ts, nW_fb = B * L.n_ut * L.n_ts, nDb_fb = (int)gdl;
     const int nC_s = single ? kBwdSlots : nC_fb, nW_s = single ? bwd_nblk : nW_fb, nDb_s = single ? 2 * bwd_nblk : nDb_fb;
-    hipLaunchKernelGGL(reduce_enc_kernel, dim3(1024), dim3(256), 0, s, d_enc_proj, jp.dApart, L.n_ut, jp.lp, J);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1024), dim3(256), 0, s, d_pred_proj, jp.dCpart, nC_s, nC, jp.tflag, nC_fb);
+    hipLaunchKernelGGL(reduce_enc_kernel, dim3(kHookBlocks), dim3(256), 0, s, d_enc_proj, jp.dApart, L.n_ut, jp.lp, J,
+                       hooks ? hooks->dmax_enc : (unsigned *)nullptr);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(kHookBlocks), dim3(256), 0, s, d_pred_proj, jp.dCpart, nC_s, nC, jp.tflag, nC_fb,
+                       hooks ? hooks->dmax_pred : (unsigned *)nullptr);
     hipLaunchKernelGGL((reduce_small_kernel<true>), dim3((J * V + 31) / 32), dim3(256), 0, s, dW2, jp.dWpart, nW_s, J * V, J, V,
                        jp.tflag, nW_fb);
     hipLaunchKernelGGL((reduce_small_kernel<false>), dim3(1), dim3(256), 0, s, db2, jp.dbpart, nDb_s, V, J, V, jp.tflag, nDb_fb);

@@ -135,6 +135,17 @@ inline TileGeom make_tile(int T, int U, int V) {
     return g;
 }
 
+// Hooks of the fused joint for a caller that also owns the joint's first Dense layer (rnnt_entrypoint.hip joint_net_call,
+// dense_kernels.hip): work the dense kernels can do on the way, so that the joint need not redo it.
+constexpr int kHookBlocks = 1024;  // grid of the two reductions that produce d enc_proj / d pred_proj
+struct JointHooks {
+    int prep_mode;        // 0: full prep kernel.  1: the e^{2x} tables of the projections and tflag[0] (zeroed, then raised by the
+                          //    table writer) are already in the workspace: the prep kernel only does the W2 images.  2: the
+                          //    workspace still holds the state of the forward call with the same inputs: no prep at all.
+    unsigned *dmax_enc;   // nullable: [kHookBlocks] per-block abs-max bit patterns of d enc_proj, written by its reduction
+    unsigned *dmax_pred;  // nullable: the same for d pred_proj
+};
+
 // kernel launchers (rnnt_kernels.hip); return hipError_t from the launch
 bool tile_path_ok(const LossParams &p, bool grad);
 hipError_t launch_lsm(const LossParams &p, hipStream_t s);

@@ -16,14 +16,16 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
                              const int *labels, const int *label_lengths, const int *input_lengths,
                              const float *cost_scale, int J, int V, int B, int T, int U, int blank, float *costs,
                              float *d_enc_proj, float *d_pred_proj, float *dW2, float *db2, int joint_dtype,
-                             int phases, void *workspace, hipStream_t s);
+                             int phases, void *workspace, hipStream_t s, const JointHooks *hooks);
+hipError_t joint_aux_pointers(void *workspace, int T, int U, int B, int J, int V, float **expE, float **expP, float **tflag);
 // dense_kernels.hip (the joint's first Dense layer)
 bool dense_supported(int H, int J);
 hipError_t dense_workspace_bytes(int B, int T, int U, int H, int J, size_t base, size_t *bytes);
 void dense_proj_pointers(void *workspace, int B, int T, int U, int H, int J, size_t base, float **enc_proj, float **pred_proj,
                          float **d_enc_proj, float **d_pred_proj);
+void dense_hook_pointers(void *workspace, int B, int T, int U, int H, int J, size_t base, unsigned **dmax_enc, unsigned **dmax_pred);
 hipError_t launch_dense_fwd(const float *enc, const float *pred, const float *W1, const float *b1, int B, int T, int U, int H, int J,
-                            void *workspace, size_t base, hipStream_t s);
+                            void *workspace, size_t base, float *expE, float *expP, float *tflag, hipStream_t s);
 hipError_t launch_dense_bwd(int B, int T, int U, int H, int J, float *d_enc, float *d_pred, float *dW1, float *db1, void *workspace,
                             size_t base, hipStream_t s);
 hipError_t launch_joint_logits(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2, int J, int V,
@@ -217,7 +219,7 @@ static rnntStatus_t joint_call(const float *enc_proj, const float *pred_proj, co
     return from_hip(launch_joint_loss(enc_proj, pred_proj, W2, b2, flat_labels, label_lengths, input_lengths,
                                       cost_scale, joint_size, alphabet_size, minibatch, options.maxT, options.maxU,
                                       options.blank_label, costs, d_enc_proj, d_pred_proj, dW2, db2, joint_dtype,
-                                      phases, workspace, (hipStream_t)options.stream));
+                                      phases, workspace, (hipStream_t)options.stream, nullptr));
 }
 
 rnntStatus_t compute_rnnt_joint_loss(const float *enc_proj, const float *pred_proj, const float *W2,
@@ -278,20 +280,36 @@ static rnntStatus_t joint_net_call(const float *enc, const float *pred, const fl
     if (((uintptr_t)workspace & 255) != 0 || !dense_supported(hidden_size, joint_size)) return RNNT_STATUS_INVALID_VALUE;
     const bool any_grad = d_enc || d_pred || dW1 || db1 || dW2 || db2;
     if (any_grad && !(d_enc && d_pred && dW1 && db1 && dW2 && db2)) return RNNT_STATUS_INVALID_VALUE;
+    if (any_grad && ((((uintptr_t)dW1 | (uintptr_t)db1) & 15) != 0)) return RNNT_STATUS_INVALID_VALUE;  // 16-byte stores
     if ((phases & 2) && !(phases & 1) && !any_grad) return RNNT_STATUS_INVALID_VALUE;
     const int B = minibatch, T = options.maxT, U = options.maxU;
     hipStream_t s = (hipStream_t)options.stream;
     size_t base = 0;
     hipError_t e = joint_workspace_bytes(T, U, B, joint_size, alphabet_size, &base);
     if (e != hipSuccess) return from_hip(e);
-    if ((phases & 1) && (e = launch_dense_fwd(enc, pred, W1, b1, B, T, U, hidden_size, joint_size, workspace, base, s)) != hipSuccess)
-        return from_hip(e);
+    // What the dense layer does on the way for the fused joint (JointHooks): with the f32-grade joint, the forward GEMM's
+    // epilogue writes the e^{2x} tables and the table-range flag (the prep kernel then only builds the W2 images), the
+    // backward-only call reuses the forward's workspace state; the reductions that produce d enc_proj / d pred_proj leave
+    // their per-block abs-max entries for the backward GEMMs' operand scales.
+    JointHooks hooks;
+    hooks.prep_mode = 0;
+    dense_hook_pointers(workspace, B, T, U, hidden_size, joint_size, base, &hooks.dmax_enc, &hooks.dmax_pred);
+    float *expE = nullptr, *expP = nullptr, *tflag = nullptr;
+    if (joint_dtype == 0) {
+        if ((e = joint_aux_pointers(workspace, T, U, B, joint_size, alphabet_size, &expE, &expP, &tflag)) != hipSuccess) return from_hip(e);
+        hooks.prep_mode = (phases & 1) ? 1 : 2;
+    }
+    if (phases & 1) {
+        if (tflag && hipMemsetAsync(tflag, 0, 256, s) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
+        if ((e = launch_dense_fwd(enc, pred, W1, b1, B, T, U, hidden_size, joint_size, workspace, base, expE, expP, tflag, s)) != hipSuccess)
+            return from_hip(e);
+    }
     float *ep, *pp, *dep, *dpp;
     dense_proj_pointers(workspace, B, T, U, hidden_size, joint_size, base, &ep, &pp, &dep, &dpp);
     const bool bwd = (phases & 2) && any_grad;
     e = launch_joint_loss(ep, pp, W2, b2, flat_labels, label_lengths, input_lengths, cost_scale, joint_size, alphabet_size, B, T, U,
                           options.blank_label, costs, bwd ? dep : nullptr, bwd ? dpp : nullptr, bwd ? dW2 : nullptr,
-                          bwd ? db2 : nullptr, joint_dtype, phases, workspace, s);
+                          bwd ? db2 : nullptr, joint_dtype, phases, workspace, s, &hooks);
     if (e != hipSuccess || !bwd) return from_hip(e);
     return from_hip(launch_dense_bwd(B, T, U, hidden_size, joint_size, d_enc, d_pred, dW1, db1, workspace, base, s));
 }
