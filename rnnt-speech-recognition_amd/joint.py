@@ -44,7 +44,7 @@ class _JointLossFunction(torch.autograd.Function):
         if il.numel() != B or ll.numel() != B:
             raise ValueError("rnnt_joint_loss: input_lengths and label_lengths must be [B]")
         with torch.cuda.device(dev):
-            ws = torch.empty(_lib.joint_workspace_bytes(T, U, B, J, V), dtype=torch.uint8, device=dev)
+            ws = _new_workspace(_lib.joint_workspace_bytes(T, U, B, J, V), dev)
             costs = torch.empty(B, dtype=torch.float32, device=dev)
             opts = _lib.make_options(torch.cuda.current_stream().cuda_stream, int(blank_label), T, U)
             st = lib.compute_rnnt_joint_loss_fwd(ep.data_ptr(), pp.data_ptr(), w2.data_ptr(), bb.data_ptr(),
@@ -104,7 +104,7 @@ class _JointNetLossFunction(torch.autograd.Function):
         if il.numel() != B or ll.numel() != B:
             raise ValueError("rnnt_joint_loss: input_lengths and label_lengths must be [B]")
         with torch.cuda.device(dev):
-            ws = torch.empty(_lib.joint_net_workspace_bytes(T, U, B, H, J, V), dtype=torch.uint8, device=dev)
+            ws = _new_workspace(_lib.joint_net_workspace_bytes(T, U, B, H, J, V), dev)
             costs = torch.empty(B, dtype=torch.float32, device=dev)
             opts = _lib.make_options(torch.cuda.current_stream().cuda_stream, int(blank_label), T, U)
             st = lib.compute_rnnt_joint_net_loss_fwd(e.data_ptr(), p.data_ptr(), w1.data_ptr(), bb1.data_ptr(), w2.data_ptr(),
@@ -137,6 +137,17 @@ class _JointNetLossFunction(torch.autograd.Function):
 
 
 JOINT_DTYPES = {"f32": 0, "f16": 1}
+
+# Test hook: when set to a byte value, every workspace this module allocates is filled with it before the forward call
+# (0xFF = a NaN bit pattern in every float: a backward kernel that read a workspace word nobody wrote would show it).
+_WORKSPACE_FILL = None
+
+
+def _new_workspace(nbytes: int, dev) -> torch.Tensor:
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if _WORKSPACE_FILL is not None:
+        ws.fill_(int(_WORKSPACE_FILL))
+    return ws
 
 
 def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_lengths, blank_label: int = 0,

@@ -1,4 +1,6 @@
 """Shape extremes of the fused joint entry points (limits of include/rnnt.h) against the float64 oracle."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -55,3 +57,43 @@ def test_fused_joint_at_its_limits(case):
     out = run(*case)
     tol = 2e-3 if case[-1] == "f16" else 1e-4  # relative to max |reference| per tensor; f16: binary16 dlogits (test_joint_f16_gpu.py)
     assert all(v <= tol for v in out.values()), out
+
+
+@pytest.mark.parametrize("route", ["single_bwd_J640", "two_kernel_J704", "f32_fallback_W2_out_of_binary16", "f16_joint", "engine_first_layer"])
+def test_backward_reads_nothing_it_did_not_write(route, monkeypatch):
+    """The partial buffers of the backward are not zero-filled any more (the reductions know which rows exist), and the dense
+    layer's operand images, scales and abs-max entries are written on the way: with the WHOLE workspace pre-filled with 0xFF
+    (NaN in every float, -1 in every int) each backward path must return finite gradients, bit-identical to the run on a
+    workspace of unspecified contents."""
+    import rnnt_speech_recognition_amd as pkg
+    from rnnt_speech_recognition_amd import joint as jmod
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(17)
+    B, T, U = 3, 41, 37
+    if route == "f16_joint":
+        H, J, V, gain = 64, 128, 512, 1.0
+    else:
+        H, J, V, gain = 64, 704 if route == "two_kernel_J704" else 640, 28, (1.0e6 if route == "f32_fallback_W2_out_of_binary16" else 1.0)
+    enc, pred = torch.randn(B, T, H, generator=g), torch.randn(B, U, H, generator=g)
+    W1 = (torch.rand(H, J, generator=g) * 2 - 1) * math.sqrt(6.0 / (H + J))
+    b1 = 0.1 * torch.randn(J, generator=g)
+    W2 = (torch.rand(J, V, generator=g) * 2 - 1) * math.sqrt(6.0 / (J + V)) * gain
+    b2 = 0.1 * torch.randn(V, generator=g)
+    labels = torch.randint(1, V, (B, U - 1), generator=g, dtype=torch.int32)
+    il = torch.tensor([T, T - 9, 5], dtype=torch.int32)   # ragged: rows / u-tiles / slots that no workgroup writes
+    ll = torch.tensor([U - 1, 3, U - 6], dtype=torch.int32)
+    first = "engine" if route == "engine_first_layer" else "torch"
+
+    def run():
+        ps = [x.clone().to(dev).requires_grad_(True) for x in (enc, pred, W1, b1, W2, b2)]
+        costs = pkg.rnnt_joint_loss(*ps, labels.to(dev), il.to(dev), ll.to(dev), first_layer=first)
+        (costs.sum() / B).backward()
+        torch.cuda.synchronize()
+        return costs.detach().cpu(), [p.grad.cpu() for p in ps]
+
+    c0, g0 = run()
+    monkeypatch.setattr(jmod, "_WORKSPACE_FILL", 0xFF)
+    c1, g1 = run()
+    assert bool(torch.isfinite(c1).all()) and all(bool(torch.isfinite(x).all()) for x in g1)
+    assert torch.equal(c0, c1) and all(torch.equal(a, b) for a, b in zip(g0, g1))

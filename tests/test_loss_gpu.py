@@ -340,3 +340,67 @@ def test_calls_can_be_captured_in_a_hip_graph():
         cr, gr = orc.rnnt_loss_and_grad(x, labels.cpu().numpy(), il.cpu().numpy(), ll.cpu().numpy())
         assert np.abs(costs.cpu().numpy() - cr).max() <= CTOL * max(1.0, np.abs(cr).max())
         assert np.abs(grads.cpu().numpy() - gr).max() <= GTOL
+
+
+def test_wide_sweeps_and_the_whole_joint_network_record_into_a_hip_graph():
+    """Launch paths the small capture above does not reach: sweeps whose LDS ring exceeds 64 KB (hipFuncSetAttribute on the
+    launch path, K >= 3 columns per lane at U = 150), the persistent joint forward / backward kernels and the dense layer's
+    GEMMs (dynamic LDS above 64 KB, device-attribute queries).  One compute_rnnt_loss and one compute_rnnt_joint_net_loss
+    call are captured; replays on new inputs must equal direct calls on the same inputs bit for bit."""
+    from rnnt_speech_recognition_amd import _lib
+
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    B, T, U, V, H, J = 2, 40, 150, 28, 64, 128
+    g = torch.Generator().manual_seed(3)
+    acts = torch.zeros(B, T, U, V, device=dev)
+    enc, pred = torch.zeros(B, T, H, device=dev), torch.zeros(B, U, H, device=dev)
+    W1 = ((torch.rand(H, J, generator=g) * 2 - 1) * 0.2).to(dev)
+    b1 = (0.1 * torch.randn(J, generator=g)).to(dev)
+    W2 = ((torch.rand(J, V, generator=g) * 2 - 1) * 0.3).to(dev)
+    b2 = (0.1 * torch.randn(V, generator=g)).to(dev)
+    labels = torch.randint(1, V, (B, U - 1), generator=g, dtype=torch.int32).to(dev)
+    il = torch.tensor([T, T - 7], dtype=torch.int32, device=dev)
+    ll = torch.tensor([U - 1, U - 30], dtype=torch.int32, device=dev)
+    scale = torch.full((B,), 0.5, device=dev)
+    costs, costs_j = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    grads = torch.empty_like(acts)
+    outs = [torch.empty_like(x) for x in (enc, pred, W1, b1, W2, b2)]
+    ws = torch.empty(_lib.workspace_bytes(T, U, B), dtype=torch.uint8, device=dev)
+    wsj = torch.empty(_lib.joint_net_workspace_bytes(T, U, B, H, J, V), dtype=torch.uint8, device=dev)
+
+    def call(stream):
+        opts = _lib.make_options(stream.cuda_stream, 0, T, U)
+        _lib.check(lib.compute_rnnt_loss(acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), ll.data_ptr(), il.data_ptr(),
+                                         V, B, costs.data_ptr(), ws.data_ptr(), opts), "compute_rnnt_loss")
+        _lib.check(lib.compute_rnnt_joint_net_loss(enc.data_ptr(), pred.data_ptr(), W1.data_ptr(), b1.data_ptr(), W2.data_ptr(),
+                                                   b2.data_ptr(), labels.data_ptr(), ll.data_ptr(), il.data_ptr(), scale.data_ptr(),
+                                                   H, J, V, B, costs_j.data_ptr(), *(o.data_ptr() for o in outs), 0, wsj.data_ptr(),
+                                                   opts), "compute_rnnt_joint_net_loss")
+
+    def snapshot():
+        torch.cuda.synchronize()
+        return [x.clone() for x in (costs, grads, costs_j, *outs)]
+
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        call(side)  # first use outside the capture
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call(torch.cuda.current_stream())
+    for seed in (11, 12):
+        gg = torch.Generator().manual_seed(seed)
+        acts.copy_(torch.randn(B, T, U, V, generator=gg))
+        enc.copy_(torch.randn(B, T, H, generator=gg))
+        pred.copy_(torch.randn(B, U, H, generator=gg))
+        graph.replay()
+        replayed = snapshot()
+        for x in (costs, grads, costs_j, *outs):
+            x.fill_(float("nan"))
+        with torch.cuda.stream(side):
+            call(side)
+        side.synchronize()
+        direct = snapshot()
+        assert all(bool(torch.isfinite(x).all()) for x in direct)
+        assert all(torch.equal(a, b) for a, b in zip(replayed, direct))
