@@ -84,15 +84,21 @@ __global__ __launch_bounds__(256) void dense_absmax_kernel(const AbsmaxJob job) 
         __syncthreads();
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
         __syncthreads();
-        if (threadIdx.x == 0) job.out[t][blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
+        // write-through store / L2-coherent loads for these few words (see dense_max_of)
+        if (threadIdx.x == 0)
+            __hip_atomic_store(job.out[t] + blockIdx.x, max(max(red[0], red[1]), max(red[2], red[3])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-// the tensor's maximum from its per-block entries (every block of a consumer kernel redoes this small reduction)
+// the tensor's maximum from its per-block entries (every block of a consumer kernel redoes this small reduction).
+// These few KB are re-written by every call and read by every workgroup on every XCD: a clean copy of the PREVIOUS call's
+// entries can still sit in a reader's L2 / L1 (observed under HIP-graph replay: the operand scales lagged one call behind,
+// results stayed f32-grade but were not bit-identical to a direct call, and NaN when the lagging scale overflowed binary16).
+// Agent-scope (sc1) accesses on both sides keep them coherent whatever a launch path does at kernel boundaries.
 __device__ __forceinline__ unsigned dense_max_of(const unsigned *arr, const int count) {
     __shared__ unsigned red2[4];
     unsigned m = 0u;
-    for (int i = threadIdx.x; i < count; i += 256) m = max(m, arr[i]);
+    for (int i = threadIdx.x; i < count; i += 256) m = max(m, __hip_atomic_load(arr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
     if ((threadIdx.x & 63) == 0) red2[threadIdx.x >> 6] = m;
@@ -123,7 +129,7 @@ __device__ __forceinline__ void dense_split4(const float4 v, const float S, dh4 
 __global__ __launch_bounds__(256) void dense_split_kernel(const float *__restrict__ x, df16 *__restrict__ hi, df16 *__restrict__ lo,
                                                           size_t n, size_t elem_off, const unsigned *maxarr, int maxcount, float *scal, int slot) {
     const float S = dense_scale_from_bits(dense_max_of(maxarr, maxcount));
-    if (blockIdx.x == 0 && threadIdx.x == 0) scal[slot] = S;
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(scal + slot, S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const size_t n4 = n >> 2;  // cols % 8 == 0 (checked by the launcher): n % 4 == 0 and the images are 8-byte aligned
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const float4 v = ((const float4 *)x)[i];
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(256) void dense_split_colsum_kernel(const float *__
                                                                  int rows, int cols, const unsigned *maxarr, int maxcount, float *scal, int slot,
                                                                  float *__restrict__ colpart) {
     const float S = dense_scale_from_bits(dense_max_of(maxarr, maxcount));
-    if (blockIdx.x == 0 && threadIdx.x == 0) scal[slot] = S;
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(scal + slot, S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int c4 = cols >> 2;
     const int r0 = blockIdx.x * kDbRows, nr = min(kDbRows, rows - r0);
     for (int cq = threadIdx.x; cq < c4; cq += 256) {
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256) void dense_zero_rows_kernel(df16 *hi, df16 *lo
 __global__ __launch_bounds__(256) void dense_split_w_kernel(const float *W, df16 *whi, df16 *wlo, df16 *thi, df16 *tlo, int H, int J,
                                                             const unsigned *maxarr, int maxcount, float *scal, int slot) {
     const float S = dense_scale_from_bits(dense_max_of(maxarr, maxcount));
-    if (blockIdx.x == 0 && threadIdx.x == 0) scal[slot] = S;
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(scal + slot, S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const size_t n = (size_t)H * J;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int h = (int)(i / (size_t)J), j = (int)(i - (size_t)h * J);
@@ -306,7 +312,9 @@ __global__ __launch_bounds__(512) void dense_gemm_nt_kernel(const DenseNT g) {
         sc = (sc + 1) % kNtStages;
     }
     // epilogue: exact power-of-two rescale, bias, row segment
-    const float inv0 = 1.0f / (g.scal[g.sa0] * g.scal[g.sb]), inv1 = 1.0f / (g.scal[g.sa1] * g.scal[g.sb]);
+    const float sB = __hip_atomic_load(g.scal + g.sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float inv0 = 1.0f / (__hip_atomic_load(g.scal + g.sa0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * sB);
+    const float inv1 = 1.0f / (__hip_atomic_load(g.scal + g.sa1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * sB);
     const bool tables = g.E0 != nullptr;
     bool big = false;
 #pragma unroll
@@ -462,7 +470,8 @@ __global__ __launch_bounds__(256) void dense_gemm_tn_kernel(const DenseTN g) {
         __builtin_amdgcn_sched_barrier(0);
         sc = (sc + 1) % kTnStages;
     }
-    const float inv = first ? 1.0f / (g.scal[g.sa0] * g.scal[g.sb0]) : 1.0f / (g.scal[g.sa1] * g.scal[g.sb1]);
+    const float inv = 1.0f / (__hip_atomic_load(g.scal + (first ? g.sa0 : g.sa1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) *
+                              __hip_atomic_load(g.scal + (first ? g.sb0 : g.sb1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     float *P = g.P + (size_t)split * g.M * g.N;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {

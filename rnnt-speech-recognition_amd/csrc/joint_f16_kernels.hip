@@ -1083,11 +1083,11 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
         return hipErrorInvalidValue;
     };
     // the binary16 weight copies and the scale are rebuilt by whichever phase runs (cheap; W2 or cost_scale may differ)
-    if (hipMemsetAsync(jp.scal, 0, 64, s) != hipSuccess) return hipErrorUnknown;
+    if (launch_fill(jp.scal, 0, 64, s) != hipSuccess) return hipErrorUnknown;
     hipLaunchKernelGGL(jh_prep_kernel, dim3(1024), dim3(256), 0, s, jp);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (phases & 1) {
-        if (hipMemsetAsync(jp.lp.W, kFillByte, L.w.A - L.w.W, s) != hipSuccess) return hipErrorUnknown;
+        if (launch_fill(jp.lp.W, kFillByte, L.w.A - L.w.W, s) != hipSuccess) return hipErrorUnknown;
         if ((e = logits(false)) != hipSuccess) return e;
 #ifdef JH_TRACE
         {
@@ -1107,7 +1107,7 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
 
     if ((e = logits(true)) != hipSuccess) return e;
     // dC partials + the zero row (the dA partials need no zero-fill: launch_reduce_enc reads only the rows K3 writes)
-    if (hipMemsetAsync(jp.dCpart, 0, L.dWpart - L.dCpart, s) != hipSuccess) return hipErrorUnknown;
+    if (launch_fill(jp.dCpart, 0, L.dWpart - L.dCpart, s) != hipSuccess) return hipErrorUnknown;
     {
         const size_t shm = 3 * (size_t)(256 + 128) * 128;
         if ((e = set_lds_f16(jh_dh_kernel, shm)) != hipSuccess) return e;

@@ -993,7 +993,7 @@ __global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp)
     }
     JT1(60);
     // rows of this u-tile / J slab that no block visits (t >= T_b, or a dead tile) must read as zero
-    // in the partial buffers: they are zero-filled before the launch (hipMemsetAsync).
+    // in the partial buffers: they are zero-filled before the launch (launch_fill).
 
     // ---- deterministic cross-wave reductions, then the partial buffers
     if (!tile_live) return;
@@ -1728,7 +1728,9 @@ __device__ __forceinline__ void store_block_max(unsigned m, unsigned *blockmax) 
     for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) blockmax[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
+    // (write-through: the consumer's loads are agent-scope too, dense_kernels.hip dense_max_of)
+    if (threadIdx.x == 0)
+        __hip_atomic_store(blockmax + blockIdx.x, max(max(red[0], red[1]), max(red[2], red[3])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // out[i] = sum_p in[p*n + i]  (fixed order)
@@ -1997,8 +1999,8 @@ hipError_t launch_joint_logits(const float *enc_proj, const float *pred_proj, co
     jp.J = J, jp.n_ut = L.n_ut, jp.TR = L.TR, jp.n_tr = L.n_tr, jp.TS = L.TS, jp.n_ts = L.n_ts;
     jp.logits_only = 1, jp.single_bwd = 0, jp.tables_ready = 0;
     hipError_t e;
-    if (hipMemsetAsync(jp.tflag, 0, 256, s) != hipSuccess) return hipErrorUnknown;
-    if (U > 1 && hipMemsetAsync(labels, 0, (size_t)B * (U - 1) * sizeof(int), s) != hipSuccess) return hipErrorUnknown;
+    if (launch_fill(jp.tflag, 0, 256, s) != hipSuccess) return hipErrorUnknown;
+    if (U > 1 && launch_fill(labels, 0, (size_t)B * (U - 1) * sizeof(int), s) != hipSuccess) return hipErrorUnknown;
     hipLaunchKernelGGL(joint_prep_kernel, dim3(1024), dim3(256), 0, s, jp);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const unsigned g1 = (unsigned)B * L.n_ut * L.n_tr;
@@ -2075,12 +2077,12 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     const unsigned g1 = (unsigned)B * L.n_ut * L.n_tr;
     // tanh tables + W2 images (rebuilt by whichever phase runs: the projections may have changed -- unless the caller vouches
     // for the workspace, JointHooks::prep_mode)
-    if (prep_mode == 0 && hipMemsetAsync(jp.tflag, 0, 256, s) != hipSuccess) return hipErrorUnknown;
+    if (prep_mode == 0 && launch_fill(jp.tflag, 0, 256, s) != hipSuccess) return hipErrorUnknown;
     if (prep_mode != 2) hipLaunchKernelGGL(joint_prep_kernel, dim3(jp.tables_ready ? 64 : 1024), dim3(256), 0, s, jp);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (phases & 1) {
         // forward: edge weights (W pre-filled with log zero) -> sweeps -> costs
-        if (hipMemsetAsync(jp.lp.W, kFillByte, L.w.A - L.w.W, s) != hipSuccess) return hipErrorUnknown;
+        if (launch_fill(jp.lp.W, kFillByte, L.w.A - L.w.W, s) != hipSuccess) return hipErrorUnknown;
         // Both forms are enqueued; the prep kernel's range flag (tflag[1], device data) decides which one works and which one
         // exits at once: split-precision f16 MFMAs whenever W2 fits binary16 hi + lo parts, plain f32 MFMAs otherwise.
         const size_t shm_fwd = (size_t)J * 256;  // Ct tile + W2 fragment image, both resident
@@ -2102,7 +2104,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
 
     // backward.  Partial buffers first: zero (rows / slots / workgroups a path does not write must read as zero)
     // (the d enc_proj partials need none: reduce_enc_kernel knows which of their rows exist)
-    if (hipMemsetAsync(jp.dCpart, 0, (L.dbpart - L.dCpart) + (size_t)L.nDb * 32 * sizeof(float), s) != hipSuccess) return hipErrorUnknown;
+    if (launch_fill(jp.dCpart, 0, (L.dbpart - L.dCpart) + (size_t)L.nDb * 32 * sizeof(float), s) != hipSuccess) return hipErrorUnknown;
     const int n_groups = bwd_groups(J);
     const bool single = (J / 32) % n_groups == 0 && J <= 640;  // consumers per group must come out even; LDS / wave budget
     jp.single_bwd = single ? 1 : 0;

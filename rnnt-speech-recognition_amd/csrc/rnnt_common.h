@@ -146,6 +146,12 @@ struct JointHooks {
     unsigned *dmax_pred;  // nullable: the same for d pred_proj
 };
 
+// Every fill the library enqueues goes through its own kernel, not hipMemsetAsync: a memset NODE recorded by stream capture
+// replayed a 16-byte garbage pattern instead of the 0xF1 bytes on this stack (ROCm 7.2, found by the HIP-graph tests) -- the
+// fused paths survived it only because positions no lattice cell owns are never a source of probability mass.
+// `bytes` must be a multiple of 4, `dst` 4-byte aligned; `byte` is replicated into every byte.
+hipError_t launch_fill(void *dst, int byte, size_t bytes, hipStream_t s);
+
 // kernel launchers (rnnt_kernels.hip); return hipError_t from the launch
 bool tile_path_ok(const LossParams &p, bool grad);
 hipError_t launch_lsm(const LossParams &p, hipStream_t s);

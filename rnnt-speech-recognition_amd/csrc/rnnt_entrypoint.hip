@@ -115,7 +115,7 @@ rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool gpu, siz
 static rnntStatus_t run_forward(LossParams &p, const WsLayout &w, hipStream_t s) {
     // the patch kernels write the log-zero part of W themselves; the wave-per-cell kernels (large or unaligned vocabularies)
     // rely on a pre-filled W
-    if (!tile_path_ok(p, false) && hipMemsetAsync(p.W, kFillByte, w.A - w.W, s) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
+    if (!tile_path_ok(p, false) && launch_fill(p.W, kFillByte, w.A - w.W, s) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
     hipError_t e = launch_lsm(p, s);
     if (e != hipSuccess) return from_hip(e);
     return from_hip(launch_sweeps(p, s));
@@ -300,7 +300,7 @@ static rnntStatus_t joint_net_call(const float *enc, const float *pred, const fl
         hooks.prep_mode = (phases & 1) ? 1 : 2;
     }
     if (phases & 1) {
-        if (tflag && hipMemsetAsync(tflag, 0, 256, s) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
+        if (tflag && launch_fill(tflag, 0, 256, s) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
         if ((e = launch_dense_fwd(enc, pred, W1, b1, B, T, U, hidden_size, joint_size, workspace, base, expE, expP, tflag, s)) != hipSuccess)
             return from_hip(e);
     }
