@@ -212,7 +212,7 @@ RNNT_API rnntStatus_t compute_rnnt_joint_loss_bwd(const float *enc_proj, const f
  *   d_enc [B,maxT,H], d_pred [B,maxU,H], dW1 [H,J], db1 [J], dW2 [J,V], db2 [V]: gradients of sum_b cost_scale[b] * cost_b
  *   (all six or none; fully overwritten; padded frames / label positions get exact zeros in d_enc / d_pred).
  * hidden_size a multiple of 32, joint_size a multiple of 64 (both <= 4096), then the (joint_size, alphabet_size, joint_dtype)
- * rules of compute_rnnt_joint_loss; enc, pred, W1, dW1, db1 16-byte aligned.  workspace: get_joint_net_workspace_size() bytes, 256-byte
+ * rules of compute_rnnt_joint_loss; enc, pred, W1, b1 and the four first-layer gradients (d_enc, d_pred, dW1, db1) 16-byte aligned.  workspace: get_joint_net_workspace_size() bytes, 256-byte
  * aligned; _bwd needs the workspace left by _fwd of the same inputs (projections and operand images live there). */
 RNNT_API rnntStatus_t get_joint_net_workspace_size(int maxT, int maxU, int minibatch, int hidden_size,
                                                    int joint_size, int alphabet_size, size_t *size_bytes);

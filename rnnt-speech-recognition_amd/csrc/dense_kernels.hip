@@ -215,38 +215,79 @@ constexpr int kNtPartA = kNtM * 64, kNtPartB = kNtN * 64;      // bytes per hi (
 constexpr int kNtStage = 2 * kNtPartA + 2 * kNtPartB;          // 48 KB
 constexpr int kNtStages = 3;
 
-__global__ __launch_bounds__(512) void dense_gemm_nt_kernel(const DenseNT g) {
+#ifndef DENSE_NT_LOADERS
+#define DENSE_NT_LOADERS 0  // loader waves per workgroup; 0 (shipped): the compute waves issue the LDS-DMA themselves.  Measured at
+                            // C2: 4 loaders 75.5 us, 0 loaders 73.7 us -- the fill is not issue-bound (PMC: matrix pipe 40 % busy,
+                            // HBM fetch 94 MB for 451 MB of tile loads, L2 hit rate 83 %: the stages wait for L2 -> LDS data)
+#endif
+constexpr int kNtLoaders = DENSE_NT_LOADERS;
+constexpr int kNtThreads = (8 + kNtLoaders) * 64;
+constexpr int kNtIssuers = kNtLoaders ? kNtLoaders : 8;   // waves that issue DMA pieces
+constexpr int kNtPieces = 48 / kNtIssuers;                // pieces per issuing wave and stage
+
+__global__ __launch_bounds__(kNtThreads) void dense_gemm_nt_kernel(const DenseNT g) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, n31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 3, wn = wave >> 2;
+    const int wm = wave & 3, wn = (wave >> 2) & 1;
     // the N tiles of one M tile are neighbours in ONE XCD's queue: the A rows are fetched from HBM once and shared through that L2
     const uint32_t lid = dxcd_remap(blockIdx.x, gridDim.x);
     const int nt = (int)(lid % (unsigned)g.tiles_n), mt = (int)(lid / (unsigned)g.tiles_n);
     const int m0 = mt * kNtM, n0 = nt * kNtN;
     const int K = g.K;
+    const int nK = K / kNtK;
+    const bool loader = kNtLoaders && wave >= 8;          // wave-uniform
+    const int iw = kNtLoaders ? wave - 8 : wave;          // index among the issuing waves
 
-    // LDS-DMA pieces of this wave: wave-instructions i = wave + 8 k (k = 0..5) of the 48 that fill one stage.
+    // LDS-DMA pieces: wave-instructions i = iw + kNtIssuers k of the 48 that fill one stage.
     //   i <  16: A hi rows 16 i .. ; i < 32: A lo ; i < 40: B hi rows 16 (i - 32) .. ; else B lo.
     // A lane moves 16 bytes: row = 16 (block) + lane / 4, LDS chunk position p = lane & 3 holds logical chunk p ^ ((row >> 2) & 3)
-    const df16 *src[6];
-    int ldsoff[6];
+    // (Issuing a piece costs a wave 60-180 cycles of its in-order stream; moving the pieces to dedicated loader waves --
+    // DENSE_NT_LOADERS -- did not change the kernel's time, see above.)
+    const df16 *src[kNtPieces];
+    int ldsoff[kNtPieces];
+    if (!kNtLoaders || loader) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const int i = wave + 8 * k;
-        const bool isA = i < 32;
-        const int blk = isA ? (i & 15) : ((i - 32) & 7);
-        const bool lo = isA ? (i >= 16) : (i >= 40);
-        const int row = blk * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ((row >> 2) & 3);
-        const int grow = isA ? min(m0 + row, g.M - 1) : min(n0 + row, g.N - 1);
-        const df16 *base = isA ? (lo ? g.Alo : g.Ahi) : (lo ? g.Blo : g.Bhi);
-        src[k] = base + (size_t)grow * K + c * 8;
-        ldsoff[k] = (isA ? (lo ? kNtPartA : 0) : 2 * kNtPartA + (lo ? kNtPartB : 0)) + blk * 1024;
+        for (int k = 0; k < kNtPieces; ++k) {
+            const int i = iw + kNtIssuers * k;
+            const bool isA = i < 32;
+            const int blk = isA ? (i & 15) : ((i - 32) & 7);
+            const bool lo = isA ? (i >= 16) : (i >= 40);
+            const int row = blk * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            const int grow = isA ? min(m0 + row, g.M - 1) : min(n0 + row, g.N - 1);
+            const df16 *base = isA ? (lo ? g.Alo : g.Ahi) : (lo ? g.Blo : g.Bhi);
+            src[k] = base + (size_t)grow * K + c * 8;
+            ldsoff[k] = (isA ? (lo ? kNtPartA : 0) : 2 * kNtPartA + (lo ? kNtPartB : 0)) + blk * 1024;
+        }
     }
     auto dma_piece = [&](const int k, const int kc, const int stage) {
         __builtin_amdgcn_global_load_lds((dglb_cvoid *)(src[k] + kc * kNtK), (dlds_void *)(dsm + stage * kNtStage + ldsoff[k]), 16, 0, 0);
     };
+
+    if (loader) {
+        // ---- loader wave: stage kc + 2 goes out right after the barrier that frees its ring slot
+#pragma unroll
+        for (int k = 0; k < kNtPieces; ++k) dma_piece(k, 0, 0);
+        if (nK > 1) {
+#pragma unroll
+            for (int k = 0; k < kNtPieces; ++k) dma_piece(k, 1, 1);
+        }
+        int sc = 0;
+        for (int kc = 0; kc < nK; ++kc) {
+            if (kc + 1 < nK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kNtPieces) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // stage kc complete in LDS; every compute wave is done with stage kc - 1
+            if (kc + 2 < nK) {
+                const int sp = (sc + 2) % kNtStages;
+#pragma unroll
+                for (int k = 0; k < kNtPieces; ++k) dma_piece(k, kc + 2, sp);
+            }
+            sc = (sc + 1) % kNtStages;
+        }
+        __builtin_amdgcn_s_barrier();  // the epilogue's barrier (the compute waves re-use the ring as staging tiles)
+        return;
+    }
 
     df32x16 acc[2][2];
 #pragma unroll
@@ -256,12 +297,13 @@ __global__ __launch_bounds__(512) void dense_gemm_nt_kernel(const DenseNT g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    const int nK = K / kNtK;
+    if (!kNtLoaders) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) dma_piece(k, 0, 0);
-    if (nK > 1) {
+        for (int k = 0; k < kNtPieces; ++k) dma_piece(k, 0, 0);
+        if (nK > 1) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) dma_piece(k, 1, 1);
+            for (int k = 0; k < kNtPieces; ++k) dma_piece(k, 1, 1);
+        }
     }
     // fragment addresses of this lane inside a stage (bytes): rows of its two A tiles and its two B tiles
     int arow[2], brow[2];
@@ -270,12 +312,14 @@ __global__ __launch_bounds__(512) void dense_gemm_nt_kernel(const DenseNT g) {
 
     int sc = 0;
     for (int kc = 0; kc < nK; ++kc) {
-        if (kc + 1 < nK) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // stage kc complete in LDS; the stage of kc - 1 (refilled below) is free
+        if (!kNtLoaders) {
+            if (kc + 1 < nK) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // stage kc complete in LDS; the stage of kc - 1 (refilled next) is free
         asm volatile("" ::: "memory");
         const char *S = dsm + sc * kNtStage;
-        const bool pf = kc + 2 < nK;
+        const bool pf = !kNtLoaders && kc + 2 < nK;
         const int sp = (sc + 2) % kNtStages;
         // fragments of k-step ks in [ks & 1]: read one k-step ahead of their MFMAs
         dh8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
@@ -294,10 +338,12 @@ __global__ __launch_bounds__(512) void dense_gemm_nt_kernel(const DenseNT g) {
         for (int ks = 0; ks < 2; ++ks) {
             if (ks == 0) rd(1, ah[1], al[1], bh[1], bl[1]);
             __builtin_amdgcn_sched_barrier(0);
-            if (pf) {  // three of the six pieces of stage kc + 2 per k-step, between the MFMA groups
-                dma_piece(3 * ks + 0, kc + 2, sp);
-                dma_piece(3 * ks + 1, kc + 2, sp);
-                dma_piece(3 * ks + 2, kc + 2, sp);
+            if constexpr (kNtLoaders == 0) {
+                if (pf) {  // three of the six pieces of stage kc + 2 per k-step, between the MFMA groups
+                    dma_piece(3 * ks + 0, kc + 2, sp);
+                    dma_piece(3 * ks + 1, kc + 2, sp);
+                    dma_piece(3 * ks + 2, kc + 2, sp);
+                }
             }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
@@ -311,34 +357,54 @@ __global__ __launch_bounds__(512) void dense_gemm_nt_kernel(const DenseNT g) {
         }
         sc = (sc + 1) % kNtStages;
     }
-    // epilogue: exact power-of-two rescale, bias, row segment
+    // epilogue: exact power-of-two rescale, bias, row segment.  The C/D layout gives a lane ONE column of 16 rows: stored from
+    // there it is 64 four-byte store instructions per wave and output (store-issue bound: a 256 x 128 tile with its table took
+    // as long to write as 8 of the 20 K stages took to multiply).  Each wave passes its 64 x 64 tile through LDS instead (the
+    // stage ring is free now) and writes row segments of 256 bytes with 16-byte stores: 16 store instructions per output.
     const float sB = __hip_atomic_load(g.scal + g.sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float inv0 = 1.0f / (__hip_atomic_load(g.scal + g.sa0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * sB);
     const float inv1 = 1.0f / (__hip_atomic_load(g.scal + g.sa1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * sB);
     const bool tables = g.E0 != nullptr;
+    __builtin_amdgcn_s_barrier();  // every compute wave is done reading the last stage (the loaders join this barrier, then leave)
+    constexpr int kPitch = 68;     // floats per tile row in LDS: 16-byte aligned rows, conflict-free column writes
+    float *tile = (float *)dsm + wave * 64 * kPitch;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[(mi * 32 + dcd_row(r, half)) * kPitch + ni * 32 + n31] = acc[mi][ni][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // a wave only reads its own tile: no barrier
+    const int cq = lane & 15, rsub = lane >> 4;         // 16 lanes x 4 columns = one 64-column row segment; 4 rows per pass
+    const int col = n0 + wn * 64 + cq * 4;
     bool big = false;
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int col = n0 + wn * 64 + ni * 32 + n31;
-        if (col >= g.N) continue;
-        const float bv = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + mi * 32 + dcd_row(r, half);
-                float v;
-                size_t o;
-                float *C, *E;
-                if (row < g.R0) v = fmaf(acc[mi][ni][r], inv0, bv), o = (size_t)row * g.ldc + col, C = g.C0, E = g.E0;
-                else if (row >= g.R0p && row < g.R0p + g.R1) v = acc[mi][ni][r] * inv1, o = (size_t)(row - g.R0p) * g.ldc + col, C = g.C1, E = g.E1;
-                else continue;
-                C[o] = v;
-                if (tables) {
-                    big |= !(fabsf(v) <= 43.0f);  // kExpTabLimit; also catches NaN
-                    E[o] = __builtin_amdgcn_exp2f(v * 2.8853900817779268f);
-                }
+    if (col < g.N) {  // N % 4 == 0: a 4-column group is inside or outside as a whole
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias) bv = *(const float4 *)(g.bias + col);
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int rl = it * 4 + rsub;
+            const int row = m0 + wm * 64 + rl;
+            const float4 a = *(const float4 *)(tile + rl * kPitch + cq * 4);
+            float4 v;
+            size_t o;
+            float *C, *E;
+            if (row < g.R0) {
+                v = make_float4(fmaf(a.x, inv0, bv.x), fmaf(a.y, inv0, bv.y), fmaf(a.z, inv0, bv.z), fmaf(a.w, inv0, bv.w));
+                o = (size_t)row * g.ldc + col, C = g.C0, E = g.E0;
+            } else if (row >= g.R0p && row < g.R0p + g.R1) {
+                v = make_float4(a.x * inv1, a.y * inv1, a.z * inv1, a.w * inv1);
+                o = (size_t)(row - g.R0p) * g.ldc + col, C = g.C1, E = g.E1;
+            } else {
+                continue;
             }
+            *(float4 *)(C + o) = v;
+            if (tables) {
+                big |= !(fabsf(v.x) <= 43.0f) || !(fabsf(v.y) <= 43.0f) || !(fabsf(v.z) <= 43.0f) || !(fabsf(v.w) <= 43.0f);  // kExpTabLimit; NaN too
+                *(float4 *)(E + o) = make_float4(__builtin_amdgcn_exp2f(v.x * 2.8853900817779268f), __builtin_amdgcn_exp2f(v.y * 2.8853900817779268f),
+                                                 __builtin_amdgcn_exp2f(v.z * 2.8853900817779268f), __builtin_amdgcn_exp2f(v.w * 2.8853900817779268f));
+            }
+        }
     }
     if (tables && __any(big) && lane == 0) g.tflag[0] = 1.0f;
 }
@@ -619,7 +685,7 @@ static hipError_t dense_nt_launch(DenseNT &g, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute((const void *)dense_gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
     g.tiles_n = (g.N + kNtN - 1) / kNtN;
-    hipLaunchKernelGGL(dense_gemm_nt_kernel, dim3((unsigned)(((g.M + kNtM - 1) / kNtM) * g.tiles_n)), dim3(512), shm, s, g);
+    hipLaunchKernelGGL(dense_gemm_nt_kernel, dim3((unsigned)(((g.M + kNtM - 1) / kNtM) * g.tiles_n)), dim3(kNtThreads), shm, s, g);
     return hipGetLastError();
 }
 
@@ -628,7 +694,7 @@ static hipError_t dense_nt_launch(DenseNT &g, hipStream_t s) {
 hipError_t launch_dense_fwd(const float *enc, const float *pred, const float *W1, const float *b1, int B, int T, int U, int H, int J,
                             void *workspace, size_t base, float *expE, float *expP, float *tflag, hipStream_t s) {
     if (!dense_supported(H, J)) return hipErrorInvalidValue;
-    if ((((uintptr_t)enc | (uintptr_t)pred | (uintptr_t)W1) & 15) != 0) return hipErrorInvalidValue;
+    if ((((uintptr_t)enc | (uintptr_t)pred | (uintptr_t)W1 | (uintptr_t)b1) & 15) != 0) return hipErrorInvalidValue;
     const DenseLayout L = make_dense_layout(B, T, U, H, J, base);
     char *ws = (char *)workspace;
     float *scal = (float *)(ws + L.scal);
@@ -667,6 +733,7 @@ hipError_t launch_dense_fwd(const float *enc, const float *pred, const float *W1
 hipError_t launch_dense_bwd(int B, int T, int U, int H, int J, float *d_enc, float *d_pred, float *dW1, float *db1, void *workspace,
                             size_t base, hipStream_t s) {
     if (!dense_supported(H, J)) return hipErrorInvalidValue;
+    if ((((uintptr_t)d_enc | (uintptr_t)d_pred) & 15) != 0) return hipErrorInvalidValue;  // 16-byte row-segment stores
     const DenseLayout L = make_dense_layout(B, T, U, H, J, base);
     char *ws = (char *)workspace;
     float *scal = (float *)(ws + L.scal);

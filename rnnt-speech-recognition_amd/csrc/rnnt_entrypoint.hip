@@ -280,7 +280,8 @@ static rnntStatus_t joint_net_call(const float *enc, const float *pred, const fl
     if (((uintptr_t)workspace & 255) != 0 || !dense_supported(hidden_size, joint_size)) return RNNT_STATUS_INVALID_VALUE;
     const bool any_grad = d_enc || d_pred || dW1 || db1 || dW2 || db2;
     if (any_grad && !(d_enc && d_pred && dW1 && db1 && dW2 && db2)) return RNNT_STATUS_INVALID_VALUE;
-    if (any_grad && ((((uintptr_t)dW1 | (uintptr_t)db1) & 15) != 0)) return RNNT_STATUS_INVALID_VALUE;  // 16-byte stores
+    if (any_grad && ((((uintptr_t)dW1 | (uintptr_t)db1 | (uintptr_t)d_enc | (uintptr_t)d_pred) & 15) != 0)) return RNNT_STATUS_INVALID_VALUE;  // 16-byte stores
+    if ((((uintptr_t)enc | (uintptr_t)pred | (uintptr_t)W1 | (uintptr_t)b1) & 15) != 0) return RNNT_STATUS_INVALID_VALUE;
     if ((phases & 2) && !(phases & 1) && !any_grad) return RNNT_STATUS_INVALID_VALUE;
     const int B = minibatch, T = options.maxT, U = options.maxU;
     hipStream_t s = (hipStream_t)options.stream;

@@ -36,6 +36,30 @@ __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x)
 __device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Dev variants (scripts/build_variant.sh): cache policy of the gradient pass's 16-byte stores / of its logit loads.
+#ifndef RNNT_GSTORE
+#define RNNT_GSTORE 0  // 0 nt (shipped), 1 plain, 2 sc1, 3 sc0 sc1, 4 sc1 nt, 5 sc0 sc1 nt
+#endif
+#ifndef RNNT_GLOAD
+#define RNNT_GLOAD 0   // aux bits of the gradient pass's global_load_lds (0 default policy, 2 nt)
+#endif
+typedef float gs_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void grad_store16(gs_v4f *dst, const gs_v4f v) {
+#if RNNT_GSTORE == 0
+    __builtin_nontemporal_store(v, dst);
+#elif RNNT_GSTORE == 1
+    *dst = v;
+#elif RNNT_GSTORE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+#elif RNNT_GSTORE == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+#elif RNNT_GSTORE == 4
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(dst), "v"(v) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(v) : "memory");
+#endif
+}
+
 // Everything one lane does for its lattice cell once the cell's V logits sit in LDS at `xs`:
 // GRAD=false: softmax denominator + the two lattice edge weights;  GRAD=true: the V gradients
 // (written back into `xs`, zeros for padded cells).
@@ -186,7 +210,7 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
             for (int q = lane; q < q_in; q += 64) {
                 typedef float v4f __attribute__((ext_vector_type(4)));
                 const v4f v = src ? ((const v4f *)src)[q] : (v4f){0.f, 0.f, 0.f, 0.f};
-                __builtin_nontemporal_store(v, (v4f *)(p.grads + s0 + q * 4));
+                grad_store16((v4f *)(p.grads + s0 + q * 4), v);
             }
         } else {
             const int a = (int)(s0 & 3), len = cols_in * V;
@@ -225,7 +249,7 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
             const int q = q0 + lane;
             if (q < nq) {
                 // default cache policy: non-temporal loads lose the Infinity-Cache reuse between the two cell passes
-                __builtin_amdgcn_global_load_lds((glb_void *)(src + q * 4), (lds_void *)(dst + q0 * 4), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void *)(src + q * 4), (lds_void *)(dst + q0 * 4), 16, 0, GRAD ? RNNT_GLOAD : 0);
             }
         }
     }
@@ -255,7 +279,7 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
             // gradients are written once and not re-read by this op: keep them out of L2 / Infinity Cache
             for (int q = lane; q < q_in; q += 64) {
                 typedef float v4f __attribute__((ext_vector_type(4)));
-                __builtin_nontemporal_store(((const v4f *)srcl)[q], (v4f *)(dstg + q * 4));
+                grad_store16((v4f *)(dstg + q * 4), ((const v4f *)srcl)[q]);
             }
         }
     }
