@@ -416,9 +416,9 @@ def joint_bucket_floats(H, J, V):
 
 def rocprof_grad_ms():
     """Average duration of the full-length gradient-pass launches from the committed rocprofv3 kernel trace of this same
-    command (profiles/r02_kernel_stats.json, written by scripts/summarize_trace.py), if present."""
+    command (profiles/r03_kernel_stats.json, written by scripts/summarize_trace.py), if present."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_kernel_stats.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_kernel_stats.json")))
         return d["headline_kernels"]["grad_pass"]["avg_ms"]
     except Exception:
         return None
