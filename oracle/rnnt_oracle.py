@@ -241,15 +241,55 @@ def dl_scale_f16(cost_scale, B):
     return 2.0 ** (14 - e)
 
 
+_LOG2E = 1.4426950408889634
+
+
+def park_factor_f16(y, labels, blank, has_label=None):
+    """What parking the softmax numerators in binary16 does to the loss gradient w.r.t. the logits, as a factor per logit.
+
+    The forward kernel of the f16 joint keeps, per (cell, chunk of 32 symbols), 2^(y log2 e - R) rounded to binary16, R = the
+    integer at or above the chunk's largest y log2 e; the backward pass multiplies them back (one f32 factor per chunk).
+    occupancy * softmax therefore carries the relative rounding error of its parked numerator: factor = rne(p) / p.  The
+    blank column of every cell and the label column of the cells that have a label edge are formed from the unrounded
+    edge logits instead (factor 1).  y [..., U, V] natural-log logits, labels [..., U-1] broadcastable to y's leading axes,
+    has_label (same shape, optional): which of them exist (u < L_b)."""
+    y2 = np.asarray(y, np.float64) * _LOG2E
+    V = y2.shape[-1]
+    Vp = (V + 31) // 32 * 32  # (the kernels only take whole chunks; a ragged last chunk is a chunk of its own here)
+    ch = np.full(y2.shape[:-1] + (Vp,), -np.inf)
+    ch[..., :V] = y2
+    ch = ch.reshape(y2.shape[:-1] + (Vp // 32, 32))
+    R = np.ceil(ch.max(axis=-1, keepdims=True))
+    pe = np.exp2(ch - R)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        f = np.where(pe > 0, _rne_half(pe) / pe, 1.0).reshape(y2.shape[:-1] + (Vp,))[..., :V].copy()
+    f[..., blank] = 1.0
+    U = y2.shape[-2]
+    if U > 1:
+        shape = y2.shape[:-2] + (U - 1,)
+        lab = np.broadcast_to(np.asarray(labels, np.int64)[..., : U - 1], shape)
+        sub = f[..., : U - 1, :]
+        cur = np.take_along_axis(sub, lab[..., None], axis=-1)
+        if has_label is not None:
+            new = np.where(np.broadcast_to(np.asarray(has_label, bool)[..., : U - 1], shape)[..., None], 1.0, cur)
+        else:
+            new = np.ones_like(cur)
+        np.put_along_axis(sub, lab[..., None], new, axis=-1)
+        f[..., blank] = 1.0
+    return f
+
+
 def joint_loss_and_grads_f16(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_lengths,
-                             blank=0, cost_scale=None):
+                             blank=0, cost_scale=None, parked=True):
     """Oracle of the f16-MFMA joint (BASELINE config 5: "fp16 joint MFMA", fp32 lattice).
 
     Same mathematics as joint_loss_and_grads (model.py:158-166 + utils/loss.py:24-36 + autodiff), with the operand
     roundings the MFMA path makes stated explicitly: h = tanh(.) and W2 are rounded to binary16 before the J x V
     product (exact products, wide accumulation), and the loss gradient w.r.t. the logits is scaled by a power of two
     and rounded to binary16 before the two backward products (dh = dl . W2^T, dW2 = h^T . dl, db2 = sum dl).
-    tanh' = 1 - h^2 uses the unrounded h (straight-through for the rounding)."""
+    tanh' = 1 - h^2 uses the unrounded h (straight-through for the rounding).  parked=True (what a forward + backward
+    pair does): the softmax numerators went through binary16 on their way from the forward to the backward pass
+    (park_factor_f16); parked=False: the backward pass recomputed the logits (a second backward over one forward)."""
     enc = np.asarray(enc, np.float64)
     pred = np.asarray(pred, np.float64)
     W1 = np.asarray(W1, np.float64)
@@ -262,6 +302,12 @@ def joint_loss_and_grads_f16(enc, pred, W1, b1, W2, b2, labels, input_lengths, l
     B = y.shape[0]
     s = np.ones(B) if cost_scale is None else np.broadcast_to(np.asarray(cost_scale, np.float64), (B,))
     g = g * s[:, None, None, None]
+    if parked:
+        lab = np.asarray(labels, np.int64).reshape(B, -1)
+        U = y.shape[2]
+        lab = lab[:, : U - 1] if lab.shape[1] >= U - 1 else np.zeros((B, U - 1), np.int64)
+        has = np.arange(U - 1)[None, :] < np.asarray(label_lengths, np.int64).reshape(B, 1)
+        g = g * park_factor_f16(y, np.clip(lab, 0, y.shape[-1] - 1)[:, None, :], blank, has[:, None, :])
     S = dl_scale_f16(cost_scale, B)
     gq = _rne_half(g * S) / S
     J, V = W2q.shape
@@ -288,11 +334,11 @@ def joint_loss_and_grads_f16(enc, pred, W1, b1, W2, b2, labels, input_lengths, l
 # (2) dlogits chunk by chunk -> dW2, db2, d enc_proj, d pred_proj.
 # --------------------------------------------------------------------------
 def joint_utterance_streamed(enc_proj, pred_proj, W2, b2, labels, blank=0, cost_scale=1.0, f16=False,
-                             dl_scale=None, rows_per_chunk=None, want_grads=True):
+                             dl_scale=None, rows_per_chunk=None, want_grads=True, parked=True):
     """enc_proj [T, J] (= enc @ W1 + b1), pred_proj [U, J] (= pred @ W1), W2 [J, V], b2 [V], labels [U-1], exact lengths.
 
-    f16=True states the operand roundings of the f16-MFMA joint (h, W2 and the scaled dlogits to binary16, see
-    joint_loss_and_grads_f16); dl_scale is that path's power-of-two dlogits scale (dl_scale_f16 of the WHOLE batch's
+    f16=True states the operand roundings of the f16-MFMA joint (h, W2, the parked softmax numerators and the scaled
+    dlogits to binary16, see joint_loss_and_grads_f16); dl_scale is that path's power-of-two dlogits scale (dl_scale_f16 of the WHOLE batch's
     cost_scale).  Returns dict(cost, d_enc_proj [T,J], d_pred_proj [U,J], dW2, db2)."""
     A = np.asarray(enc_proj, np.float64)
     C = np.asarray(pred_proj, np.float64)
@@ -310,13 +356,13 @@ def joint_utterance_streamed(enc_proj, pred_proj, W2, b2, labels, blank=0, cost_
         h = np.tanh(A[t0:t1, None, :] + C[None, :, :])           # [r, U, J]
         hq = _rne_half(h) if f16 else h
         y = hq @ Wq + bias                                        # [r, U, V]
-        return h, hq, log_softmax(y)
+        return h, hq, log_softmax(y), (park_factor_f16(y, lab, blank) if (f16 and parked) else None)
 
     lpb = np.empty((T, U))
     lpl = np.empty((T, max(U - 1, 0)))
     for t0 in range(0, T, rows_per_chunk):
         t1 = min(T, t0 + rows_per_chunk)
-        _, _, lp = rows(t0, t1)
+        _, _, lp, _ = rows(t0, t1)
         lpb[t0:t1] = lp[:, :, blank]
         if U > 1:
             lpl[t0:t1] = np.take_along_axis(lp[:, : U - 1, :], lab[None, :, None], axis=2)[:, :, 0]
@@ -333,7 +379,7 @@ def joint_utterance_streamed(enc_proj, pred_proj, W2, b2, labels, blank=0, cost_
     uu = np.arange(max(U - 1, 0))
     for t0 in range(0, T, rows_per_chunk):
         t1 = min(T, t0 + rows_per_chunk)
-        h, hq, lp = rows(t0, t1)
+        h, hq, lp, pf = rows(t0, t1)
         r = t1 - t0
         with np.errstate(invalid="ignore", over="ignore"):
             occ = np.nan_to_num(np.exp(a[t0:t1] + b[t0:t1] - ll), nan=0.0)
@@ -351,6 +397,8 @@ def joint_utterance_streamed(enc_proj, pred_proj, W2, b2, labels, blank=0, cost_
                 gl = np.nan_to_num(np.exp(a[t0:t1, : U - 1] + lpl[t0:t1] + b[t0:t1, 1:] - ll), nan=0.0)
                 np.subtract.at(g, (np.arange(r)[:, None], uu[None, :], lab[None, :]), gl)
         g *= s
+        if pf is not None:
+            g *= pf
         if f16:
             g = _rne_half(g * S) / S
         g2 = g.reshape(-1, V)

@@ -71,6 +71,9 @@ __device__ __forceinline__ float dot8(const h8 a, const h8 b, float c) {
     c = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 6, 7), __builtin_shufflevector(b, b, 6, 7), c, false);
     return c;
 }
+__device__ __forceinline__ float lane_f32(float x, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
+}
 // XCD-aware bijective remap: XCD (blockIdx % 8) owns a contiguous range of logical work items
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
     const uint32_t xcd = bid & 7u, idx = bid >> 3, q = nwg >> 3, r = nwg & 7u;
@@ -78,7 +81,9 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
 }
 
 constexpr int kDlScaleLog2 = 14;   // |dlogits * S| <= 2^14 before the binary16 rounding
-constexpr int kStageStride = 136;  // halfs per row of the K2 staging tile (128 + 8: 16-byte aligned, bank-shifted rows)
+constexpr int kStageStride = 136;  // halfs per row of the K1/K2 staging tile (128 + 8: 16-byte aligned, bank-shifted rows;
+                                   // the first 8 bytes of the padding carry the row's four chunk references in park mode)
+constexpr float kRefLimit = 30000.0f;  // chunk references are kept as int16
 #ifndef JH_TQ
 #define JH_TQ 128
 #endif
@@ -91,7 +96,9 @@ struct JhParams {
     f16 *W2Tp;    // [V/32][J/16][2 halves][32 v][8 j]  W2^T packed so that lane l of an MFMA A fragment reads
                   // bytes [16 l, 16 l + 16) of a contiguous 1 KB block (conflict-free ds_read_b128)
     f16 *W2h;     // [J][V]
-    f16 *dl;      // [cells][V]  dlogits * S
+    f16 *dl;      // [cells][V]  parked softmax numerators 2^(y - ref) after K1 (park mode), dlogits * S after K2
+    short *pref;  // [cells][V/32]  the integer references of the parked values, one per (cell, 32-symbol chunk)
+    int *state;   // [0]: 1 = dl holds the parked values of the forward call with these inputs; anything else: it does not
     float *xbl;   // [cells][2]  blank / label logits, log2-scaled (x * log2 e)
     float *scal;  // [0] = S, [1] = 1/S, [2] != 0: some |enc_proj| or |pred_proj| exceeds kExpTabLimit (use htanh)
     float *expE;  // [B][T][J]  e^{2 enc_proj}
@@ -166,8 +173,14 @@ __global__ __launch_bounds__(256) void jh_prep_kernel(const JhParams jp) {
 // column u0+n and the joint units {16 ks + 8 half + 0..7} of its h row.
 // LDS: W2^T chunk [2][J/16][2][32 v][8 j] (2 x 64 J bytes)  |  BWD: staging [8 waves][32 cells][kStageStride]
 // ---------------------------------------------------------------------------------------------
-template <int KS, bool BWD>
+// MODE 0: forward (lse, edge weights, edge logits).  MODE 1: forward + PARK: the softmax numerators of every chunk are also
+// written to dl as binary16, relative to the chunk's own integer reference, so that the backward pass is a streaming kernel
+// (jh_dlogits_kernel) instead of this product a second time.  MODE 2: the product again with the dlogits epilogue (the
+// route a backward call takes when the parked values are not there any more: a second backward over one forward).
+template <int KS, int MODE>
 __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
+    constexpr bool BWD = MODE == 2, PARK = MODE == 1;
+    if (BWD && jp.state[0] == 1) return;  // the streaming kernel has the parked values: nothing to recompute
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LossParams &p = jp.lp;
     constexpr int J = KS * 16;
@@ -288,6 +301,25 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
         }
     }
 
+    // ---- the wave's staged [32 cells][128 columns] tile (and, PARK, the four references of each cell) -> global memory,
+    // row-contiguous 256-byte segments
+    auto flush = [&](const int vc) {
+        wait_lgkm();
+        const int vbase = (vc - 3) * 32;
+        const size_t cell0 = (size_t)(b * p.T + t) * p.U + u0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = lane + 64 * i, rr = q >> 4, c16 = q & 15;
+            if (u0 + rr < p.U) {
+                const h8 v = *(const h8 *)(my_stage + rr * kStageStride + c16 * 8);
+                *(h8 *)(jp.dl + (cell0 + rr) * V + vbase + c16 * 8) = v;
+            }
+        }
+        if (PARK && lane < 32 && u0 + lane < p.U)
+            *(uint2 *)(jp.pref + (cell0 + lane) * (size_t)(V >> 5) + (vc - 3)) = *(const uint2 *)(my_stage + lane * kStageStride + 128);
+        wait_lgkm();  // the staging tile is rewritten by the next chunk
+    };
+
     // ---- epilogue of one 32-column chunk: acc[r] = logit (without bias) of this lane's cell at v = 32 vc + cdrow(r, half)
     auto epilogue = [&](const f32x16 &acc, const int vc) {
         // the four float4 of bias values this lane needs for chunk vc (typed LDS / global loads: a merged pointer would
@@ -327,15 +359,36 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
                 y[4 * q + 3] = fmaf(acc[4 * q + 3], kLog2e, bq.w);
                 m = fmaxf(fmaxf(m, y[4 * q]), fmaxf(fmaxf(y[4 * q + 1], y[4 * q + 2]), y[4 * q + 3]));
             }
-            if (__any(m > mref + 64.0f)) {
-                const float nr = fmaxf(mref, m);
+            // PARK: the chunk's reference = the integer at or above the largest of the cell's 32 values (both half-lanes
+            // agree on it), so the parked 2^(y - ref) lie in (0, 1] whatever the rest of the vocabulary holds
+            float ref = 0.f;
+            if (PARK) ref = __builtin_amdgcn_fmed3f(ceilf(fmaxf(m, __shfl_xor(m, 32))), -kRefLimit, kRefLimit);
+            const float top = PARK ? ref : m;
+            if (__any(top > mref + 64.0f)) {
+                const float nr = fmaxf(mref, top);
                 ssum *= hex2(mref - nr);
                 mref = nr;
             }
-            float s = ssum;
+            if (!PARK) {
+                float s = ssum;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s += hex2(y[r] - mref);
-            ssum = s;
+                for (int r = 0; r < 16; ++r) s += hex2(y[r] - mref);
+                ssum = s;
+            } else {
+                f16 *row = my_stage + n * kStageStride + (vc & 3) * 32 + 4 * half;
+                float sc = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float p0 = hex2(y[4 * q + 0] - ref), p1 = hex2(y[4 * q + 1] - ref);
+                    const float p2 = hex2(y[4 * q + 2] - ref), p3 = hex2(y[4 * q + 3] - ref);
+                    sc += (p0 + p1) + (p2 + p3);
+                    h4 d;
+                    d[0] = (f16)p0, d[1] = (f16)p1, d[2] = (f16)p2, d[3] = (f16)p3;
+                    *(h4 *)(row + 8 * q) = d;
+                }
+                ssum = fmaf(sc, hex2(ref - mref), ssum);
+                if (half == 0) ((short *)(my_stage + n * kStageStride + 128))[vc & 3] = (short)(int)ref;
+            }
             if (vc == vcb) {  // wave-uniform
                 asm volatile("" ::: "memory");  // keep this a branch (if-converted, it costs 17 selects per chunk)
                 float v = y[0];
@@ -378,18 +431,10 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
                     if (g.has_label && !same && (unsigned)(g.lab - vbase) < 128u)
                         my_stage[n * kStageStride + g.lab - vbase] = (f16)(scaleS * (sm_l - clb));
                 }
-                wait_lgkm();
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int q = lane + 64 * i, rr = q >> 4, c16 = q & 15;
-                    if (u0 + rr < p.U) {
-                        const h8 v = *(const h8 *)(my_stage + rr * kStageStride + c16 * 8);
-                        *(h8 *)(jp.dl + ((size_t)(b * p.T + t) * p.U + u0 + rr) * V + vbase + c16 * 8) = v;
-                    }
-                }
-                wait_lgkm();  // the staging tile is rewritten by the next chunk
+                flush(vc);
             }
         }
+        if (PARK && (vc & 3) == 3) flush(vc);
     };
 
     // Waves w and w+4 share a SIMD.  Waves 4..7 run their epilogue one chunk late (before the next chunk's MFMAs instead
@@ -412,7 +457,7 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
         if (late && vc > 0) epilogue(acc, vc - 1);
         JT(4 + 4 * vc);
         const char *wb = ((vc & 1) ? wbuf1 : wbuf0) + lane * 16;
-        constexpr bool kTwoChains = !(BWD && KS > 32);  // two accumulation chains unless registers are short
+        constexpr bool kTwoChains = !(MODE != 0 && KS > 32);  // two accumulation chains unless registers are short
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
@@ -477,6 +522,90 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
             p.lse[c] = lse2 * kLn2;
             ((float2 *)p.W)[((size_t)b * p.Nr + (t + u)) * p.Up + u] = make_float2(ob, ol);
             ((float2 *)jp.xbl)[c] = make_float2(xb, xl);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2 (streaming): dl[cell][v] = binary16( S * scale * 2^(ref + c0) * parked ), edge columns as in the recompute epilogue.
+// In place, one pass over the parked values: 4 B of HBM traffic per logit instead of 2 J flop.  Same tiles and the same set
+// of written rows as K1 (rows t < T_b of live tiles, zeros for the columns u >= U_b inside them); a wave owns one lattice
+// row of the tile, lane n sets up cell u0 + n, then the wave walks over its 32 rows of V values, 16 bytes per lane.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void jh_dlogits_kernel(const JhParams jp) {
+    if (jp.state[0] != 1) return;  // no parked values: the recompute kernel (MODE 2) does this call's work
+    const LossParams &p = jp.lp;
+    const int V = p.V;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    const int ut = bid % jp.n_ut;
+    bid /= jp.n_ut;
+    const int tt = bid % jp.n_tt;
+    const int b = bid / jp.n_tt;
+    const int u0 = ut * 32, t = tt * 8 + wave;
+    const int Tb = length_T(p, b), Ub = length_U(p, b);
+    if (tt * 8 >= Tb || u0 >= Ub || t >= Tb) return;
+    const int u = u0 + n;
+    float mulS = 0.f, c0 = kNeg, eb = 0.f, el = 0.f;
+    int labc = -1;
+    if (u < Ub) {
+        const uint32_t c = ((uint32_t)(b * p.T + t)) * (uint32_t)p.U + (uint32_t)u;
+        Cell cl;
+        cl.b = b, cl.t = t, cl.u = u, cl.Tb = Tb, cl.Ub = Ub, cl.valid = true;
+        const CellGrad g = cell_grad_setup(p, cl, c);
+        mulS = g.scale * jp.scal[0];
+        c0 = g.c0;
+        const float2 x = ((const float2 *)jp.xbl)[c];  // log2-scaled blank / label logits
+        const float cb = g.has_blank_corr ? hex2(x.x + g.nl + g.cb) : 0.f;
+        const float clb = g.has_label ? hex2(x.y + g.nl + g.cl) : 0.f;
+        const bool same = g.has_label && (g.lab == p.blank);
+        eb = mulS * (hex2(x.x + c0) - cb - (same ? clb : 0.f));
+        el = mulS * (hex2(x.y + c0) - clb);
+        labc = (g.has_label && !same) ? g.lab : -1;
+    }
+    const int nu = min(32, p.U - u0);
+    const int ppr = V >> 9;  // 64-lane x 16-byte pieces per row
+    const size_t cell0 = (size_t)(b * p.T + t) * p.U + u0;
+    f16 *const dl0 = jp.dl + cell0 * V;
+    const short *const pr0 = jp.pref + cell0 * (size_t)(V >> 5);
+    constexpr int kAhead = 4;  // pieces a lane has in flight
+    int i = 0, sub = 0;
+    while (i < nu) {
+        h8 v[kAhead];
+        short rf[kAhead];
+        int ci[kAhead], cs[kAhead];
+#pragma unroll
+        for (int j = 0; j < kAhead; ++j) {
+            ci[j] = i, cs[j] = sub;
+            if (i < nu) {
+                const int k = sub * 64 + lane;
+                v[j] = __builtin_nontemporal_load((const h8 *)(dl0 + (size_t)i * V) + k);
+                rf[j] = pr0[(size_t)i * (V >> 5) + (k >> 2)];
+                if (++sub == ppr) sub = 0, ++i;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kAhead; ++j) {
+            if (ci[j] >= nu) break;
+            const float sS = lane_f32(mulS, ci[j]), cc = lane_f32(c0, ci[j]);  // ci[j] is wave-uniform
+            const float ebi = lane_f32(eb, ci[j]), eli = lane_f32(el, ci[j]);
+            const int li = __builtin_amdgcn_readlane(labc, ci[j]);
+            const int k = cs[j] * 64 + lane, vb = 8 * k;
+            const float mult = sS * hex2((float)rf[j] + cc);
+            h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (f16)(mult * (float)v[j][e]);
+            const int ib = p.blank - vb, il = li - vb;
+            if ((unsigned)ib < 8u) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (e == ib) ? (f16)ebi : o[e];
+            }
+            if ((unsigned)il < 8u) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (e == il) ? (f16)eli : o[e];
+            }
+            __builtin_nontemporal_store(o, (h8 *)(dl0 + (size_t)ci[j] * V) + k);
         }
     }
 }
@@ -951,7 +1080,7 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
 // ---------------------------------------------------------------------------------------------
 struct JhLayout {
     WsLayout w;
-    size_t W2Tp, W2h, dl, xbl, scal, expE, expP, b2l, dApart, dCpart, zrow, dWpart, dbpart, total;
+    size_t W2Tp, W2h, dl, pref, xbl, scal, expE, expP, b2l, dApart, dCpart, zrow, dWpart, dbpart, total;
     int n_ut, n_tt, n_ts, TS, n_tq, n_units, n_ranges;
 };
 
@@ -985,6 +1114,7 @@ static JhLayout make_jh_layout(int T, int U, int B, int J, int V) {
     L.W2Tp = take((size_t)J * V * 2);
     L.W2h = take((size_t)J * V * 2);
     L.dl = take(cells * V * 2);
+    L.pref = take(cells * (size_t)(V / 32) * sizeof(short));
     L.xbl = take(cells * 2 * sizeof(float));
     L.scal = take(64);
     L.expE = take((size_t)B * T * J * sizeof(float));
@@ -1017,10 +1147,11 @@ static hipError_t set_lds_f16(K kernel, size_t bytes) {
     return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int KS>
-static hipError_t launch_logits(const JhParams &jp, bool bwd, unsigned grid, hipStream_t s) {
-    // W2^T double buffer (+ BWD staging), overlaid during the prologue by the enc_proj / pred_proj images; bias table last
-    size_t shm = 2 * (size_t)64 * (KS * 16) + (bwd ? (size_t)8 * 32 * kStageStride * sizeof(f16) : 0);
+template <int KS, int MODE>
+static hipError_t launch_logits_mode(const JhParams &jp, unsigned grid, hipStream_t s) {
+    // W2^T double buffer (+ staging tile when the epilogue writes [cells][V] rows), overlaid during the prologue by the
+    // enc_proj / pred_proj images; bias table last
+    size_t shm = 2 * (size_t)64 * (KS * 16) + (MODE != 0 ? (size_t)8 * 32 * kStageStride * sizeof(f16) : 0);
     const size_t images = (size_t)KS * 4 * 32 * 16 + (size_t)8 * KS * 64;
     if (shm < images) shm = images;
     JhParams jq = jp;
@@ -1030,15 +1161,21 @@ static hipError_t launch_logits(const JhParams &jp, bool bwd, unsigned grid, hip
         shm += (size_t)jp.lp.V * 4;
     }
     hipError_t e;
-    if (bwd) {
-        if ((e = set_lds_f16(jh_logits_kernel<KS, true>, shm)) != hipSuccess) return e;
-        hipLaunchKernelGGL((jh_logits_kernel<KS, true>), dim3(grid), dim3(512), shm, s, jq);
-    } else {
-        if ((e = set_lds_f16(jh_logits_kernel<KS, false>, shm)) != hipSuccess) return e;
-        hipLaunchKernelGGL((jh_logits_kernel<KS, false>), dim3(grid), dim3(512), shm, s, jq);
-    }
+    if ((e = set_lds_f16(jh_logits_kernel<KS, MODE>, shm)) != hipSuccess) return e;
+    hipLaunchKernelGGL((jh_logits_kernel<KS, MODE>), dim3(grid), dim3(512), shm, s, jq);
     return hipGetLastError();
 }
+template <int KS>
+static hipError_t launch_logits(const JhParams &jp, int mode, unsigned grid, hipStream_t s) {
+    switch (mode) {
+        case 0: return launch_logits_mode<KS, 0>(jp, grid, s);
+        case 1: return launch_logits_mode<KS, 1>(jp, grid, s);
+        default: return launch_logits_mode<KS, 2>(jp, grid, s);
+    }
+}
+
+// one word of workspace state, set on the stream between the kernels that depend on it
+__global__ void jh_set_state_kernel(int *state, int value) { state[0] = value; }
 
 hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2,
                                  const int *labels, const int *label_lengths, const int *input_lengths,
@@ -1056,7 +1193,9 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     char *ws = (char *)workspace;
     jp.enc_proj = enc_proj, jp.pred_proj = pred_proj, jp.W2 = W2, jp.b2 = b2;
     jp.W2Tp = (f16 *)(ws + L.W2Tp), jp.W2h = (f16 *)(ws + L.W2h), jp.dl = (f16 *)(ws + L.dl);
+    jp.pref = (short *)(ws + L.pref);
     jp.xbl = (float *)(ws + L.xbl), jp.scal = (float *)(ws + L.scal);
+    jp.state = (int *)(ws + L.scal) + 8;  // behind the words the prep kernel owns (zeroed below, 32 bytes)
     jp.expE = (float *)(ws + L.expE), jp.expP = (float *)(ws + L.expP), jp.b2l = (float *)(ws + L.b2l);
     jp.dApart = (float *)(ws + L.dApart), jp.dCpart = (float *)(ws + L.dCpart);
     jp.dWpart = (float *)(ws + L.dWpart), jp.dbpart = (float *)(ws + L.dbpart);
@@ -1072,23 +1211,37 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     jp.trace = trace_dev;
 #endif
     hipError_t e;
-    auto logits = [&](bool bwd) -> hipError_t {
-        const unsigned grid = (unsigned)B * L.n_tt * L.n_ut;
+    const unsigned tiles = (unsigned)B * L.n_tt * L.n_ut;
+    auto logits = [&](int mode) -> hipError_t {
         switch (J) {
-            case 128: return launch_logits<8>(jp, bwd, grid, s);
-            case 256: return launch_logits<16>(jp, bwd, grid, s);
-            case 512: return launch_logits<32>(jp, bwd, grid, s);
-            case 640: return launch_logits<40>(jp, bwd, grid, s);
+            case 128: return launch_logits<8>(jp, mode, tiles, s);
+            case 256: return launch_logits<16>(jp, mode, tiles, s);
+            case 512: return launch_logits<32>(jp, mode, tiles, s);
+            case 640: return launch_logits<40>(jp, mode, tiles, s);
         }
         return hipErrorInvalidValue;
     };
+    auto set_state = [&](int value) -> hipError_t {
+        hipLaunchKernelGGL(jh_set_state_kernel, dim3(1), dim3(1), 0, s, jp.state, value);
+        return hipGetLastError();
+    };
+    // Park the softmax numerators in the forward pass when a backward pass will use them: this call's own, or (phases bit 2,
+    // the _fwd entry points) a later backward-only call on the same workspace.
+    const bool want_bwd = (phases & 2) && d_enc_proj;
+#ifdef JH_RECOMPUTE
+    const bool park = false;  // dev builds: the round-2 route (the product twice), for A/B timing
+#else
+    const bool park = (phases & 1) && (want_bwd || (phases & 4));
+#endif
     // the binary16 weight copies and the scale are rebuilt by whichever phase runs (cheap; W2 or cost_scale may differ)
-    if (launch_fill(jp.scal, 0, 64, s) != hipSuccess) return hipErrorUnknown;
+    if (launch_fill(jp.scal, 0, 32, s) != hipSuccess) return hipErrorUnknown;
     hipLaunchKernelGGL(jh_prep_kernel, dim3(1024), dim3(256), 0, s, jp);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (phases & 1) {
         if (launch_fill(jp.lp.W, kFillByte, L.w.A - L.w.W, s) != hipSuccess) return hipErrorUnknown;
-        if ((e = logits(false)) != hipSuccess) return e;
+        if ((e = set_state(0)) != hipSuccess) return e;  // dl is about to be overwritten
+        if ((e = logits(park ? 1 : 0)) != hipSuccess) return e;
+        if (park && (e = set_state(1)) != hipSuccess) return e;
 #ifdef JH_TRACE
         {
             hipStreamSynchronize(s);
@@ -1105,7 +1258,13 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     }
     if (!(phases & 2) || !d_enc_proj) return hipSuccess;
 
-    if ((e = logits(true)) != hipSuccess) return e;
+    // dlogits: one streaming pass over the parked values, or -- when a backward call finds none (state != 1: they were
+    // consumed by an earlier backward call, or the forward call did not park) -- the J x V product again.  Both kernels
+    // are enqueued; the one whose precondition does not hold returns at once.
+    hipLaunchKernelGGL(jh_dlogits_kernel, dim3(tiles), dim3(512), 0, s, jp);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = logits(2)) != hipSuccess) return e;
+    if ((e = set_state(2)) != hipSuccess) return e;
     // dC partials + the zero row (the dA partials need no zero-fill: launch_reduce_enc reads only the rows K3 writes)
     if (launch_fill(jp.dCpart, 0, L.dWpart - L.dCpart, s) != hipSuccess) return hipErrorUnknown;
     {

@@ -2030,7 +2030,8 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
                              const float *cost_scale, int J, int V, int B, int T, int U, int blank, float *costs,
                              float *d_enc_proj, float *d_pred_proj, float *dW2, float *db2, int joint_dtype,
                              int phases, void *workspace, hipStream_t s, const JointHooks *hooks) {
-    // phases: bit 0 = forward (costs + lattice state in the workspace), bit 1 = backward (needs that state)
+    // phases: bit 0 = forward (costs + lattice state in the workspace), bit 1 = backward (needs that state),
+    // bit 2 = a backward-only call will follow this forward-only one (the f16 joint parks its softmax numerators for it)
     if (joint_dtype == 1)
         return launch_joint_loss_f16(enc_proj, pred_proj, W2, b2, labels, label_lengths, input_lengths, cost_scale, J, V,
                                      B, T, U, blank, costs, d_enc_proj, d_pred_proj, dW2, db2, phases, workspace, s, hooks);

@@ -238,8 +238,8 @@ rnntStatus_t compute_rnnt_joint_loss_fwd(const float *enc_proj, const float *pre
                                          const int *input_lengths, int joint_size, int alphabet_size, int minibatch,
                                          float *costs, int joint_dtype, void *workspace, rnntOptions options) {
     return joint_call(enc_proj, pred_proj, W2, b2, flat_labels, label_lengths, input_lengths, nullptr, joint_size,
-                      alphabet_size, minibatch, costs, nullptr, nullptr, nullptr, nullptr, joint_dtype, 1, workspace,
-                      options);
+                      alphabet_size, minibatch, costs, nullptr, nullptr, nullptr, nullptr, joint_dtype, 1 | 4, workspace,
+                      options);  // bit 2: a backward-only call follows (the forward leaves what that call needs)
 }
 
 rnntStatus_t compute_rnnt_joint_loss_bwd(const float *enc_proj, const float *pred_proj, const float *W2,
@@ -329,7 +329,7 @@ rnntStatus_t compute_rnnt_joint_net_loss_fwd(const float *enc, const float *pred
                                              const int *input_lengths, int hidden_size, int joint_size, int alphabet_size,
                                              int minibatch, float *costs, int joint_dtype, void *workspace, rnntOptions options) {
     return joint_net_call(enc, pred, W1, b1, W2, b2, flat_labels, label_lengths, input_lengths, nullptr, hidden_size, joint_size,
-                          alphabet_size, minibatch, costs, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, joint_dtype, 1,
+                          alphabet_size, minibatch, costs, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, joint_dtype, 1 | 4,
                           workspace, options);
 }
 

@@ -47,9 +47,15 @@ class _JointLossFunction(torch.autograd.Function):
             ws = _new_workspace(_lib.joint_workspace_bytes(T, U, B, J, V), dev)
             costs = torch.empty(B, dtype=torch.float32, device=dev)
             opts = _lib.make_options(torch.cuda.current_stream().cuda_stream, int(blank_label), T, U)
-            st = lib.compute_rnnt_joint_loss_fwd(ep.data_ptr(), pp.data_ptr(), w2.data_ptr(), bb.data_ptr(),
-                                                 labels.data_ptr(), ll.data_ptr(), il.data_ptr(), J, V, B,
-                                                 costs.data_ptr(), int(joint_dtype), ws.data_ptr(), opts)
+            if any(ctx.needs_input_grad[:4]):
+                # _fwd = "a _bwd call on this workspace follows": the f16 joint parks its softmax numerators for it
+                st = lib.compute_rnnt_joint_loss_fwd(ep.data_ptr(), pp.data_ptr(), w2.data_ptr(), bb.data_ptr(),
+                                                     labels.data_ptr(), ll.data_ptr(), il.data_ptr(), J, V, B,
+                                                     costs.data_ptr(), int(joint_dtype), ws.data_ptr(), opts)
+            else:  # costs only (evaluation)
+                st = lib.compute_rnnt_joint_loss(ep.data_ptr(), pp.data_ptr(), w2.data_ptr(), bb.data_ptr(),
+                                                 labels.data_ptr(), ll.data_ptr(), il.data_ptr(), None, J, V, B,
+                                                 costs.data_ptr(), None, None, None, None, int(joint_dtype), ws.data_ptr(), opts)
         _lib.check(st, "compute_rnnt_joint_loss_fwd")
         ctx.save_for_backward(ep, pp, w2, bb, labels, il, ll, ws)
         ctx.blank = int(blank_label)
@@ -107,9 +113,15 @@ class _JointNetLossFunction(torch.autograd.Function):
             ws = _new_workspace(_lib.joint_net_workspace_bytes(T, U, B, H, J, V), dev)
             costs = torch.empty(B, dtype=torch.float32, device=dev)
             opts = _lib.make_options(torch.cuda.current_stream().cuda_stream, int(blank_label), T, U)
-            st = lib.compute_rnnt_joint_net_loss_fwd(e.data_ptr(), p.data_ptr(), w1.data_ptr(), bb1.data_ptr(), w2.data_ptr(),
-                                                     bb2.data_ptr(), labels.data_ptr(), ll.data_ptr(), il.data_ptr(), H, J, V, B,
-                                                     costs.data_ptr(), int(joint_dtype), ws.data_ptr(), opts)
+            if any(ctx.needs_input_grad[:6]):
+                st = lib.compute_rnnt_joint_net_loss_fwd(e.data_ptr(), p.data_ptr(), w1.data_ptr(), bb1.data_ptr(), w2.data_ptr(),
+                                                         bb2.data_ptr(), labels.data_ptr(), ll.data_ptr(), il.data_ptr(), H, J, V, B,
+                                                         costs.data_ptr(), int(joint_dtype), ws.data_ptr(), opts)
+            else:  # costs only (evaluation)
+                st = lib.compute_rnnt_joint_net_loss(e.data_ptr(), p.data_ptr(), w1.data_ptr(), bb1.data_ptr(), w2.data_ptr(),
+                                                     bb2.data_ptr(), labels.data_ptr(), ll.data_ptr(), il.data_ptr(), None, H, J, V, B,
+                                                     costs.data_ptr(), None, None, None, None, None, None, int(joint_dtype),
+                                                     ws.data_ptr(), opts)
         _lib.check(st, "compute_rnnt_joint_net_loss_fwd")
         ctx.save_for_backward(e, p, w1, bb1, w2, bb2, labels, il, ll, ws)
         ctx.blank = int(blank_label)

@@ -186,3 +186,45 @@ def test_joint_f16_limits_are_reported():
     from rnnt_speech_recognition_amd import _lib
     with pytest.raises(RuntimeError, match="invalid value"):
         _lib.joint_workspace_bytes(4, 3, 1, 128, 100)
+
+
+def test_joint_f16_second_backward_recomputes_the_logits():
+    """The first backward call turns the parked softmax numerators into dlogits in place; a second backward over the same
+    forward (retain_graph) finds none and takes the recompute route (the J x V product again, one binary16 rounding less):
+    each matches the oracle statement of its own route."""
+    case = make(2, 20, 40, 24, 256, 1024, True, seed=5)
+    enc, pred, W1, b1, W2, b2, labels, il, ll = case
+    scale = np.array([1.0, 0.75])
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.tensor(x, device=dev)
+    params = [t(x).requires_grad_(True) for x in (enc, pred, W1, b1, W2, b2)]
+    costs = pkg.rnnt_joint_loss(*params, t(labels), t(il), t(ll), joint_dtype="f16")
+    loss = (costs * t(scale.astype(np.float32))).sum()
+    got = []
+    for _ in range(3):
+        for p in params:
+            p.grad = None
+        loss.backward(retain_graph=True)
+        torch.cuda.synchronize()
+        got.append([p.grad.cpu().numpy() for p in params])
+    refs = [orc.joint_loss_and_grads_f16(*case, cost_scale=scale, parked=pk) for pk in (True, False, False)]
+    for grads, ref in zip(got, refs):
+        for g, key in zip(grads, ("d_enc", "d_pred", "dW1", "db1", "dW2", "db2")):
+            assert np.abs(g - ref[key]).max() <= 1e-3 * max(1.0, np.abs(ref[key]).max()), key
+    for a, b in zip(got[1], got[2]):  # the recompute route is repeatable
+        assert np.array_equal(a, b)
+
+
+def test_joint_f16_costs_only_call_matches_the_training_forward():
+    """Under no_grad the costs-only entry runs (nothing parked); same costs as the forward of a training step."""
+    case = make(2, 20, 40, 24, 256, 1024, True, seed=6)
+    enc, pred, W1, b1, W2, b2, labels, il, ll = case
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.tensor(x, device=dev)
+    args = [t(x) for x in (enc, pred, W1, b1, W2, b2)]
+    with torch.no_grad():
+        c0 = pkg.rnnt_joint_loss(*args, t(labels), t(il), t(ll), joint_dtype="f16").cpu().numpy()
+    c1, _ = run(case, np.ones(2))
+    ref = orc.joint_loss_and_grads_f16(*case)
+    np.testing.assert_allclose(c0, ref["costs"], rtol=1e-4)
+    np.testing.assert_allclose(c0, c1, rtol=2e-6)
