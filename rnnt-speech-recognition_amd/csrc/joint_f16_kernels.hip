@@ -81,8 +81,8 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
 }
 
 constexpr int kDlScaleLog2 = 14;   // |dlogits * S| <= 2^14 before the binary16 rounding
-constexpr int kStageStride = 136;  // halfs per row of the K1/K2 staging tile (128 + 8: 16-byte aligned, bank-shifted rows;
-                                   // the first 8 bytes of the padding carry the row's four chunk references in park mode)
+constexpr int kStageStride = 40;   // halfs per row of the K1/K2 staging tile: one chunk of 32 columns + 16 bytes (bank-shifted
+                                   // rows); in park mode the first 8 bytes of the padding carry the row's four chunk references
 constexpr float kRefLimit = 30000.0f;  // chunk references are kept as int16
 #ifndef JH_TQ
 #define JH_TQ 128
@@ -171,13 +171,13 @@ __global__ __launch_bounds__(256) void jh_prep_kernel(const JhParams jp) {
 // ---------------------------------------------------------------------------------------------
 // K1 / K2: workgroup = 8 waves = 8 lattice rows x 32 lattice columns; wave w owns row t0+w, lane (n, half) owns
 // column u0+n and the joint units {16 ks + 8 half + 0..7} of its h row.
-// LDS: W2^T chunk [2][J/16][2][32 v][8 j] (2 x 64 J bytes)  |  BWD: staging [8 waves][32 cells][kStageStride]
+// LDS: W2^T chunk [2][J/16][2][32 v][8 j] (2 x 64 J bytes)  |  MODE 1, 2: staging [8 waves][32 cells][kStageStride]
 // ---------------------------------------------------------------------------------------------
 // MODE 0: forward (lse, edge weights, edge logits).  MODE 1: forward + PARK: the softmax numerators of every chunk are also
 // written to dl as binary16, relative to the chunk's own integer reference, so that the backward pass is a streaming kernel
 // (jh_dlogits_kernel) instead of this product a second time.  MODE 2: the product again with the dlogits epilogue (the
 // route a backward call takes when the parked values are not there any more: a second backward over one forward).
-template <int KS, int MODE>
+template <int KS, int MODE, bool B2LDS>
 __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
     constexpr bool BWD = MODE == 2, PARK = MODE == 1;
     if (BWD && jp.state[0] == 1) return;  // the streaming kernel has the parked values: nothing to recompute
@@ -218,8 +218,9 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
             __builtin_amdgcn_global_load_lds((glb_cvoid *)((const char *)jp.W2Tp + (size_t)vc * chunk_bytes + i * 1024 + lane * 16),
                                              (lds_void *)(dst + i * 1024), 16, 0, 0);
     };
-    // bias table (FWD: b2 * log2 e) in LDS behind everything else when it fits (kernel-uniform switch)
-    const bool b2_in_lds = jp.b2_lds_off >= 0;
+    // bias table (FWD: b2 * log2 e) in LDS behind everything else when it fits.  A compile-time switch: with both routes in
+    // one kernel the epilogue's wait for the table values became `vmcnt(0)` as well -- a wait for the next chunk's LDS-DMA.
+    constexpr bool b2_in_lds = B2LDS;
     const float *b2tab = BWD ? jp.b2 : jp.b2l;
     const float *b2img = (const float *)(smem + (b2_in_lds ? jp.b2_lds_off : 0));
 
@@ -301,23 +302,21 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
         }
     }
 
-    // ---- the wave's staged [32 cells][128 columns] tile (and, PARK, the four references of each cell) -> global memory,
-    // row-contiguous 256-byte segments
-    auto flush = [&](const int vc) {
-        wait_lgkm();
-        const int vbase = (vc - 3) * 32;
-        const size_t cell0 = (size_t)(b * p.T + t) * p.U + u0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int q = lane + 64 * i, rr = q >> 4, c16 = q & 15;
-            if (u0 + rr < p.U) {
-                const h8 v = *(const h8 *)(my_stage + rr * kStageStride + c16 * 8);
-                *(h8 *)(jp.dl + (cell0 + rr) * V + vbase + c16 * 8) = v;
-            }
-        }
-        if (PARK && lane < 32 && u0 + lane < p.U)
-            *(uint2 *)(jp.pref + (cell0 + lane) * (size_t)(V >> 5) + (vc - 3)) = *(const uint2 *)(my_stage + lane * kStageStride + 128);
-        wait_lgkm();  // the staging tile is rewritten by the next chunk
+    // ---- the wave's staged chunk ([32 cells][32 columns], written by the epilogue) leaves as two 1 KB store instructions
+    // (16 rows x 64 bytes each), issued BETWEEN the MFMA groups of the next chunk: a burst of stores right after the
+    // epilogue held the wave for 150-250 cycles per instruction (measured: 8 KB per wave in 1200-2100 cycles), spread out
+    // they drain behind the matrix pipe.
+    const size_t cell0 = (size_t)(b * p.T + t) * p.U + u0;
+    const f16 *const st_src = my_stage + (lane >> 2) * kStageStride + (lane & 3) * 8;
+    const uint32_t st_off = (uint32_t)(lane >> 2) * (uint32_t)(2 * V) + (uint32_t)(lane & 3) * 16u;
+    auto stage_read = [&](const int j) -> h8 { return *(const h8 *)(st_src + 16 * j * kStageStride); };
+    auto stage_store = [&](const int j, const int vcf, const h8 v) {
+        char *const base = (char *)(jp.dl + cell0 * V + vcf * 32);  // wave-uniform
+        if (u0 + 16 * j + (lane >> 2) < p.U) *(h8 *)(base + st_off + (uint32_t)(32 * j * V)) = v;
+    };
+    auto store_refs = [&](const int vcf) {  // after the fourth chunk of a group: the cell's four references, 8 bytes
+        if (PARK && (vcf & 3) == 3 && lane < 32 && u0 + lane < p.U)
+            *(uint2 *)(jp.pref + (cell0 + lane) * (size_t)(V >> 5) + (vcf - 3)) = *(const uint2 *)(my_stage + lane * kStageStride + 32);
     };
 
     // ---- epilogue of one 32-column chunk: acc[r] = logit (without bias) of this lane's cell at v = 32 vc + cdrow(r, half)
@@ -362,7 +361,10 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
             // PARK: the chunk's reference = the integer at or above the largest of the cell's 32 values (both half-lanes
             // agree on it), so the parked 2^(y - ref) lie in (0, 1] whatever the rest of the vocabulary holds
             float ref = 0.f;
-            if (PARK) ref = __builtin_amdgcn_fmed3f(ceilf(fmaxf(m, __shfl_xor(m, 32))), -kRefLimit, kRefLimit);
+            if (PARK) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                ref = __builtin_amdgcn_fmed3f(ceilf(fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]))), -kRefLimit, kRefLimit);
+            }
             const float top = PARK ? ref : m;
             if (__any(top > mref + 64.0f)) {
                 const float nr = fmaxf(mref, top);
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
                 for (int r = 0; r < 16; ++r) s += hex2(y[r] - mref);
                 ssum = s;
             } else {
-                f16 *row = my_stage + n * kStageStride + (vc & 3) * 32 + 4 * half;
+                f16 *row = my_stage + n * kStageStride + 4 * half;
                 float sc = 0.f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
                     *(h4 *)(row + 8 * q) = d;
                 }
                 ssum = fmaf(sc, hex2(ref - mref), ssum);
-                if (half == 0) ((short *)(my_stage + n * kStageStride + 128))[vc & 3] = (short)(int)ref;
+                if (half == 0) ((short *)(my_stage + n * kStageStride + 32))[vc & 3] = (short)(int)ref;
             }
             if (vc == vcb) {  // wave-uniform
                 asm volatile("" ::: "memory");  // keep this a branch (if-converted, it costs 17 selects per chunk)
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
                 xl = (mine && half == hl) ? v : xl;
             }
         } else {
-            f16 *row = my_stage + n * kStageStride + (vc & 3) * 32 + 4 * half;
+            f16 *row = my_stage + n * kStageStride + 4 * half;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bq = bqs[q];
@@ -416,29 +418,25 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
                 d[3] = (f16)(scaleS * hex2(fmaf(acc[4 * q + 3] + bq.w, kLog2e, c0)));
                 *(h4 *)(row + 8 * q) = d;
             }
-            if ((vc & 3) == 3) {
-                // 128 vocabulary columns of 32 cells are staged: patch the two edge columns, then store row-contiguous
-                wait_lgkm();
-                const int vbase = (vc - 3) * 32;
-                if (cell_valid && half == 0) {
-                    const float sm_b = hex2(xb + c0);
-                    const float sm_l = hex2(xl + c0);
+            // the two edge columns, where this chunk holds them (LDS writes of one wave land in program order)
+            const int vbase = vc * 32;
+            if (cell_valid && half == 0) {
+                const bool same = g.has_label && (g.lab == p.blank);
+                const bool pb = (unsigned)(p.blank - vbase) < 32u, pl = g.has_label && !same && (unsigned)(g.lab - vbase) < 32u;
+                if (pb || pl) {
                     const float cb = g.has_blank_corr ? hex2(xb + g.nl + g.cb) : 0.f;
                     const float clb = g.has_label ? hex2(xl + g.nl + g.cl) : 0.f;
-                    const bool same = g.has_label && (g.lab == p.blank);
-                    if ((unsigned)(p.blank - vbase) < 128u)
-                        my_stage[n * kStageStride + p.blank - vbase] = (f16)(scaleS * (sm_b - cb - (same ? clb : 0.f)));
-                    if (g.has_label && !same && (unsigned)(g.lab - vbase) < 128u)
-                        my_stage[n * kStageStride + g.lab - vbase] = (f16)(scaleS * (sm_l - clb));
+                    if (pb) my_stage[n * kStageStride + p.blank - vbase] = (f16)(scaleS * (hex2(xb + c0) - cb - (same ? clb : 0.f)));
+                    if (pl) my_stage[n * kStageStride + g.lab - vbase] = (f16)(scaleS * (hex2(xl + c0) - clb));
                 }
-                flush(vc);
             }
         }
-        if (PARK && (vc & 3) == 3) flush(vc);
     };
 
     // Waves w and w+4 share a SIMD.  Waves 4..7 run their epilogue one chunk late (before the next chunk's MFMAs instead
     // of after their own), so that on every SIMD one wave is in its VALU phase while the other feeds the matrix pipe.
+    // Either way the chunk a wave staged last is chunk vc - 1 when it enters the MFMA groups of chunk vc: that is where its
+    // two store instructions are issued (stage_store).
     const bool late = wave >= 4;  // wave-uniform
     const int NC = V >> 5;
     f32x16 acc;
@@ -457,7 +455,11 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
         if (late && vc > 0) epilogue(acc, vc - 1);
         JT(4 + 4 * vc);
         const char *wb = ((vc & 1) ? wbuf1 : wbuf0) + lane * 16;
+#ifdef JH_PARK_TWO_CHAINS
+        constexpr bool kTwoChains = !(BWD && KS > 32);
+#else
         constexpr bool kTwoChains = !(MODE != 0 && KS > 32);  // two accumulation chains unless registers are short
+#endif
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
@@ -465,6 +467,11 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
             // A fragments one group of k-steps ahead of their MFMAs (bounded: the compiler would otherwise hoist all KS
             // reads); groups of 4, or of 2 where registers are short
             constexpr int G = kTwoChains ? 4 : 2;
+            constexpr int NG = KS / G;
+            // groups after which the staged chunk's pieces are read / stored (kE2 == NG: behind the loop)
+            constexpr int kE1 = NG >= 3 ? NG / 3 : 1, kE2 = NG >= 3 ? 2 * NG / 3 : NG;
+            const bool staged = MODE != 0 && vc > 0;
+            h8 sp;
             h8 acur[G], anxt[G];
 #pragma unroll
             for (int q = 0; q < G; ++q) acur[q] = *(const h8 *)(wb + q * 1024);
@@ -492,8 +499,23 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
                         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[q], hf[G * g4 + q], acc0, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (MODE != 0 && staged) {
+                    if (g4 == 0) sp = stage_read(0);
+                    if (g4 == kE1) {
+                        stage_store(0, vc - 1, sp);
+                        sp = stage_read(1);
+                    }
+                    if (g4 == kE2) {
+                        stage_store(1, vc - 1, sp);
+                        store_refs(vc - 1);
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < G; ++q) acur[q] = anxt[q];
+            }
+            if (MODE != 0 && staged && kE2 >= NG) {
+                stage_store(1, vc - 1, sp);
+                store_refs(vc - 1);
             }
         }
 #pragma unroll
@@ -503,6 +525,11 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
     }
     JT(2 + 4 * 32);
     if (late && wave_live) epilogue(acc, NC - 1);
+    if (MODE != 0 && wave_live) {  // the last chunk's pieces
+        stage_store(0, NC - 1, stage_read(0));
+        stage_store(1, NC - 1, stage_read(1));
+        store_refs(NC - 1);
+    }
 
     if (!BWD && wave_live) {
         // merge the two half-lanes of a cell, then the same outputs as the lsm pass of rnnt_kernels.hip
@@ -542,7 +569,7 @@ __global__ __launch_bounds__(512) void jh_dlogits_kernel(const JhParams jp) {
     const int ut = bid % jp.n_ut;
     bid /= jp.n_ut;
     const int tt = bid % jp.n_tt;
-    const int b = bid / jp.n_tt;
+    const int b = p.b0 + bid / jp.n_tt;  // the launch covers utterances [b0, b0 + nb)
     const int u0 = ut * 32, t = tt * 8 + wave;
     const int Tb = length_T(p, b), Ub = length_U(p, b);
     if (tt * 8 >= Tb || u0 >= Ub || t >= Tb) return;
@@ -569,7 +596,10 @@ __global__ __launch_bounds__(512) void jh_dlogits_kernel(const JhParams jp) {
     const size_t cell0 = (size_t)(b * p.T + t) * p.U + u0;
     f16 *const dl0 = jp.dl + cell0 * V;
     const short *const pr0 = jp.pref + cell0 * (size_t)(V >> 5);
-    constexpr int kAhead = 4;  // pieces a lane has in flight
+#ifndef JH_K2_AHEAD
+#define JH_K2_AHEAD 4
+#endif
+    constexpr int kAhead = JH_K2_AHEAD;  // pieces a lane has in flight
     int i = 0, sub = 0;
     while (i < nu) {
         h8 v[kAhead];
@@ -580,7 +610,11 @@ __global__ __launch_bounds__(512) void jh_dlogits_kernel(const JhParams jp) {
             ci[j] = i, cs[j] = sub;
             if (i < nu) {
                 const int k = sub * 64 + lane;
+#ifdef JH_K2_PLAIN
+                v[j] = ((const h8 *)(dl0 + (size_t)i * V))[k];
+#else
                 v[j] = __builtin_nontemporal_load((const h8 *)(dl0 + (size_t)i * V) + k);
+#endif
                 rf[j] = pr0[(size_t)i * (V >> 5) + (k >> 2)];
                 if (++sub == ppr) sub = 0, ++i;
             }
@@ -605,7 +639,11 @@ __global__ __launch_bounds__(512) void jh_dlogits_kernel(const JhParams jp) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (e == il) ? (f16)eli : o[e];
             }
+#ifdef JH_K2_PLAIN
+            ((h8 *)(dl0 + (size_t)ci[j] * V))[k] = o;
+#else
             __builtin_nontemporal_store(o, (h8 *)(dl0 + (size_t)ci[j] * V) + k);
+#endif
         }
     }
 }
@@ -633,7 +671,7 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
     const int ts = (int)(bid % (uint32_t)jp.n_ts);
     bid /= (uint32_t)jp.n_ts;
     const int ut = (int)(bid % (uint32_t)jp.n_ut);
-    const int b = (int)(bid / (uint32_t)jp.n_ut);
+    const int b = p.b0 + (int)(bid / (uint32_t)jp.n_ut);  // the launch covers utterances [b0, b0 + nb)
     const int u0 = ut * 32, j0 = jt * 128;
     const int Tb = length_T(p, b), Ub = length_U(p, b);
     const int t_begin = ts * jp.TS, t_end = min(min(t_begin + jp.TS, p.T), Tb);
@@ -1161,8 +1199,13 @@ static hipError_t launch_logits_mode(const JhParams &jp, unsigned grid, hipStrea
         shm += (size_t)jp.lp.V * 4;
     }
     hipError_t e;
-    if ((e = set_lds_f16(jh_logits_kernel<KS, MODE>, shm)) != hipSuccess) return e;
-    hipLaunchKernelGGL((jh_logits_kernel<KS, MODE>), dim3(grid), dim3(512), shm, s, jq);
+    if (jq.b2_lds_off >= 0) {
+        if ((e = set_lds_f16(jh_logits_kernel<KS, MODE, true>, shm)) != hipSuccess) return e;
+        hipLaunchKernelGGL((jh_logits_kernel<KS, MODE, true>), dim3(grid), dim3(512), shm, s, jq);
+    } else {
+        if ((e = set_lds_f16(jh_logits_kernel<KS, MODE, false>, shm)) != hipSuccess) return e;
+        hipLaunchKernelGGL((jh_logits_kernel<KS, MODE, false>), dim3(grid), dim3(512), shm, s, jq);
+    }
     return hipGetLastError();
 }
 template <int KS>
@@ -1261,10 +1304,11 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     // dlogits: one streaming pass over the parked values, or -- when a backward call finds none (state != 1: they were
     // consumed by an earlier backward call, or the forward call did not park) -- the J x V product again.  Both kernels
     // are enqueued; the one whose precondition does not hold returns at once.
+    // (Cutting the batch into utterance ranges and converting range q + 1 on a second stream beside the dh kernel of range q
+    // was measured at config 5: the two kernels do overlap, and slow each other down by as much as the overlap hides.)
     hipLaunchKernelGGL(jh_dlogits_kernel, dim3(tiles), dim3(512), 0, s, jp);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = logits(2)) != hipSuccess) return e;
-    if ((e = set_state(2)) != hipSuccess) return e;
     // dC partials + the zero row (the dA partials need no zero-fill: launch_reduce_enc reads only the rows K3 writes)
     if (launch_fill(jp.dCpart, 0, L.dWpart - L.dCpart, s) != hipSuccess) return hipErrorUnknown;
     {
@@ -1274,6 +1318,7 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
         hipLaunchKernelGGL(jh_dh_kernel, dim3(grid), dim3(512), shm, s, jp);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
+    if ((e = set_state(2)) != hipSuccess) return e;
     {
         const size_t shm = 3 * (size_t)(32 * kDRow + 2 * 4 * 32 * 32) + 4 * 512;
         if ((e = set_lds_f16(jh_dw_kernel, shm)) != hipSuccess) return e;

@@ -16,6 +16,11 @@ for blk in range(4):
             rows.append((vc, int(t[w, b + 1] - t[w, b]), int(t[w, b + 2] - t[w, b + 1]), int(t[w, b + 3] - t[w, b + 2]),
                          int(t[w, b + 4] - t[w, b + 3])))
         print("  wave", w, "(chunk, wait+barrier, epilogue-before, mfma, epilogue-after):", rows)
+    for w in (0, 4):  # phase averages by position of the chunk in its group of four (park mode flushes once per group)
+        for r in range(4):
+            vcs = [vc for vc in range(4, 32) if vc % 4 == r]
+            ph = np.array([[t[w, 2 + 4 * vc + k + 1] - t[w, 2 + 4 * vc + k] for k in range(4)] for vc in vcs], float).mean(0)
+            print("  wave %d chunk%%4=%d  wait+barrier %.0f  before %.0f  mfma %.0f  after %.0f" % (w, r, *ph))
     print("  tile total", int(t[:, 2 + 128].max() - t0), " chunk period avg", float(np.mean(t[0, 6:130:4] - t[0, 2:126:4])))
 
 raw = np.fromfile(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/trace/jh_trace.bin", dtype=np.int64)

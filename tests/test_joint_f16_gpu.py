@@ -58,6 +58,7 @@ SHAPES = [
     (1, 140, 33, 16, 128, 512),   # row splits of the dh kernel, several dW2 work units, u-tile boundary at 32/33
     (1, 9, 5, 32, 640, 512),      # the BASELINE joint width
     (3, 17, 12, 8, 512, 1536),    # three V tiles
+    (4, 64, 64, 16, 128, 1024),   # 16.8 M logits, eight row tiles x two column tiles per utterance
 ]
 
 

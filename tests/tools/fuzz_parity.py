@@ -13,6 +13,7 @@ from oracle import rnnt_oracle as orc
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+kinds = sys.argv[3].split(",") if len(sys.argv) > 3 else ["loss", "loss", "loss_wide", "joint", "joint16"]  # e.g. "joint16"
 fails, worst = [], {"loss_cost": 0.0, "loss_grad": 0.0, "joint_grad": 0.0, "joint16_grad": 0.0}
 worst_case = {}
 t = lambda x: torch.tensor(x, device=dev)
@@ -28,7 +29,7 @@ def lengths(B, T, U):
 
 t_start = time.time()
 for case in range(n_cases):
-    kind = rng.choice(["loss", "loss", "loss_wide", "joint", "joint16"])
+    kind = rng.choice(kinds)
     try:
         if kind in ("loss", "loss_wide"):
             if kind == "loss":
