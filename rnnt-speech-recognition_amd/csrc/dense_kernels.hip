@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kNtThreads) void dense_gemm_nt_kernel(const DenseNT
         }
     }
     auto dma_piece = [&](const int k, const int kc, const int stage) {
-        __builtin_amdgcn_global_load_lds((dglb_cvoid *)(src[k] + kc * kNtK), (dlds_void *)(dsm + stage * kNtStage + ldsoff[k]), 16, 0, 0);
+        lds_dma16(src[k] + kc * kNtK, dsm + stage * kNtStage + ldsoff[k]);
     };
 
     if (loader) {
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256) void dense_gemm_tn_kernel(const DenseTN g) {
         ldsoff[k] = part * kTnPart + (i & 3) * 1024;
     }
     auto dma_piece = [&](const int k, const int chunk, const int stage) {
-        __builtin_amdgcn_global_load_lds((dglb_cvoid *)(src[k] + (size_t)chunk * ld[k]), (dlds_void *)(dsm + stage * kTnStage + ldsoff[k]), 16, 0, 0);
+        lds_dma16(src[k] + (size_t)chunk * ld[k], dsm + stage * kTnStage + ldsoff[k]);
     };
 
     df32x16 acc[2][2];

@@ -81,8 +81,7 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
 }
 
 constexpr int kDlScaleLog2 = 14;   // |dlogits * S| <= 2^14 before the binary16 rounding
-constexpr int kStageStride = 40;   // halfs per row of the K1/K2 staging tile: one chunk of 32 columns + 16 bytes (bank-shifted
-                                   // rows); in park mode the first 8 bytes of the padding carry the row's four chunk references
+constexpr int kStageStride = 40;   // halfs per row of the K1/K2 staging tile: one chunk of 32 columns + 16 bytes (bank-shifted rows)
 constexpr float kRefLimit = 30000.0f;  // chunk references are kept as int16
 #ifndef JH_TQ
 #define JH_TQ 128
@@ -214,9 +213,8 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
     constexpr int kPieces = (KS + 7) / 8;
     auto dma_piece = [&](const int vc, char *dst, const int k) {
         const int i = wave + 8 * k;
-        if (i < KS)
-            __builtin_amdgcn_global_load_lds((glb_cvoid *)((const char *)jp.W2Tp + (size_t)vc * chunk_bytes + i * 1024 + lane * 16),
-                                             (lds_void *)(dst + i * 1024), 16, 0, 0);
+        static_assert(KS % 8 == 0, "every wave owns the same number of pieces");
+        lds_dma16((const char *)jp.W2Tp + (size_t)vc * chunk_bytes + i * 1024 + lane * 16, dst + i * 1024);
     };
     // bias table (FWD: b2 * log2 e) in LDS behind everything else when it fits.  A compile-time switch: with both routes in
     // one kernel the epilogue's wait for the table values became `vmcnt(0)` as well -- a wait for the next chunk's LDS-DMA.
@@ -239,16 +237,14 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
         {
             const float *prow = Ptab + ((size_t)b * p.U + uc) * J + 4 * (lane >> 5);
             for (int i = wave; i < KS * 2; i += 8)  // piece i = chunks 2i, 2i+1 of all 32 columns
-                __builtin_amdgcn_global_load_lds((glb_cvoid *)(prow + 8 * i), (lds_void *)(Pimg + i * 1024), 16, 0, 0);
+                lds_dma16(prow + 8 * i, Pimg + i * 1024);
             const float *erow = Etab + ((size_t)b * p.T + tc) * J;
             for (int k = 0; k * 64 < KS * 4; ++k)
                 if (k * 64 + lane < KS * 4)
-                    __builtin_amdgcn_global_load_lds((glb_cvoid *)(erow + 4 * (k * 64 + lane)),
-                                                     (lds_void *)(Eimg + wave * (KS * 64) + k * 1024), 16, 0, 0);
+                    lds_dma16(erow + 4 * (k * 64 + lane), Eimg + wave * (KS * 64) + k * 1024);
             if (b2_in_lds)
                 for (int i = wave; i < (V >> 8); i += 8)
-                    __builtin_amdgcn_global_load_lds((glb_cvoid *)(b2tab + i * 256 + lane * 4),
-                                                     (lds_void *)(smem + jp.b2_lds_off + i * 1024), 16, 0, 0);
+                    lds_dma16(b2tab + i * 256 + lane * 4, smem + jp.b2_lds_off + i * 1024);
         }
         wait_vm();
         __syncthreads();
@@ -303,9 +299,10 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
     }
 
     // ---- the wave's staged chunk ([32 cells][32 columns], written by the epilogue) leaves as two 1 KB store instructions
-    // (16 rows x 64 bytes each), issued BETWEEN the MFMA groups of the next chunk: a burst of stores right after the
-    // epilogue held the wave for 150-250 cycles per instruction (measured: 8 KB per wave in 1200-2100 cycles), spread out
-    // they drain behind the matrix pipe.
+    // (16 rows x 64 bytes each), issued BETWEEN the MFMA groups of the next chunk.  The first version staged 128 columns and
+    // stored 8 KB per wave in one burst behind every fourth epilogue: that burst held the wave for 1200-2100 shader clocks
+    // (s_memtime timeline, with or without the LDS reads in front of it); spread out, the stores cost no visible cycles and
+    // the staging tile is 2.5 KB per wave instead of 8.7.  (Run time: the same within noise -- the kernel is power-limited.)
     const size_t cell0 = (size_t)(b * p.T + t) * p.U + u0;
     const f16 *const st_src = my_stage + (lane >> 2) * kStageStride + (lane & 3) * 8;
     const uint32_t st_off = (uint32_t)(lane >> 2) * (uint32_t)(2 * V) + (uint32_t)(lane & 3) * 16u;
@@ -314,9 +311,10 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
         char *const base = (char *)(jp.dl + cell0 * V + vcf * 32);  // wave-uniform
         if (u0 + 16 * j + (lane >> 2) < p.U) *(h8 *)(base + st_off + (uint32_t)(32 * j * V)) = v;
     };
+    uint32_t ref01 = 0, ref23 = 0;  // PARK: the references of the current group of four chunks, as packed int16
     auto store_refs = [&](const int vcf) {  // after the fourth chunk of a group: the cell's four references, 8 bytes
         if (PARK && (vcf & 3) == 3 && lane < 32 && u0 + lane < p.U)
-            *(uint2 *)(jp.pref + (cell0 + lane) * (size_t)(V >> 5) + (vcf - 3)) = *(const uint2 *)(my_stage + lane * kStageStride + 32);
+            *(uint2 *)(jp.pref + (cell0 + lane) * (size_t)(V >> 5) + (vcf - 3)) = make_uint2(ref01, ref23);
     };
 
     // ---- epilogue of one 32-column chunk: acc[r] = logit (without bias) of this lane's cell at v = 32 vc + cdrow(r, half)
@@ -389,7 +387,15 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
                     *(h4 *)(row + 8 * q) = d;
                 }
                 ssum = fmaf(sc, hex2(ref - mref), ssum);
-                if (half == 0) ((short *)(my_stage + n * kStageStride + 32))[vc & 3] = (short)(int)ref;
+                {
+                    const uint32_t r16 = (uint32_t)(int)ref & 0xffffu;
+                    switch (vc & 3) {  // wave-uniform
+                        case 0: ref01 = r16; break;
+                        case 1: ref01 |= r16 << 16; break;
+                        case 2: ref23 = r16; break;
+                        default: ref23 |= r16 << 16; break;
+                    }
+                }
             }
             if (vc == vcb) {  // wave-uniform
                 asm volatile("" ::: "memory");  // keep this a branch (if-converted, it costs 17 selects per chunk)
@@ -455,11 +461,7 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
         if (late && vc > 0) epilogue(acc, vc - 1);
         JT(4 + 4 * vc);
         const char *wb = ((vc & 1) ? wbuf1 : wbuf0) + lane * 16;
-#ifdef JH_PARK_TWO_CHAINS
-        constexpr bool kTwoChains = !(BWD && KS > 32);
-#else
         constexpr bool kTwoChains = !(MODE != 0 && KS > 32);  // two accumulation chains unless registers are short
-#endif
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
@@ -596,10 +598,7 @@ __global__ __launch_bounds__(512) void jh_dlogits_kernel(const JhParams jp) {
     const size_t cell0 = (size_t)(b * p.T + t) * p.U + u0;
     f16 *const dl0 = jp.dl + cell0 * V;
     const short *const pr0 = jp.pref + cell0 * (size_t)(V >> 5);
-#ifndef JH_K2_AHEAD
-#define JH_K2_AHEAD 4
-#endif
-    constexpr int kAhead = JH_K2_AHEAD;  // pieces a lane has in flight
+    constexpr int kAhead = 4;  // pieces a lane has in flight (8: no faster)
     int i = 0, sub = 0;
     while (i < nu) {
         h8 v[kAhead];
@@ -610,11 +609,7 @@ __global__ __launch_bounds__(512) void jh_dlogits_kernel(const JhParams jp) {
             ci[j] = i, cs[j] = sub;
             if (i < nu) {
                 const int k = sub * 64 + lane;
-#ifdef JH_K2_PLAIN
-                v[j] = ((const h8 *)(dl0 + (size_t)i * V))[k];
-#else
-                v[j] = __builtin_nontemporal_load((const h8 *)(dl0 + (size_t)i * V) + k);
-#endif
+                v[j] = __builtin_nontemporal_load((const h8 *)(dl0 + (size_t)i * V) + k);  // (plain loads / stores: 6.13 vs 5.83 ms)
                 rf[j] = pr0[(size_t)i * (V >> 5) + (k >> 2)];
                 if (++sub == ppr) sub = 0, ++i;
             }
@@ -639,11 +634,7 @@ __global__ __launch_bounds__(512) void jh_dlogits_kernel(const JhParams jp) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (e == il) ? (f16)eli : o[e];
             }
-#ifdef JH_K2_PLAIN
-            ((h8 *)(dl0 + (size_t)ci[j] * V))[k] = o;
-#else
             __builtin_nontemporal_store(o, (h8 *)(dl0 + (size_t)ci[j] * V) + k);
-#endif
         }
     }
 }
@@ -734,7 +725,7 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
         return;  // timing experiment: no L2 -> LDS traffic at all (results wrong)
 #endif
         const f16 *src = (k < 4 ? arowP[k] : jp.W2h) + doff[k] + kp * 64;
-        __builtin_amdgcn_global_load_lds((glb_cvoid *)src, (lds_void *)(smem + sp * kStage + (wave + 8 * k) * 1024), 16, 0, 0);
+        lds_dma16(src, smem + sp * kStage + (wave + 8 * k) * 1024);
     };
     auto advance = [&]() {  // move the prefetch cursor to the next chunk
         sp = (sp == 2) ? 0 : sp + 1;
@@ -957,7 +948,7 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
         auto dma_e = [&](const int s) {  // wave 0, lanes 0..31: 128 floats
             if (wave == 0 && lane < 32) {
                 const float *src = Etab + ((size_t)b * p.T + min(t_begin + s, t_end - 1)) * J + j0 + lane * 4;
-                __builtin_amdgcn_global_load_lds((glb_cvoid *)src, (lds_void *)(ebuf + (s & 3) * 512), 16, 0, 0);
+                lds_dma16(src, ebuf + (s & 3) * 512);
             }
         };
         auto dma_d = [&](const int s, char *st) {
@@ -967,14 +958,14 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
                 const int i = wave + 8 * k;
                 const f16 *src = (u0 + i < p.U) ? jp.dl + ((size_t)(b * p.T + t) * p.U + u0 + i) * V + v0 + lane * 8
                                                 : jp.zrow + lane * 8;
-                __builtin_amdgcn_global_load_lds((glb_cvoid *)src, (lds_void *)(st + i * kDRow), 16, 0, 0);
+                lds_dma16(src, st + i * kDRow);
             }
         };
         auto dma_d_piece = [&](const int s, char *st, const int k) {  // piece k (0..3) of the same
             const int t = t_begin + s, i = wave + 8 * k;
             const f16 *src = (u0 + i < p.U) ? jp.dl + ((size_t)(b * p.T + t) * p.U + u0 + i) * V + v0 + lane * 8
                                             : jp.zrow + lane * 8;
-            __builtin_amdgcn_global_load_lds((glb_cvoid *)src, (lds_void *)(st + i * kDRow), 16, 0, 0);
+            lds_dma16(src, st + i * kDRow);
         };
         auto build_h = [&](const int s, char *st) {
             const float ej = ((const float *)(ebuf + (s & 3) * 512))[jl];

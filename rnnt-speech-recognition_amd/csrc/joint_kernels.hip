@@ -433,7 +433,7 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1s_kernel(const Join
     const int nchunk = J / 64;  // 4 k-steps (64 joint units, 8 KB of hi/lo fragments) per chunk; wave w copies KB w
     auto w2_dma = [&](const int jc) {
         const char *src = (const char *)jp.W2s + (size_t)jc * 8192 + wave * 1024 + lane * 16;
-        __builtin_amdgcn_global_load_lds((jglb_cvoid *)src, (lds_void *)(W2c + (jc & 1) * 8192 + wave * 1024), 16, 0, 0);
+        lds_dma16(src, W2c + (jc & 1) * 8192 + wave * 1024);
     };
     for (int it = 0; it < n_iter; ++it) {
         const int t = t_begin + it * kP1Waves + wave;
@@ -712,8 +712,7 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
     const int cpr = J / 4;                  // 16-byte chunks per Ct row
 
     for (int pc = wave; pc < J / 8; pc += kFwdWaves)  // W2 fragment image: J/8 pieces of 1 KB, once per workgroup
-        __builtin_amdgcn_global_load_lds((jglb_cvoid *)((const char *)jp.W2s + (size_t)pc * 1024 + lane * 16),
-                                         (lds_void *)(Wimg + pc * 1024), 16, 0, 0);
+        lds_dma16((const char *)jp.W2s + (size_t)pc * 1024 + lane * 16, Wimg + pc * 1024);
     const int rsel_b = (((p.blank >> 2) & 1) == half) ? (p.blank & 3) + 4 * (p.blank >> 3) : -1;
     const uint32_t ct_lane = (uint32_t)(l31 * cpr);          // this lane's Ct row, in chunks
     const uint32_t ct_swz = (uint32_t)(l31 & 15);
@@ -744,7 +743,7 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
                 const uint32_t ur = q / (uint32_t)cpr, cpos = q - ur * (uint32_t)cpr;
                 const uint32_t c = cpos ^ (ur & 15u);                    // ... with this logical chunk of row ur
                 const float *src = Ptab + ((size_t)b * p.U + min(u0 + (int)ur, p.U - 1)) * J + c * 4u;
-                __builtin_amdgcn_global_load_lds((jglb_cvoid *)src, (lds_void *)(Ct + (size_t)pc * 1024), 16, 0, 0);
+                lds_dma16(src, Ct + (size_t)pc * 1024);
             }
             rsel_l = -1;
             if (u < Ub - 1) {

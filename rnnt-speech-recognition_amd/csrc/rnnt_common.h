@@ -146,6 +146,24 @@ struct JointHooks {
     unsigned *dmax_pred;  // nullable: the same for d pred_proj
 };
 
+// LDS-DMA (global -> LDS, 16 bytes per lane, lane l lands at lds + 16 l; `lds` wave-uniform).
+// The compiler models the builtin as a FLAT access that may touch LDS: from then on every wait for a plain ds_read is
+// `s_waitcnt lgkmcnt(0)` ("pending flat"), so an MFMA loop that prefetches its LDS fragments exposes one LDS latency per DMA
+// instruction.  -DRNNT_DMA_ASM issues the instruction as inline assembly instead (the waits become lgkmcnt(N) again; the
+// callers already order the DMA with `s_waitcnt vmcnt` themselves).  Measured at config 5 (round 3): K1's chunk period drops
+// from 4830 to 4210 shader clocks and its run time does not move (the kernels are power-limited: the clock drops instead),
+// and K3 + K4 lose 3 ms (the asm statement is a barrier for the compiler's own LDS scheduling): the builtin stays.
+#ifdef __HIPCC__
+__device__ __forceinline__ void lds_dma16(const void *global, void *lds) {
+#ifdef RNNT_DMA_ASM
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(global), "s"(a) : "memory", "m0");
+#else
+    __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void *)global, (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
+#endif
+}
+#endif
+
 // Every fill the library enqueues goes through its own kernel, not hipMemsetAsync: a memset NODE recorded by stream capture
 // replayed a 16-byte garbage pattern instead of the 0xF1 bytes on this stack (ROCm 7.2, found by the HIP-graph tests) -- the
 // fused paths survived it only because positions no lattice cell owns are never a source of probability mass.
