@@ -219,8 +219,12 @@ def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
                 "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F16_PEAK_TFLOPS,
                              "algorithmic_flops_per_step": flops,
-                             "note": "all four J x V products (forward, backward recompute, dh, dW2) are executed on "
-                                     "v_mfma_f32_32x32x16_f16; the only [cells x V] array is dlogits in binary16"},
+                             "executed_tflops": 6.0 * J * V * cells / dt / 1e12,
+                             "note": "achieved / frac use SURVEY.md 8(d)'s 8*J*V convention; executed on "
+                                     "v_mfma_f32_32x32x16_f16: three J x V products (forward, dh, dW2) -- the backward's "
+                                     "recompute of the forward product is replaced by one streaming pass over the softmax "
+                                     "numerators the forward pass parks in binary16 (the only [cells x V] array, turned "
+                                     "into dlogits in place)"},
                 "workspace_GB": ws.numel() / 1e9}
     # The f32-parity joint runs its J x V products on v_mfma_f32_32x32x16_f16 with both operands split into binary16
     # hi + lo parts (three MFMAs per product, f32-grade result; csrc/joint_kernels.hip joint_phase1s / phase2s), so the

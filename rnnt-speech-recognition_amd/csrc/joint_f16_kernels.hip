@@ -81,7 +81,9 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
 }
 
 constexpr int kDlScaleLog2 = 14;   // |dlogits * S| <= 2^14 before the binary16 rounding
-constexpr int kStageStride = 40;   // halfs per row of the K1/K2 staging tile: one chunk of 32 columns + 16 bytes (bank-shifted rows)
+constexpr int kStageStride = 36;   // halfs per row of the K1/K2 staging tile: one chunk of 32 columns + 8 bytes.  18 dwords per row:
+                                   // the 32 rows a half-wave writes (8 bytes per lane) fall into 32 different bank pairs
+                                   // (20 dwords per row: 2.5e8 conflict cycles per launch at config 5, rows n and n + 16 collide)
 constexpr float kRefLimit = 30000.0f;  // chunk references are kept as int16
 #ifndef JH_TQ
 #define JH_TQ 128
@@ -306,7 +308,10 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
     const size_t cell0 = (size_t)(b * p.T + t) * p.U + u0;
     const f16 *const st_src = my_stage + (lane >> 2) * kStageStride + (lane & 3) * 8;
     const uint32_t st_off = (uint32_t)(lane >> 2) * (uint32_t)(2 * V) + (uint32_t)(lane & 3) * 16u;
-    auto stage_read = [&](const int j) -> h8 { return *(const h8 *)(st_src + 16 * j * kStageStride); };
+    auto stage_read = [&](const int j) -> h8 {  // rows are 8-byte aligned: two 8-byte reads
+        const h4 a = *(const h4 *)(st_src + 16 * j * kStageStride), c = *(const h4 *)(st_src + 16 * j * kStageStride + 4);
+        return __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
     auto stage_store = [&](const int j, const int vcf, const h8 v) {
         char *const base = (char *)(jp.dl + cell0 * V + vcf * 32);  // wave-uniform
         if (u0 + 16 * j + (lane >> 2) < p.U) *(h8 *)(base + st_off + (uint32_t)(32 * j * V)) = v;

@@ -164,12 +164,14 @@ def test_c3_joint_shape_at_size():
 def test_c5_fused_f16_joint_at_full_size():
     B, T, U, J, V = 16, 1500, 300, 640, 1024
     case = make_proj_case(B, T, U, J, V, seed=555, w2_gain=3.0)
-    case[5][1], case[6][1] = 420, 140  # a short utterance keeps the second oracle pass cheap
+    case[5][1], case[6][1] = 420, 140  # short utterances keep the other oracle passes cheap
+    case[5][2], case[6][2] = 701, 97
+    case[5][3], case[6][3] = 233, 299
     # utterance 0 carries the largest upstream gradient: the masked call below then derives the same power-of-two dlogits
     # scale (from max|cost_scale| of the call) as the full call
     scale = torch.linspace(1.5, 0.5, B) / B
     costs, grads = run_fused(case, scale, "f16")
-    picks = [0, 1]  # one FULL-length utterance (450,000 cells x 1024 symbols, streamed in float64) and the short one
+    picks = [0, 1, 2, 3]  # one FULL-length utterance (450,000 cells x 1024 symbols, streamed in float64) and three short ones
     mask = torch.zeros(B)
     mask[picks] = 1.0
     _, grads_masked = run_fused(case, scale * mask, "f16")
