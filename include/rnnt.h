@@ -166,15 +166,24 @@ RNNT_API rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, cons
  *                                    (round-to-nearest-even) before the products, accumulation is f32; the loss gradient
  *                                    w.r.t. the logits is scaled by 2^(14 - ceil(log2 max|cost_scale|)) and rounded to
  *                                    binary16 before dh = dl.W2^T and dW2 = h^T.dl.  The lattice (log-softmax, alpha,
- *                                    beta, costs) stays f32.  Counterpart of the reference's `mixed_float16` policy
- *                                    (run_rnnt.py:96-99); oracle: oracle/rnnt_oracle.py joint_loss_and_grads_f16.
+ *                                    beta, costs) stays f32.  A forward pass that knows a backward pass follows (the
+ *                                    one-call entry with gradients, or _fwd) PARKS the softmax numerators in the workspace:
+ *                                    per (cell, 32-symbol chunk) 2^(x log2 e - R) rounded to binary16, R = the integer at or
+ *                                    above the chunk's largest x log2 e (|R| <= 30000); the backward pass multiplies them back
+ *                                    with one f32 factor per chunk, in place (one more binary16 rounding of occupancy x softmax;
+ *                                    the blank and label columns come from the unrounded f32 edge logits).  A SECOND _bwd
+ *                                    call on the same workspace finds the parked values consumed and recomputes the
+ *                                    logits instead (one rounding less; results differ by binary16 rounding noise).
+ *                                    Counterpart of the reference's `mixed_float16` policy (run_rnnt.py:96-99); oracle:
+ *                                    oracle/rnnt_oracle.py joint_loss_and_grads_f16 (parked=True / False).
  *                                Any other (joint_dtype, shape) combination returns RNNT_STATUS_INVALID_VALUE.
  *                                get_joint_workspace_size needs no dtype: the two shape domains are disjoint.
  * Both: maxU <= 1024; enc_proj, pred_proj (and b2 for joint_dtype 1) 16-byte aligned.
  * compute_rnnt_joint_loss      = costs and all four gradients in one call
- * compute_rnnt_joint_loss_fwd  = costs only (+ lattice state kept in `workspace`)
+ * compute_rnnt_joint_loss_fwd  = costs (+ the state a _bwd call needs, kept in `workspace`); for costs ONLY (evaluation) call
+ *                                compute_rnnt_joint_loss with NULL gradient pointers -- it leaves nothing for a backward pass
  * compute_rnnt_joint_loss_bwd  = the gradients, from the same inputs and that workspace (autograd split,
- *                                as compute_rnnt_loss_fwd/_bwd)
+ *                                as compute_rnnt_loss_fwd/_bwd); may be called more than once per _fwd
  */
 RNNT_API rnntStatus_t get_joint_workspace_size(int maxT, int maxU, int minibatch, int joint_size,
                                       int alphabet_size, size_t *size_bytes);
