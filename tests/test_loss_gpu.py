@@ -370,6 +370,16 @@ def test_wide_sweeps_and_the_whole_joint_network_record_into_a_hip_graph():
     outs = [torch.empty_like(x) for x in (enc, pred, W1, b1, W2, b2)]
     ws = torch.empty(_lib.workspace_bytes(T, U, B), dtype=torch.uint8, device=dev)
     wsj = torch.empty(_lib.joint_net_workspace_bytes(T, U, B, H, J, V), dtype=torch.uint8, device=dev)
+    # the f16 joint through its autograd split: _fwd parks the softmax numerators, the first _bwd consumes them in place
+    # (streaming kernel), the second one finds the workspace state changed and recomputes the logits
+    V16 = 512
+    ep16, pp16 = torch.zeros(B, T, J, device=dev), torch.zeros(B, U, J, device=dev)
+    W216 = ((torch.rand(J, V16, generator=g) * 2 - 1) * 0.3).to(dev)
+    b216 = (0.1 * torch.randn(V16, generator=g)).to(dev)
+    labels16 = torch.randint(1, V16, (B, U - 1), generator=g, dtype=torch.int32).to(dev)
+    costs16 = torch.empty(B, device=dev)
+    outs16 = [[torch.empty_like(x) for x in (ep16, pp16, W216, b216)] for _ in range(2)]
+    ws16 = torch.empty(_lib.joint_workspace_bytes(T, U, B, J, V16), dtype=torch.uint8, device=dev)
 
     def call(stream):
         opts = _lib.make_options(stream.cuda_stream, 0, T, U)
@@ -379,10 +389,18 @@ def test_wide_sweeps_and_the_whole_joint_network_record_into_a_hip_graph():
                                                    b2.data_ptr(), labels.data_ptr(), ll.data_ptr(), il.data_ptr(), scale.data_ptr(),
                                                    H, J, V, B, costs_j.data_ptr(), *(o.data_ptr() for o in outs), 0, wsj.data_ptr(),
                                                    opts), "compute_rnnt_joint_net_loss")
+        args16 = (ep16.data_ptr(), pp16.data_ptr(), W216.data_ptr(), b216.data_ptr(), labels16.data_ptr(), ll.data_ptr(), il.data_ptr())
+        _lib.check(lib.compute_rnnt_joint_loss_fwd(*args16, J, V16, B, costs16.data_ptr(), 1, ws16.data_ptr(), opts),
+                   "compute_rnnt_joint_loss_fwd")
+        for o in outs16:
+            _lib.check(lib.compute_rnnt_joint_loss_bwd(*args16, scale.data_ptr(), J, V16, B, *(x.data_ptr() for x in o), 1,
+                                                       ws16.data_ptr(), opts), "compute_rnnt_joint_loss_bwd")
+
+    everything = lambda: (costs, grads, costs_j, *outs, costs16, *outs16[0], *outs16[1])
 
     def snapshot():  # (the clones run on the default stream, the direct calls on `side`: fence both ways)
         torch.cuda.synchronize()
-        snap = [x.clone() for x in (costs, grads, costs_j, *outs)]
+        snap = [x.clone() for x in everything()]
         torch.cuda.synchronize()
         return snap
 
@@ -398,9 +416,11 @@ def test_wide_sweeps_and_the_whole_joint_network_record_into_a_hip_graph():
         acts.copy_(torch.randn(B, T, U, V, generator=gg))
         enc.copy_(torch.randn(B, T, H, generator=gg))
         pred.copy_(torch.randn(B, U, H, generator=gg))
+        ep16.copy_(torch.randn(B, T, J, generator=gg))
+        pp16.copy_(torch.randn(B, U, J, generator=gg))
         graph.replay()
         replayed = snapshot()
-        for x in (costs, grads, costs_j, *outs):
+        for x in everything():
             x.fill_(float("nan"))
         torch.cuda.synchronize()
         with torch.cuda.stream(side):
@@ -408,6 +428,13 @@ def test_wide_sweeps_and_the_whole_joint_network_record_into_a_hip_graph():
         side.synchronize()
         direct = snapshot()
         assert all(bool(torch.isfinite(x).all()) for x in direct)
-        names = ("costs", "grads", "costs_joint", "d_enc", "d_pred", "dW1", "db1", "dW2", "db2")
+        names = ("costs", "grads", "costs_joint", "d_enc", "d_pred", "dW1", "db1", "dW2", "db2", "costs_f16",
+                 "f16_bwd1_d_enc_proj", "f16_bwd1_d_pred_proj", "f16_bwd1_dW2", "f16_bwd1_db2",
+                 "f16_bwd2_d_enc_proj", "f16_bwd2_d_pred_proj", "f16_bwd2_dW2", "f16_bwd2_db2")
         bad = [(n, float((a - b).abs().max())) for n, a, b in zip(names, replayed, direct) if not torch.equal(a, b)]
         assert not bad, bad
+        # the two backward routes agree to binary16 rounding noise, and are not the same computation
+        d1, d2 = direct[10:14], direct[14:18]
+        for a, b in zip(d1, d2):
+            assert float((a - b).abs().max()) <= 2e-3 * max(1.0, float(b.abs().max()))
+        assert any(not torch.equal(a, b) for a, b in zip(d1, d2))
