@@ -109,6 +109,9 @@ SHAPES = [
     (1, 4, 1000, 4),        # K=16
     (1, 7, 5, 31),          # reference char vocab (31), total % 4 != 0 -> wave path, scalar loads
     (2, 7, 6, 31),          # same V, total % 4 == 0 -> lane-per-cell path without float4 LDS reads
+    (4, 37, 70, 31),        # ... several patches per utterance, ragged patch edges in t and u
+    (4, 20, 33, 29),        # the 29-symbol character set
+    (4, 12, 9, 30),         # V % 4 == 2
     (2, 6, 5, 60),          # largest lane-per-cell vocabulary
     (2, 6, 5, 61),          # first wave-per-cell vocabulary
     (2, 6, 5, 64),
@@ -139,6 +142,15 @@ def test_nonzero_blank_and_label_equal_to_blank():
     acts, labels, il, ll = make_case(2, 8, 5, 9, False, seed=6)
     labels[:, 1] = 0
     check(acts, labels, il, ll, blank=0)
+
+
+def test_char_vocab_31_edge_symbols():
+    """The reference's 31-symbol character set with the blank / labels among the last symbols of the row."""
+    for blank in (30, 28, 27):
+        acts, labels, il, ll = make_case(4, 26, 35, 31, True, seed=70 + blank, blank=blank)
+        labels[:, ::3] = 29 if blank != 29 else 28
+        labels[:, 1::3] = 27 if blank != 27 else 26
+        check(acts, labels, il, ll, blank=blank)
 
 
 def test_large_magnitude_logits():
