@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
     cl.valid = ((int)r < rows_valid) && (cu < cols_valid);
     const uint32_t c = ((uint32_t)(b * p.T + cl.t)) * (uint32_t)p.U + (uint32_t)cl.u;
     if (AL) {
-        if (GRAD || cl.valid) cell_body<VP, true, GRAD>(p, cl, c, lds + tid * V);
+        if ((GRAD && tid < tg.TT * tg.UU) || cl.valid) cell_body<VP, true, GRAD>(p, cl, c, lds + tid * V);  // (lanes beyond the patch own no LDS)
     } else if ((int)r < tg.TT) {
         const int a = (int)((patch0 + r * row_f) & 3);
         if (GRAD || cl.valid) cell_body<VP, false, GRAD>(p, cl, c, lds + r * row_lds + a + cu * V);
@@ -751,7 +751,9 @@ static hipError_t launch_cell(const LossParams &p, hipStream_t s) {
     if (tile_path_ok(p, GRAD)) {
         // (the lsm launch fills the log-zero part of W itself: see cell_tile_kernel)
         const unsigned blocks = (unsigned)p.nb * p.tile.tiles_t * p.tile.tiles_u + (GRAD ? 0u : (unsigned)p.nb * (unsigned)(p.Nr / kFillRows));
-        const size_t shm = (size_t)256 * p.V * sizeof(float) + 64;
+        // the patch image: TT x UU cells (<= 256) of V floats.  Sized by the patch, not by the 256 lanes: at V = 32 that is
+        // 30.8 KB instead of 32.8 KB, the difference between five and four workgroups per CU (gradient pass 146 -> 131 us)
+        const size_t shm = (size_t)p.tile.TT * p.tile.UU * p.V * sizeof(float) + 64;
         if ((p.V % 4) != 0) {
             const size_t pitch = (size_t)((p.tile.UU * p.V + 3 + 3) & ~3);
             size_t shmu = (size_t)p.tile.TT * pitch * sizeof(float);

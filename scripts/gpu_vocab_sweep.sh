@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-for shape in 32,600,150,28 32,600,150,31 32,600,150,32; do
+for shape in ${SHAPES:-32,600,150,28 32,600,150,31 32,600,150,32}; do
   (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$shape -o b -- python $GRAFT_REPO_ROOT/bench.py --shape $shape --steps 30 --warmup 5 --no-cpu-baseline --no-fused --no-ragged --no-e2e --no-config5 > /tmp/log_$shape 2>/dev/null)
   python - /tmp/prof_$shape $shape /tmp/log_$shape <<'PY'
 import csv,glob,sys,json
