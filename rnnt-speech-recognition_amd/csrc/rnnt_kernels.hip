@@ -217,11 +217,11 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
             float *base = p.grads + (s0 - a);
             for (int q = lane; q * 4 < a + len; q += 64) {
                 const int e0 = q * 4 - a;  // element of the row segment held by the chunk's first float
-                float v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = src ? src[q * 4 + k] : 0.f;
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f vv = src ? ((const v4f *)src)[q] : (v4f){0.f, 0.f, 0.f, 0.f};  // (LDS rows are 16-byte aligned)
+                const float v[4] = {vv[0], vv[1], vv[2], vv[3]};
                 if (e0 >= 0 && e0 + 3 < len) {
-                    *(float4 *)(base + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                    grad_store16((v4f *)(base + q * 4), vv);  // non-temporal, like the aligned path
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
