@@ -135,13 +135,15 @@ __global__ __launch_bounds__(256) void joint_prep_kernel(const JointParams jp) {
         __shared__ double part[8][32];
         const int v = threadIdx.x & 31, q = threadIdx.x >> 5;
         double sum = 0.0;
-        if (v < p.V) {  // eight loads in flight per thread: the block is alone on its CU and would otherwise wait out every load
-            float w[8];
-            for (int j0 = q; j0 < jp.J; j0 += 64) {
+        if (v < p.V) {  // 32 loads in flight per thread: the block is alone on its CU and waits out a full memory latency per
+                        // round (with 8 per round, ten rounds at J = 640, this block alone made the kernel 28 us long)
+            constexpr int kRound = 32;
+            float w[kRound];
+            for (int j0 = q; j0 < jp.J; j0 += 8 * kRound) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) w[k] = (j0 + 8 * k < jp.J) ? jp.W2[(size_t)(j0 + 8 * k) * p.V + v] : 0.f;
+                for (int k = 0; k < kRound; ++k) w[k] = (j0 + 8 * k < jp.J) ? jp.W2[(size_t)(j0 + 8 * k) * p.V + v] : 0.f;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) sum += (double)w[k];
+                for (int k = 0; k < kRound; ++k) sum += (double)w[k];
             }
         }
         part[q][v] = sum;
