@@ -145,6 +145,9 @@ __device__ __forceinline__ void cell_body(const LossParams &p, const Cell &cl, c
 // (a = start & 3, per row) into a 16-byte-aligned LDS row; cells read their logits with scalar LDS reads, and the gradient
 // rows go back with float4 stores for the aligned interior and single floats at the two ragged ends.  Needs B*T*U*V % 4 == 0
 // (then no aligned span reaches past the tensor).
+#ifndef RNNT_TILE_LDS_PAD
+#define RNNT_TILE_LDS_PAD 0  // dev builds: extra LDS bytes per patch workgroup (occupancy experiments)
+#endif
 constexpr int kFillRows = 16;  // W diagonals per fill workgroup of the lsm launch
 
 template <int VP, bool GRAD, bool AL = true>
@@ -751,9 +754,10 @@ static hipError_t launch_cell(const LossParams &p, hipStream_t s) {
     if (tile_path_ok(p, GRAD)) {
         // (the lsm launch fills the log-zero part of W itself: see cell_tile_kernel)
         const unsigned blocks = (unsigned)p.nb * p.tile.tiles_t * p.tile.tiles_u + (GRAD ? 0u : (unsigned)p.nb * (unsigned)(p.Nr / kFillRows));
-        // the patch image: TT x UU cells (<= 256) of V floats.  Sized by the patch, not by the 256 lanes: at V = 32 that is
-        // 30.8 KB instead of 32.8 KB, the difference between five and four workgroups per CU (gradient pass 146 -> 131 us)
-        const size_t shm = (size_t)p.tile.TT * p.tile.UU * p.V * sizeof(float) + 64;
+        // the patch image: TT x UU cells (<= 256) of V floats, to the byte.  Sized by the patch, not by the 256 lanes, and without
+        // padding: at V = 28 that is 26,880 B -- six workgroups per CU instead of five (gradient pass 115 -> 110.5 us); at V = 32
+        // 30,720 B instead of 32,832 B -- five instead of four (146 -> 140 us)
+        const size_t shm = (size_t)p.tile.TT * p.tile.UU * p.V * sizeof(float) + RNNT_TILE_LDS_PAD;
         if ((p.V % 4) != 0) {
             const size_t pitch = (size_t)((p.tile.UU * p.V + 3 + 3) & ~3);
             size_t shmu = (size_t)p.tile.TT * pitch * sizeof(float);
