@@ -112,9 +112,9 @@ def test_register_budgets_match_the_occupancy_assumptions(kernels):
     # split-precision phase 2: two 4-wave workgroups per CU -> at most 256 registers
     for k in _find(meta, "joint_phase2s_kernel"):
         assert int(meta[k]["vgpr_count"]) + int(meta[k].get("agpr_count", "0")) <= 256, (k, meta[k]["vgpr_count"])
-    # lane-per-cell patch kernels: five 28 KB workgroups per CU = 20 waves -> at most 96 registers for full residency
+    # lane-per-cell patch kernels: six 26.9 KB workgroups per CU at V = 28 = 24 waves -> at most 80 registers for full residency
     for k in _find(meta, "cell_tile_kernel", "Li32"):
-        assert int(meta[k]["vgpr_count"]) <= 128, (k, meta[k]["vgpr_count"])
+        assert int(meta[k]["vgpr_count"]) <= 80, (k, meta[k]["vgpr_count"])
 
 
 def test_instruction_selection(kernels):
