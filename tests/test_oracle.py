@@ -242,3 +242,33 @@ def test_streamed_utterance_oracle_equals_the_dense_oracles(f16):
         assert np.abs(o["d_pred_proj"] - ref["d_c"][b, :Ub]).max() < 1e-10
         dW2, db2 = dW2 + o["dW2"], db2 + o["db2"]
     assert np.abs(dW2 - ref["dW2"]).max() < 1e-10 and np.abs(db2 - ref["db2"]).max() < 1e-10
+
+
+def test_park_factor_of_the_f16_joint_oracle():
+    """park_factor_f16 (the binary16 parking of the softmax numerators between the f16 joint's forward and backward pass):
+    a relative perturbation of at most half a binary16 step for everything within 2^14 of its chunk's maximum, exactly 1 at the
+    blank column and at the label columns of cells that have a label edge, and independent of the other chunks' values."""
+    rng = np.random.default_rng(5)
+    T, U, V = 3, 4, 96
+    y = rng.normal(size=(T, U, V))  # (nothing more than 2^14 below its chunk's maximum)
+    labels = np.array([5, 40, 70])
+    f = orc.park_factor_f16(y, labels, blank=0)
+    assert f.shape == y.shape
+    assert np.all(np.abs(f - 1.0) <= 2.0 ** -11 * (1 + 1e-12))
+    assert np.all(f[..., 0] == 1.0)
+    for u, lab in enumerate(labels):
+        assert np.all(f[:, u, lab] == 1.0)
+    assert np.any(f[:, U - 1, :] != 1.0)  # the last column has no label edge, only the blank column is exact there
+    y2 = y.copy()
+    y2[..., 32:64] += 40.0  # another chunk's values do not move this chunk's factors
+    f2 = orc.park_factor_f16(y2, labels, blank=0)
+    assert np.array_equal(f[..., :32], f2[..., :32]) and np.array_equal(f[..., 64:], f2[..., 64:])
+    # has_label: a cell without a label edge keeps the parked value in what would be its label column
+    f3 = orc.park_factor_f16(y, labels, blank=0, has_label=np.array([True, False, True]))
+    assert np.array_equal(f3[:, 0], f[:, 0]) and np.array_equal(f3[:, 2], f[:, 2])
+    assert not np.all(f3[:, 1, labels[1]] == 1.0) or np.all(orc._rne_half(np.exp2(y[:, 1, labels[1]] * orc._LOG2E)) == 1)
+    # far below the chunk maximum the numerator sinks into binary16's subnormals and finally to zero: factor 0, not NaN
+    y4 = np.zeros((1, 2, 32))
+    y4[..., 1] = -30.0
+    f4 = orc.park_factor_f16(y4, np.array([3]), blank=0)
+    assert f4[0, 0, 1] == 0.0 and np.isfinite(f4).all()
