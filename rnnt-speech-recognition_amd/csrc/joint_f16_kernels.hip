@@ -2,22 +2,24 @@
 // (gfx950, v_mfma_f32_32x32x16_f16).  BASELINE config 5 ("fp16 joint MFMA, fp32 lattice"): V = 1024, J = 640.
 //
 // Same path as joint_kernels.hip (model.py:158-166 + autodiff through it),
-// but the [cells x V] logits no longer fit a per-cell register tile, so the work is four GEMM-shaped kernels around
-// the unchanged alpha/beta sweeps.  Nothing of size [cells x J] is ever stored; the only [cells x V] array is the
-// loss gradient w.r.t. the logits in binary16 (2 B per logit instead of the 4+4 B of the unfused path).
+// but the [cells x V] logits no longer fit a per-cell register tile, so the work is three GEMM-shaped kernels and one
+// streaming pass around the unchanged alpha/beta sweeps.  Nothing of size [cells x J] is ever stored; the only [cells x V]
+// array is binary16 (2 B per logit instead of the 4+4 B of the unfused path): the softmax numerators the forward pass parks,
+// turned in place into the loss gradient w.r.t. the logits by the backward pass.
 //
 //   prep      W2 -> binary16 in two layouts (MFMA-fragment-packed W2^T, row-major W2); power-of-two dlogits scale;
 //             tables e^{2 enc_proj}, e^{2 pred_proj}: tanh(a+c) = 1 - 2/(1 + e^{2a} e^{2c}) costs one reciprocal per
 //             (cell, joint unit) instead of an exponential and a reciprocal (the kernels are VALU-bound on it)
-//   K1 logits (jh_logits_kernel<KS,false>)  logits^T tile = W2^T . h^T with h = tanh(enc_proj_t + pred_proj_u) built
+//   K1 logits (jh_logits_kernel<KS, MODE, B2LDS>)  logits^T tile = W2^T . h^T with h = tanh(enc_proj_t + pred_proj_u) built
 //             straight into the B-operand registers (a wave owns 32 lattice cells of one row t, h never leaves the
 //             register file); W2^T streams through LDS by LDS-DMA, 32 vocabulary rows per step, shared by 8 waves.
 //             In the transposed product a LANE owns a cell and its registers run over the vocabulary, so the
-//             log-softmax is an in-register online reduction.  Out: lse, lattice edge weights W (-> sweeps), and the
-//             blank / label logits of every cell.
-//   K2 dlogits (jh_logits_kernel<KS,true>)  same product again (recompute, 2JV flop/cell instead of 8 B/logit of
-//             HBM), epilogue forms dlogits = occupancy-weighted softmax - edge terms, scales by 2^k, rounds to binary16
-//             and writes [cells][V] through a per-wave LDS transpose (row-contiguous 256 B stores).
+//             log-softmax is an in-register online reduction.  Out: lse, lattice edge weights W (-> sweeps), the
+//             blank / label logits of every cell, and (MODE 1, when a backward pass follows) the PARKED softmax
+//             numerators 2^(y - R) in binary16, R = the integer at or above the largest y of the cell's 32-symbol chunk.
+//   K2 dlogits (jh_dlogits_kernel)  one streaming pass over the parked values: dl = binary16(S scale 2^(R + c0) parked),
+//             blank / label columns from the f32 edge logits; in place.  (Rounds 1-2 ran the product a second time here;
+//             that kernel -- MODE 2 of jh_logits_kernel -- still serves a second backward call over one forward.)
 //   K3 dh     (jh_dh_kernel)  dh = dl . W2^T as an "NT" GEMM (both operands K-contiguous, XOR-swizzled LDS images
 //             filled by LDS-DMA), epilogue dz = dh (1 - h^2), sum_u -> d enc_proj partials, sum_t -> d pred_proj.
 //   K4 dW2    (jh_dw_kernel)  dW2 = h^T . dl, split over ranges of cells; h^T is generated in A-fragment layout,
