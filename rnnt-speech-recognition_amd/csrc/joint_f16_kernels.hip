@@ -113,6 +113,7 @@ struct JhParams {
     float *dbpart;  // [n_ranges][V]
     const f16 *zrow;  // 1 KB of zeros: stands in for dl rows beyond the tensor (u >= U) in K4
     int J, n_ut, n_tt, n_ts, TS, n_tq, n_units, n_ranges;
+    FastDiv div_ppc;  // K2: 16-byte pieces per cell (V / 8)
     int b2_lds_off;  // K1/K2: byte offset of the bias table in LDS, -1 = read it from global memory (does not fit)
 #ifdef JH_TRACE
     long long *trace;  // dev builds only (-DJH_TRACE): per-wave s_memtime stamps of a few workgroups of K1
@@ -564,85 +565,90 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
 
 // ---------------------------------------------------------------------------------------------
 // K2 (streaming): dl[cell][v] = binary16( S * scale * 2^(ref + c0) * parked ), edge columns as in the recompute epilogue.
-// In place, one pass over the parked values: 4 B of HBM traffic per logit instead of 2 J flop.  Same tiles and the same set
-// of written rows as K1 (rows t < T_b of live tiles, zeros for the columns u >= U_b inside them); a wave owns one lattice
-// row of the tile, lane n sets up cell u0 + n, then the wave walks over its 32 rows of V values, 16 bytes per lane.
+// In place, one pass over the parked values: 4 B of HBM traffic per logit instead of 2 J flop.  Writes what K1 wrote: the
+// cells of lattice rows t < T_b in column tiles that start below U_b (zeros for the columns u >= U_b inside them).
+// Shape: ONE contiguous 16 KB span per 256-thread workgroup, four 16-byte pieces per thread, no grid stride -- what reaches
+// 6.1 TB/s in place on this part (scripts/probes/probe_hbm.hip: 4.7-5.0 TB/s for grid-stride loops, 4.5 for 32 KB spans; the
+// first version, a wave per lattice row of K1's tiles, ran at 5.2 TB/s).  The span's loads are issued first; the few threads
+// that set the span's cells up (gathers from the lattice state) work under their latency.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void jh_dlogits_kernel(const JhParams jp) {
+#ifndef JH_K2_SPAN
+#define JH_K2_SPAN 1024
+#endif
+constexpr int kK2Span = JH_K2_SPAN;  // 16-byte pieces per workgroup (16 KB; 8 KB and 32 KB spans measured slower)
+constexpr int kK2Per = kK2Span / 256;   // ... per thread
+__global__ __launch_bounds__(256) void jh_dlogits_kernel(const JhParams jp) {
     if (jp.state[0] != 1) return;  // no parked values: the recompute kernel (MODE 2) does this call's work
+    __shared__ float4 sset[32];    // per cell of the span: factor scale * S, c0, blank value, label value
+    __shared__ int slab[32];       // ... the label column to patch (-1: none), -2: the cell is not written at all
     const LossParams &p = jp.lp;
-    const int V = p.V;
-    const int tid = threadIdx.x, lane = tid & 63, n = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bid = blockIdx.x;
-    const int ut = bid % jp.n_ut;
-    bid /= jp.n_ut;
-    const int tt = bid % jp.n_tt;
-    const int b = p.b0 + bid / jp.n_tt;  // the launch covers utterances [b0, b0 + nb)
-    const int u0 = ut * 32, t = tt * 8 + wave;
-    const int Tb = length_T(p, b), Ub = length_U(p, b);
-    if (tt * 8 >= Tb || u0 >= Ub || t >= Tb) return;
-    const int u = u0 + n;
-    float mulS = 0.f, c0 = kNeg, eb = 0.f, el = 0.f;
-    int labc = -1;
-    if (u < Ub) {
-        const uint32_t c = ((uint32_t)(b * p.T + t)) * (uint32_t)p.U + (uint32_t)u;
-        Cell cl;
-        cl.b = b, cl.t = t, cl.u = u, cl.Tb = Tb, cl.Ub = Ub, cl.valid = true;
-        const CellGrad g = cell_grad_setup(p, cl, c);
-        mulS = g.scale * jp.scal[0];
-        c0 = g.c0;
-        const float2 x = ((const float2 *)jp.xbl)[c];  // log2-scaled blank / label logits
-        const float cb = g.has_blank_corr ? hex2(x.x + g.nl + g.cb) : 0.f;
-        const float clb = g.has_label ? hex2(x.y + g.nl + g.cl) : 0.f;
-        const bool same = g.has_label && (g.lab == p.blank);
-        eb = mulS * (hex2(x.x + c0) - cb - (same ? clb : 0.f));
-        el = mulS * (hex2(x.y + c0) - clb);
-        labc = (g.has_label && !same) ? g.lab : -1;
+    const int V = p.V, tid = threadIdx.x;
+    const int ppc = V >> 3, cw = kK2Span / ppc;  // pieces per cell, cells per workgroup (1 .. 16)
+    const uint32_t cell_lo = (uint32_t)p.b0 * (uint32_t)(p.T * p.U), cell_hi = cell_lo + (uint32_t)p.nb * (uint32_t)(p.T * p.U);
+    const uint32_t c0w = cell_lo + blockIdx.x * (uint32_t)cw;  // first cell of this workgroup
+    h8 v[kK2Per];
+    short rf[kK2Per];
+    int cl[kK2Per], pj[kK2Per];
+#pragma unroll
+    for (int k = 0; k < kK2Per; ++k) {
+        const int q = tid + 256 * k;
+        cl[k] = (int)fdiv((uint32_t)q, jp.div_ppc), pj[k] = q - cl[k] * ppc;
+        if (cl[k] < cw && c0w + cl[k] < cell_hi) {
+            const size_t c = c0w + cl[k];
+            v[k] = __builtin_nontemporal_load((const h8 *)(jp.dl + c * V) + pj[k]);
+            rf[k] = jp.pref[c * (size_t)(V >> 5) + (pj[k] >> 2)];
+        } else {
+            cl[k] = -1;
+        }
     }
-    const int nu = min(32, p.U - u0);
-    const int ppr = V >> 9;  // 64-lane x 16-byte pieces per row
-    const size_t cell0 = (size_t)(b * p.T + t) * p.U + u0;
-    f16 *const dl0 = jp.dl + cell0 * V;
-    const short *const pr0 = jp.pref + cell0 * (size_t)(V >> 5);
-    constexpr int kAhead = 4;  // pieces a lane has in flight (8: no faster)
-    int i = 0, sub = 0;
-    while (i < nu) {
-        h8 v[kAhead];
-        short rf[kAhead];
-        int ci[kAhead], cs[kAhead];
-#pragma unroll
-        for (int j = 0; j < kAhead; ++j) {
-            ci[j] = i, cs[j] = sub;
-            if (i < nu) {
-                const int k = sub * 64 + lane;
-                v[j] = __builtin_nontemporal_load((const h8 *)(dl0 + (size_t)i * V) + k);  // (plain loads / stores: 6.13 vs 5.83 ms)
-                rf[j] = pr0[(size_t)i * (V >> 5) + (k >> 2)];
-                if (++sub == ppr) sub = 0, ++i;
-            }
+    if (tid < cw && c0w + tid < cell_hi) {
+        const uint32_t c = c0w + tid;
+        const Cell cel = decode(p, c);
+        float mulS = 0.f, c0 = kNeg, eb = 0.f, el = 0.f;
+        int labc = -1;
+        if (!(cel.t < cel.Tb && (cel.u & ~31) < cel.Ub)) {
+            labc = -2;  // a row or a column tile K1 did not touch
+        } else if (cel.valid) {
+            const CellGrad g = cell_grad_setup(p, cel, c);
+            mulS = g.scale * jp.scal[0];
+            c0 = g.c0;
+            const float2 x = ((const float2 *)jp.xbl)[c];  // log2-scaled blank / label logits
+            const float cb = g.has_blank_corr ? hex2(x.x + g.nl + g.cb) : 0.f;
+            const float clb = g.has_label ? hex2(x.y + g.nl + g.cl) : 0.f;
+            const bool same = g.has_label && (g.lab == p.blank);
+            eb = mulS * (hex2(x.x + c0) - cb - (same ? clb : 0.f));
+            el = mulS * (hex2(x.y + c0) - clb);
+            labc = (g.has_label && !same) ? g.lab : -1;
         }
+        sset[tid] = make_float4(mulS, c0, eb, el);
+        slab[tid] = labc;
+    }
+    __syncthreads();
 #pragma unroll
-        for (int j = 0; j < kAhead; ++j) {
-            if (ci[j] >= nu) break;
-            const float sS = lane_f32(mulS, ci[j]), cc = lane_f32(c0, ci[j]);  // ci[j] is wave-uniform
-            const float ebi = lane_f32(eb, ci[j]), eli = lane_f32(el, ci[j]);
-            const int li = __builtin_amdgcn_readlane(labc, ci[j]);
-            const int k = cs[j] * 64 + lane, vb = 8 * k;
-            const float mult = sS * hex2((float)rf[j] + cc);
-            h8 o;
+    for (int k = 0; k < kK2Per; ++k) {
+        if (cl[k] < 0) continue;
+        const int li = slab[cl[k]];
+        if (li == -2) continue;
+        const float4 st = sset[cl[k]];
+        const int vb = 8 * pj[k];
+        const float mult = st.x * hex2((float)rf[k] + st.y);
+        h8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (f16)(mult * (float)v[j][e]);
-            const int ib = p.blank - vb, il = li - vb;
-            if ((unsigned)ib < 8u) {
+        for (int e = 0; e < 8; ++e) o[e] = (f16)(mult * (float)v[k][e]);
+        if (li == -1 && st.x == 0.f) {  // a padded column (u >= U_b) inside a live tile: exact zeros whatever was parked
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (e == ib) ? (f16)ebi : o[e];
-            }
-            if ((unsigned)il < 8u) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (e == il) ? (f16)eli : o[e];
-            }
-            __builtin_nontemporal_store(o, (h8 *)(dl0 + (size_t)ci[j] * V) + k);
+            for (int e = 0; e < 8; ++e) o[e] = (f16)0.f;
         }
+        const int ib = p.blank - vb, il = li - vb;
+        if ((unsigned)ib < 8u) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (e == ib) ? (f16)st.z : o[e];
+        }
+        if ((unsigned)il < 8u) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (e == il) ? (f16)st.w : o[e];
+        }
+        __builtin_nontemporal_store(o, (h8 *)(jp.dl + (size_t)(c0w + cl[k]) * V) + pj[k]);
     }
 }
 
@@ -1243,6 +1249,7 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     jp.zrow = (const f16 *)(ws + L.zrow);
     jp.J = J, jp.n_ut = L.n_ut, jp.n_tt = L.n_tt, jp.n_ts = L.n_ts, jp.TS = L.TS, jp.n_tq = L.n_tq;
     jp.n_units = L.n_units, jp.n_ranges = L.n_ranges;
+    jp.div_ppc = make_fastdiv((uint32_t)(V >> 3));
 
 #ifdef JH_TRACE
     static long long *trace_dev = nullptr;
@@ -1304,7 +1311,10 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     // are enqueued; the one whose precondition does not hold returns at once.
     // (Cutting the batch into utterance ranges and converting range q + 1 on a second stream beside the dh kernel of range q
     // was measured at config 5: the two kernels do overlap, and slow each other down by as much as the overlap hides.)
-    hipLaunchKernelGGL(jh_dlogits_kernel, dim3(tiles), dim3(512), 0, s, jp);
+    {
+        const unsigned cw = (unsigned)(kK2Span / (V >> 3)), cells = (unsigned)B * T * U;
+        hipLaunchKernelGGL(jh_dlogits_kernel, dim3((cells + cw - 1) / cw), dim3(256), 0, s, jp);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = logits(2)) != hipSuccess) return e;
     // dC partials + the zero row (the dA partials need no zero-fill: launch_reduce_enc reads only the rows K3 writes)

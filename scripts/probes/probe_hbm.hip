@@ -112,6 +112,27 @@ __global__ __launch_bounds__(256) void rw_k(const v4f *x, v4f *y, size_t n16) {
     }
 }
 
+// read + write with one contiguous 16 KB span per workgroup (no grid stride: what torch's elementwise kernels do)
+template <bool INPLACE, bool NT, int SPAN16>
+__global__ __launch_bounds__(256) void rw_span_k(const v4f *x, v4f *y, size_t n16) {
+    const size_t base = (size_t)blockIdx.x * (256 * SPAN16) + threadIdx.x;
+    v4f v[SPAN16];
+#pragma unroll
+    for (int k = 0; k < SPAN16; ++k) {
+        const size_t j = base + k * 256;
+        if (j < n16) v[k] = NT ? __builtin_nontemporal_load(x + j) : x[j];
+    }
+#pragma unroll
+    for (int k = 0; k < SPAN16; ++k) {
+        const size_t j = base + k * 256;
+        if (j < n16) {
+            const v4f o = v[k] * 1.0001f;
+            if (NT) __builtin_nontemporal_store(o, (INPLACE ? (v4f *)x : y) + j);
+            else ((INPLACE ? (v4f *)x : y))[j] = o;
+        }
+    }
+}
+
 template <typename F>
 static double timed(F f) {
     hipEvent_t a, b;
@@ -162,5 +183,18 @@ int main() {
                2 * bytes / timed([&] { hipLaunchKernelGGL((rw_k<false, true>), dim3(grid), dim3(256), 0, 0, x, y, n16); }) / 1e12,
                2 * bytes / timed([&] { hipLaunchKernelGGL((rw_k<true, false>), dim3(grid), dim3(256), 0, 0, x, y, n16); }) / 1e12,
                2 * bytes / timed([&] { hipLaunchKernelGGL((rw_k<true, true>), dim3(grid), dim3(256), 0, 0, x, y, n16); }) / 1e12);
+    {
+        const unsigned g4 = (unsigned)((n16 + 1023) / 1024), g8 = (unsigned)((n16 + 2047) / 2048);
+        printf("one 16 KB span per workgroup: r+w out of place %.2f (nt %.2f)   in place %.2f (nt %.2f) TB/s\n",
+               2 * bytes / timed([&] { hipLaunchKernelGGL((rw_span_k<false, false, 4>), dim3(g4), dim3(256), 0, 0, x, y, n16); }) / 1e12,
+               2 * bytes / timed([&] { hipLaunchKernelGGL((rw_span_k<false, true, 4>), dim3(g4), dim3(256), 0, 0, x, y, n16); }) / 1e12,
+               2 * bytes / timed([&] { hipLaunchKernelGGL((rw_span_k<true, false, 4>), dim3(g4), dim3(256), 0, 0, x, y, n16); }) / 1e12,
+               2 * bytes / timed([&] { hipLaunchKernelGGL((rw_span_k<true, true, 4>), dim3(g4), dim3(256), 0, 0, x, y, n16); }) / 1e12);
+        printf("one 32 KB span per workgroup: r+w out of place %.2f (nt %.2f)   in place %.2f (nt %.2f) TB/s\n",
+               2 * bytes / timed([&] { hipLaunchKernelGGL((rw_span_k<false, false, 8>), dim3(g8), dim3(256), 0, 0, x, y, n16); }) / 1e12,
+               2 * bytes / timed([&] { hipLaunchKernelGGL((rw_span_k<false, true, 8>), dim3(g8), dim3(256), 0, 0, x, y, n16); }) / 1e12,
+               2 * bytes / timed([&] { hipLaunchKernelGGL((rw_span_k<true, false, 8>), dim3(g8), dim3(256), 0, 0, x, y, n16); }) / 1e12,
+               2 * bytes / timed([&] { hipLaunchKernelGGL((rw_span_k<true, true, 8>), dim3(g8), dim3(256), 0, 0, x, y, n16); }) / 1e12);
+    }
     return 0;
 }

@@ -122,8 +122,8 @@ def test_instruction_selection(kernels):
     for mode in ("Li40ELi0", "Li40ELi1"):  # forward, forward + park
         k1 = asm[_find(asm, "jh_logits_kernel", mode)[0]]
         assert k1.count("v_mfma_f32_32x32x16_f16") >= 40 and "global_load_lds_dwordx4" in k1 and "v_cvt_pk_f16_f32" in k1
-    k2 = asm[_find(asm, "jh_dlogits_kernel")[0]]  # streaming dlogits: 16-byte non-temporal accesses, wave-uniform broadcasts
-    assert "global_load_dwordx4" in k2 and "global_store_dwordx4" in k2 and "v_readlane_b32" in k2 and "ds_bpermute" not in k2
+    k2 = asm[_find(asm, "jh_dlogits_kernel")[0]]  # streaming dlogits: four 16-byte non-temporal loads and stores per thread
+    assert k2.count("global_load_dwordx4") >= 4 and k2.count("global_store_dwordx4") >= 4 and " nt" in k2 and "ds_bpermute" not in k2
     dw = asm[_find(asm, "jh_dw_kernel")[0]]
     assert "ds_read_b64_tr_b16" in dw and "v_mfma_f32_32x32x16_f16" in dw and "v_dot2" in dw
     dh = asm[_find(asm, "jh_dh_kernel")[0]]
