@@ -297,13 +297,19 @@ __device__ __forceinline__ void online_upd(float &m, float &s, float xv) {
     m = mn;
 }
 
+// consecutive cells one wave of cell_wave_kernel walks: about 4 KB of logits
+__host__ __device__ inline int wave_cells(int V) { return V >= 1024 ? 1 : 1024 / V; }
+
 template <bool V4, bool GRAD>
 __global__ __launch_bounds__(256) void cell_wave_kernel(const LossParams p) {
     const int lane = threadIdx.x & 63;
-    const uint32_t w0 = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t nw = gridDim.x * 4u;
     const int V = p.V;
-    for (uint32_t c = w0; c < p.cells; c += nw) {
+    // No grid stride: a workgroup owns ONE contiguous span of cells (about 16 KB of logits: 4 waves x wave_cells(V) cells), as the
+    // streaming kernels that reach 6 TB/s on this part do (scripts/probes/probe_hbm.hip; grid-stride loops: 4.7-5.0 TB/s).
+    const uint32_t cpw = (uint32_t)wave_cells(V);
+    const uint32_t c_lo = (blockIdx.x * 4u + (threadIdx.x >> 6)) * cpw;
+    const uint32_t c_hi = min(c_lo + cpw, p.cells);
+    for (uint32_t c = c_lo; c < c_hi; ++c) {
         const Cell cl = decode(p, c);
         const float *x = p.acts + (size_t)c * V;
         if (!GRAD) {
@@ -772,8 +778,8 @@ static hipError_t launch_cell(const LossParams &p, hipStream_t s) {
             hipLaunchKernelGGL((cell_tile_kernel<64, GRAD>), dim3(blocks), dim3(256), shm, s, p);
     } else {
         const bool v4 = (p.V % 4) == 0 && ((uintptr_t)p.acts & 15) == 0 && (!GRAD || ((uintptr_t)p.grads & 15) == 0);
-        unsigned blocks = (p.cells + 3u) / 4u;
-        if (blocks > 256u * 16u) blocks = 256u * 16u;
+        const unsigned per_wg = 4u * (unsigned)wave_cells(p.V);
+        const unsigned blocks = (p.cells + per_wg - 1u) / per_wg;
         if (v4)
             hipLaunchKernelGGL((cell_wave_kernel<true, GRAD>), dim3(blocks), dim3(256), 0, s, p);
         else
