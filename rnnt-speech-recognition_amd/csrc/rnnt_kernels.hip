@@ -718,16 +718,21 @@ __device__ __forceinline__ void beta_fast_steps(float (&bv)[K], f32x2 (&wq)[2][K
 // ---------------------------------------------------------------------------------------------
 // fills (see launch_fill in rnnt_common.h)
 // ---------------------------------------------------------------------------------------------
+// One contiguous 16 KB span per workgroup (four 16-byte stores per thread), no grid stride.
 __global__ __launch_bounds__(256) void fill_kernel(uint32_t *dst, const uint32_t word, const size_t nwords) {
-    const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if ((((uintptr_t)dst) & 15) == 0) {
         const size_t n4 = nwords >> 2;
         const uint4 q = make_uint4(word, word, word, word);
-        for (size_t k = i; k < n4; k += stride) ((uint4 *)dst)[k] = q;
-        for (size_t k = n4 * 4 + i; k < nwords; k += stride) dst[k] = word;
+        const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (base + 256 * k < n4) ((uint4 *)dst)[base + 256 * k] = q;
+        if (blockIdx.x == 0 && threadIdx.x < (nwords & 3)) dst[n4 * 4 + threadIdx.x] = word;
     } else {
-        for (; i < nwords; i += stride) dst[i] = word;
+        const size_t base = (size_t)blockIdx.x * 4096 + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (base + 256 * k < nwords) dst[base + 256 * k] = word;
     }
 }
 
@@ -735,9 +740,10 @@ hipError_t launch_fill(void *dst, int byte, size_t bytes, hipStream_t s) {
     if (bytes == 0) return hipSuccess;
     if ((bytes & 3) != 0 || (((uintptr_t)dst) & 3) != 0) return hipErrorInvalidValue;
     const uint32_t b = (uint32_t)(byte & 0xff), word = b | (b << 8) | (b << 16) | (b << 24);
-    const size_t nwords = bytes >> 2, n16 = (nwords + 3) >> 2;
-    const unsigned grid = (unsigned)((n16 + 255) / 256 < 2048 ? (n16 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(fill_kernel, dim3(grid), dim3(256), 0, s, (uint32_t *)dst, word, nwords);
+    const size_t nwords = bytes >> 2;
+    const size_t grid = (nwords + 4095) / 4096;  // 16 KB per workgroup
+    if (grid > 0x7fffffffu) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)grid), dim3(256), 0, s, (uint32_t *)dst, word, nwords);
     return hipGetLastError();
 }
 
