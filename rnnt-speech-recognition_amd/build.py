@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libwarprnnt.so")
-SOURCES = ["rnnt_kernels.hip", "joint_kernels.hip", "joint_f16_kernels.hip", "dense_kernels.hip", "rnnt_entrypoint.hip"]
+SOURCES = ["rnnt_kernels.hip", "rnnt_lin_kernels.hip", "joint_kernels.hip", "joint_f16_kernels.hip", "dense_kernels.hip", "rnnt_entrypoint.hip"]
 # -fvisibility=hidden: the library exports exactly the entry points include/rnnt.h marks RNNT_API (tests/test_abi.py)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-inline-asm"]
 

@@ -66,6 +66,13 @@ struct LossParams {
     float *offA;  // integer-valued offsets, exact in f32
     float *offB;
     double *ll;
+    // linear-domain lattice (rnnt_lin.h): integer frames per (block of kLinR diagonals, sweep lane), the likelihoods as
+    // {mantissa, frame} pairs, and the per-utterance hand-back flags
+    int *EA;
+    int *EB;
+    float *lik;  // [B][4]: alpha side {mantissa (float), frame (int)}, beta side {mantissa, frame}
+    int *flags;  // [B][4]: kFlagA, kFlagB, kFlagG, kFlagState
+    int NCl;     // frame blocks per utterance (tables are [NCl][64])
     int B, T, U, V, blank;
     int b0, nb;  // this launch covers utterances [b0, b0+nb)
     int N, Nr, Up, NC, NG;  // NG = Up/OG offset groups (offset tables are [NC][NG])
@@ -75,7 +82,8 @@ struct LossParams {
 };
 
 struct WsLayout {
-    size_t lse, W, A, Bt, offA, offB, ll, total;
+    size_t lse, W, A, Bt, offA, offB, ll, EA, EB, lik, flags, total;
+    int NCl;
     int N, Nr, Up, NC, NG, OG;
 };
 
@@ -115,6 +123,11 @@ inline WsLayout make_layout(int T, int U, int B) {
     w.offA = take((size_t)B * w.NC * w.NG * sizeof(float));
     w.offB = take((size_t)B * w.NC * w.NG * sizeof(float));
     w.ll = take((size_t)B * 2 * sizeof(double));
+    w.NCl = w.Nr / 4 + 1;  // kLinR = 4 diagonals per frame block (rnnt_lin.h)
+    w.EA = take((size_t)B * w.NCl * 64 * sizeof(int));
+    w.EB = take((size_t)B * w.NCl * 64 * sizeof(int));
+    w.lik = take((size_t)B * 4 * sizeof(float));
+    w.flags = take((size_t)B * 4 * sizeof(int));
     w.total = off;
     return w;
 }
@@ -175,5 +188,11 @@ bool tile_path_ok(const LossParams &p, bool grad);
 hipError_t launch_lsm(const LossParams &p, hipStream_t s);
 hipError_t launch_sweeps(const LossParams &p, hipStream_t s);
 hipError_t launch_grad(const LossParams &p, hipStream_t s);
+// the linear-domain path of the small-vocabulary loss (rnnt_lin.h, rnnt_lin_kernels.hip)
+bool lin_path_ok(const LossParams &p);
+hipError_t launch_lsm_lin(const LossParams &p, hipStream_t s);
+hipError_t launch_sweeps_lin(const LossParams &p, hipStream_t s);
+hipError_t launch_grad_lin(const LossParams &p, hipStream_t s);
+hipError_t launch_redo_lin(const LossParams &p, bool force, hipStream_t s);
 
 }  // namespace rnnt

@@ -62,6 +62,11 @@ static bool fill_params(LossParams &p, const float *acts, float *grads, const in
     p.offA = (float *)(ws + w.offA);
     p.offB = (float *)(ws + w.offB);
     p.ll = (double *)(ws + w.ll);
+    p.EA = (int *)(ws + w.EA);
+    p.EB = (int *)(ws + w.EB);
+    p.lik = (float *)(ws + w.lik);
+    p.flags = (int *)(ws + w.flags);
+    p.NCl = w.NCl;
     p.B = B, p.T = o.maxT, p.U = o.maxU, p.V = V, p.blank = o.blank_label;
     p.b0 = 0, p.nb = B;
     p.tile = make_tile(o.maxT, o.maxU, V);
@@ -113,6 +118,11 @@ rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool gpu, siz
 
 // fill + lsm + sweeps on the caller's stream (stream order is the only dependency between the stages)
 static rnntStatus_t run_forward(LossParams &p, const WsLayout &w, hipStream_t s) {
+    if (lin_path_ok(p)) {  // small vocabulary, <= 256 lattice columns: the linear-domain lattice (rnnt_lin.h)
+        hipError_t e = launch_lsm_lin(p, s);
+        if (e != hipSuccess) return from_hip(e);
+        return from_hip(launch_sweeps_lin(p, s));
+    }
     // the patch kernels write the log-zero part of W themselves; the wave-per-cell kernels (large or unaligned vocabularies)
     // rely on a pre-filled W
     if (!tile_path_ok(p, false) && launch_fill(p.W, kFillByte, w.A - w.W, s) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
@@ -146,7 +156,21 @@ rnntStatus_t compute_rnnt_loss_fwd(const float *acts, const int *flat_labels, co
         return RNNT_STATUS_INVALID_VALUE;
     hipStream_t s = (hipStream_t)options.stream;
     const WsLayout w = make_layout(options.maxT, options.maxU, minibatch);
-    return run_forward(p, w, s);
+    st = run_forward(p, w, s);
+    if (st != RNNT_STATUS_SUCCESS || !lin_path_ok(p)) return st;
+    return from_hip(launch_redo_lin(p, false, s));  // utterances the linear lattice handed back: log-domain sweeps (costs)
+}
+
+// The gradient pass.  On the linear path it ends with the hand-back launch (rnnt_lin_kernels.hip); a gradient buffer the
+// patch kernels cannot write (not 16-byte aligned) sends every utterance through that launch.
+static rnntStatus_t run_backward(LossParams &p, hipStream_t s) {
+    if (!lin_path_ok(p)) return from_hip(launch_grad(p, s));
+    const bool patch = tile_path_ok(p, true);
+    if (patch) {
+        hipError_t e = launch_grad_lin(p, s);
+        if (e != hipSuccess) return from_hip(e);
+    }
+    return from_hip(launch_redo_lin(p, !patch, s));
 }
 
 rnntStatus_t compute_rnnt_loss_bwd(const float *acts, float *grads, const int *flat_labels,
@@ -160,7 +184,7 @@ rnntStatus_t compute_rnnt_loss_bwd(const float *acts, float *grads, const int *f
     if (!fill_params(p, acts, grads, flat_labels, label_lengths, input_lengths, cost_scale, alphabet_size,
                      minibatch, nullptr, workspace, options))
         return RNNT_STATUS_INVALID_VALUE;
-    return from_hip(launch_grad(p, (hipStream_t)options.stream));
+    return run_backward(p, (hipStream_t)options.stream);
 }
 
 // compute_rnnt_loss with the upstream gradient folded in (cost_scale NULL = 1).
@@ -183,7 +207,7 @@ rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, const int *fl
     const WsLayout w = make_layout(options.maxT, options.maxU, minibatch);
     st = run_forward(p, w, s);
     if (st != RNNT_STATUS_SUCCESS) return st;
-    return from_hip(launch_grad(p, s));
+    return run_backward(p, s);
 }
 
 rnntStatus_t compute_rnnt_loss(const float *acts, float *grads, const int *flat_labels,

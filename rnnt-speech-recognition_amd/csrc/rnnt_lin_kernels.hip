@@ -1,0 +1,409 @@
+// rnnt_lin_kernels.hip -- LINEAR-domain alpha / beta sweeps of the small-vocabulary transducer loss, and the log-domain redo
+// of the utterances that path hands back (rnnt_lin.h has the scheme and the per-cell code of the two cell passes).
+//
+// Replaces warp-transducer's compute_alphas_kernel / compute_betas_kernel (reached from
+// utils/loss.py:34-35).  Same structure as sweep_ld_kernel (rnnt_sweep.h): one workgroup of two waves per (utterance,
+// direction) -- a sweeping wave with the live anti-diagonal in VGPRs (K lattice columns per lane, ONE DPP wave-shift per
+// diagonal, no barrier, no masks: probability zero is carried by the data) and a loader wave that streams the edge
+// probabilities HBM -> LDS through a ring of chunks.  What changed is the arithmetic on the serial chain: a step is
+//     alpha(t,u) = alpha(t-1,u) p_blank(t-1,u) + alpha(t,u-1) p_label(t,u-1)
+// in float32 -- multiplies and adds, no exp2 / log2 -- on mantissas relative to one integer FRAME per lane; every kLinR = 4
+// diagonals a lane renormalises against its own maximum by an exact power of two (v_frexp_exp / v_ldexp), and frames are
+// dragged up so that whatever can arrive from the neighbouring lanes within a block fits.  What crosses a lane boundary is
+// rescaled by the frame difference (one v_ldexp on the value handed over).  Frames go to [block][64 lanes] tables.
+#include "rnnt_common.h"
+#include "rnnt_cell.h"
+#include "rnnt_sweep.h"
+#include "rnnt_cellwave.h"
+#include "rnnt_lin.h"
+
+namespace rnnt {
+
+__device__ __forceinline__ float dpp_lower_zero(float x) {  // lane i <- lane i-1, lane 0 <- 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_upper_zero(float x) {  // lane i <- lane i+1, lane 63 <- 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
+}
+__device__ __forceinline__ int dpp_lower_i(int x, int fill) {
+    return __builtin_amdgcn_update_dpp(fill, x, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int dpp_upper_i(int x, int fill) {
+    return __builtin_amdgcn_update_dpp(fill, x, 0x130, 0xf, 0xf, false);
+}
+
+struct LinState {
+    int E;       // this lane's frame: true value = mantissa x 2^E
+    int d;       // alpha: E - E[lane + 1] (applied by the SENDER to what it hands to lane + 1);  beta: E[lane + 1] - E (applied by
+                 // the RECEIVER to what arrives from lane + 1) -- either way the product is formed in the receiver's frame
+    int *tab;    // this utterance's frame table [NCl][64], advanced by `lane`
+    float *row;  // wave-uniform base of the output row of the next diagonal to be stored
+};
+
+// Renormalise a lane's K mantissas against their maximum, choose the frames of the next block, record them.
+template <int K, bool BETA>
+__device__ __forceinline__ void lin_renorm(float (&v)[K], LinState &st, const int kc) {
+    float m = v[0];
+#pragma unroll
+    for (int j = 1; j < K; ++j) m = fmaxf(m, v[j]);
+    const int own = (m > 0.f) ? st.E + frexp_e(m) : kFrameNone;  // where this lane's mass is (no mass: no claim)
+    // Within one block mass travels at most kLinR columns = LOOK lanes: the frame must leave room for what those lanes hold.
+    constexpr int LOOK = (kLinR + K - 1) / K;
+    int nb = own, reach = kFrameNone;
+#pragma unroll
+    for (int r = 0; r < LOOK; ++r) {
+        nb = BETA ? dpp_upper_i(nb, kFrameNone) : dpp_lower_i(nb, kFrameNone);
+        reach = max(reach, nb);
+    }
+    const int En = max(own, reach - kLinDrag);
+    const int sh = st.E - En;  // <= 0 for a lane with mass; a lane without mass holds zeros whatever its frame
+#pragma unroll
+    for (int j = 0; j < K; ++j) v[j] = ldexp_f(v[j], sh);
+    st.E = En;
+    const int up = dpp_upper_i(En, En);  // lane 63 sees itself (nothing crosses)
+    st.d = BETA ? up - En : En - up;
+    st_i32_wt(st.tab + (size_t)kc * 64, En);
+}
+
+// One alpha step: diagonal r -> r+1 with the outgoing edge probabilities w[j] = {blank, label} of diagonal r.
+template <int K>
+__device__ __forceinline__ void lin_alpha_step(float (&a)[K], const f32x2 (&w)[K], const int d) {
+    const float hand = ldexp_f(a[K - 1], d) * w[K - 1][1];  // into lane + 1's frame, product formed there
+    float pr[K];
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) pr[j] = a[j] * w[j][1];
+    const float left = dpp_lower_zero(hand);
+#pragma unroll
+    for (int j = K - 1; j >= 1; --j) a[j] = fmaf(a[j], w[j][0], pr[j - 1]);
+    a[0] = fmaf(a[0], w[0][0], left);
+}
+// One beta step: diagonal n+1 -> n with the outgoing edge probabilities of diagonal n.
+template <int K>
+__device__ __forceinline__ void lin_beta_step(float (&bv)[K], const f32x2 (&w)[K], const int d) {
+    const float right = ldexp_f(dpp_upper_zero(bv[0]), d);  // lane + 1's first column, into this lane's frame
+#pragma unroll
+    for (int j = 0; j < K; ++j) bv[j] = fmaf(w[j][0], bv[j], w[j][1] * ((j == K - 1) ? right : bv[j + 1]));
+}
+
+template <int K, int G, int II>
+__device__ __forceinline__ void lin_alpha_fast_steps(float (&a)[K], f32x2 (&wq)[2][K], const uint32_t abase, LinState &st,
+                                                     const int voff, const int lane, const int r0) {
+    if constexpr (II < G) {
+        constexpr int cur = II & 1, nxt = cur ^ 1;
+        if constexpr (II + 1 < G) {
+            lds_issue_row<K, II + 1>(wq[nxt], abase);
+            lds_wait<K>();  // row II has landed, row II+1 stays in flight
+        } else {
+            lds_wait<0>();
+        }
+        lin_alpha_step<K>(a, wq[cur], st.d);
+        if constexpr (((II + 1) % kLinR) == 0) lin_renorm<K, false>(a, st, (r0 + II + 1) / kLinR);  // (r0 is a multiple of G)
+        constexpr int R = rows_per_base(K);
+        store_diag<K, true, (II % R) * 64 * K * 4>(st.row, voff, lane, a);
+        if constexpr (II % R == R - 1 || II == G - 1) st.row += (II % R + 1) * 64 * K;
+        lin_alpha_fast_steps<K, G, II + 1>(a, wq, abase, st, voff, lane, r0);
+    }
+}
+template <int K, int G, int II>
+__device__ __forceinline__ void lin_beta_fast_steps(float (&bv)[K], f32x2 (&wq)[2][K], const uint32_t abase, LinState &st,
+                                                    const int voff, const int lane, const int r0) {
+    if constexpr (II < G) {
+        constexpr int cur = II & 1, nxt = cur ^ 1;
+        constexpr int i = G - 1 - II;  // row inside the chunk (descending)
+        if constexpr (i > 0) {
+            lds_issue_row<K, i - 1>(wq[nxt], abase);
+            lds_wait<K>();
+        } else {
+            lds_wait<0>();
+        }
+        lin_beta_step<K>(bv, wq[cur], st.d);
+        if constexpr ((i % kLinR) == kLinR - 1) lin_renorm<K, true>(bv, st, (r0 + i) / kLinR);
+        constexpr int R = rows_per_base(K);
+        store_diag<K, true, -(II % R) * 64 * K * 4>(st.row, voff, lane, bv);
+        if constexpr (II % R == R - 1 || II == G - 1) st.row -= (II % R + 1) * 64 * K;
+        lin_beta_fast_steps<K, G, II + 1>(bv, wq, abase, st, voff, lane, r0);
+    }
+}
+
+// The likelihood one side arrived at: {mantissa in [0.5, 1), frame}, its log2 in float64, the hand-back flag.
+__device__ __forceinline__ void lin_record(const LossParams &p, const int b, const int side, const float L, const int E, bool bad) {
+    bad = bad || !(L > 0.f) || !(L <= FLT_MAX);  // zero (everything flushed), NaN (an edge the lsm pass refused), inf
+    const float mL = frexp_m(L);
+    const int EL = E + frexp_e(L);
+    st_f32_wt(p.lik + 4 * b + 2 * side, bad ? NAN : mL);
+    st_i32_wt((int *)p.lik + 4 * b + 2 * side + 1, EL);
+    const double ll2 = bad ? (double)NAN : log2((double)mL) + (double)EL;
+    st_f64_wt(p.ll + 2 * b + side, ll2);
+    st_i32_wt(p.flags + 4 * b + (side ? kFlagB : kFlagA), bad ? 1 : 0);
+    if (side == 0 && p.costs) st_f32_wt(p.costs + b, (float)(-ll2 * 0.6931471805599453));
+}
+
+template <int K, int G, int NB>
+__device__ void lin_alpha_sweep(const LossParams &p, float *bufs, const LdLink lk, const int b, const int lane) {
+    constexpr int Up = 64 * K, chunkf = G * 2 * Up;
+    static_assert(G % kLinR == 0, "frame blocks must not straddle chunks");
+    const int Tb = length_T(p, b), Ub = length_U(p, b);
+    const int Nb = Tb + Ub - 1;
+    float *out = p.A + (size_t)b * p.Nr * Up;
+    const int voff = lane * K * 4;
+    const int u0 = lane * K;
+    if (lane == 0) {  // this forward call owns the utterance's hand-back state from here on
+        st_i32_wt(p.flags + 4 * b + kFlagG, 0);
+        st_i32_wt(p.flags + 4 * b + kFlagState, 0);
+    }
+    float a[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = (u0 + j == 0) ? 1.f : 0.f;
+    LinState st;
+    st.E = 0, st.d = 0;
+    st.tab = p.EA + (size_t)b * p.NCl * 64 + lane;
+    lin_renorm<K, false>(a, st, 0);
+    store_diag<K, false>(out, voff, lane, a);
+    st.row = out + Up;
+    const int last_row = Nb - 1;
+    const int nchunks = last_row / G + 1;
+
+    int have = 0;
+    bool timed_out = lengths_invalid(p, b);
+    for (int ck = 0; ck < nchunks; ++ck) {
+        if (have < ck + 1) {
+            have = lds_wait_ge(lk.landed, ck + 1);
+            timed_out |= have < ck + 1;
+        }
+        const float *cur = bufs + (ck % NB) * chunkf + 2 * u0;
+        const int r0 = ck * G;
+        if (r0 + G <= last_row) {
+            const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
+            f32x2 wq[2][K];
+            lds_issue_row<K, 0>(wq[0], abase);
+            lin_alpha_fast_steps<K, G, 0>(a, wq, abase, st, voff, lane, r0);
+        } else {
+            for (int i = 0; i < G; ++i) {
+                const int n = r0 + i + 1;
+                if (n > last_row) break;
+                f32x2 wc[K];
+                load_w<K>(wc, cur + i * 2 * Up);
+                lin_alpha_step<K>(a, wc, st.d);
+                if ((n % kLinR) == 0) lin_renorm<K, false>(a, st, n / kLinR);
+                store_diag<K, false>(st.row, voff, lane, a);
+                st.row += Up;
+            }
+        }
+        if (ck + 1 < nchunks) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read of this chunk's buffer has returned
+            if (lane == 0) lds_post(lk.consumed, ck + 1);
+        }
+    }
+    {
+        const float *wrow = bufs + ((nchunks - 1) % NB) * chunkf + (last_row % G) * 2 * Up + 2 * u0;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (u0 + j == Ub - 1) lin_record(p, b, 0, a[j] * wrow[2 * j], st.E, timed_out);  // x p(blank | T_b-1, U_b-1)
+    }
+}
+
+template <int K, int G, int NB>
+__device__ void lin_beta_sweep(const LossParams &p, float *bufs, const LdLink lk, const int b, const int lane) {
+    constexpr int Up = 64 * K, chunkf = G * 2 * Up;
+    const int Tb = length_T(p, b), Ub = length_U(p, b);
+    const int Nb = Tb + Ub - 1;
+    float *out = p.Bt + (size_t)b * p.Nr * Up;
+    const int voff = lane * K * 4;
+    const int u0 = lane * K;
+
+    float bv[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) bv[j] = (u0 + j == Ub - 1) ? 1.f : 0.f;  // the virtual terminal node (T_b, U_b - 1)
+    const int last = Nb - 1;
+    const int ckl = last / G;
+    LinState st;
+    st.E = 0, st.d = 0;
+    st.tab = p.EB + (size_t)b * p.NCl * 64 + lane;
+    st.row = out + (size_t)last * Up;
+
+    int have = 0;
+    bool timed_out = lengths_invalid(p, b);
+    for (int ck = ckl; ck >= 0; --ck) {
+        const int i_ring = ckl - ck;  // the loader's chunk index
+        if (have < i_ring + 1) {
+            have = lds_wait_ge(lk.landed, i_ring + 1);
+            timed_out |= have < i_ring + 1;
+        }
+        const float *cur = bufs + (i_ring % NB) * chunkf + 2 * u0;
+        const int r0 = ck * G;
+        if (r0 + G - 1 < last) {
+            const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
+            f32x2 wq[2][K];
+            lds_issue_row<K, G - 1>(wq[0], abase);
+            lin_beta_fast_steps<K, G, 0>(bv, wq, abase, st, voff, lane, r0);
+        } else {
+            for (int ii = 0; ii < G; ++ii) {
+                const int i = G - 1 - ii;
+                const int n = r0 + i;
+                if (n > last) continue;
+                f32x2 wc[K];
+                load_w<K>(wc, cur + i * 2 * Up);
+                lin_beta_step<K>(bv, wc, st.d);
+                if ((n % kLinR) == kLinR - 1 || n == last) lin_renorm<K, true>(bv, st, n / kLinR);
+                store_diag<K, false>(st.row, voff, lane, bv);
+                st.row -= Up;
+            }
+        }
+        if (ck > 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) lds_post(lk.consumed, i_ring + 1);
+        }
+    }
+    if (lane == 0) lin_record(p, b, 1, bv[0], st.E, timed_out);
+}
+
+template <int K, int G, int NB>
+__global__ __launch_bounds__(128) void lin_sweep_kernel(const LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int chunkf = G * 2 * 64 * K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = p.b0 + (int)(blockIdx.x >> 1);
+    const bool beta = (blockIdx.x & 1) != 0;
+    int *ctr = (int *)(lds + NB * chunkf);
+    if (tid < 2) ctr[tid] = 0;
+    __syncthreads();
+    LdLink lk;
+    lk.landed = (uint32_t)(uintptr_t)((lds_void *)ctr);
+    lk.consumed = lk.landed + 4u;
+    if (wave == 1) {
+        if (beta)
+            sweep_loader<K, G, NB, true>(p, lds, lk, b, lane);
+        else
+            sweep_loader<K, G, NB, false>(p, lds, lk, b, lane);
+    } else {
+        if (beta)
+            lin_beta_sweep<K, G, NB>(p, lds, lk, b, lane);
+        else
+            lin_alpha_sweep<K, G, NB>(p, lds, lk, b, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The hand-back: ONE small launch at the end of every call of the linear path (grid = utterances; a workgroup whose
+// utterance is fine returns at once).  An utterance is redone when a sweep flagged it (kFlagA / kFlagB), when the two
+// likelihoods disagree, when the gradient pass's certificate failed for one of its cells (kFlagG), or when `force` is set
+// (a gradient buffer the patch kernels cannot write): the workgroup rebuilds the utterance's edge weights in the log2 domain
+// from the logits, runs the round-3 log-domain sweeps (exact for any range) and, if gradients are wanted, writes all of the
+// utterance's gradients -- every stage the code the large-vocabulary path runs, by one workgroup.  Slow (a millisecond for a
+// 600 x 150 lattice) and rare.  Afterwards the utterance's state word says that its lattice is in the log format, so that a
+// later backward-only call goes straight to the gradient stage here.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void redo_phase_sync() {
+    __threadfence();  // this workgroup's global stores are visible device-wide ...
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ... and nothing stale is served from this CU's vector L1
+}
+
+template <int K, int G, int NB>
+__global__ __launch_bounds__(128) void lin_redo_kernel(const LossParams p, const int force) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int chunkf = G * 2 * 64 * K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = p.b0 + (int)blockIdx.x;
+    int *fl = p.flags + 4 * b;
+    const int state = ld_i32_sc1(fl + kFlagState);
+    bool redo = false;
+    if (state != 2) {
+        const double la = ld_f64<true>(p.ll + 2 * b), lb = ld_f64<true>(p.ll + 2 * b + 1);
+        // |cost_alpha - cost_beta| in nats against what two float32 sweeps of the same lattice differ by (<= 1e-6 measured)
+        const bool agree = fabs(la - lb) * 0.6931471805599453 <= 2e-5 + 1e-8 * fabs(la);
+        redo = force || (ld_i32_sc1(fl + kFlagA) | ld_i32_sc1(fl + kFlagB) | ld_i32_sc1(fl + kFlagG)) != 0 || !agree;
+        if (!redo) return;
+    } else if (!p.grads) {
+        return;
+    }
+    const uint32_t c0 = (uint32_t)b * (uint32_t)p.T * (uint32_t)p.U, c1 = c0 + (uint32_t)p.T * (uint32_t)p.U;
+    const uint32_t cm = c0 + (c1 - c0) / 2;
+    if (redo) {
+        // ---- log2-domain edge weights of this utterance: log zero everywhere, then the cells ----
+        uint32_t *Wb = (uint32_t *)(p.W + (size_t)b * p.Nr * 2 * p.Up);
+        const uint32_t fw = (uint32_t)kFillByte * 0x01010101u;
+        for (size_t i = tid; i < (size_t)p.Nr * 2 * p.Up; i += 128) Wb[i] = fw;
+        redo_phase_sync();
+        cell_wave_range<false, false>(p, wave ? cm : c0, wave ? c1 : cm, lane);
+        redo_phase_sync();
+        // ---- the log-domain sweeps, one after the other ----
+        int *ctr = (int *)(lds + NB * chunkf);
+        LdLink lk;
+        lk.landed = (uint32_t)(uintptr_t)((lds_void *)ctr);
+        lk.consumed = lk.landed + 4u;
+        if (tid < 2) ctr[tid] = 0;
+        __syncthreads();
+        if (wave == 1)
+            sweep_loader<K, G, NB, false>(p, lds, lk, b, lane);
+        else
+            alpha_sweep_ld<K, G, NB>(p, lds, lk, b, lane);
+        __syncthreads();
+        if (tid < 2) ctr[tid] = 0;
+        __syncthreads();
+        if (wave == 1)
+            sweep_loader<K, G, NB, true>(p, lds, lk, b, lane);
+        else
+            beta_sweep_ld<K, G, NB>(p, lds, lk, b, lane);
+        redo_phase_sync();
+        if (tid == 0) st_i32_wt(fl + kFlagState, 2);
+    }
+    if (p.grads) cell_wave_range<false, true, true>(p, wave ? cm : c0, wave ? c1 : cm, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+// The linear path covers what the patch kernels cover (V <= 60, 16-byte-aligned logits) on lattices of up to 256 columns
+// (K <= 4 columns per sweep lane: one frame per lane then spans few enough columns; wider lattices keep the log-domain sweeps).
+bool lin_path_ok(const LossParams &p) {
+    const int K = sweep_K(p.U);
+    return K >= 1 && K <= 4 && tile_path_ok(p, false);
+}
+
+template <int K, int G>
+static hipError_t launch_lin_sweep(const LossParams &p, hipStream_t s) {
+    constexpr int NB = 4;
+    constexpr size_t shm = (size_t)NB * G * 2 * 64 * K * sizeof(float) + 16;
+    static_assert(shm <= 160 * 1024, "chunk ring exceeds the LDS");
+    if (shm > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)lin_sweep_kernel<K, G, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((lin_sweep_kernel<K, G, NB>), dim3(2 * p.nb), dim3(128), shm, s, p);
+    return hipGetLastError();
+}
+template <int K, int G>
+static hipError_t launch_lin_redo(const LossParams &p, const bool force, hipStream_t s) {
+    constexpr int NB = 4;
+    constexpr size_t shm = (size_t)NB * G * 2 * 64 * K * sizeof(float) + 16;
+    if (shm > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)lin_redo_kernel<K, G, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((lin_redo_kernel<K, G, NB>), dim3(p.nb), dim3(128), shm, s, p, force ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_sweeps_lin(const LossParams &p, hipStream_t s) {
+    switch (sweep_K(p.U)) {
+        case 1: return launch_lin_sweep<1, 16>(p, s);
+        case 2: return launch_lin_sweep<2, 16>(p, s);
+        case 3: return launch_lin_sweep<3, 16>(p, s);
+        case 4: return launch_lin_sweep<4, 16>(p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+hipError_t launch_redo_lin(const LossParams &p, const bool force, hipStream_t s) {
+    switch (sweep_K(p.U)) {
+        case 1: return launch_lin_redo<1, 16>(p, force, s);
+        case 2: return launch_lin_redo<2, 16>(p, force, s);
+        case 3: return launch_lin_redo<3, 16>(p, force, s);
+        case 4: return launch_lin_redo<4, 16>(p, force, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace rnnt

@@ -5,5 +5,5 @@
 set -e
 NAME=$1; shift
 D=$(cd "$(dirname "$0")/.." && pwd)/rnnt-speech-recognition_amd
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -Wno-inline-asm "$@" $D/csrc/rnnt_kernels.hip $D/csrc/joint_kernels.hip $D/csrc/joint_f16_kernels.hip $D/csrc/dense_kernels.hip $D/csrc/rnnt_entrypoint.hip -o $D/lib/libwarprnnt_$NAME.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -Wno-inline-asm "$@" $D/csrc/rnnt_kernels.hip $D/csrc/rnnt_lin_kernels.hip $D/csrc/joint_kernels.hip $D/csrc/joint_f16_kernels.hip $D/csrc/dense_kernels.hip $D/csrc/rnnt_entrypoint.hip -o $D/lib/libwarprnnt_$NAME.so
 echo $D/lib/libwarprnnt_$NAME.so
