@@ -16,6 +16,8 @@ LIB_PATH = os.path.join(LIB_DIR, "libwarprnnt.so")
 SOURCES = ["rnnt_kernels.hip", "rnnt_lin_kernels.hip", "joint_kernels.hip", "joint_f16_kernels.hip", "dense_kernels.hip", "rnnt_entrypoint.hip"]
 # -fvisibility=hidden: the library exports exactly the entry points include/rnnt.h marks RNNT_API (tests/test_abi.py)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-inline-asm"]
+# per-source extras: the linear sweeps are written for instruction count (rnnt_lin_kernels.hip lin_alpha_step)
+EXTRA_FLAGS = {"rnnt_lin_kernels.hip": ["-fno-slp-vectorize"]}
 
 
 def _deps():
@@ -33,7 +35,7 @@ def needs_build() -> bool:
 
 def _compile_one(args):
     hipcc, src, obj, verbose = args
-    cmd = [hipcc] + [f for f in HIPCC_FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
+    cmd = [hipcc] + [f for f in HIPCC_FLAGS if f != "-shared"] + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

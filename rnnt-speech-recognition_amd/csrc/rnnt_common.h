@@ -73,6 +73,7 @@ struct LossParams {
     float *lik;  // [B][4]: alpha side {mantissa (float), frame (int)}, beta side {mantissa, frame}
     int *flags;  // [B][4]: kFlagA, kFlagB, kFlagG, kFlagState
     int NCl;     // frame blocks per utterance (tables are [NCl][64])
+    int linShift;  // log2 of the diagonals per frame block (rnnt_lin.h lin_shift)
     int B, T, U, V, blank;
     int b0, nb;  // this launch covers utterances [b0, b0+nb)
     int N, Nr, Up, NC, NG;  // NG = Up/OG offset groups (offset tables are [NC][NG])
@@ -123,7 +124,7 @@ inline WsLayout make_layout(int T, int U, int B) {
     w.offA = take((size_t)B * w.NC * w.NG * sizeof(float));
     w.offB = take((size_t)B * w.NC * w.NG * sizeof(float));
     w.ll = take((size_t)B * 2 * sizeof(double));
-    w.NCl = w.Nr / 4 + 1;  // kLinR = 4 diagonals per frame block (rnnt_lin.h)
+    w.NCl = w.Nr / 4 + 1;  // frame blocks of >= 4 diagonals (rnnt_lin.h)
     w.EA = take((size_t)B * w.NCl * 64 * sizeof(int));
     w.EB = take((size_t)B * w.NCl * 64 * sizeof(int));
     w.lik = take((size_t)B * 4 * sizeof(float));

@@ -9,6 +9,11 @@
 
 using namespace rnnt;
 
+#ifndef RNNT_LINSHIFT
+#define RNNT_LINSHIFT 3
+#endif
+#define RNNT_LINSHIFT_HOST RNNT_LINSHIFT  // rnnt_lin.h lin_shift(K) for K > 1 (device header: not included here)
+
 namespace rnnt {
 // joint_kernels.hip
 hipError_t joint_workspace_bytes(int T, int U, int B, int J, int V, size_t *bytes);
@@ -67,6 +72,7 @@ static bool fill_params(LossParams &p, const float *acts, float *grads, const in
     p.lik = (float *)(ws + w.lik);
     p.flags = (int *)(ws + w.flags);
     p.NCl = w.NCl;
+    p.linShift = (sweep_K(o.maxU) == 1) ? 2 : RNNT_LINSHIFT_HOST;
     p.B = B, p.T = o.maxT, p.U = o.maxU, p.V = V, p.blank = o.blank_label;
     p.b0 = 0, p.nb = B;
     p.tile = make_tile(o.maxT, o.maxU, V);

@@ -17,7 +17,14 @@
 
 namespace rnnt {
 
-constexpr int kLinR = 4;                 // diagonals per frame block
+// Diagonals per frame block: a lane renormalises (and the frame tables get a row) every 2^lin_shift(K) diagonals.  Eight, where
+// measured: the renormalisation is ~22 instructions of the sweeping wave (4 us of the sweep at B32 T600 U150 with blocks of four).
+// N(0,1) logits lose ~5 bits per diagonal, i.e. 40 of the 126 bits of room per block; 4 x N(0,1) logits exceed the room and
+// take the log-domain path.  K = 1: blocks of four (mass crosses a lane per diagonal: the frame look-back is 4 lanes deep).
+#ifndef RNNT_LINSHIFT
+#define RNNT_LINSHIFT 3
+#endif
+__host__ __device__ constexpr int lin_shift(int K) { return K == 1 ? 2 : RNNT_LINSHIFT; }
 constexpr int kLinDrag = 118;            // a lane's frame is at most this far below the lanes mass can reach it from within a block
 constexpr int kFrameNone = -(1 << 28);   // frame of a lane without mass and without a neighbour to copy from
 constexpr int kCertBits = -40;           // per-cell bound (bits) on flush loss x other side / likelihood
@@ -79,7 +86,7 @@ __device__ __forceinline__ LinGrad lin_grad_setup(const LossParams &p, const Cel
     const int n = cl.t + cl.u;
     const size_t sk = ((size_t)cl.b * p.Nr + n) * p.Up + cl.u;
     const float ma = p.A[sk], mb = p.Bt[sk];
-    const int kc = n / kLinR, kc1 = (n + 1) / kLinR;
+    const int kc = n >> p.linShift, kc1 = (n + 1) >> p.linShift;
     const int l0 = (int)fdiv((uint32_t)cl.u, p.divOG), l1 = (int)fdiv((uint32_t)cl.u + 1u, p.divOG);
     const size_t tb = (size_t)cl.b * p.NCl * 64;
     const int ea = p.EA[tb + (size_t)kc * 64 + l0], eb = p.EB[tb + (size_t)kc * 64 + l0];

@@ -16,6 +16,11 @@
 #include "rnnt_sweep.h"
 #include "rnnt_cellwave.h"
 #include "rnnt_lin.h"
+#include "rnnt_cellbody.h"
+
+#ifndef LIN_KO
+#define LIN_KO 0  // dev builds (timing only, wrong results): 1 no diagonal stores, 2 no renormalisation, 3 no LDS reads, 4 no step arithmetic
+#endif
 
 namespace rnnt {
 
@@ -47,8 +52,8 @@ __device__ __forceinline__ void lin_renorm(float (&v)[K], LinState &st, const in
 #pragma unroll
     for (int j = 1; j < K; ++j) m = fmaxf(m, v[j]);
     const int own = (m > 0.f) ? st.E + frexp_e(m) : kFrameNone;  // where this lane's mass is (no mass: no claim)
-    // Within one block mass travels at most kLinR columns = LOOK lanes: the frame must leave room for what those lanes hold.
-    constexpr int LOOK = (kLinR + K - 1) / K;
+    // Within one block mass travels at most 2^lin_shift(K) columns = LOOK lanes: the frame must leave room for what those lanes hold.
+    constexpr int LOOK = ((1 << lin_shift(K)) + K - 1) / K;
     int nb = own, reach = kFrameNone;
 #pragma unroll
     for (int r = 0; r < LOOK; ++r) {
@@ -65,62 +70,102 @@ __device__ __forceinline__ void lin_renorm(float (&v)[K], LinState &st, const in
     st_i32_wt(st.tab + (size_t)kc * 64, En);
 }
 
-// One alpha step: diagonal r -> r+1 with the outgoing edge probabilities w[j] = {blank, label} of diagonal r.
+// One step of the recurrence.  A lone wave issues ONE instruction of any kind (VALU, LDS, VMEM, s_nop) per ~5 clocks, ~8.5 when
+// a VALU instruction consumes the result of the one just before it (scripts/probes/probe_lat.hip; profiles/r04_notes.md): the
+// time of a step is its instruction count.  Two VALU instructions per lattice column plus the hand-over (v_ldexp into the
+// receiver's frame, one DPP wave shift), in an order in which no instruction reads what its predecessor wrote and the DPP move
+// finds its source two instructions old.  Plain scalar C++ with scheduling fences: this file is compiled with
+// -fno-slp-vectorize (build.py), because the packed-f32 forms the vectoriser picks cost more in register moves than they save,
+// and inline-asm statements get padded with s_nop 0 by the compiler (a full issue slot each).
+#define LIN_FENCE() __builtin_amdgcn_sched_barrier(0)
+// alpha: diagonal r -> r+1 with the outgoing edge probabilities w[j] = {blank, label} of diagonal r:
+//   a[j] <- a[j] p_blank[j] + a[j-1] p_label[j-1];  what leaves column K-1 is scaled into lane + 1's frame BEFORE the product
 template <int K>
 __device__ __forceinline__ void lin_alpha_step(float (&a)[K], const f32x2 (&w)[K], const int d) {
-    const float hand = ldexp_f(a[K - 1], d) * w[K - 1][1];  // into lane + 1's frame, product formed there
-    float pr[K];
+    // ONE asm block: the compiler puts the hand-over product right in front of the DPP move (s_nop 1).  Inputs and outputs are
+    // separate registers, so that the new diagonal can land in the register triple the store instruction wants.
+    static_assert(K >= 1 && K <= 4, "spelled out for K = 1 .. 4");
+    float n[K], as, q, pr[K > 1 ? K - 1 : 1];
+    if constexpr (K == 1) {
+        asm volatile("v_ldexp_f32 %[as], %[a0], %[d]\n\tv_mul_f32 %[as], %[as], %[l0]\n\ts_nop 1\n\tv_mov_b32_dpp %[q], %[as] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fma_f32 %[n0], %[a0], %[b0], %[q]"
+                     : [n0] "=&v"(n[0]), [as] "=&v"(as), [q] "=&v"(q)
+                     : [a0] "v"(a[0]), [b0] "v"(w[0][0]), [l0] "v"(w[0][1]), [d] "v"(d));
+    } else if constexpr (K == 2) {
+        asm volatile("v_ldexp_f32 %[as], %[a1], %[d]\n\tv_mul_f32 %[p0], %[a0], %[l0]\n\tv_mul_f32 %[as], %[as], %[l1]\n\tv_fma_f32 %[n1], %[a1], %[b1], %[p0]\n\ts_nop 0\n\tv_mov_b32_dpp %[q], %[as] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fma_f32 %[n0], %[a0], %[b0], %[q]"
+                     : [n0] "=&v"(n[0]), [n1] "=&v"(n[1]), [as] "=&v"(as), [q] "=&v"(q), [p0] "=&v"(pr[0])
+                     : [a0] "v"(a[0]), [a1] "v"(a[1]), [b0] "v"(w[0][0]), [b1] "v"(w[1][0]), [l0] "v"(w[0][1]), [l1] "v"(w[1][1]), [d] "v"(d));
+    } else if constexpr (K == 3) {
+        asm volatile("v_ldexp_f32 %[as], %[a2], %[d]\n\tv_mul_f32 %[p0], %[a0], %[l0]\n\tv_mul_f32 %[p1], %[a1], %[l1]\n\tv_mul_f32 %[as], %[as], %[l2]\n\tv_fma_f32 %[n2], %[a2], %[b2], %[p1]\n\tv_fma_f32 %[n1], %[a1], %[b1], %[p0]\n\tv_mov_b32_dpp %[q], %[as] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fma_f32 %[n0], %[a0], %[b0], %[q]"
+                     : [n0] "=&v"(n[0]), [n1] "=&v"(n[1]), [n2] "=&v"(n[2]), [as] "=&v"(as), [q] "=&v"(q), [p0] "=&v"(pr[0]), [p1] "=&v"(pr[1])
+                     : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [b0] "v"(w[0][0]), [b1] "v"(w[1][0]), [b2] "v"(w[2][0]), [l0] "v"(w[0][1]), [l1] "v"(w[1][1]), [l2] "v"(w[2][1]), [d] "v"(d));
+    } else {
+        asm volatile("v_ldexp_f32 %[as], %[a3], %[d]\n\tv_mul_f32 %[p0], %[a0], %[l0]\n\tv_mul_f32 %[p1], %[a1], %[l1]\n\tv_mul_f32 %[p2], %[a2], %[l2]\n\tv_mul_f32 %[as], %[as], %[l3]\n\tv_fma_f32 %[n3], %[a3], %[b3], %[p2]\n\tv_fma_f32 %[n2], %[a2], %[b2], %[p1]\n\tv_fma_f32 %[n1], %[a1], %[b1], %[p0]\n\tv_mov_b32_dpp %[q], %[as] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fma_f32 %[n0], %[a0], %[b0], %[q]"
+                     : [n0] "=&v"(n[0]), [n1] "=&v"(n[1]), [n2] "=&v"(n[2]), [n3] "=&v"(n[3]), [as] "=&v"(as), [q] "=&v"(q), [p0] "=&v"(pr[0]), [p1] "=&v"(pr[1]), [p2] "=&v"(pr[2])
+                     : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [b0] "v"(w[0][0]), [b1] "v"(w[1][0]), [b2] "v"(w[2][0]), [b3] "v"(w[3][0]), [l0] "v"(w[0][1]), [l1] "v"(w[1][1]), [l2] "v"(w[2][1]), [l3] "v"(w[3][1]), [d] "v"(d));
+    }
 #pragma unroll
-    for (int j = 0; j < K - 1; ++j) pr[j] = a[j] * w[j][1];
-    const float left = dpp_lower_zero(hand);
-#pragma unroll
-    for (int j = K - 1; j >= 1; --j) a[j] = fmaf(a[j], w[j][0], pr[j - 1]);
-    a[0] = fmaf(a[0], w[0][0], left);
+    for (int j = 0; j < K; ++j) a[j] = n[j];
 }
-// One beta step: diagonal n+1 -> n with the outgoing edge probabilities of diagonal n.
+// beta: diagonal n+1 -> n with the outgoing edge probabilities of diagonal n:
+//   b[j] <- b[j] p_blank[j] + b[j+1] p_label[j];  what arrives from lane + 1 is scaled into this lane's frame BEFORE the product
 template <int K>
 __device__ __forceinline__ void lin_beta_step(float (&bv)[K], const f32x2 (&w)[K], const int d) {
-    const float right = ldexp_f(dpp_upper_zero(bv[0]), d);  // lane + 1's first column, into this lane's frame
+    float st[K];
+    float right = dpp_upper_zero(bv[0]);
+    LIN_FENCE();
 #pragma unroll
-    for (int j = 0; j < K; ++j) bv[j] = fmaf(w[j][0], bv[j], w[j][1] * ((j == K - 1) ? right : bv[j + 1]));
+    for (int j = 0; j < K; ++j) st[j] = bv[j] * w[j][0];
+    LIN_FENCE();
+    right = ldexp_f(right, d);
+    LIN_FENCE();
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) bv[j] = fmaf(bv[j + 1], w[j][1], st[j]);
+    LIN_FENCE();
+    bv[K - 1] = fmaf(right, w[K - 1][1], st[K - 1]);
+    LIN_FENCE();
 }
 
+// Fully unrolled steps of one chunk.  Edge probabilities are read from LDS TWO rows ahead (three register sets): the reads of
+// row II + 2 are issued behind the arithmetic of step II (LDS latency ~64 clocks against a step of ~65), and they separate the
+// step's asm block from the diagonal's store (the compiler would otherwise pad with an s_nop).
 template <int K, int G, int II>
-__device__ __forceinline__ void lin_alpha_fast_steps(float (&a)[K], f32x2 (&wq)[2][K], const uint32_t abase, LinState &st,
+__device__ __forceinline__ void lin_alpha_fast_steps(float (&a)[K], f32x2 (&wq)[3][K], const uint32_t abase, LinState &st,
                                                      const int voff, const int lane, const int r0) {
     if constexpr (II < G) {
-        constexpr int cur = II & 1, nxt = cur ^ 1;
-        if constexpr (II + 1 < G) {
-            lds_issue_row<K, II + 1>(wq[nxt], abase);
-            lds_wait<K>();  // row II has landed, row II+1 stays in flight
-        } else {
-            lds_wait<0>();
+        constexpr int R = 1 << lin_shift(K);
+        if constexpr (LIN_KO != 3) {
+            if constexpr (II + 1 < G)
+                lds_wait<K>();  // row II has landed, row II+1 stays in flight
+            else
+                lds_wait<0>();
         }
-        lin_alpha_step<K>(a, wq[cur], st.d);
-        if constexpr (((II + 1) % kLinR) == 0) lin_renorm<K, false>(a, st, (r0 + II + 1) / kLinR);  // (r0 is a multiple of G)
-        constexpr int R = rows_per_base(K);
-        store_diag<K, true, (II % R) * 64 * K * 4>(st.row, voff, lane, a);
-        if constexpr (II % R == R - 1 || II == G - 1) st.row += (II % R + 1) * 64 * K;
+        if constexpr (LIN_KO != 4) lin_alpha_step<K>(a, wq[II % 3], st.d);
+        if constexpr (LIN_KO != 3 && II + 2 < G) lds_issue_row<K, II + 2>(wq[(II + 2) % 3], abase);
+        if constexpr (((II + 1) % R) == 0 && LIN_KO != 2) lin_renorm<K, false>(a, st, (r0 + II + 1) >> lin_shift(K));  // (r0 is a multiple of G)
+        constexpr int RB = rows_per_base(K);
+        if constexpr (LIN_KO != 1) store_diag<K, true, (II % RB) * 64 * K * 4>(st.row, voff, lane, a);
+        if constexpr (II % RB == RB - 1 || II == G - 1) st.row += (II % RB + 1) * 64 * K;
         lin_alpha_fast_steps<K, G, II + 1>(a, wq, abase, st, voff, lane, r0);
     }
 }
 template <int K, int G, int II>
-__device__ __forceinline__ void lin_beta_fast_steps(float (&bv)[K], f32x2 (&wq)[2][K], const uint32_t abase, LinState &st,
+__device__ __forceinline__ void lin_beta_fast_steps(float (&bv)[K], f32x2 (&wq)[3][K], const uint32_t abase, LinState &st,
                                                     const int voff, const int lane, const int r0) {
     if constexpr (II < G) {
-        constexpr int cur = II & 1, nxt = cur ^ 1;
+        constexpr int R = 1 << lin_shift(K);
         constexpr int i = G - 1 - II;  // row inside the chunk (descending)
-        if constexpr (i > 0) {
-            lds_issue_row<K, i - 1>(wq[nxt], abase);
-            lds_wait<K>();
-        } else {
-            lds_wait<0>();
+        if constexpr (LIN_KO != 3) {
+            if constexpr (i > 0)
+                lds_wait<K>();
+            else
+                lds_wait<0>();
         }
-        lin_beta_step<K>(bv, wq[cur], st.d);
-        if constexpr ((i % kLinR) == kLinR - 1) lin_renorm<K, true>(bv, st, (r0 + i) / kLinR);
-        constexpr int R = rows_per_base(K);
-        store_diag<K, true, -(II % R) * 64 * K * 4>(st.row, voff, lane, bv);
-        if constexpr (II % R == R - 1 || II == G - 1) st.row -= (II % R + 1) * 64 * K;
+        if constexpr (LIN_KO != 4) lin_beta_step<K>(bv, wq[II % 3], st.d);
+        if constexpr (LIN_KO != 3 && i >= 2) lds_issue_row<K, (i >= 2 ? i - 2 : 0)>(wq[(II + 2) % 3], abase);
+        if constexpr ((i % R) == R - 1 && LIN_KO != 2) lin_renorm<K, true>(bv, st, (r0 + i) >> lin_shift(K));
+        constexpr int RB = rows_per_base(K);
+        if constexpr (LIN_KO != 1) store_diag<K, true, -(II % RB) * 64 * K * 4>(st.row, voff, lane, bv);
+        if constexpr (II % RB == RB - 1 || II == G - 1) st.row -= (II % RB + 1) * 64 * K;
         lin_beta_fast_steps<K, G, II + 1>(bv, wq, abase, st, voff, lane, r0);
     }
 }
@@ -141,7 +186,7 @@ __device__ __forceinline__ void lin_record(const LossParams &p, const int b, con
 template <int K, int G, int NB>
 __device__ void lin_alpha_sweep(const LossParams &p, float *bufs, const LdLink lk, const int b, const int lane) {
     constexpr int Up = 64 * K, chunkf = G * 2 * Up;
-    static_assert(G % kLinR == 0, "frame blocks must not straddle chunks");
+    static_assert(G % (1 << lin_shift(K)) == 0, "frame blocks must not straddle chunks");
     const int Tb = length_T(p, b), Ub = length_U(p, b);
     const int Nb = Tb + Ub - 1;
     float *out = p.A + (size_t)b * p.Nr * Up;
@@ -174,8 +219,9 @@ __device__ void lin_alpha_sweep(const LossParams &p, float *bufs, const LdLink l
         const int r0 = ck * G;
         if (r0 + G <= last_row) {
             const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
-            f32x2 wq[2][K];
+            f32x2 wq[3][K];
             lds_issue_row<K, 0>(wq[0], abase);
+            lds_issue_row<K, 1>(wq[1], abase);
             lin_alpha_fast_steps<K, G, 0>(a, wq, abase, st, voff, lane, r0);
         } else {
             for (int i = 0; i < G; ++i) {
@@ -184,7 +230,7 @@ __device__ void lin_alpha_sweep(const LossParams &p, float *bufs, const LdLink l
                 f32x2 wc[K];
                 load_w<K>(wc, cur + i * 2 * Up);
                 lin_alpha_step<K>(a, wc, st.d);
-                if ((n % kLinR) == 0) lin_renorm<K, false>(a, st, n / kLinR);
+                if ((n & ((1 << lin_shift(K)) - 1)) == 0) lin_renorm<K, false>(a, st, n >> lin_shift(K));
                 store_diag<K, false>(st.row, voff, lane, a);
                 st.row += Up;
             }
@@ -233,8 +279,9 @@ __device__ void lin_beta_sweep(const LossParams &p, float *bufs, const LdLink lk
         const int r0 = ck * G;
         if (r0 + G - 1 < last) {
             const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
-            f32x2 wq[2][K];
+            f32x2 wq[3][K];
             lds_issue_row<K, G - 1>(wq[0], abase);
+            lds_issue_row<K, G - 2>(wq[1], abase);
             lin_beta_fast_steps<K, G, 0>(bv, wq, abase, st, voff, lane, r0);
         } else {
             for (int ii = 0; ii < G; ++ii) {
@@ -244,7 +291,7 @@ __device__ void lin_beta_sweep(const LossParams &p, float *bufs, const LdLink lk
                 f32x2 wc[K];
                 load_w<K>(wc, cur + i * 2 * Up);
                 lin_beta_step<K>(bv, wc, st.d);
-                if ((n % kLinR) == kLinR - 1 || n == last) lin_renorm<K, true>(bv, st, n / kLinR);
+                if ((n & ((1 << lin_shift(K)) - 1)) == (1 << lin_shift(K)) - 1 || n == last) lin_renorm<K, true>(bv, st, n >> lin_shift(K));
                 store_diag<K, false>(st.row, voff, lane, bv);
                 st.row -= Up;
             }
@@ -286,50 +333,78 @@ __global__ __launch_bounds__(128) void lin_sweep_kernel(const LossParams p) {
 
 // ---------------------------------------------------------------------------------------------
 // The hand-back: ONE small launch at the end of every call of the linear path (grid = utterances; a workgroup whose
-// utterance is fine returns at once).  An utterance is redone when a sweep flagged it (kFlagA / kFlagB), when the two
-// likelihoods disagree, when the gradient pass's certificate failed for one of its cells (kFlagG), or when `force` is set
-// (a gradient buffer the patch kernels cannot write): the workgroup rebuilds the utterance's edge weights in the log2 domain
-// from the logits, runs the round-3 log-domain sweeps (exact for any range) and, if gradients are wanted, writes all of the
-// utterance's gradients -- every stage the code the large-vocabulary path runs, by one workgroup.  Slow (a millisecond for a
-// 600 x 150 lattice) and rare.  Afterwards the utterance's state word says that its lattice is in the log format, so that a
-// later backward-only call goes straight to the gradient stage here.
+// utterance is fine reads two 16-byte words and returns).  An utterance is redone when a sweep flagged it (kFlagA / kFlagB),
+// when the two likelihoods disagree, when the gradient pass's certificate failed for one of its cells (kFlagG), or when
+// `force` is set (a gradient buffer the patch kernels cannot write): the workgroup rebuilds the utterance's edge weights in the
+// log2 domain from the logits (one lattice cell per thread, straight from global memory), runs the round-3 log-domain sweeps
+// (exact for any range; two of its eight waves) and, if gradients are wanted, writes all of the utterance's gradients (again a
+// cell per thread).  Slow -- about a millisecond for a 600 x 150 lattice -- and rare.  Afterwards the utterance's state word
+// says that its lattice is in the log format, so that a later backward-only call goes straight to the gradient stage here.
 // ---------------------------------------------------------------------------------------------
+constexpr int kRedoThreads = 512;
+
 __device__ __forceinline__ void redo_phase_sync() {
     __threadfence();  // this workgroup's global stores are visible device-wide ...
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ... and nothing stale is served from this CU's vector L1
 }
 
+// The cells [c0, c1) of one utterance, one per thread, logits and gradients in global memory.
+template <bool GRAD>
+__device__ __forceinline__ void redo_cells(const LossParams &p, const uint32_t c0, const uint32_t c1, const int tid) {
+    const bool v4 = (p.V % 4) == 0 && (((uintptr_t)p.acts | (uintptr_t)p.grads) & 15) == 0;
+    for (uint32_t c = c0 + (uint32_t)tid; c < c1; c += kRedoThreads) {
+        const Cell cl = decode(p, c);
+        const float *xs = p.acts + (size_t)c * p.V;
+        float *out = GRAD ? p.grads + (size_t)c * p.V : nullptr;
+        if (!GRAD && !cl.valid) continue;
+        if (p.V <= 32) {
+            if (v4)
+                cell_body<32, true, GRAD, false, true>(p, cl, c, xs, out);
+            else
+                cell_body<32, false, GRAD, false, true>(p, cl, c, xs, out);
+        } else {
+            if (v4)
+                cell_body<64, true, GRAD, false, true>(p, cl, c, xs, out);
+            else
+                cell_body<64, false, GRAD, false, true>(p, cl, c, xs, out);
+        }
+    }
+}
+
 template <int K, int G, int NB>
-__global__ __launch_bounds__(128) void lin_redo_kernel(const LossParams p, const int force) {
+__global__ __launch_bounds__(kRedoThreads) void lin_redo_kernel(const LossParams p, const int force) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int chunkf = G * 2 * 64 * K;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = p.b0 + (int)blockIdx.x;
     int *fl = p.flags + 4 * b;
-    const int state = ld_i32_sc1(fl + kFlagState);
+    // one round trip: the four flag words and the two likelihoods (both written write-through by the sweeps / the gradient pass)
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const i32x4 fw = __builtin_nontemporal_load((const i32x4 *)fl);
+    const f64x2 lw = __builtin_nontemporal_load((const f64x2 *)(p.ll + 2 * b));
+    const int state = fw[kFlagState];
     bool redo = false;
     if (state != 2) {
-        const double la = ld_f64<true>(p.ll + 2 * b), lb = ld_f64<true>(p.ll + 2 * b + 1);
         // |cost_alpha - cost_beta| in nats against what two float32 sweeps of the same lattice differ by (<= 1e-6 measured)
-        const bool agree = fabs(la - lb) * 0.6931471805599453 <= 2e-5 + 1e-8 * fabs(la);
-        redo = force || (ld_i32_sc1(fl + kFlagA) | ld_i32_sc1(fl + kFlagB) | ld_i32_sc1(fl + kFlagG)) != 0 || !agree;
+        const bool agree = fabs(lw[0] - lw[1]) * 0.6931471805599453 <= 2e-5 + 1e-8 * fabs(lw[0]);
+        redo = force || (fw[kFlagA] | fw[kFlagB] | fw[kFlagG]) != 0 || !agree;
         if (!redo) return;
     } else if (!p.grads) {
         return;
     }
     const uint32_t c0 = (uint32_t)b * (uint32_t)p.T * (uint32_t)p.U, c1 = c0 + (uint32_t)p.T * (uint32_t)p.U;
-    const uint32_t cm = c0 + (c1 - c0) / 2;
     if (redo) {
         // ---- log2-domain edge weights of this utterance: log zero everywhere, then the cells ----
         uint32_t *Wb = (uint32_t *)(p.W + (size_t)b * p.Nr * 2 * p.Up);
-        const uint32_t fw = (uint32_t)kFillByte * 0x01010101u;
-        for (size_t i = tid; i < (size_t)p.Nr * 2 * p.Up; i += 128) Wb[i] = fw;
+        const uint32_t lz = (uint32_t)kFillByte * 0x01010101u;
+        for (size_t i = tid; i < (size_t)p.Nr * 2 * p.Up; i += kRedoThreads) Wb[i] = lz;
         redo_phase_sync();
-        cell_wave_range<false, false>(p, wave ? cm : c0, wave ? c1 : cm, lane);
+        redo_cells<false>(p, c0, c1, tid);
         redo_phase_sync();
-        // ---- the log-domain sweeps, one after the other ----
+        // ---- the log-domain sweeps, one after the other, by waves 0 (sweeping) and 1 (loading) ----
         int *ctr = (int *)(lds + NB * chunkf);
         LdLink lk;
         lk.landed = (uint32_t)(uintptr_t)((lds_void *)ctr);
@@ -338,19 +413,19 @@ __global__ __launch_bounds__(128) void lin_redo_kernel(const LossParams p, const
         __syncthreads();
         if (wave == 1)
             sweep_loader<K, G, NB, false>(p, lds, lk, b, lane);
-        else
+        else if (wave == 0)
             alpha_sweep_ld<K, G, NB>(p, lds, lk, b, lane);
         __syncthreads();
         if (tid < 2) ctr[tid] = 0;
         __syncthreads();
         if (wave == 1)
             sweep_loader<K, G, NB, true>(p, lds, lk, b, lane);
-        else
+        else if (wave == 0)
             beta_sweep_ld<K, G, NB>(p, lds, lk, b, lane);
         redo_phase_sync();
         if (tid == 0) st_i32_wt(fl + kFlagState, 2);
     }
-    if (p.grads) cell_wave_range<false, true, true>(p, wave ? cm : c0, wave ? c1 : cm, lane);
+    if (p.grads) redo_cells<true>(p, c0, c1, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -383,7 +458,7 @@ static hipError_t launch_lin_redo(const LossParams &p, const bool force, hipStre
         hipError_t e = hipFuncSetAttribute((const void *)lin_redo_kernel<K, G, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((lin_redo_kernel<K, G, NB>), dim3(p.nb), dim3(128), shm, s, p, force ? 1 : 0);
+    hipLaunchKernelGGL((lin_redo_kernel<K, G, NB>), dim3(p.nb), dim3(kRedoThreads), shm, s, p, force ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -2,8 +2,17 @@
 # Dev tool: build an experimental variant of libwarprnnt.so with extra -D flags, e.g.
 #   scripts/build_variant.sh trace -DJH_TRACE      -> rnnt-speech-recognition_amd/lib/libwarprnnt_trace.so
 # and run anything with RNNT_LIBWARPRNNT=<that path> to load it instead of the product library.
+# (Same per-source flags as rnnt-speech-recognition_amd/build.py.)
 set -e
 NAME=$1; shift
 D=$(cd "$(dirname "$0")/.." && pwd)/rnnt-speech-recognition_amd
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -Wno-inline-asm "$@" $D/csrc/rnnt_kernels.hip $D/csrc/rnnt_lin_kernels.hip $D/csrc/joint_kernels.hip $D/csrc/joint_f16_kernels.hip $D/csrc/dense_kernels.hip $D/csrc/rnnt_entrypoint.hip -o $D/lib/libwarprnnt_$NAME.so
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-inline-asm"
+T=$(mktemp -d)
+for s in rnnt_kernels rnnt_lin_kernels joint_kernels joint_f16_kernels dense_kernels rnnt_entrypoint; do
+  X=""; [[ $s == rnnt_lin_kernels ]] && X="-fno-slp-vectorize"
+  /opt/rocm/bin/hipcc $F $X "$@" -c $D/csrc/$s.hip -o $T/$s.o &
+done
+wait
+/opt/rocm/bin/hipcc $F -shared $T/*.o -o $D/lib/libwarprnnt_$NAME.so
+rm -rf $T
 echo $D/lib/libwarprnnt_$NAME.so

@@ -21,7 +21,7 @@ F = np.float32
 LOG2E = F(1.4426950408889634)
 BIG = -1.0e30       # frame of a lane that holds no mass and has no neighbour to copy from
 DRAG = 118.0        # a lane's frame is at most this far below the frames of the lanes mass can arrive from within a block
-CERT_BITS = -45.0   # per-cell bound on (lost mass x other side) / likelihood, in bits
+CERT_BITS = -40.0   # (csrc/rnnt_lin.h kCertBits) per-cell bound on (lost mass x other side) / likelihood, in bits
 TINY_EDGE = -100.0  # an edge the lattice owns with log2 p below this is not representable safely: log-domain path
 
 
@@ -213,7 +213,7 @@ def run(kind, T, U, V, seed, K, R):
 
 if __name__ == "__main__":
     T, U, V = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "600,150,28").split(","))
-    R = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    R = int(sys.argv[2]) if len(sys.argv) > 2 else (4 if (U + 63) // 64 == 1 else 8)  # csrc/rnnt_lin.h lin_shift
     k = (U + 63) // 64
     K = next(a for a in (1, 2, 3, 4, 6, 8, 12, 16) if k <= a)
     kinds = ["sigma1", "sigma4", "sigma8", "trained10", "trained10late", "trained20late"]
