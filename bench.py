@@ -405,10 +405,15 @@ def bench_op_shape(lib, _lib, dev, B, T, U, V, stream, reps):
     cells = B * T * U
     alg = 8.0 * V * cells
     finite = bool(torch.isfinite(costs).all())
+    picks = [0, B - 1]
+    ref = f64_costs(acts, labels, picks)
+    got = costs.cpu().numpy().astype(np.float64)
+    dcost = max(abs(got[b] - r) / max(1.0, abs(r)) for b, r in zip(picks, ref))
     del acts, grads, ws
     torch.cuda.empty_cache()
     return {"workload": f"transducer loss+grad on given f32 logits, B={B} T={T} U={U} V={V}, full lengths, acts~N(0,1)",
             "dtype": "f32", "ms_per_step": dt * 1e3, "cells_per_s": cells / dt, "costs_finite": finite,
+            "max_rel_dcost": dcost, "max_rel_dcost_note": f"utterances {picks} against a float64 evaluation of the same logits (bar 1e-4)",
             "roofline": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / dt / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg,
                          "note": "whole op (lsm + sweeps + gradient pass), 8*V bytes per cell"}}
@@ -418,14 +423,76 @@ def joint_bucket_floats(H, J, V):
     return H * J + J + J * V + V
 
 
-def rocprof_grad_ms():
-    """Average duration of the full-length gradient-pass launches from the committed rocprofv3 kernel trace of this same
-    command (profiles/r03_kernel_stats.json, written by scripts/summarize_trace.py), if present."""
+def csrc_sha16():
+    """Fingerprint of the kernel sources (scripts/summarize_trace.py stamps the committed profiles with the same one): a
+    profile is quoted only while the kernels it was taken from are the ones in the tree."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rnnt-speech-recognition_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_profile(name):
+    """profiles/<name> if it was taken from the kernel sources of this tree, else None (a stale profile is not quoted)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r03_kernel_stats.json")))
-        return d["headline_kernels"]["grad_pass"]["avg_ms"]
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        return d if d.get("csrc_sha16") == csrc_sha16() else None
     except Exception:
         return None
+
+
+def rocprof_grad_ms():
+    """Average duration of the full-length gradient-pass launches from the committed rocprofv3 kernel trace of this same
+    command (profiles/kernel_stats_latest.json, written by scripts/summarize_trace.py), if it matches the tree."""
+    d = committed_profile("kernel_stats_latest.json")
+    try:
+        return d["headline_kernels"]["grad_pass"]["avg_ms"] if d else None
+    except Exception:
+        return None
+
+
+def sweep_ns_per_diagonal(n_diag):
+    """The alpha / beta sweeps are a lone wave's dependent chain of T + U - 1 steps per utterance: kernel time / steps, from the
+    committed rocprofv3 trace (None when the kernels changed since)."""
+    d = committed_profile("kernel_stats_latest.json")
+    try:
+        return d["headline_kernels"]["sweeps"]["avg_ms"] * 1e6 / n_diag if d else None
+    except Exception:
+        return None
+
+
+def f64_costs(acts, labels, picks):
+    """Checker (outside every timed region): float64 transducer costs of the full-length utterances `picks` -- log-softmax in
+    float64 on the device, the forward recurrence alpha(t,u) = lse(alpha(t-1,u) + lp_blank(t-1,u), alpha(t,u-1) +
+    lp_label(t,u-1)) by anti-diagonals on the host (Graves 2012 eq. 16)."""
+    out = []
+    for b in picks:
+        T, U, V = acts.shape[1:]
+        lpb = torch.empty(T, U, dtype=torch.float64)
+        lpl = torch.empty(T, max(U - 1, 1), dtype=torch.float64)
+        lab = labels[b].long()
+        for t0 in range(0, T, 100):
+            x = acts[b, t0:t0 + 100].double()
+            lse = torch.logsumexp(x, dim=-1)
+            lpb[t0:t0 + 100] = (x[:, :, 0] - lse).cpu()
+            if U > 1:
+                lpl[t0:t0 + 100] = (torch.gather(x[:, :U - 1], 2, lab[None, :, None].expand(x.shape[0], -1, 1))[:, :, 0] - lse[:, :U - 1]).cpu()
+        lpb, lpl = lpb.numpy(), lpl.numpy()
+        a = np.full((T, U), -np.inf)
+        a[0, 0] = 0.0
+        for n in range(1, T + U - 1):
+            u = np.arange(max(0, n - T + 1), min(n, U - 1) + 1)
+            t = n - u
+            up = np.where(t >= 1, a[np.maximum(t - 1, 0), u] + lpb[np.maximum(t - 1, 0), u], -np.inf)
+            lf = np.where(u >= 1, a[t, np.maximum(u - 1, 0)] + lpl[t, np.maximum(u - 1, 0)], -np.inf)
+            a[t, u] = np.logaddexp(up, lf)
+        out.append(-(a[T - 1, U - 1] + lpb[T - 1, U - 1]))
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -594,24 +661,23 @@ def main():
         t_b = float(np.mean([e1.elapsed_time(e2) for _, e1, e2 in ef])) * 1e-3
         alg = 8.0 * V * cells  # read each f32 logit once + write each f32 gradient once
         ach_grad = alg / t_b / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("grad_kernel_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        pmc = committed_profile("pmc_latest.json")  # None when the kernels changed since it was taken
+        traffic = pmc.get("grad_kernel_hbm_bytes_per_launch") if pmc else None
         roof = {
             "bound": "hbm",
-            "kernel": "gradient pass rnnt::cell_tile_kernel<32, true>: reads V logits + writes V grads per cell",
+            "kernel": "gradient pass rnnt::cell_tile_kernel<32, true, true, true>: reads V logits + writes V grads per cell",
             "achieved": ach_grad, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_grad / HBM_PEAK_GBS,
             "traffic": traffic,
             "algorithmic_bytes_per_launch": alg,
             "kernel_avg_ms": t_b * 1e3,
-            "kernel_avg_ms_source": "HIP events on the launch stream around compute_rnnt_loss_bwd, which is exactly one launch "
-                                    "of this kernel (full-length utterances, rotating logits buffers)",
+            "kernel_avg_ms_source": "HIP events on the launch stream around compute_rnnt_loss_bwd = ONE launch of this kernel + the "
+                                    "hand-back launch of the linear lattice, whose workgroups read two words and return (~4 us: the "
+                                    "figure is that much on the safe side; full-length utterances, rotating logits buffers)",
+            "profiles_csrc_sha16": csrc_sha16(),
+            "step_traffic_over_algorithmic": (pmc.get("step_traffic_over_algorithmic") if pmc else None),
             "rocprof_avg_ms": rocprof_grad_ms(),
-            "whole_op": {"note": "same algorithmic bytes over the whole timed step (fill + lsm + sweeps + gradient pass)",
+            "sweep_ns_per_diagonal": sweep_ns_per_diagonal(T + U - 1),
+            "whole_op": {"note": "same algorithmic bytes over the whole timed step (lsm + sweeps + gradient pass + hand-back launch)",
                          "achieved": alg / (dt / a.steps) / 1e9, "frac": alg / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
                          "fwd_ms": t_f * 1e3, "bwd_ms": t_b * 1e3},
         }

@@ -6,13 +6,9 @@
 // RNNT_STATUS_INVALID_VALUE; nothing is allocated; everything is enqueued on the caller's stream.
 #include "../../include/rnnt.h"
 #include "rnnt_common.h"
+#include "rnnt_lin.h"
 
 using namespace rnnt;
-
-#ifndef RNNT_LINSHIFT
-#define RNNT_LINSHIFT 3
-#endif
-#define RNNT_LINSHIFT_HOST RNNT_LINSHIFT  // rnnt_lin.h lin_shift(K) for K > 1 (device header: not included here)
 
 namespace rnnt {
 // joint_kernels.hip
@@ -72,7 +68,7 @@ static bool fill_params(LossParams &p, const float *acts, float *grads, const in
     p.lik = (float *)(ws + w.lik);
     p.flags = (int *)(ws + w.flags);
     p.NCl = w.NCl;
-    p.linShift = (sweep_K(o.maxU) == 1) ? 2 : RNNT_LINSHIFT_HOST;
+    p.linShift = lin_shift(sweep_K(o.maxU));
     p.B = B, p.T = o.maxT, p.U = o.maxU, p.V = V, p.blank = o.blank_label;
     p.b0 = 0, p.nb = B;
     p.tile = make_tile(o.maxT, o.maxU, V);

@@ -20,11 +20,12 @@ namespace rnnt {
 // Diagonals per frame block: a lane renormalises (and the frame tables get a row) every 2^lin_shift(K) diagonals.  Eight, where
 // measured: the renormalisation is ~22 instructions of the sweeping wave (4 us of the sweep at B32 T600 U150 with blocks of four).
 // N(0,1) logits lose ~5 bits per diagonal, i.e. 40 of the 126 bits of room per block; 4 x N(0,1) logits exceed the room and
-// take the log-domain path.  K = 1: blocks of four (mass crosses a lane per diagonal: the frame look-back is 4 lanes deep).
+// take the log-domain path.  K = 1: blocks of four (mass crosses a lane per diagonal: the frame look-back is 4 lanes deep);
+// K = 12, 16: blocks of four (their LDS chunks are four diagonals long, and a frame spans many columns).
 #ifndef RNNT_LINSHIFT
 #define RNNT_LINSHIFT 3
 #endif
-__host__ __device__ constexpr int lin_shift(int K) { return K == 1 ? 2 : RNNT_LINSHIFT; }
+__host__ __device__ constexpr int lin_shift(int K) { return (K == 1 || K >= 12) ? 2 : RNNT_LINSHIFT; }
 constexpr int kLinDrag = 118;            // a lane's frame is at most this far below the lanes mass can reach it from within a block
 constexpr int kFrameNone = -(1 << 28);   // frame of a lane without mass and without a neighbour to copy from
 constexpr int kCertBits = -40;           // per-cell bound (bits) on flush loss x other side / likelihood

@@ -84,7 +84,16 @@ template <int K>
 __device__ __forceinline__ void lin_alpha_step(float (&a)[K], const f32x2 (&w)[K], const int d) {
     // ONE asm block: the compiler puts the hand-over product right in front of the DPP move (s_nop 1).  Inputs and outputs are
     // separate registers, so that the new diagonal can land in the register triple the store instruction wants.
-    static_assert(K >= 1 && K <= 4, "spelled out for K = 1 .. 4");
+    if constexpr (K > 4) {  // wide lattices: left to the compiler (their step is long enough to hide its own latencies)
+        float pr[K];
+        const float hand = ldexp_f(a[K - 1], d) * w[K - 1][1];
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) pr[j] = a[j] * w[j][1];
+        const float left = dpp_lower_zero(hand);
+#pragma unroll
+        for (int j = K - 1; j >= 1; --j) a[j] = fmaf(a[j], w[j][0], pr[j - 1]);
+        a[0] = fmaf(a[0], w[0][0], left);
+    } else {
     float n[K], as, q, pr[K > 1 ? K - 1 : 1];
     if constexpr (K == 1) {
         asm volatile("v_ldexp_f32 %[as], %[a0], %[d]\n\tv_mul_f32 %[as], %[as], %[l0]\n\ts_nop 1\n\tv_mov_b32_dpp %[q], %[as] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fma_f32 %[n0], %[a0], %[b0], %[q]"
@@ -105,6 +114,7 @@ __device__ __forceinline__ void lin_alpha_step(float (&a)[K], const f32x2 (&w)[K
     }
 #pragma unroll
     for (int j = 0; j < K; ++j) a[j] = n[j];
+    }
 }
 // beta: diagonal n+1 -> n with the outgoing edge probabilities of diagonal n:
 //   b[j] <- b[j] p_blank[j] + b[j+1] p_label[j];  what arrives from lane + 1 is scaled into this lane's frame BEFORE the product
@@ -217,7 +227,7 @@ __device__ void lin_alpha_sweep(const LossParams &p, float *bufs, const LdLink l
         }
         const float *cur = bufs + (ck % NB) * chunkf + 2 * u0;
         const int r0 = ck * G;
-        if (r0 + G <= last_row) {
+        if (K <= 15 && r0 + G <= last_row) {  // (lgkmcnt counts to 15)
             const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
             f32x2 wq[3][K];
             lds_issue_row<K, 0>(wq[0], abase);
@@ -277,7 +287,7 @@ __device__ void lin_beta_sweep(const LossParams &p, float *bufs, const LdLink lk
         }
         const float *cur = bufs + (i_ring % NB) * chunkf + 2 * u0;
         const int r0 = ck * G;
-        if (r0 + G - 1 < last) {
+        if (K <= 15 && r0 + G - 1 < last) {
             const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
             f32x2 wq[3][K];
             lds_issue_row<K, G - 1>(wq[0], abase);
@@ -431,16 +441,14 @@ __global__ __launch_bounds__(kRedoThreads) void lin_redo_kernel(const LossParams
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-// The linear path covers what the patch kernels cover (V <= 60, 16-byte-aligned logits) on lattices of up to 256 columns
-// (K <= 4 columns per sweep lane: one frame per lane then spans few enough columns; wider lattices keep the log-domain sweeps).
-bool lin_path_ok(const LossParams &p) {
-    const int K = sweep_K(p.U);
-    return K >= 1 && K <= 4 && tile_path_ok(p, false);
-}
+// The linear path covers what the patch kernels cover (V <= 60, 16-byte-aligned logits) on every lattice the register-resident
+// sweeps cover (up to 1024 columns).  One frame per lane spans up to 16 columns there: lattices on which that is too coarse
+// (more label columns than frames, unstructured logits) fail the certificate and are redone in the log domain.
+bool lin_path_ok(const LossParams &p) { return sweep_K(p.U) >= 1 && tile_path_ok(p, false); }
 
 template <int K, int G>
 static hipError_t launch_lin_sweep(const LossParams &p, hipStream_t s) {
-    constexpr int NB = 4;
+    constexpr int NB = ((size_t)4 * G * 2 * 64 * K * sizeof(float) + 16 <= 128 * 1024) ? 4 : 3;
     constexpr size_t shm = (size_t)NB * G * 2 * 64 * K * sizeof(float) + 16;
     static_assert(shm <= 160 * 1024, "chunk ring exceeds the LDS");
     if (shm > 64 * 1024) {
@@ -452,7 +460,7 @@ static hipError_t launch_lin_sweep(const LossParams &p, hipStream_t s) {
 }
 template <int K, int G>
 static hipError_t launch_lin_redo(const LossParams &p, const bool force, hipStream_t s) {
-    constexpr int NB = 4;
+    constexpr int NB = ((size_t)4 * G * 2 * 64 * K * sizeof(float) + 16 <= 128 * 1024) ? 4 : 3;
     constexpr size_t shm = (size_t)NB * G * 2 * 64 * K * sizeof(float) + 16;
     if (shm > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)lin_redo_kernel<K, G, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -468,6 +476,10 @@ hipError_t launch_sweeps_lin(const LossParams &p, hipStream_t s) {
         case 2: return launch_lin_sweep<2, 16>(p, s);
         case 3: return launch_lin_sweep<3, 16>(p, s);
         case 4: return launch_lin_sweep<4, 16>(p, s);
+        case 6: return launch_lin_sweep<6, 8>(p, s);
+        case 8: return launch_lin_sweep<8, 8>(p, s);
+        case 12: return launch_lin_sweep<12, 4>(p, s);
+        case 16: return launch_lin_sweep<16, 4>(p, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -477,6 +489,10 @@ hipError_t launch_redo_lin(const LossParams &p, const bool force, hipStream_t s)
         case 2: return launch_lin_redo<2, 16>(p, force, s);
         case 3: return launch_lin_redo<3, 16>(p, force, s);
         case 4: return launch_lin_redo<4, 16>(p, force, s);
+        case 6: return launch_lin_redo<6, 8>(p, force, s);
+        case 8: return launch_lin_redo<8, 8>(p, force, s);
+        case 12: return launch_lin_redo<12, 4>(p, force, s);
+        case 16: return launch_lin_redo<16, 4>(p, force, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -13,18 +13,23 @@ if has smoke; then
 fi
 if has loss; then
   echo "== loss-op parity (tests/test_loss_gpu.py + peaked logits)"
-  timeout 1200 python -m pytest tests/test_loss_gpu.py tests/test_peaky_gpu.py -m gpu -q --durations=5 ${PYTEST_ARGS} > $OUT/pytest_loss.log 2>&1; echo "loss rc=$?"
+  timeout 1200 python -m pytest tests/test_loss_gpu.py tests/test_lin_gpu.py tests/test_peaky_gpu.py -m gpu -q --durations=5 ${PYTEST_ARGS} > $OUT/pytest_loss.log 2>&1; echo "loss rc=$?"
   tail -25 $OUT/pytest_loss.log
 fi
 if has test; then
   echo "== pytest -m gpu (without the peaked-logit file)"
-  timeout 1500 python -m pytest tests -m gpu -q --durations=8 --deselect tests/test_peaky_gpu.py ${PYTEST_ARGS} > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+  timeout 1500 python -m pytest tests -m gpu -q --durations=8 --deselect tests/test_peaky_gpu.py --deselect tests/test_peaky_wide_gpu.py ${PYTEST_ARGS} > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"
   tail -25 $OUT/pytest_gpu.log
 fi
 if has peaky; then
   echo "== peaked-logit parity"
   timeout 900 python -m pytest tests/test_peaky_gpu.py -m gpu -q > $OUT/pytest_peaky.log 2>&1; echo "peaky rc=$?"
-  tail -15 $OUT/pytest_peaky.log; cp gpurun_out/r04_accuracy.json $OUT/ 2>/dev/null; cat $OUT/r04_accuracy.json
+  tail -15 $OUT/pytest_peaky.log; cp gpurun_out/r04_accuracy*.json $OUT/ 2>/dev/null; cat $OUT/r04_accuracy.json
+fi
+if has wide; then
+  echo "== peaked logits on wide lattices + the op at configs[4]'s shape at full size"
+  timeout 1500 python -m pytest tests/test_peaky_wide_gpu.py -m gpu -q --durations=5 > $OUT/pytest_wide.log 2>&1; echo "wide rc=$?"
+  tail -25 $OUT/pytest_wide.log; cp gpurun_out/r04_accuracy_wide.json $OUT/ 2>/dev/null; cat $OUT/r04_accuracy_wide.json
 fi
 if has bench; then
   echo "== bench"; timeout 900 python bench.py ${BENCH_ARGS} > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
@@ -34,6 +39,7 @@ if has prof; then
   echo "== rocprof kernel trace of the op-level bench (full-length launches only)"
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fused --no-ragged --no-e2e --no-config5 > $R/$OUT/rocprof.log 2>&1); echo "rocprof rc=$?"
   python scripts/summarize_trace.py stats $OUT/prof $OUT/kernel_stats.json $OUT/kernel_stats.csv
+  cp $OUT/kernel_stats.json $OUT/kernel_stats_latest.json
 fi
 if has profj; then
   echo "== rocprof kernel trace, fused f32-grade joint at C2"
@@ -54,6 +60,7 @@ if has pmc; then
     (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/pmc/$c -o pmc -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fused --no-ragged --no-e2e --no-config5 > $R/$OUT/pmc_$c.log 2>&1); echo "pmc $c rc=$?"
   done
   python scripts/summarize_trace.py pmc $OUT/pmc $OUT/pmc_op.json
+  python scripts/summarize_trace.py latest $OUT/pmc_op.json $OUT/pmc_latest.json 645120000
 fi
 if has c5; then
   echo "== config 5 fused f16 joint: time + kernel trace"

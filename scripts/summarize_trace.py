@@ -10,7 +10,21 @@ import glob
 import json
 import os
 import re
+import hashlib
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_sha16():
+    """Fingerprint of the kernel sources a profile was taken from (bench.py quotes a committed profile only while it matches)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rnnt-speech-recognition_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def short(name):
@@ -22,7 +36,9 @@ def short(name):
 HEADLINE = {  # names the bench's roofline object refers to
     "grad_pass": ("cell_tile_kernel", "true"),
     "lsm_pass": ("cell_tile_kernel", "false"),
-    "sweeps": ("sweep_ld_kernel",),
+    "sweeps": ("sweep_kernel",),
+    "sweeps_log": ("sweep_ld_kernel",),
+    "redo": ("lin_redo_kernel",),
     "fill": ("fillBuffer",),
     "step": ("rnnt_step_kernel",),
 }
@@ -54,7 +70,7 @@ def stats(d, out_json, out_csv=None):
                 head[key] = {"kernel": k["kernel"], "calls": k["calls"], "avg_ms": k["avg_ms"], "min_ms": k["min_ms"],
                              "max_ms": k["max_ms"]}
                 break
-    json.dump({"source": "rocprofv3 --kernel-trace --stats", "headline_kernels": head, "kernels": kernels[:40]},
+    json.dump({"source": "rocprofv3 --kernel-trace --stats", "csrc_sha16": csrc_sha16(), "headline_kernels": head, "kernels": kernels[:40]},
               open(out_json, "w"), indent=1)
     if out_csv:
         with open(out_csv, "w") as f:
@@ -77,15 +93,41 @@ def pmc(d, out_json):
     out = collections.defaultdict(dict)
     for (kern, ctr), (n, tot) in sorted(agg.items()):
         out[kern][ctr] = {"launches": n, "avg": tot / n}
-    json.dump({"source": "rocprofv3 --pmc (one counter group per pass)", "kernels": out}, open(out_json, "w"), indent=1)
+    json.dump({"source": "rocprofv3 --pmc (one counter group per pass)", "csrc_sha16": csrc_sha16(), "kernels": out}, open(out_json, "w"), indent=1)
     for kern, c in out.items():
         if any(s in kern for s in ("rnnt", "fill")):
             print(kern[:80], {k: round(v["avg"]) for k, v in c.items()})
 
 
+def latest(pmc_json, out_json, cells_bytes):
+    """HBM bytes per launch of the op-level kernels from a FETCH_SIZE / WRITE_SIZE pmc summary (KiB; FETCH doubled: on gfx950
+    FETCH_SIZE reports half of the bytes of wide streaming reads, /opt/skills/guides/MI355X_MICROARCH.md)."""
+    d = json.load(open(pmc_json))
+    roles = {"grad": ("cell_tile_kernel", ", true,"), "lsm": ("cell_tile_kernel", ", false,"), "sweep": ("sweep_kernel",),
+             "redo": ("lin_redo_kernel",)}
+    out = {"source": f"{os.path.basename(pmc_json)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB; FETCH doubled per "
+                     "the gfx950 note of MI355X_MICROARCH.md)", "csrc_sha16": d.get("csrc_sha16")}
+    step = 0.0
+    for role, needles in roles.items():
+        for kern, c in d["kernels"].items():
+            if all(n in kern for n in needles) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                b = (2.0 * c["FETCH_SIZE"]["avg"] + c["WRITE_SIZE"]["avg"]) * 1024.0
+                out[f"{role}_kernel_hbm_bytes_per_launch"] = b
+                out[f"{role}_kernel"] = kern
+                step += b
+                break
+    out["step_hbm_bytes"] = step
+    out["algorithmic_bytes_per_step"] = float(cells_bytes)
+    out["step_traffic_over_algorithmic"] = step / float(cells_bytes)
+    json.dump(out, open(out_json, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
-    if mode == "stats":
+    if mode == "latest":
+        latest(sys.argv[2], sys.argv[3], float(sys.argv[4]) if len(sys.argv) > 4 else 645120000.0)
+    elif mode == "stats":
         stats(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
     else:
         pmc(sys.argv[2], sys.argv[3])

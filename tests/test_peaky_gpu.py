@@ -14,7 +14,7 @@ set by the float32 REPRESENTATION of the lattice's inputs, not by the recurrence
 (the sweep re-run in float64 over the GPU's own f32 edge weights): at 8 sigma the rounding of the log2-probabilities to f32
 (|log2 p| up to ~100, costs of 7,500 nats) alone moves alpha by up to 1.4e-4 nats at cells that carry posterior mass, the
 sweeps add 0.7-1.0e-4 (per-lane re-basing; 2-3e-4 with one offset per diagonal).  include/rnnt.h states this bound.
-The measured maxima are written to gpurun_out/r03_accuracy.json (copied to profiles/ by hand)."""
+The measured maxima are written to gpurun_out/r04_accuracy.json (copied to profiles/ by hand)."""
 import json
 import math
 import os
@@ -42,7 +42,7 @@ def _setup():
     yield
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r03_accuracy.json"), "w") as f:
+    with open(os.path.join(out, "r04_accuracy.json"), "w") as f:
         json.dump(_report, f, indent=1, sort_keys=True)
 
 
