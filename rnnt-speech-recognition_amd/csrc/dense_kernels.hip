@@ -400,9 +400,8 @@ __global__ __launch_bounds__(kNtThreads) void dense_gemm_nt_kernel(const DenseNT
             }
             *(float4 *)(C + o) = v;
             if (tables) {
-                big |= !(fabsf(v.x) <= 43.0f) || !(fabsf(v.y) <= 43.0f) || !(fabsf(v.z) <= 43.0f) || !(fabsf(v.w) <= 43.0f);  // kExpTabLimit; NaN too
-                *(float4 *)(E + o) = make_float4(__builtin_amdgcn_exp2f(v.x * 2.8853900817779268f), __builtin_amdgcn_exp2f(v.y * 2.8853900817779268f),
-                                                 __builtin_amdgcn_exp2f(v.z * 2.8853900817779268f), __builtin_amdgcn_exp2f(v.w * 2.8853900817779268f));
+                big |= exp_tab_out_of_range(v.x) || exp_tab_out_of_range(v.y) || exp_tab_out_of_range(v.z) || exp_tab_out_of_range(v.w);  // (rnnt_common.h)
+                *(float4 *)(E + o) = make_float4(exp_tab(v.x), exp_tab(v.y), exp_tab(v.z), exp_tab(v.w));
             }
         }
     }

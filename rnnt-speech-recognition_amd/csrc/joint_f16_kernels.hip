@@ -62,7 +62,6 @@ __device__ __forceinline__ float htanh(float x) {
 __device__ __forceinline__ float htanh2(float ea, float ec) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(fmaf(ea, ec, 1.0f));
 }
-constexpr float kExpTabLimit = 43.0f;
 __device__ __forceinline__ constexpr int cdrow(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -147,8 +146,8 @@ __global__ __launch_bounds__(256) void jh_prep_kernel(const JhParams jp) {
         bool big = false;
         for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nE + nP; i += (size_t)gridDim.x * 256) {
             const float x = (i < nE) ? jp.enc_proj[i] : jp.pred_proj[i - nE];
-            big |= !(fabsf(x) <= kExpTabLimit);  // also catches NaN
-            const float ex = hex2(x * 2.8853900817779268f);
+            big |= exp_tab_out_of_range(x);  // also catches NaN
+            const float ex = exp_tab(x);
             if (i < nE) jp.expE[i] = ex;
             else jp.expP[i - nE] = ex;
         }

@@ -58,7 +58,6 @@ __device__ __forceinline__ float tanh_from_exp(float ea, float ec) {
 // saturation behaviour: 0 for an overflowing product, 1 for an underflowing one)
 __device__ __forceinline__ float r_from_exp(float ea, float ec) { return __builtin_amdgcn_rcpf(fmaf(ea, ec, 1.0f)); }
 __device__ __forceinline__ float fast_r(float x) { return __builtin_amdgcn_rcpf(1.0f + jex2(x * 2.8853900817779268f)); }
-constexpr float kExpTabLimit = 43.0f;
 constexpr float kSplitLimit = 60000.0f;  // |W2| beyond this leaves binary16's range (65504): no hi/lo split
 // row of the 32x32 MFMA C/D tile held in register `reg` of a lane in half `half` (= lane >> 5)
 __device__ __forceinline__ constexpr int cd_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
@@ -75,7 +74,8 @@ __device__ __forceinline__ constexpr int cd_row(int reg, int half) { return (reg
 struct JointParams {
     LossParams lp;  // lattice workspace, labels, lengths, costs, cost_scale (acts/grads unused)
     const float *enc_proj, *pred_proj, *W2, *b2;
-    float *dl;      // [cells][32] parked logits (forward) / dlogits of the two-kernel backward
+    float *dl;      // [cells][32] logits parked by the forward pass (read-only in every backward: a backward call may be repeated)
+    float *dlg;     // [cells][32] dlogits of the two-kernel backward (joint_dl_kernel -> joint_phase2s / joint_phase2 kernels)
     float4 *rec;    // [cells] per-cell gradient set-up of the single-kernel backward (joint_cellrec_kernel)
     int *reclab;    // [cells] label of the cell, or -1
     float2 *xbl;    // [cells] blank / label logits of the cell, written by joint_fwd_kernel for joint_cellrec_kernel
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void joint_prep_kernel(const JointParams jp) {
     const size_t nE = (size_t)p.B * p.T * jp.J, nP = (size_t)p.B * p.U * jp.J;
     bool big = false;
     auto one = [&](const float x) {
-        big |= !(fabsf(x) <= kExpTabLimit);  // also catches NaN
-        return jex2(x * 2.8853900817779268f);
+        big |= exp_tab_out_of_range(x);  // also catches NaN
+        return exp_tab(x);
     };
     if (jp.tables_ready) {
         // nothing to tabulate
@@ -126,6 +126,10 @@ __global__ __launch_bounds__(256) void joint_prep_kernel(const JointParams jp) {
         }
     }
     if (__any(big) && (threadIdx.x & 63) == 0) jp.tflag[0] = 1.0f;
+    // tflag[3]: "the workspace holds the state of a whole-network forward call" (tables by the dense layer's epilogue, W2 images
+    // by this launch).  Any other call on the workspace zero-fills the flag words; a backward-only call that skips this kernel
+    // (JointHooks::prep_mode 2) checks the word and returns NaN gradients instead of numbers from someone else's tables.
+    if (jp.tables_ready && blockIdx.x == 0 && threadIdx.x == 0) jp.tflag[3] = 1.0f;
     if (jp.logits_only && blockIdx.x == 1)  // every lattice cell is wanted: full lengths (the arrays live in the workspace)
         for (int b = threadIdx.x; b < p.B; b += 256) {
             const_cast<int *>(p.input_lengths)[b] = p.T;
@@ -794,7 +798,8 @@ __global__ __launch_bounds__(256) void joint_dl_kernel(const JointParams jp) {
         const uint32_t c = c0 + tid;
         // the chunk's 256 tiles are 32 KB of contiguous memory: move them with fully coalesced 16-byte accesses and hand
         // every lane its own cell through LDS (a lane reading its 128 bytes directly uses a quarter of every request)
-        float4 *g4 = (float4 *)(jp.dl + (size_t)c0 * 32);
+        const float4 *g4 = (const float4 *)(jp.dl + (size_t)c0 * 32);
+        float4 *o4 = (float4 *)(jp.dlg + (size_t)c0 * 32);  // NOT in place: the parked logits serve a repeated backward call
         __syncthreads();  // the previous chunk's write-back is done with `red`
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -841,7 +846,7 @@ __global__ __launch_bounds__(256) void joint_dl_kernel(const JointParams jp) {
             const int e = i * 256 + tid;
             if ((size_t)c0 * 32 + (size_t)e * 4 < total) {
                 const float *r = &red[e >> 3][4 * (e & 7)];
-                g4[e] = make_float4(r[0], r[1], r[2], r[3]);
+                o4[e] = make_float4(r[0], r[1], r[2], r[3]);
             }
         }
     }
@@ -924,7 +929,7 @@ __global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int e = lane + q * 64, uu = e >> 5, v = e & 31;
-            d[q] = (t < t_end && u0 + uu < p.U) ? jp.dl[(((size_t)(b * p.T + t)) * p.U + u0 + uu) * 32 + v] : 0.f;
+            d[q] = (t < t_end && u0 + uu < p.U) ? jp.dlg[(((size_t)(b * p.T + t)) * p.U + u0 + uu) * 32 + v] : 0.f;
         }
     };
     float dnext[16];
@@ -1118,7 +1123,7 @@ __global__ __launch_bounds__(256, P2S_WG_PER_CU) void joint_phase2s_kernel(const
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int e = lane + q * 64, uu = e >> 5, v = e & 31;
-            d[q] = (t < t_end && u0 + uu < p.U) ? jp.dl[(((size_t)(b * p.T + t)) * p.U + u0 + uu) * 32 + v] : 0.f;
+            d[q] = (t < t_end && u0 + uu < p.U) ? jp.dlg[(((size_t)(b * p.T + t)) * p.U + u0 + uu) * 32 + v] : 0.f;
         }
     };
     float dnext[16];
@@ -1739,8 +1744,10 @@ __device__ __forceinline__ void store_block_max(unsigned m, unsigned *blockmax) 
 // `blockmax` (nullable): [gridDim.x] abs-max bit patterns of the block's outputs
 __global__ __launch_bounds__(256) void reduce_partials_kernel(float *out, const float *in, int nparts, size_t n,
                                                               const float *flag = nullptr, int nparts_fb = 0,
-                                                              unsigned *blockmax = nullptr) {
+                                                              unsigned *blockmax = nullptr, int need_state = 0) {
     if (flag && flag[1] != 0.f) nparts = nparts_fb;
+    // a backward-only call that trusted the workspace (prep_mode 2) on a workspace some other call has touched since: NaN, loudly
+    const float poison = (need_state && flag && flag[3] != 1.0f) ? NAN : 0.f;
     unsigned bm = 0u;
     // fixed order q = 0, 1, ... for every element (deterministic); 16-byte accesses, up to four partials in flight per thread
     if ((n & 3) == 0 && (((uintptr_t)out | (uintptr_t)in) & 15) == 0) {
@@ -1759,6 +1766,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(float *out, const 
                 const float4 a = in4[(size_t)q * n4 + i];
                 s.x += a.x, s.y += a.y, s.z += a.z, s.w += a.w;
             }
+            s.x += poison, s.y += poison, s.z += poison, s.w += poison;
             ((float4 *)out)[i] = s;
             bm = max(bm, absbits4(s));
         }
@@ -1768,6 +1776,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(float *out, const 
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float s = 0.f;
         for (int q = 0; q < nparts; ++q) s += in[(size_t)q * n + i];
+        s += poison;
         out[i] = s;
         bm = max(bm, __float_as_uint(s) & 0x7fffffffu);
     }
@@ -1854,7 +1863,7 @@ __global__ __launch_bounds__(256) void reduce_small_kernel(float *out, const flo
 // ---------------------------------------------------------------------------------------------
 struct JointLayout {
     WsLayout w;
-    size_t dl, rec, reclab, xbl, dApart, dCpart, dWpart, dbpart, expE, expP, tflag, W2s, total;
+    size_t dl, dlg, rec, reclab, xbl, dApart, dCpart, dWpart, dbpart, expE, expP, tflag, W2s, total;
     int n_ut, TR, n_tr, TS, n_ts, nC, nW, nDb;
 };
 
@@ -1874,6 +1883,7 @@ static JointLayout make_joint_layout(int T, int U, int B, int J) {
         return o;
     };
     L.dl = take((size_t)B * T * U * 32 * sizeof(float));
+    L.dlg = take((size_t)B * T * U * 32 * sizeof(float));  // touched only by the two-kernel backward (J outside the single-kernel domain, W2 outside binary16)
     L.rec = take((size_t)B * T * U * sizeof(float4));
     L.reclab = take((size_t)B * T * U * sizeof(int));
     L.xbl = take((size_t)B * T * U * sizeof(float2));
@@ -1987,6 +1997,7 @@ hipError_t launch_joint_logits(const float *enc_proj, const float *pred_proj, co
         return hipErrorInvalidValue;
     jp.enc_proj = enc_proj, jp.pred_proj = pred_proj, jp.W2 = W2, jp.b2 = b2;
     jp.dl = (float *)(ws + L.dl);
+    jp.dlg = (float *)(ws + L.dlg);
     jp.rec = nullptr, jp.reclab = nullptr;
     jp.xbl = (float2 *)(ws + L.xbl);
     jp.dApart = jp.dCpart = jp.dWpart = jp.dbpart = nullptr;
@@ -2048,6 +2059,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     char *ws = (char *)workspace;
     jp.enc_proj = enc_proj, jp.pred_proj = pred_proj, jp.W2 = W2, jp.b2 = b2;
     jp.dl = (float *)(ws + L.dl);
+    jp.dlg = (float *)(ws + L.dlg);
     jp.rec = (float4 *)(ws + L.rec);
     jp.reclab = (int *)(ws + L.reclab);
     jp.xbl = (float2 *)(ws + L.xbl);
@@ -2141,7 +2153,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     hipLaunchKernelGGL(reduce_enc_kernel, dim3(kHookBlocks), dim3(256), 0, s, d_enc_proj, jp.dApart, L.n_ut, jp.lp, J,
                        hooks ? hooks->dmax_enc : (unsigned *)nullptr);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(kHookBlocks), dim3(256), 0, s, d_pred_proj, jp.dCpart, nC_s, nC, jp.tflag, nC_fb,
-                       hooks ? hooks->dmax_pred : (unsigned *)nullptr);
+                       hooks ? hooks->dmax_pred : (unsigned *)nullptr, prep_mode == 2 ? 1 : 0);
     hipLaunchKernelGGL((reduce_small_kernel<true>), dim3((J * V + 31) / 32), dim3(256), 0, s, dW2, jp.dWpart, nW_s, J * V, J, V,
                        jp.tflag, nW_fb);
     hipLaunchKernelGGL((reduce_small_kernel<false>), dim3(1), dim3(256), 0, s, db2, jp.dbpart, nDb_s, V, J, V, jp.tflag, nDb_fb);

@@ -149,6 +149,16 @@ inline TileGeom make_tile(int T, int U, int V) {
     return g;
 }
 
+// The fused joints' tanh tables (joint_kernels.hip, joint_f16_kernels.hip; also written by the dense layer's GEMM epilogue,
+// dense_kernels.hip): tab(x) = e^{2x} = 2^(x * kExpTab2Log2e), valid while |x| <= kExpTabLimit (beyond that the table-range flag
+// sends the kernels to the exact tanh on the raw projections).  One definition for the three files that must agree.
+constexpr float kExpTabLimit = 43.0f;
+constexpr float kExpTab2Log2e = 2.8853900817779268f;
+#ifdef __HIPCC__
+__device__ __forceinline__ float exp_tab(float x) { return __builtin_amdgcn_exp2f(x * kExpTab2Log2e); }
+__device__ __forceinline__ bool exp_tab_out_of_range(float x) { return !(fabsf(x) <= kExpTabLimit); }  // NaN too
+#endif
+
 // Hooks of the fused joint for a caller that also owns the joint's first Dense layer (rnnt_entrypoint.hip joint_net_call,
 // dense_kernels.hip): work the dense kernels can do on the way, so that the joint need not redo it.
 constexpr int kHookBlocks = 1024;  // grid of the two reductions that produce d enc_proj / d pred_proj

@@ -1,12 +1,13 @@
 """Joint network fused with the transducer loss (host side).
 
 Reference: model.py:158-166 (broadcast add -> Dense(J, tanh) -> Dense(V)) followed by
-utils/loss.py:24-36 and TF autodiff (run_rnnt.py:284).  Here the first Dense layer is applied to the
-encoder and prediction-network outputs separately (exact factorisation, two small library GEMMs via
-torch.matmul on hipBLASLt) and libwarprnnt.so's compute_rnnt_joint_loss_* entry points do the rest:
-tanh, the J x V projection on the MFMA units, log-softmax, alpha/beta, and the gradient scatter back
-to enc_proj / pred_proj / W2 / b2, without ever materialising [B,T,U,J] or [B,T,U,V] tensors.
-PyTorch autograd chains the returned d_enc_proj / d_pred_proj into W1, b1 and the two networks.
+utils/loss.py:24-36 and TF autodiff (run_rnnt.py:284).  The first Dense layer is applied to the
+encoder and prediction-network outputs separately (exact factorisation) and the whole network runs
+behind the C ABI: libwarprnnt.so's compute_rnnt_joint_net_loss_* entry points do the two W1 GEMMs and
+their backward (csrc/dense_kernels.hip), tanh, the J x V projection on the MFMA units, log-softmax,
+alpha/beta, and the gradient scatter back to enc / pred / W1 / b1 / W2 / b2, without ever materialising
+[B,T,U,J] or [B,T,U,V] tensors.  Hidden sizes the dense kernels do not take (not a multiple of 32) go
+through torch.matmul + autograd around compute_rnnt_joint_loss_* (first_layer="torch").
 """
 from __future__ import annotations
 
@@ -100,6 +101,9 @@ class _JointNetLossFunction(torch.autograd.Function):
             raise ValueError("rnnt_joint_loss: inconsistent shapes")
         dev = enc.device
         e, p, w1, bb1, w2, bb2 = (x.detach().contiguous() for x in (enc, pred, W1, b1, W2, b2))
+        # the dense kernels move 16 bytes per access: an operand that is contiguous but starts off that grid (a slice of a flat
+        # parameter bucket, say) is copied to a fresh allocation instead of being refused
+        e, p, w1, bb1 = (x if x.data_ptr() % 16 == 0 else x.clone() for x in (e, p, w1, bb1))
         labels = labels.to(device=dev, dtype=torch.int32).contiguous()
         if U > 1 and tuple(labels.shape) != (B, U - 1):
             raise ValueError(f"rnnt_joint_loss: labels must be [B, U-1] = [{B}, {U - 1}], got {tuple(labels.shape)}")
@@ -212,8 +216,11 @@ def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_leng
                                     JOINT_DTYPES[joint_dtype])
 
 
+_LOGITS_CACHE = {}  # (device, T, U, B, J, V) -> (workspace, output): a greedy decoder asks for one cell per emitted symbol
+
+
 @torch.no_grad()
-def joint_logits(enc, pred, W1, b1, W2, b2):
+def joint_logits(enc, pred, W1, b1, W2, b2, reuse_buffers: bool = False):
     """logits [B, T, U, V] of the joint network through libwarprnnt.so's compute_rnnt_joint_logits (no autograd): the decoding
     twin of the joint (utils/decoding.py:6-18).  Same factorisation, tables and split-precision products as the fused loss, so
     a decoder sees the logits the loss was trained on.  V <= 32 (the f32-grade joint); joint sizes are padded to a multiple of
@@ -237,8 +244,16 @@ def joint_logits(enc, pred, W1, b1, W2, b2):
     ep, pp, w2, bb = (x.detach().contiguous().float() for x in (enc_proj, pred_proj, W2, b2))
     dev = ep.device
     with torch.cuda.device(dev):
-        ws = torch.empty(_lib.joint_workspace_bytes(T, U, B, Jp, V), dtype=torch.uint8, device=dev)
-        out = torch.empty(B, T, U, V, dtype=torch.float32, device=dev)
+        key = (dev, T, U, B, Jp, V)
+        if reuse_buffers and key in _LOGITS_CACHE:
+            ws, out = _LOGITS_CACHE[key]
+        else:
+            ws = torch.empty(_lib.joint_workspace_bytes(T, U, B, Jp, V), dtype=torch.uint8, device=dev)
+            out = torch.empty(B, T, U, V, dtype=torch.float32, device=dev)
+            if reuse_buffers:  # (the caller consumes `out` before the next call: decoding.greedy_decode_fn does)
+                if len(_LOGITS_CACHE) > 8:
+                    _LOGITS_CACHE.clear()
+                _LOGITS_CACHE[key] = (ws, out)
         opts = _lib.make_options(torch.cuda.current_stream().cuda_stream, 0, T, U)
         st = lib.compute_rnnt_joint_logits(ep.data_ptr(), pp.data_ptr(), w2.data_ptr(), bb.data_ptr(), Jp, V, B,
                                            out.data_ptr(), ws.data_ptr(), opts)
