@@ -256,15 +256,27 @@ RNNT_API rnntStatus_t compute_rnnt_joint_net_loss_bwd(const float *enc, const fl
  * decoder (utils/decoding.py:6-18: dense_1 (tanh) and dense_2 on f + g for one lattice cell per step; called at :63-69):
  *   logits[b,t,u,:] = tanh(enc_proj[b,t,:] + pred_proj[b,u,:]) @ W2 + b2        device f32 [minibatch, maxT, maxU, alphabet_size]
  * with enc_proj / pred_proj as for compute_rnnt_joint_loss (the first Dense layer factored, bias folded into enc_proj).
- * It runs the forward kernels of compute_rnnt_joint_loss with joint_dtype 0 -- the same f32-grade split-precision products
- * and the same device-side switch to plain f32 MFMAs -- on a lattice whose every cell is live, so a decoder sees bit for bit
- * the logits the loss was trained on.  Shapes: alphabet_size <= 32, joint_size a multiple of 64 (<= 704), maxU <= 1024;
- * a greedy decoder calls it with maxT = maxU = 1 and minibatch = the number of hypotheses.
+ * It runs the forward kernels of compute_rnnt_joint_loss with the same joint_dtype on a lattice whose every cell is live, so a
+ * decoder sees the logits the loss was trained on:
+ *   joint_dtype 0  f32-grade split-precision products (and the same device-side switch to plain f32 MFMAs): alphabet_size <= 32,
+ *                  joint_size a multiple of 64 (<= 704);
+ *   joint_dtype 1  operands rounded to binary16, f32 accumulation (the reference's default vocabulary of 4096 word pieces,
+ *                  hparams.py:4): alphabet_size a multiple of 512 (<= 8192), joint_size in {128, 256, 512, 640}; logits 16-byte aligned.
+ * maxU <= 1024; a greedy decoder calls it with maxT = maxU = 1 and minibatch = the number of hypotheses.
  * workspace: get_joint_workspace_size(maxT, maxU, minibatch, joint_size, alphabet_size) bytes, 256-byte aligned. */
 RNNT_API rnntStatus_t compute_rnnt_joint_logits(const float *enc_proj, const float *pred_proj,
                                                 const float *W2, const float *b2, int joint_size,
                                                 int alphabet_size, int minibatch, float *logits,
-                                                void *workspace, rnntOptions options);
+                                                int joint_dtype, void *workspace, rnntOptions options);
+
+/* The same from the encoder / prediction-network outputs: the first Dense layer (model.py:162-163, utils/decoding.py:8,15) runs
+ * in the library too (the split-precision GEMMs of compute_rnnt_joint_net_loss), then the joint as above.
+ *   enc [minibatch, maxT, hidden_size], pred [minibatch, maxU, hidden_size], W1 [hidden_size, joint_size], b1 [joint_size]
+ *   (16-byte aligned; hidden_size a multiple of 32).  workspace: get_joint_net_workspace_size(...) bytes. */
+RNNT_API rnntStatus_t compute_rnnt_joint_net_logits(const float *enc, const float *pred, const float *W1, const float *b1,
+                                                    const float *W2, const float *b2, int hidden_size, int joint_size,
+                                                    int alphabet_size, int minibatch, float *logits, int joint_dtype,
+                                                    void *workspace, rnntOptions options);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,7 @@ SYMBOLS = [
     "compute_rnnt_joint_loss_fwd",
     "compute_rnnt_joint_loss_bwd",
     "compute_rnnt_joint_logits",
+    "compute_rnnt_joint_net_logits",
     "get_joint_net_workspace_size",
     "compute_rnnt_joint_net_loss",
     "compute_rnnt_joint_net_loss_fwd",
@@ -96,7 +97,10 @@ def load():
     lib.compute_rnnt_joint_loss_bwd.argtypes = [vp] * 8 + [ci, ci, ci] + [vp] * 4 + [ci, vp, rnntOptions]
     if LIB_PATH == _DEFAULT_LIB_PATH or hasattr(lib, "compute_rnnt_joint_logits"):  # (an older dev variant may lack it)
         lib.compute_rnnt_joint_logits.restype = ci
-        lib.compute_rnnt_joint_logits.argtypes = [vp] * 4 + [ci, ci, ci, vp, vp, rnntOptions]
+        lib.compute_rnnt_joint_logits.argtypes = [vp] * 4 + [ci, ci, ci, vp, ci, vp, rnntOptions]
+    if LIB_PATH == _DEFAULT_LIB_PATH or hasattr(lib, "compute_rnnt_joint_net_logits"):
+        lib.compute_rnnt_joint_net_logits.restype = ci
+        lib.compute_rnnt_joint_net_logits.argtypes = [vp] * 6 + [ci] * 4 + [vp, ci, vp, rnntOptions]
     if LIB_PATH == _DEFAULT_LIB_PATH or hasattr(lib, "compute_rnnt_joint_net_loss"):
         lib.get_joint_net_workspace_size.restype = ci
         lib.get_joint_net_workspace_size.argtypes = [ci] * 6 + [ctypes.POINTER(ctypes.c_size_t)]

@@ -114,6 +114,8 @@ struct JhParams {
     int J, n_ut, n_tt, n_ts, TS, n_tq, n_units, n_ranges;
     FastDiv div_ppc;  // K2: 16-byte pieces per cell (V / 8)
     int b2_lds_off;  // K1/K2: byte offset of the bias table in LDS, -1 = read it from global memory (does not fit)
+    float *logits_out;  // MODE 3 of K1 (compute_rnnt_joint_logits, decoding): f32 logits [cells][V]
+    int logits_only;    // every lattice cell is wanted: the prep kernel writes full lengths + zero labels into the workspace
 #ifdef JH_TRACE
     long long *trace;  // dev builds only (-DJH_TRACE): per-wave s_memtime stamps of a few workgroups of K1
 #endif
@@ -154,6 +156,14 @@ __global__ __launch_bounds__(256) void jh_prep_kernel(const JhParams jp) {
         if (__any(big) && (threadIdx.x & 63) == 0) jp.scal[2] = 1.0f;  // scal[2] is zeroed before the launch
         for (int v = blockIdx.x * 256 + threadIdx.x; v < V; v += gridDim.x * 256) jp.b2l[v] = jp.b2[v] * kLog2e;
     }
+    if (jp.logits_only && blockIdx.x == 1) {  // (the three arrays live in workspace regions the forward kernel does not touch)
+        const LossParams &p = jp.lp;
+        for (int b = threadIdx.x; b < p.B; b += 256) {
+            const_cast<int *>(p.input_lengths)[b] = p.T;
+            const_cast<int *>(p.label_lengths)[b] = p.U - 1;
+        }
+        for (int i = threadIdx.x; i < p.B * (p.U - 1); i += 256) const_cast<int *>(p.labels)[i] = 0;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         float m = 1.0f;
         if (jp.lp.cost_scale) {
@@ -182,7 +192,7 @@ __global__ __launch_bounds__(256) void jh_prep_kernel(const JhParams jp) {
 // route a backward call takes when the parked values are not there any more: a second backward over one forward).
 template <int KS, int MODE, bool B2LDS>
 __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
-    constexpr bool BWD = MODE == 2, PARK = MODE == 1;
+    constexpr bool BWD = MODE == 2, PARK = MODE == 1, STAGE = MODE == 1 || MODE == 2, LOGITS = MODE == 3;
     if (BWD && jp.state[0] == 1) return;  // the streaming kernel has the parked values: nothing to recompute
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LossParams &p = jp.lp;
@@ -404,6 +414,12 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
                     }
                 }
             }
+            if (LOGITS && cell_valid) {  // decoding: the chunk's 16 logits of this half-lane, natural scale, straight to the caller
+                float *o = jp.logits_out + (size_t)c * V + vc * 32 + 4 * half;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(float4 *)(o + 8 * q) = make_float4(y[4 * q] * kLn2, y[4 * q + 1] * kLn2, y[4 * q + 2] * kLn2, y[4 * q + 3] * kLn2);
+            }
             if (vc == vcb) {  // wave-uniform
                 asm volatile("" ::: "memory");  // keep this a branch (if-converted, it costs 17 selects per chunk)
                 float v = y[0];
@@ -468,7 +484,7 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
         if (late && vc > 0) epilogue(acc, vc - 1);
         JT(4 + 4 * vc);
         const char *wb = ((vc & 1) ? wbuf1 : wbuf0) + lane * 16;
-        constexpr bool kTwoChains = !(MODE != 0 && KS > 32);  // two accumulation chains unless registers are short
+        constexpr bool kTwoChains = !(STAGE && KS > 32);  // two accumulation chains unless registers are short
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
@@ -479,7 +495,7 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
             constexpr int NG = KS / G;
             // groups after which the staged chunk's pieces are read / stored (kE2 == NG: behind the loop)
             constexpr int kE1 = NG >= 3 ? NG / 3 : 1, kE2 = NG >= 3 ? 2 * NG / 3 : NG;
-            const bool staged = MODE != 0 && vc > 0;
+            const bool staged = STAGE && vc > 0;
             h8 sp;
             h8 acur[G], anxt[G];
 #pragma unroll
@@ -508,7 +524,7 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
                         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[q], hf[G * g4 + q], acc0, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (MODE != 0 && staged) {
+                if (STAGE && staged) {
                     if (g4 == 0) sp = stage_read(0);
                     if (g4 == kE1) {
                         stage_store(0, vc - 1, sp);
@@ -522,7 +538,7 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
 #pragma unroll
                 for (int q = 0; q < G; ++q) acur[q] = anxt[q];
             }
-            if (MODE != 0 && staged && kE2 >= NG) {
+            if (STAGE && staged && kE2 >= NG) {
                 stage_store(1, vc - 1, sp);
                 store_refs(vc - 1);
             }
@@ -534,7 +550,7 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
     }
     JT(2 + 4 * 32);
     if (late && wave_live) epilogue(acc, NC - 1);
-    if (MODE != 0 && wave_live) {  // the last chunk's pieces
+    if (STAGE && wave_live) {  // the last chunk's pieces
         stage_store(0, NC - 1, stage_read(0));
         stage_store(1, NC - 1, stage_read(1));
         store_refs(NC - 1);
@@ -1192,7 +1208,7 @@ template <int KS, int MODE>
 static hipError_t launch_logits_mode(const JhParams &jp, unsigned grid, hipStream_t s) {
     // W2^T double buffer (+ staging tile when the epilogue writes [cells][V] rows), overlaid during the prologue by the
     // enc_proj / pred_proj images; bias table last
-    size_t shm = 2 * (size_t)64 * (KS * 16) + (MODE != 0 ? (size_t)8 * 32 * kStageStride * sizeof(f16) : 0);
+    size_t shm = 2 * (size_t)64 * (KS * 16) + ((MODE == 1 || MODE == 2) ? (size_t)8 * 32 * kStageStride * sizeof(f16) : 0);
     const size_t images = (size_t)KS * 4 * 32 * 16 + (size_t)8 * KS * 64;
     if (shm < images) shm = images;
     JhParams jq = jp;
@@ -1212,16 +1228,77 @@ static hipError_t launch_logits_mode(const JhParams &jp, unsigned grid, hipStrea
     return hipGetLastError();
 }
 template <int KS>
+static hipError_t launch_logits(const JhParams &jp, int mode, unsigned grid, hipStream_t s);
+template <int DUMMY = 0>
+static hipError_t jh_launch_logits_for_J(const JhParams &jp, int J, int mode, unsigned tiles, hipStream_t s) {
+    switch (J) {
+        case 128: return launch_logits<8>(jp, mode, tiles, s);
+        case 256: return launch_logits<16>(jp, mode, tiles, s);
+        case 512: return launch_logits<32>(jp, mode, tiles, s);
+        case 640: return launch_logits<40>(jp, mode, tiles, s);
+    }
+    return hipErrorInvalidValue;
+}
+template <int KS>
 static hipError_t launch_logits(const JhParams &jp, int mode, unsigned grid, hipStream_t s) {
     switch (mode) {
         case 0: return launch_logits_mode<KS, 0>(jp, grid, s);
         case 1: return launch_logits_mode<KS, 1>(jp, grid, s);
+        case 3: return launch_logits_mode<KS, 3>(jp, grid, s);
         default: return launch_logits_mode<KS, 2>(jp, grid, s);
     }
 }
 
 // one word of workspace state, set on the stream between the kernels that depend on it
 __global__ void jh_set_state_kernel(int *state, int value) { state[0] = value; }
+
+static hipError_t jh_fill_params(JhParams &jp, const JhLayout &L, const float *enc_proj, const float *pred_proj, const float *W2,
+                                 const float *b2, const int *labels, const int *label_lengths, const int *input_lengths,
+                                 const float *cost_scale, int J, int V, int B, int T, int U, int blank, float *costs, void *workspace) {
+    if (!fill_loss_params(jp.lp, nullptr, nullptr, labels, label_lengths, input_lengths, cost_scale, V, B, costs,
+                          workspace, T, U, blank))
+        return hipErrorInvalidValue;
+    char *ws = (char *)workspace;
+    jp.enc_proj = enc_proj, jp.pred_proj = pred_proj, jp.W2 = W2, jp.b2 = b2;
+    jp.W2Tp = (f16 *)(ws + L.W2Tp), jp.W2h = (f16 *)(ws + L.W2h), jp.dl = (f16 *)(ws + L.dl);
+    jp.pref = (short *)(ws + L.pref);
+    jp.xbl = (float *)(ws + L.xbl), jp.scal = (float *)(ws + L.scal);
+    jp.state = (int *)(ws + L.scal) + 8;  // behind the words the prep kernel owns (zeroed before it runs, 32 bytes)
+    jp.expE = (float *)(ws + L.expE), jp.expP = (float *)(ws + L.expP), jp.b2l = (float *)(ws + L.b2l);
+    jp.dApart = (float *)(ws + L.dApart), jp.dCpart = (float *)(ws + L.dCpart);
+    jp.dWpart = (float *)(ws + L.dWpart), jp.dbpart = (float *)(ws + L.dbpart);
+    jp.zrow = (const f16 *)(ws + L.zrow);
+    jp.J = J, jp.n_ut = L.n_ut, jp.n_tt = L.n_tt, jp.n_ts = L.n_ts, jp.TS = L.TS, jp.n_tq = L.n_tq;
+    jp.n_units = L.n_units, jp.n_ranges = L.n_ranges;
+    jp.div_ppc = make_fastdiv((uint32_t)(V >> 3));
+    jp.logits_out = nullptr, jp.logits_only = 0;
+    jp.b2_lds_off = -1;
+#ifdef JH_TRACE
+    jp.trace = nullptr;
+#endif
+    return hipSuccess;
+}
+
+// The joint alone on the f16 MFMA units, for decoding at large vocabularies (utils/decoding.py:6-18 evaluates dense_1 /
+// dense_2 on one lattice cell per step; hparams.py:4: 4096 word pieces): K1 with every cell live and the f32 logits written out.
+hipError_t launch_joint_logits_f16(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2, int J, int V,
+                                   int B, int T, int U, float *logits, void *workspace, hipStream_t s) {
+    if (!joint_f16_supported(J, V) || sweep_K(U) == 0) return hipErrorInvalidValue;
+    if (((uintptr_t)enc_proj & 15) || ((uintptr_t)pred_proj & 15) || ((uintptr_t)b2 & 15) || ((uintptr_t)logits & 15)) return hipErrorInvalidValue;
+    const JhLayout L = make_jh_layout(T, U, B, J, V);
+    char *ws = (char *)workspace;
+    // lengths and labels of the "everything is live" lattice: workspace regions the forward kernel does not touch
+    int *il = (int *)(ws + L.dApart), *ll = il + B, *labels = (int *)(ws + L.dCpart);
+    JhParams jp;
+    hipError_t e = jh_fill_params(jp, L, enc_proj, pred_proj, W2, b2, labels, ll, il, nullptr, J, V, B, T, U, 0, nullptr, workspace);
+    if (e != hipSuccess) return e;
+    jp.logits_out = logits, jp.logits_only = 1;
+    if (launch_fill(jp.scal, 0, 64, s) != hipSuccess) return hipErrorUnknown;  // prep words + the state word: nothing is parked
+    hipLaunchKernelGGL(jh_prep_kernel, dim3(1024), dim3(256), 0, s, jp);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (launch_fill(jp.lp.W, kFillByte, L.w.A - L.w.W, s) != hipSuccess) return hipErrorUnknown;
+    return jh_launch_logits_for_J(jp, J, 3, (unsigned)B * L.n_tt * L.n_ut, s);
+}
 
 hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2,
                                  const int *labels, const int *label_lengths, const int *input_lengths,
@@ -1233,22 +1310,9 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     if ((unsigned long long)B * T * J >= (1ull << 32) || (unsigned long long)B * U * J >= (1ull << 32)) return hipErrorInvalidValue;  // 32-bit indices in the reductions
     const JhLayout L = make_jh_layout(T, U, B, J, V);
     JhParams jp;
-    if (!fill_loss_params(jp.lp, nullptr, nullptr, labels, label_lengths, input_lengths, cost_scale, V, B, costs,
-                          workspace, T, U, blank))
-        return hipErrorInvalidValue;
-    char *ws = (char *)workspace;
-    jp.enc_proj = enc_proj, jp.pred_proj = pred_proj, jp.W2 = W2, jp.b2 = b2;
-    jp.W2Tp = (f16 *)(ws + L.W2Tp), jp.W2h = (f16 *)(ws + L.W2h), jp.dl = (f16 *)(ws + L.dl);
-    jp.pref = (short *)(ws + L.pref);
-    jp.xbl = (float *)(ws + L.xbl), jp.scal = (float *)(ws + L.scal);
-    jp.state = (int *)(ws + L.scal) + 8;  // behind the words the prep kernel owns (zeroed below, 32 bytes)
-    jp.expE = (float *)(ws + L.expE), jp.expP = (float *)(ws + L.expP), jp.b2l = (float *)(ws + L.b2l);
-    jp.dApart = (float *)(ws + L.dApart), jp.dCpart = (float *)(ws + L.dCpart);
-    jp.dWpart = (float *)(ws + L.dWpart), jp.dbpart = (float *)(ws + L.dbpart);
-    jp.zrow = (const f16 *)(ws + L.zrow);
-    jp.J = J, jp.n_ut = L.n_ut, jp.n_tt = L.n_tt, jp.n_ts = L.n_ts, jp.TS = L.TS, jp.n_tq = L.n_tq;
-    jp.n_units = L.n_units, jp.n_ranges = L.n_ranges;
-    jp.div_ppc = make_fastdiv((uint32_t)(V >> 3));
+    hipError_t e = jh_fill_params(jp, L, enc_proj, pred_proj, W2, b2, labels, label_lengths, input_lengths, cost_scale, J, V, B, T, U,
+                                  blank, costs, workspace);
+    if (e != hipSuccess) return e;
 
 #ifdef JH_TRACE
     static long long *trace_dev = nullptr;
@@ -1257,17 +1321,8 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     hipMemsetAsync(trace_dev, 0, trace_bytes, s);
     jp.trace = trace_dev;
 #endif
-    hipError_t e;
     const unsigned tiles = (unsigned)B * L.n_tt * L.n_ut;
-    auto logits = [&](int mode) -> hipError_t {
-        switch (J) {
-            case 128: return launch_logits<8>(jp, mode, tiles, s);
-            case 256: return launch_logits<16>(jp, mode, tiles, s);
-            case 512: return launch_logits<32>(jp, mode, tiles, s);
-            case 640: return launch_logits<40>(jp, mode, tiles, s);
-        }
-        return hipErrorInvalidValue;
-    };
+    auto logits = [&](int mode) -> hipError_t { return jh_launch_logits_for_J(jp, J, mode, tiles, s); };
     auto set_state = [&](int value) -> hipError_t {
         hipLaunchKernelGGL(jh_set_state_kernel, dim3(1), dim3(1), 0, s, jp.state, value);
         return hipGetLastError();

@@ -31,6 +31,10 @@ hipError_t launch_dense_bwd(int B, int T, int U, int H, int J, float *d_enc, flo
                             size_t base, hipStream_t s);
 hipError_t launch_joint_logits(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2, int J, int V,
                                int B, int T, int U, float *logits, void *workspace, hipStream_t s);
+// joint_f16_kernels.hip
+hipError_t joint_f16_workspace_bytes(int T, int U, int B, int J, int V, size_t *bytes);
+hipError_t launch_joint_logits_f16(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2, int J, int V,
+                                   int B, int T, int U, float *logits, void *workspace, hipStream_t s);
 }  // namespace rnnt
 
 static rnntStatus_t check_options(const rnntOptions &o) {
@@ -371,16 +375,49 @@ rnntStatus_t compute_rnnt_joint_net_loss_bwd(const float *enc, const float *pred
 
 // The joint alone, for decoding (utils/decoding.py:6-18 evaluates dense_1 / dense_2 on one lattice cell per step).
 rnntStatus_t compute_rnnt_joint_logits(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2,
-                                       int joint_size, int alphabet_size, int minibatch, float *logits, void *workspace,
-                                       rnntOptions options) {
+                                       int joint_size, int alphabet_size, int minibatch, float *logits, int joint_dtype,
+                                       void *workspace, rnntOptions options) {
     if (!enc_proj || !pred_proj || !W2 || !b2 || !logits || !workspace) return RNNT_STATUS_INVALID_VALUE;
     if (joint_size <= 0 || alphabet_size <= 0 || minibatch <= 0) return RNNT_STATUS_INVALID_VALUE;
+    if (joint_dtype != 0 && joint_dtype != 1) return RNNT_STATUS_INVALID_VALUE;
     rnntStatus_t st = check_options(options);
     if (st != RNNT_STATUS_SUCCESS) return st;
     if (options.maxU > 1024) return RNNT_STATUS_INVALID_VALUE;
     if (((uintptr_t)workspace & 255) != 0) return RNNT_STATUS_INVALID_VALUE;
+    hipStream_t s = (hipStream_t)options.stream;
+    if (joint_dtype == 1)
+        return from_hip(launch_joint_logits_f16(enc_proj, pred_proj, W2, b2, joint_size, alphabet_size, minibatch, options.maxT,
+                                                options.maxU, logits, workspace, s));
     return from_hip(launch_joint_logits(enc_proj, pred_proj, W2, b2, joint_size, alphabet_size, minibatch, options.maxT,
-                                        options.maxU, logits, workspace, (hipStream_t)options.stream));
+                                        options.maxU, logits, workspace, s));
+}
+
+// The whole joint network without the loss: first Dense layer (the library's split-precision GEMMs, as in the fused loss) + the
+// joint, logits [minibatch, maxT, maxU, alphabet_size] out.  Workspace: get_joint_net_workspace_size().
+rnntStatus_t compute_rnnt_joint_net_logits(const float *enc, const float *pred, const float *W1, const float *b1, const float *W2,
+                                           const float *b2, int hidden_size, int joint_size, int alphabet_size, int minibatch,
+                                           float *logits, int joint_dtype, void *workspace, rnntOptions options) {
+    if (!enc || !pred || !W1 || !b1 || !W2 || !b2 || !logits || !workspace) return RNNT_STATUS_INVALID_VALUE;
+    if (hidden_size <= 0 || joint_size <= 0 || alphabet_size <= 0 || minibatch <= 0) return RNNT_STATUS_INVALID_VALUE;
+    if (joint_dtype != 0 && joint_dtype != 1) return RNNT_STATUS_INVALID_VALUE;
+    rnntStatus_t st = check_options(options);
+    if (st != RNNT_STATUS_SUCCESS) return st;
+    if (options.maxU > 1024) return RNNT_STATUS_INVALID_VALUE;
+    if (((uintptr_t)workspace & 255) != 0 || !dense_supported(hidden_size, joint_size)) return RNNT_STATUS_INVALID_VALUE;
+    if ((((uintptr_t)enc | (uintptr_t)pred | (uintptr_t)W1 | (uintptr_t)b1) & 15) != 0) return RNNT_STATUS_INVALID_VALUE;
+    const int B = minibatch, T = options.maxT, U = options.maxU;
+    hipStream_t s = (hipStream_t)options.stream;
+    size_t base = 0;
+    hipError_t e = joint_workspace_bytes(T, U, B, joint_size, alphabet_size, &base);
+    if (e != hipSuccess) return from_hip(e);
+    // (the joint's own prep kernel builds the tanh tables here: one cell per call is the common case, nothing to save)
+    if ((e = launch_dense_fwd(enc, pred, W1, b1, B, T, U, hidden_size, joint_size, workspace, base, nullptr, nullptr, nullptr, s)) != hipSuccess)
+        return from_hip(e);
+    float *ep, *pp, *dep, *dpp;
+    dense_proj_pointers(workspace, B, T, U, hidden_size, joint_size, base, &ep, &pp, &dep, &dpp);
+    if (joint_dtype == 1)
+        return from_hip(launch_joint_logits_f16(ep, pp, W2, b2, joint_size, alphabet_size, B, T, U, logits, workspace, s));
+    return from_hip(launch_joint_logits(ep, pp, W2, b2, joint_size, alphabet_size, B, T, U, logits, workspace, s));
 }
 
 }  // extern "C"

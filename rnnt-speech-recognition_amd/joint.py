@@ -216,49 +216,65 @@ def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_leng
                                     JOINT_DTYPES[joint_dtype])
 
 
-_LOGITS_CACHE = {}  # (device, T, U, B, J, V) -> (workspace, output): a greedy decoder asks for one cell per emitted symbol
+_LOGITS_CACHE = {}  # (device, entry, shape) -> (workspace, output): a greedy decoder asks for one cell per emitted symbol
 
 
 @torch.no_grad()
-def joint_logits(enc, pred, W1, b1, W2, b2, reuse_buffers: bool = False):
-    """logits [B, T, U, V] of the joint network through libwarprnnt.so's compute_rnnt_joint_logits (no autograd): the decoding
-    twin of the joint (utils/decoding.py:6-18).  Same factorisation, tables and split-precision products as the fused loss, so
-    a decoder sees the logits the loss was trained on.  V <= 32 (the f32-grade joint); joint sizes are padded to a multiple of
-    64 with zero units, exactly."""
+def joint_logits(enc, pred, W1, b1, W2, b2, joint_dtype: str = "auto", reuse_buffers: bool = False):
+    """logits [B, T, U, V] of the joint network through libwarprnnt.so (no autograd): the decoding twin of the joint
+    (utils/decoding.py:6-18).  Same factorisation, tables and products as the fused loss of the same joint_dtype ("f32": V <= 32,
+    f32-grade; "f16": binary16 operands, up to 8192 symbols -- the reference's default 4096 word pieces; "auto" picks by V), so a
+    decoder sees the logits the loss was trained on.  The first Dense layer runs in the library too (compute_rnnt_joint_net_logits)
+    when the hidden size is a multiple of 32, else through torch.matmul in front of compute_rnnt_joint_logits.  Joint sizes /
+    vocabularies the kernels do not take natively are padded exactly as in rnnt_joint_loss."""
     lib = _lib.load()
     for name, x in (("enc", enc), ("pred", pred), ("W1", W1), ("W2", W2)):
         if not x.is_cuda:
             raise RuntimeError(f"joint_logits: {name} must live on an MI355X (cuda/HIP) device; no CPU path")
-    B, T, _ = enc.shape
+    B, T, H = enc.shape
     U = pred.shape[1]
     J, V = W2.shape
-    if V > 32:
-        raise ValueError("joint_logits: the engine's logits-only entry takes vocabularies of at most 32 symbols")
-    enc_proj = torch.matmul(enc.float(), W1) + b1
-    pred_proj = torch.matmul(pred.float(), W1)
-    Jp, _ = padded_joint_shape(J, V, "f32")
+    if joint_dtype == "auto":
+        joint_dtype = "f32" if V <= 32 else "f16"
+    Jp, Vp = padded_joint_shape(J, V, joint_dtype)
     if Jp != J:
-        enc_proj = torch.nn.functional.pad(enc_proj, (0, Jp - J))
-        pred_proj = torch.nn.functional.pad(pred_proj, (0, Jp - J))
+        W1 = torch.nn.functional.pad(W1, (0, Jp - J))
+        b1 = torch.nn.functional.pad(b1, (0, Jp - J))
         W2 = torch.nn.functional.pad(W2, (0, 0, 0, Jp - J))
-    ep, pp, w2, bb = (x.detach().contiguous().float() for x in (enc_proj, pred_proj, W2, b2))
-    dev = ep.device
+    if Vp != V:
+        W2 = torch.nn.functional.pad(W2, (0, Vp - V))
+        b2 = torch.nn.functional.pad(b2, (0, Vp - V), value=_PAD_BIAS)
+    dev = enc.device
+    engine_first_layer = H % 32 == 0 and max(H, Jp) <= 4096
+    key = (dev, engine_first_layer, T, U, B, H, Jp, Vp)
     with torch.cuda.device(dev):
-        key = (dev, T, U, B, Jp, V)
         if reuse_buffers and key in _LOGITS_CACHE:
             ws, out = _LOGITS_CACHE[key]
         else:
-            ws = torch.empty(_lib.joint_workspace_bytes(T, U, B, Jp, V), dtype=torch.uint8, device=dev)
-            out = torch.empty(B, T, U, V, dtype=torch.float32, device=dev)
+            nbytes = (_lib.joint_net_workspace_bytes(T, U, B, H, Jp, Vp) if engine_first_layer
+                      else _lib.joint_workspace_bytes(T, U, B, Jp, Vp))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            out = torch.empty(B, T, U, Vp, dtype=torch.float32, device=dev)
             if reuse_buffers:  # (the caller consumes `out` before the next call: decoding.greedy_decode_fn does)
                 if len(_LOGITS_CACHE) > 8:
                     _LOGITS_CACHE.clear()
                 _LOGITS_CACHE[key] = (ws, out)
         opts = _lib.make_options(torch.cuda.current_stream().cuda_stream, 0, T, U)
-        st = lib.compute_rnnt_joint_logits(ep.data_ptr(), pp.data_ptr(), w2.data_ptr(), bb.data_ptr(), Jp, V, B,
-                                           out.data_ptr(), ws.data_ptr(), opts)
-    _lib.check(st, "compute_rnnt_joint_logits")
-    return out
+        w2, bb = W2.detach().contiguous().float(), b2.detach().contiguous().float()
+        if engine_first_layer:
+            e, p, w1, bb1 = (x.detach().contiguous().float() for x in (enc, pred, W1, b1))
+            e, p, w1, bb1 = (x if x.data_ptr() % 16 == 0 else x.clone() for x in (e, p, w1, bb1))
+            st = lib.compute_rnnt_joint_net_logits(e.data_ptr(), p.data_ptr(), w1.data_ptr(), bb1.data_ptr(), w2.data_ptr(),
+                                                   bb.data_ptr(), H, Jp, Vp, B, out.data_ptr(), JOINT_DTYPES[joint_dtype],
+                                                   ws.data_ptr(), opts)
+            _lib.check(st, "compute_rnnt_joint_net_logits")
+        else:
+            ep = (torch.matmul(enc.float(), W1) + b1).contiguous()
+            pp = torch.matmul(pred.float(), W1).contiguous()
+            st = lib.compute_rnnt_joint_logits(ep.data_ptr(), pp.data_ptr(), w2.data_ptr(), bb.data_ptr(), Jp, Vp, B,
+                                               out.data_ptr(), JOINT_DTYPES[joint_dtype], ws.data_ptr(), opts)
+            _lib.check(st, "compute_rnnt_joint_logits")
+    return out if Vp == V else out[..., :V]
 
 
 _PAD_BIAS = -1.0e4
@@ -308,9 +324,14 @@ class JointLoss(torch.nn.Module):
         return torch.tanh(z @ self.W1 + self.b1) @ self.W2 + self.b2
 
     def cell_logits(self, enc, pred):
-        """Joint logits [B, T, U, V] for decoding (utils/decoding.py:6-18).  On an MI355X this is the ENGINE
-        (compute_rnnt_joint_logits: the fused loss's own forward kernels); CPU tensors -- the host-logic tests -- and
-        vocabularies beyond the f32-grade joint's 32 symbols take the torch composition."""
-        if enc.is_cuda and self.W2.shape[1] <= 32:
-            return joint_logits(enc, pred, self.W1, self.b1, self.W2, self.b2)
+        """Joint logits [B, T, U, V] for decoding (utils/decoding.py:6-18).  On an MI355X this is the ENGINE at every vocabulary
+        size (compute_rnnt_joint_net_logits / compute_rnnt_joint_logits: the fused loss's own forward kernels, first Dense layer
+        included); CPU tensors -- the host-logic tests -- and shapes the kernels do not take (joint sizes beyond 704 / 640) use
+        the torch composition."""
+        if enc.is_cuda:
+            try:
+                padded_joint_shape(self.W2.shape[0], self.W2.shape[1], "f32" if self.W2.shape[1] <= 32 else "f16")
+            except ValueError:
+                return self.logits(enc, pred)
+            return joint_logits(enc, pred, self.W1, self.b1, self.W2, self.b2, reuse_buffers=True)
         return self.logits(enc, pred)

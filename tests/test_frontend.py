@@ -68,11 +68,11 @@ def test_error_rate_semantics():
 
 
 # ---------------------------------------------------------------- f-4: greedy decode
-def small_model(seed=0):
+def small_model(seed=0, vocab_size=12, joint_net_size=64, projection_size=8):
     torch.manual_seed(seed)
-    hp = pkg.HParams(vocab_size=12, mel_bins=4, downsample_factor=2, embedding_size=8, encoder_layers=2,
-                     encoder_size=16, projection_size=8, time_reduction_index=0, pred_net_layers=1, pred_net_size=16,
-                     joint_net_size=64)
+    hp = pkg.HParams(vocab_size=vocab_size, mel_bins=4, downsample_factor=2, embedding_size=8, encoder_layers=2,
+                     encoder_size=16, projection_size=projection_size, time_reduction_index=0, pred_net_layers=1, pred_net_size=16,
+                     joint_net_size=joint_net_size)
     return pkg.Transducer(hp)
 
 
@@ -282,30 +282,67 @@ def test_joint_logits_entry_matches_oracle(shape):
         pkg.joint_logits(torch.tensor(enc), t(pred), t(W1), t(b1), t(W2), t(b2))
 
 
+def _joint_forward_f16(enc, pred, W1, b1, W2, b2):
+    """float64 joint with the binary16 roundings of the f16 MFMA path (include/rnnt.h: h and W2 rounded to binary16, RNE)."""
+    e, p, w1, bb1, w2, bb2 = (np.asarray(x, np.float64) for x in (enc, pred, W1, b1, W2, b2))
+    h = np.tanh((e @ w1 + bb1)[:, :, None, :] + (p @ w1)[:, None, :, :])
+    return h.astype(np.float16).astype(np.float64) @ w2.astype(np.float16).astype(np.float64) + bb2
+
+
 @pytest.mark.gpu
-def test_greedy_decode_through_the_engine_matches_a_float64_restatement():
+@pytest.mark.parametrize("shape", [(5, 1, 1, 64, 640, 4096), (2, 9, 5, 32, 128, 1000), (3, 1, 1, 40, 256, 512), (1, 3, 40, 64, 100, 600)])
+def test_joint_logits_large_vocabulary_runs_on_the_f16_engine(shape):
+    """The reference's default vocabulary (hparams.py:4: 4096 word pieces) and its neighbours: compute_rnnt_joint_net_logits /
+    compute_rnnt_joint_logits with joint_dtype 1 (K1 of the f16 joint, every cell live, f32 logits out), the first Dense layer
+    through the library's GEMMs when the hidden size allows.  Against a float64 joint with the binary16 roundings restated; the
+    bar allows the few roundings of h that flip where the two tanh evaluations differ in the seventh digit."""
+    B, T, U, H, J, V = shape
+    rng = np.random.default_rng(V + H)
+    enc, pred = rng.normal(size=(B, T, H)).astype(np.float32), rng.normal(size=(B, U, H)).astype(np.float32)
+    W1 = (rng.uniform(-1, 1, size=(H, J)) * np.sqrt(6.0 / (H + J))).astype(np.float32)
+    b1 = (0.1 * rng.normal(size=J)).astype(np.float32)
+    W2 = (rng.uniform(-1, 1, size=(J, V)) * np.sqrt(6.0 / (J + V)) * 3.0).astype(np.float32)
+    b2 = (0.1 * rng.normal(size=V)).astype(np.float32)
+    t = lambda x: torch.tensor(x, device="cuda:0")
+    got = pkg.joint_logits(t(enc), t(pred), t(W1), t(b1), t(W2), t(b2)).cpu().numpy()
+    ref = _joint_forward_f16(enc, pred, W1, b1, W2, b2)
+    assert got.shape == (B, T, U, V)
+    assert np.abs(got - ref).max() <= 5e-4 * max(1.0, np.abs(ref).max()), (np.abs(got - ref).max(), np.abs(ref).max())
+    # and against the unrounded float64 joint: the price of binary16 operands, same as the loss of that dtype
+    from oracle import rnnt_oracle as orc
+
+    full, _ = orc.joint_forward(enc, pred, W1, b1, W2, b2)
+    assert np.abs(got - full).max() <= 5e-3 * max(1.0, np.abs(full).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("vocab", [12, 4096])
+def test_greedy_decode_through_the_engine_matches_a_float64_restatement(vocab):
     """f-4 on the device: the decoder's joint is the ENGINE (JointLoss.cell_logits -> compute_rnnt_joint_logits).  The
     check is a test-side restatement of utils/decoding.py:22-108 whose joint is the float64 oracle (encoder / prediction
     network outputs taken from the same torch modules): same hypothesis, and no decision was closer than the f32-grade
     error of the engine's logits."""
     from oracle import rnnt_oracle as orc
 
-    model = small_model(3)
+    model = small_model(3) if vocab == 12 else small_model(3, vocab_size=vocab, joint_net_size=128, projection_size=32)
     with torch.no_grad():
         model.joint.b2[0] -= 0.4
+        if vocab > 32:  # 4096 near-uniform logits: give the joint some contrast so that symbols are emitted and gaps are clear
+            model.joint.W2 *= 12.0
     mel = torch.randn(2, 30, 8)
     dev = torch.device("cuda:0")
     model = model.to(dev).eval()
     got = decoding.greedy_decode(model, mel.to(dev), 40).tolist()[0]
     jn = model.joint
     W1, b1, W2, b2 = (x.detach().cpu().numpy() for x in (jn.W1, jn.b1, jn.W2, jn.b2))
+    joint64 = (lambda *a: (_joint_forward_f16(*a), None)) if vocab > 32 else orc.joint_forward  # the f16 engine's roundings restated
     with torch.no_grad():
         enc = model.encoder(mel[:1].to(dev))
         hyp, min_gap = [0], np.inf
         for i in range(enc.shape[1]):
             while True:
                 g = model.prediction(torch.tensor([hyp], device=dev))[:, -1:, :]
-                y, _ = orc.joint_forward(enc[:, i : i + 1].cpu().numpy(), g.cpu().numpy(), W1, b1, W2, b2)
+                y, _ = joint64(enc[:, i : i + 1].cpu().numpy(), g.cpu().numpy(), W1, b1, W2, b2)
                 y = y[0, 0, 0]
                 top = np.sort(y)[::-1]
                 min_gap = min(min_gap, float(top[0] - top[1]))
@@ -317,12 +354,15 @@ def test_greedy_decode_through_the_engine_matches_a_float64_restatement():
                     break
             if len(hyp) >= 41:
                 break
-    assert min_gap > 1e-5, "a near-tie on this seed: pick another seed"
+    assert min_gap > (1e-5 if vocab == 12 else 2e-3), "a near-tie on this seed: pick another seed"
     assert got == hyp[1:], (got, hyp[1:])
+    assert vocab == 12 or len(got) >= 3, got
     # and the engine really is what the decoder called: its logits differ from the torch composition in the last bits only
+    # (f32-grade joint) / by the binary16 roundings of h and W2 (f16 joint)
     f, g = enc[:, :1], model.prediction(torch.tensor([[0]], device=dev))[:, -1:, :]
     a, b = jn.cell_logits(f, g), jn.logits(f, g)
-    assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-5
+    assert a.shape == b.shape and float((a - b).abs().max()) <= (1e-5 if vocab == 12 else 2e-2)
+    assert vocab == 12 or float((a - b).abs().max()) > 0.0
 
 
 @pytest.mark.gpu

@@ -97,3 +97,39 @@ def test_backward_reads_nothing_it_did_not_write(route, monkeypatch):
     c1, g1 = run()
     assert bool(torch.isfinite(c1).all()) and all(bool(torch.isfinite(x).all()) for x in g1)
     assert torch.equal(c0, c1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
+
+
+@pytest.mark.parametrize("J,w2_gain", [(704, 1.0), (128, 1.0), (128, 7.0e5)], ids=["two-kernel-J704", "single-kernel-J128", "W2-outside-binary16"])
+def test_f32_joint_backward_can_be_repeated(J, w2_gain):
+    """include/rnnt.h: compute_rnnt_joint_loss_bwd may be called more than once per _fwd.  The two-kernel backward (J = 704, or
+    any J when some |W2| leaves the binary16 range) used to overwrite the parked logits with dlogits: a second backward read
+    dlogits as logits.  Both calls must give the same gradients, and the right ones (float64 oracle)."""
+    pkg.build()
+    dev = torch.device("cuda:0")
+    B, T, U, H, V = 2, 9, 6, 8, 12
+    rng = np.random.default_rng(J)
+    enc, pred = rng.normal(size=(B, T, H)).astype(np.float32), rng.normal(size=(B, U, H)).astype(np.float32)
+    W1, b1 = (rng.normal(size=(H, J)) * 0.3).astype(np.float32), (rng.normal(size=J) * 0.1).astype(np.float32)
+    W2, b2 = (rng.normal(size=(J, V)) * 0.1).astype(np.float32), (rng.normal(size=V) * 0.1).astype(np.float32)
+    if w2_gain != 1.0:
+        W2[0, 3] = np.float32(w2_gain)  # one weight beyond 65504: the plain-f32 MFMA kernels take the call
+        W1[:, 0] = 0.0                  # (its unit's activation is tanh(0) = 0 exactly: the weight amplifies no rounding of h)
+        b1[0] = 0.0
+    labels = rng.integers(1, V, size=(B, U - 1)).astype(np.int32)
+    il, ll = np.array([T, T - 3], np.int32), np.array([U - 1, 2], np.int32)
+    t = lambda x: torch.tensor(x, device=dev)
+    params = [t(x).requires_grad_(True) for x in (enc, pred, W1, b1, W2, b2)]
+    costs = pkg.rnnt_joint_loss(*params, t(labels), t(il), t(ll), joint_dtype="f32", first_layer="torch")
+    loss = costs.sum()
+    loss.backward(retain_graph=True)
+    g1 = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    (2.0 * loss).backward()  # another upstream gradient: the stored dlogits of the first call could not serve it
+    torch.cuda.synchronize()
+    ref = orc.joint_loss_and_grads(*(x.astype(np.float64) for x in (enc, pred, W1, b1, W2, b2)), labels, il, ll)
+    for name, a, b_, p in zip(("d_enc", "d_pred", "dW1", "db1", "dW2", "db2"), g1, [p.grad for p in params], params):
+        r = ref[name]
+        s = max(1e-30, np.abs(r).max())
+        assert np.abs(a.cpu().numpy() - r).max() / s <= 1e-4, name
+        assert np.abs(b_.cpu().numpy() - 2.0 * r).max() / s <= 2e-4, name
