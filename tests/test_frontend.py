@@ -354,7 +354,7 @@ def test_greedy_decode_through_the_engine_matches_a_float64_restatement(vocab):
                     break
             if len(hyp) >= 41:
                 break
-    assert min_gap > (1e-5 if vocab == 12 else 2e-3), "a near-tie on this seed: pick another seed"
+    assert min_gap > (1e-5 if vocab == 12 else 1e-3), "a near-tie on this seed: pick another seed"
     assert got == hyp[1:], (got, hyp[1:])
     assert vocab == 12 or len(got) >= 3, got
     # and the engine really is what the decoder called: its logits differ from the torch composition in the last bits only
