@@ -185,7 +185,7 @@ constexpr int kStagePad = 33;  // row stride of the per-wave 32x32 staging tiles
 // phase 1 (forward): one lattice row (32 cells of one u-tile) per wave per iteration.
 // LDS: Ct [J][32] (pred_proj tile, transposed) | W2c [2][32][32] | Arow [8][J] | stage [8][32][33]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const JointParams jp) {
+__device__ __forceinline__ void joint_phase1_kernel_body(const JointParams &jp, const unsigned block_id) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LossParams &p = jp.lp;
     const int J = jp.J, V = p.V;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
     const bool slow = jp.tflag[0] != 0.f;  // kernel-uniform
     const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
 
-    int bid = blockIdx.x;
+    int bid = block_id;
     const int tr = bid % jp.n_tr;
     bid /= jp.n_tr;
     const int ut = bid % jp.n_ut;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
     }
     const int n_iter = tile_live ? (t_end - t_begin + kP1Waves - 1) / kP1Waves : 0;
 #ifdef JH_TRACE
-    long long *trc = (blockIdx.x == 1201) ? jp.trace + wave * 64 : nullptr;
+    long long *trc = (block_id == 1201) ? jp.trace + wave * 64 : nullptr;
 #endif
     JT1(0);
     for (int it = 0; it < n_iter; ++it) {
@@ -346,6 +346,15 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const Joint
         }
         __syncthreads();  // staging tiles and Arow are rewritten by the next iteration
         if (it < 5) JT1(4 + 4 * it);
+    }
+}
+// The launch: a FEW workgroups that walk the body's block indices (this kernel is the fallback of its faster twin and exits on
+// the workspace's range flag in every ordinary call: a full grid of workgroups that start only to return cost 4.9 us each).
+__global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const JointParams jp, const unsigned n_blocks) {
+    if (jp.tflag[1] == 0.f) return;  // W2 fits binary16 hi + lo parts: the split-precision forward does this launch's work
+    for (unsigned bid = blockIdx.x; bid < n_blocks; bid += gridDim.x) {
+        joint_phase1_kernel_body(jp, bid);
+        __syncthreads();  // the next block's LDS image must not overtake this block's readers
     }
 }
 
@@ -783,7 +792,7 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
 // ---------------------------------------------------------------------------------------------
 constexpr int kDlChunks = 8;  // 256-cell chunks per workgroup (fewer, fatter db2 partials)
 
-__global__ __launch_bounds__(256) void joint_dl_kernel(const JointParams jp) {
+__device__ __forceinline__ void joint_dl_kernel_body(const JointParams &jp, const unsigned block_id) {
     __shared__ float red[256][33];
     const LossParams &p = jp.lp;
     const int V = p.V, tid = threadIdx.x;
@@ -793,7 +802,7 @@ __global__ __launch_bounds__(256) void joint_dl_kernel(const JointParams jp) {
     for (int v = 0; v < 32; ++v) colsum[v] = 0.f;
     const size_t total = (size_t)p.cells * 32;
     for (int ch = 0; ch < kDlChunks; ++ch) {
-        const uint32_t c0 = (blockIdx.x * kDlChunks + ch) * 256u;
+        const uint32_t c0 = (block_id * kDlChunks + ch) * 256u;
         if (c0 >= p.cells) break;  // workgroup-uniform
         const uint32_t c = c0 + tid;
         // the chunk's 256 tiles are 32 KB of contiguous memory: move them with fully coalesced 16-byte accesses and hand
@@ -858,7 +867,16 @@ __global__ __launch_bounds__(256) void joint_dl_kernel(const JointParams jp) {
     if (tid < 32) {
         float s = 0.f;
         for (int r = 0; r < 256; ++r) s += red[r][tid];
-        jp.dbpart[(size_t)blockIdx.x * 32 + tid] = s;
+        jp.dbpart[(size_t)block_id * 32 + tid] = s;
+    }
+}
+// The launch: a FEW workgroups that walk the body's block indices (this kernel is the fallback of its faster twin and exits on
+// the workspace's range flag in every ordinary call: a full grid of workgroups that start only to return cost 4.9 us each).
+__global__ __launch_bounds__(256) void joint_dl_kernel(const JointParams jp, const unsigned n_blocks) {
+    if (jp.single_bwd && jp.tflag[1] == 0.f) return;  // joint_bwd_kernel forms dlogits itself
+    for (unsigned bid = blockIdx.x; bid < n_blocks; bid += gridDim.x) {
+        joint_dl_kernel_body(jp, bid);
+        __syncthreads();  // the next block's LDS image must not overtake this block's readers
     }
 }
 
@@ -866,7 +884,7 @@ __global__ __launch_bounds__(256) void joint_dl_kernel(const JointParams jp) {
 // phase 2: block = (utterance, u-tile, 64-wide J slab, row split); one lattice row per wave per iteration.
 // LDS: Cs [64 j][36] (32 u + pad) | W2s [64 j][33] | dlr [4][32 u][33] | red [4][32][33]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp) {
+__device__ __forceinline__ void joint_phase2_kernel_body(const JointParams &jp, const unsigned block_id) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LossParams &p = jp.lp;
     const int J = jp.J, V = p.V;
@@ -882,7 +900,7 @@ __global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp)
     const bool slow = jp.tflag[0] != 0.f;  // kernel-uniform
     const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
 
-    int bid = blockIdx.x;
+    int bid = block_id;
     const int ts = bid % jp.n_ts;
     bid /= jp.n_ts;
     const int js = bid % (J / 64);
@@ -935,7 +953,7 @@ __global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp)
     float dnext[16];
     if (n_iter > 0) dl_fetch(t_begin + wave, dnext);
 #ifdef JH_TRACE
-    long long *trc = (blockIdx.x == 3001) ? jp.trace + 512 + wave * 64 : nullptr;
+    long long *trc = (block_id == 3001) ? jp.trace + 512 + wave * 64 : nullptr;
 #endif
     for (int it = 0; it < n_iter; ++it) {
         const int t = t_begin + it * 4 + wave;
@@ -1028,6 +1046,15 @@ __global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp)
             for (int w = 0; w < 4; ++w) s += red[(w * 32 + jj) * kStagePad + v];
             jp.dWpart[((size_t)wid * J + j0 + jt * 32 + jj) * 32 + v] = s;
         }
+    }
+}
+// The launch: a FEW workgroups that walk the body's block indices (this kernel is the fallback of its faster twin and exits on
+// the workspace's range flag in every ordinary call: a full grid of workgroups that start only to return cost 4.9 us each).
+__global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp, const unsigned n_blocks) {
+    if (jp.tflag[1] == 0.f) return;  // joint_phase2s_kernel / joint_bwd_kernel does this launch's work
+    for (unsigned bid = blockIdx.x; bid < n_blocks; bid += gridDim.x) {
+        joint_phase2_kernel_body(jp, bid);
+        __syncthreads();  // the next block's LDS image must not overtake this block's readers
     }
 }
 
@@ -1905,6 +1932,8 @@ static JointLayout make_joint_layout(int T, int U, int B, int J) {
     return L;
 }
 
+constexpr unsigned kFallbackGrid = 512;  // workgroups of a fallback launch (two per CU when it does run)
+
 static bool joint_supported(int J, int V) {
     // J <= 704: the streaming forward (640 < J) keeps the whole C^T tile (128 J bytes), a row of enc_proj per wave (32 J) and
     // 50 KB of staging in LDS: 162,816 of the 163,840 bytes at J = 704
@@ -2029,7 +2058,7 @@ hipError_t launch_joint_logits(const float *enc_proj, const float *pred_proj, co
     }
     const size_t shm1 = ((size_t)J * 32 + 2 * 1024 + kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
     if ((e = set_lds(joint_phase1_kernel, shm1)) != hipSuccess) return e;
-    hipLaunchKernelGGL(joint_phase1_kernel, dim3(g1), dim3(kP1Waves * 64), shm1, s, jp);  // exits at once unless W2 left binary16
+    hipLaunchKernelGGL(joint_phase1_kernel, dim3(g1 < kFallbackGrid ? g1 : kFallbackGrid), dim3(kP1Waves * 64), shm1, s, jp, g1);  // exits at once unless W2 left binary16
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const size_t n = (size_t)jp.lp.cells * V;
     const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
@@ -2110,7 +2139,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
             if ((e = set_lds(joint_phase1s_kernel, shm1s)) != hipSuccess) return e;
             hipLaunchKernelGGL(joint_phase1s_kernel, dim3(g1), dim3(kP1Waves * 64), shm1s, s, jp);
         }
-        hipLaunchKernelGGL(joint_phase1_kernel, dim3(g1), dim3(kP1Waves * 64), shm1, s, jp);
+        hipLaunchKernelGGL(joint_phase1_kernel, dim3(g1 < kFallbackGrid ? g1 : kFallbackGrid), dim3(kP1Waves * 64), shm1, s, jp, g1);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = launch_sweeps(jp.lp, s)) != hipSuccess) return e;
     }
@@ -2123,7 +2152,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     const bool single = (J / 32) % n_groups == 0 && J <= 640;  // consumers per group must come out even; LDS / wave budget
     jp.single_bwd = single ? 1 : 0;
     const unsigned gdl = (jp.lp.cells + 256u * kDlChunks - 1u) / (256u * kDlChunks);
-    hipLaunchKernelGGL(joint_dl_kernel, dim3(gdl), dim3(256), 0, s, jp);  // exits at once when joint_bwd_kernel does its work
+    hipLaunchKernelGGL(joint_dl_kernel, dim3(single ? (gdl < kFallbackGrid ? gdl : kFallbackGrid) : gdl), dim3(256), 0, s, jp, gdl);  // exits at once when joint_bwd_kernel does its work
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const unsigned g2 = (unsigned)B * L.n_ut * (J / 64) * L.n_ts;
     int bwd_nblk = 0;
@@ -2144,7 +2173,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
         const size_t shm2s = ((size_t)64 * 36 + 4 * 32 * 36 + 4 * 32 * kStagePad) * sizeof(float) + 8192;
         hipLaunchKernelGGL(joint_phase2s_kernel, dim3(g2), dim3(256), shm2s, s, jp);
     }
-    hipLaunchKernelGGL(joint_phase2_kernel, dim3(g2), dim3(256), shm2, s, jp);  // exits at once unless tflag[1] is set
+    hipLaunchKernelGGL(joint_phase2_kernel, dim3(g2 < kFallbackGrid ? g2 : kFallbackGrid), dim3(256), shm2, s, jp, g2);  // exits at once unless tflag[1] is set
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const size_t nC = (size_t)B * U * J;
     // partial counts: what the single-kernel backward wrote, or (flag set / wide J) what the two-kernel backward wrote

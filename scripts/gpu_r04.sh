@@ -62,6 +62,14 @@ if has pmc; then
   python scripts/summarize_trace.py pmc $OUT/pmc $OUT/pmc_op.json
   python scripts/summarize_trace.py latest $OUT/pmc_op.json $OUT/pmc_latest.json 645120000
 fi
+if has pmcv; then
+  echo "== PMC, fused f32-grade joint at C2: VALU / MFMA instruction counts (the VALU ceiling of bench.py's fused legs)"
+  for c in "SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_INSTS_VALU_TRANS SQ_INSTS_LDS" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
+    n=$(echo $c | tr ' ' '_')
+    (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/pmcv/$n -o pmc -- python $R/bench.py --fused-only 32,600,150,28 --steps 3 > $R/$OUT/pmcv_$n.log 2>&1); echo "pmcv $n rc=$?"
+  done
+  python scripts/summarize_trace.py pmc $OUT/pmcv $OUT/pmc_fused_valu.json | grep -i "joint_fwd\|joint_bwd\|cellrec" 
+fi
 if has c5; then
   echo "== config 5 fused f16 joint: time + kernel trace"
   timeout 600 python bench.py --fused-only 16,1500,300,1024 --steps 3 > $OUT/c5.json 2> $OUT/c5.err; echo "c5 rc=$?"; cat $OUT/c5.json

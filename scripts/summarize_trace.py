@@ -103,14 +103,14 @@ def latest(pmc_json, out_json, cells_bytes):
     """HBM bytes per launch of the op-level kernels from a FETCH_SIZE / WRITE_SIZE pmc summary (KiB; FETCH doubled: on gfx950
     FETCH_SIZE reports half of the bytes of wide streaming reads, /opt/skills/guides/MI355X_MICROARCH.md)."""
     d = json.load(open(pmc_json))
-    roles = {"grad": ("cell_tile_kernel", ", true,"), "lsm": ("cell_tile_kernel", ", false,"), "sweep": ("sweep_kernel",),
-             "redo": ("lin_redo_kernel",)}
+    roles = {"grad": (r"cell_tile_kernel<\d+, true",), "lsm": (r"cell_tile_kernel<\d+, false",), "sweep": (r"sweep_kernel",),
+             "redo": (r"lin_redo_kernel",)}
     out = {"source": f"{os.path.basename(pmc_json)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB; FETCH doubled per "
                      "the gfx950 note of MI355X_MICROARCH.md)", "csrc_sha16": d.get("csrc_sha16")}
     step = 0.0
     for role, needles in roles.items():
         for kern, c in d["kernels"].items():
-            if all(n in kern for n in needles) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            if all(re.search(n, kern) for n in needles) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 b = (2.0 * c["FETCH_SIZE"]["avg"] + c["WRITE_SIZE"]["avg"]) * 1024.0
                 out[f"{role}_kernel_hbm_bytes_per_launch"] = b
                 out[f"{role}_kernel"] = kern
