@@ -243,7 +243,8 @@ def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
                          "f32_mfma_peak_for_reference": MFMA_F32_PEAK_TFLOPS,
                          "note": "peak = dense f16 MFMA peak / 3 (hi.hi + lo.hi + hi.lo per f32-grade product); achieved "
                                  "uses the 8*J*V convention (its backward recompute is not executed: the V<=32 logits tile "
-                                 "is parked); executed_mfma_tflops counts the products actually issued (V padded to 32)"},
+                                 "is parked); executed_mfma_tflops counts the products actually issued (V padded to 32)",
+                         "issue_bound": fused_issue_bound(B, T, U, V, J, dt)},
             "workspace_GB": ws.numel() / 1e9}
 
 
@@ -462,6 +463,40 @@ def sweep_ns_per_diagonal(n_diag):
     d = committed_profile("kernel_stats_latest.json")
     try:
         return d["headline_kernels"]["sweeps"]["avg_ms"] * 1e6 / n_diag if d else None
+    except Exception:
+        return None
+
+
+def fused_issue_bound(B, T, U, V, J, dt):
+    """What actually limits the f32-grade fused joint: the issue slots of the SIMDs.  Its two big kernels spend ~18 VALU
+    instructions per MFMA (tanh from the e^{2x} tables, binary16 hi / lo splits, DPP broadcasts), and on one SIMD VALU and MFMA
+    work of the resident waves add up instead of overlapping.  From the committed instruction counters of this
+    shape (profiles/fused_valu_latest.json: rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_MFMA / SQ_VALU_MFMA_BUSY_CYCLES; None when
+    the kernels changed since or the shape differs): time at 1024 SIMDs x 2.4 GHz if every VALU instruction cost the 2 clocks of
+    a SIMD-32 (the hardware's issue floor) and if it cost the 3.8 clocks measured for independent v_fma_f32 of resident waves
+    (scripts/probes/probe_issue.hip), plus the matrix pipe's busy time."""
+    d = committed_profile("fused_valu_latest.json")
+    if not d or (B, T, U, V, J) != (32, 600, 150, 28, 640):
+        return None
+    try:
+        k = d["kernels"]
+        fwd = next(v for n, v in k.items() if "joint_fwd_kernel" in n)
+        bwd = next(v for n, v in k.items() if "joint_bwd_kernel" in n)
+        simd_hz = 1024 * 2.4e9
+        out = {}
+        for name, c in (("forward", fwd), ("backward", bwd)):
+            nv, nm = c["SQ_INSTS_VALU"]["avg"], c["SQ_INSTS_MFMA"]["avg"]
+            mfma_ms = c["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"] / simd_hz * 1e3
+            out[name] = {"valu_instructions": nv, "mfma_instructions": nm, "valu_per_mfma": nv / nm,
+                         "valu_ms_at_2_clocks": nv * 2.0 / simd_hz * 1e3, "valu_ms_at_3.8_clocks": nv * 3.8 / simd_hz * 1e3,
+                         "mfma_busy_ms": mfma_ms}
+        floor = sum(v["valu_ms_at_3.8_clocks"] + v["mfma_busy_ms"] for v in out.values())
+        out["valu_plus_mfma_ms"] = floor
+        out["frac_of_issue_bound"] = floor / (dt * 1e3)
+        out["note"] = ("valu_plus_mfma_ms = VALU instructions at 3.8 clocks + matrix-pipe busy time of the two big kernels: the time "
+                       "this instruction mix needs when nothing overlaps on a SIMD; frac_of_issue_bound = that / the measured step "
+                       "(the rest: prep / records / reductions / sweeps and stalls).  The MFMA roofline above overstates the headroom.")
+        return out
     except Exception:
         return None
 

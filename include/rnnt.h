@@ -82,12 +82,28 @@ RNNT_API rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool
  *                      the fused joint entry points stop at maxU = 1024;
  *   B*maxT*maxU < 2^31 cell indices are 32-bit;
  *   workspace 256-byte aligned.
- * Numerics (the lattice is float32, log2 domain, with exact integer re-basing per sweep lane; float64 only where offsets
- * are combined).  Against a float64 evaluation of the same logits: costs within 1e-4 max(1, |cost|); gradients within 1e-4
- * absolute for N(0,1) ... 4 x N(0,1) logits and for trained-like posteriors (one dominant symbol per cell along any monotone
- * alignment), measured 1e-6 ... 9e-5 at B=32 T=600 U=150 V=28; within 2.5e-4 for 8 x N(0,1) logits (costs of ~7,500 nats),
- * where the float32 representation of the log-probabilities themselves limits the result (profiles/r03_accuracy.json,
- * tests/test_peaky_gpu.py).
+ * Numerics.  Small vocabularies (alphabet_size <= 60, 16-byte-aligned acts) on lattices of up to 1024 columns run on a
+ * LINEAR-domain lattice: edge probabilities, alpha / beta as float32 mantissas times 2^(integer frame per sweep lane and block of
+ * 4 or 8 diagonals), exact power-of-two renormalisation -- every rounding is RELATIVE, so the gradients come out 1e-7 ... 4e-6
+ * from a float64 evaluation of the same logits (costs 1e-9 ... 5e-6 relative).  Mass that falls more than 126 bits below its
+ * frame is flushed; whether that mattered is decided per lattice cell by the gradient pass (what a flush can have cost, times
+ * the other side's mass, over the likelihood, must stay below 2^-40) and per utterance by the sweeps (likelihood zero /
+ * non-finite, alpha-side vs beta-side likelihood, an edge probability below 2^-100).  An utterance that fails is redone by the
+ * LOG-domain kernels (float32 log2 values with exact integer re-basing per sweep lane, float64 where offsets are combined) --
+ * slower by a millisecond per utterance, exact for any range -- so results never depend on the shortcut.  N(0,1) logits and
+ * trained-like posteriors (one dominant symbol per cell along any monotone alignment) stay on the linear lattice; unstructured
+ * peaked logits (4 x N(0,1) and beyond) are handed back.  Everything else (larger vocabularies, unaligned tensors, more than
+ * 1024 columns, the fused joints) runs on the log-domain kernels throughout.
+ * Bars, against a float64 evaluation of the same logits, all tested with FIXED bars (tests/test_lin_gpu.py,
+ * tests/test_peaky_gpu.py, tests/test_peaky_wide_gpu.py; measured values in profiles/r04_accuracy*.json):
+ *   costs      within 1e-4 max(1, |cost|) everywhere;
+ *   gradients  within 1e-4 absolute for N(0,1) ... 4 x N(0,1) logits and trained-like posteriors on lattices of up to 256
+ *              columns (measured 2e-7 ... 8.5e-5 at B=32 T=600 U=150 V=28) and on wider lattices with at least as many frames
+ *              as columns; within 2.5e-4 for 8 x N(0,1) logits there (costs of ~7,500 nats: the float32 representation of the
+ *              log-probabilities themselves limits the result) and, on lattices wider than 256 columns, for 4 x N(0,1) logits
+ *              and for unstructured logits when there are FEWER frames than columns (every path emits several labels per
+ *              frame; a sweep lane's 12-16 columns then span hundreds of bits, measured 1.2e-4 ... 1.8e-4); within 5e-4 for
+ *              8 x N(0,1) logits on those lattices (measured 3.7e-4).
  * Out-of-range per-utterance lengths (T_b < 1, T_b > maxT, L_b < 0, L_b > maxU-1) are device data and cannot be
  * checked at enqueue time: the kernels clamp them into the tensor (no out-of-bounds access) and report that
  * utterance with a NaN cost and NaN gradients.  Labels outside [0, alphabet_size) are clamped into range. */
@@ -122,6 +138,7 @@ RNNT_API rnntStatus_t compute_rnnt_loss(const float *acts, float *grads, const i
  *   compute_rnnt_loss_bwd  = grads[b] = cost_scale[b] * d cost_b / d acts  (cost_scale NULL = 1),
  *                            from the SAME acts and the workspace left by _fwd.
  * compute_rnnt_loss(acts, grads, ...) == _fwd followed by _bwd(cost_scale = NULL).
+ * _bwd may be called more than once per _fwd (an utterance the linear lattice handed back keeps its log-domain state for it).
  *   compute_rnnt_loss_ex   = compute_rnnt_loss with cost_scale folded into grads, in ONE call
  *                            (_fwd followed by _bwd on the caller's stream; nothing else differs). */
 RNNT_API rnntStatus_t compute_rnnt_loss_fwd(const float *acts, const int *flat_labels,

@@ -277,7 +277,8 @@ static hipError_t launch_cell(const LossParams &p, hipStream_t s) {
     if (LIN && !tile_path_ok(p, GRAD)) return hipErrorInvalidValue;
     if (tile_path_ok(p, GRAD)) {
         // (the lsm launch fills the log-zero part of W itself: see cell_tile_kernel)
-        const unsigned blocks = (unsigned)p.nb * p.tile.tiles_t * p.tile.tiles_u + (GRAD ? 0u : (unsigned)p.nb * (unsigned)(p.Nr / kFillRows));
+        // (rnnt_lin.h kLinLoaderZero: the linear lattice's loader waves can write probability zero over the unowned positions in LDS instead)
+        const unsigned blocks = (unsigned)p.nb * p.tile.tiles_t * p.tile.tiles_u + ((GRAD || (LIN && kLinLoaderZero)) ? 0u : (unsigned)p.nb * (unsigned)(p.Nr / kFillRows));
         // the patch image: TT x UU cells (<= 256) of V floats, to the byte.  Sized by the patch, not by the 256 lanes, and without
         // padding: at V = 28 that is 26,880 B -- six workgroups per CU instead of five (gradient pass 115 -> 110.5 us); at V = 32
         // 30,720 B instead of 32,832 B -- five instead of four (146 -> 140 us)

@@ -31,6 +31,13 @@ constexpr int kFrameNone = -(1 << 28);   // frame of a lane without mass and wit
 constexpr int kCertBits = -40;           // per-cell bound (bits) on flush loss x other side / likelihood
 constexpr float kTinyEdge = 7.8886091e-31f;  // 2^-100: an edge the lattice owns below this goes to the log-domain path (NaN in W)
 
+// Positions of the skewed edge array that no lattice cell owns: 1 = nobody fills them in HBM, the sweeps' loader waves write
+// probability zero over them in LDS (rnnt_sweep.h sweep_loader ZERO); 0 = the lsm launch carries fill workgroups for them.
+#ifndef RNNT_LIN_ZERO
+#define RNNT_LIN_ZERO 0  // (needs RNNT_LIN_LOADERS = 1)
+#endif
+constexpr bool kLinLoaderZero = RNNT_LIN_ZERO != 0;
+
 // per-utterance words in LossParams::flags
 enum { kFlagA = 0, kFlagB = 1, kFlagG = 2, kFlagState = 3 };  // state: 0 linear lattice, 2 log-domain lattice ready (after a redo)
 

@@ -193,6 +193,26 @@ __device__ __forceinline__ void lin_record(const LossParams &p, const int b, con
     if (side == 0 && p.costs) st_f32_wt(p.costs + b, (float)(-ll2 * 0.6931471805599453));
 }
 
+#ifndef RNNT_LIN_LOADERS
+#define RNNT_LIN_LOADERS 1
+#endif
+constexpr int kLinLoaders = RNNT_LIN_LOADERS;  // loader waves per sweep workgroup (rnnt_sweep.h sweep_loader); measured: two loaders that split every chunk give the same sweep time (41.9 vs 40.6 us at B32 T600 U150) -- the sweeping wave is not waiting for data
+
+// Chunk i of the loading order has landed when EVERY loader has counted i + 1 chunks (each brings its share of the pieces).
+struct LandedView {
+    uint32_t addr0;  // LDS byte address of loader 0's counter; loader w's is 8 w bytes further
+    int have[kLinLoaders];
+    __device__ __forceinline__ bool wait(const int i) {  // false: a bounded poll gave up
+        bool ok = true;
+#pragma unroll
+        for (int w = 0; w < kLinLoaders; ++w) {
+            if (have[w] < i + 1) have[w] = lds_wait_ge(addr0 + 8u * (uint32_t)w, i + 1);
+            ok &= have[w] >= i + 1;
+        }
+        return ok;
+    }
+};
+
 template <int K, int G, int NB>
 __device__ void lin_alpha_sweep(const LossParams &p, float *bufs, const LdLink lk, const int b, const int lane) {
     constexpr int Up = 64 * K, chunkf = G * 2 * Up;
@@ -218,13 +238,13 @@ __device__ void lin_alpha_sweep(const LossParams &p, float *bufs, const LdLink l
     const int last_row = Nb - 1;
     const int nchunks = last_row / G + 1;
 
-    int have = 0;
+    LandedView lv;
+    lv.addr0 = lk.landed;
+#pragma unroll
+    for (int w = 0; w < kLinLoaders; ++w) lv.have[w] = 0;
     bool timed_out = lengths_invalid(p, b);
     for (int ck = 0; ck < nchunks; ++ck) {
-        if (have < ck + 1) {
-            have = lds_wait_ge(lk.landed, ck + 1);
-            timed_out |= have < ck + 1;
-        }
+        timed_out |= !lv.wait(ck);
         const float *cur = bufs + (ck % NB) * chunkf + 2 * u0;
         const int r0 = ck * G;
         if (K <= 15 && r0 + G <= last_row) {  // (lgkmcnt counts to 15)
@@ -277,14 +297,14 @@ __device__ void lin_beta_sweep(const LossParams &p, float *bufs, const LdLink lk
     st.tab = p.EB + (size_t)b * p.NCl * 64 + lane;
     st.row = out + (size_t)last * Up;
 
-    int have = 0;
+    LandedView lv;
+    lv.addr0 = lk.landed;
+#pragma unroll
+    for (int w = 0; w < kLinLoaders; ++w) lv.have[w] = 0;
     bool timed_out = lengths_invalid(p, b);
     for (int ck = ckl; ck >= 0; --ck) {
         const int i_ring = ckl - ck;  // the loader's chunk index
-        if (have < i_ring + 1) {
-            have = lds_wait_ge(lk.landed, i_ring + 1);
-            timed_out |= have < i_ring + 1;
-        }
+        timed_out |= !lv.wait(i_ring);
         const float *cur = bufs + (i_ring % NB) * chunkf + 2 * u0;
         const int r0 = ck * G;
         if (K <= 15 && r0 + G - 1 < last) {
@@ -315,24 +335,27 @@ __device__ void lin_beta_sweep(const LossParams &p, float *bufs, const LdLink lk
 }
 
 template <int K, int G, int NB>
-__global__ __launch_bounds__(128) void lin_sweep_kernel(const LossParams p) {
+__global__ __launch_bounds__(64 * (1 + kLinLoaders)) void lin_sweep_kernel(const LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int chunkf = G * 2 * 64 * K;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = p.b0 + (int)(blockIdx.x >> 1);
     const bool beta = (blockIdx.x & 1) != 0;
+    // counters: [0] landed by loader 0, [1] consumed, [2] landed by loader 1, ...
     int *ctr = (int *)(lds + NB * chunkf);
-    if (tid < 2) ctr[tid] = 0;
+    if (tid < 2 * kLinLoaders) ctr[tid] = 0;
     __syncthreads();
     LdLink lk;
     lk.landed = (uint32_t)(uintptr_t)((lds_void *)ctr);
     lk.consumed = lk.landed + 4u;
-    if (wave == 1) {
+    if (wave >= 1) {
+        LdLink mine = lk;
+        mine.landed = lk.landed + 8u * (uint32_t)(wave - 1);
         if (beta)
-            sweep_loader<K, G, NB, true>(p, lds, lk, b, lane);
+            sweep_loader<K, G, NB, true, kLinLoaderZero, kLinLoaders>(p, lds, mine, b, lane, wave - 1);
         else
-            sweep_loader<K, G, NB, false>(p, lds, lk, b, lane);
+            sweep_loader<K, G, NB, false, kLinLoaderZero, kLinLoaders>(p, lds, mine, b, lane, wave - 1);
     } else {
         if (beta)
             lin_beta_sweep<K, G, NB>(p, lds, lk, b, lane);
@@ -450,12 +473,12 @@ template <int K, int G>
 static hipError_t launch_lin_sweep(const LossParams &p, hipStream_t s) {
     constexpr int NB = ((size_t)4 * G * 2 * 64 * K * sizeof(float) + 16 <= 128 * 1024) ? 4 : 3;
     constexpr size_t shm = (size_t)NB * G * 2 * 64 * K * sizeof(float) + 16;
-    static_assert(shm <= 160 * 1024, "chunk ring exceeds the LDS");
+    static_assert(shm <= 160 * 1024 && 2 * kLinLoaders * sizeof(int) <= 16, "chunk ring exceeds the LDS");
     if (shm > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)lin_sweep_kernel<K, G, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((lin_sweep_kernel<K, G, NB>), dim3(2 * p.nb), dim3(128), shm, s, p);
+    hipLaunchKernelGGL((lin_sweep_kernel<K, G, NB>), dim3(2 * p.nb), dim3(64 * (1 + kLinLoaders)), shm, s, p);
     return hipGetLastError();
 }
 template <int K, int G>

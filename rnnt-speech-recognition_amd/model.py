@@ -1,5 +1,6 @@
 """The callers of the hot path: encoder, prediction network and TimeReduction as stock
-PyTorch-ROCm modules (MIOpen LSTM with projection), wired to the fused joint + loss.
+PyTorch-ROCm modules (stock nn.LSTM with proj_size; PyTorch runs projected LSTMs through its own
+per-timestep implementation, not MIOpen's fused one), wired to the fused joint + loss.
 
 Reference: model.py:8-36 (TimeReduction), :39-81 (encoder), :84-116 (prediction network), :119-169
 (build_keras_model); defaults hparams.py:3-37.  Nothing here is a custom kernel -- the point of this file is

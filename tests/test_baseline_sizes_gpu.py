@@ -71,9 +71,27 @@ def check_against_oracle(case, dtype, picks, scale, costs, grads, grads_masked, 
             assert abs(c[b] - ex["cost"]) <= ctol * max(1.0, abs(ex["cost"])), (b, c[b], ex["cost"])
         for name, got, ref in (("d_enc_proj", d_ep[b, :Tb], o["d_enc_proj"]), ("d_pred_proj", d_pp[b, :Ub], o["d_pred_proj"])):
             assert np.abs(got - ref).max() <= gtol * max(1.0, np.abs(ref).max()), (b, name, np.abs(got - ref).max())
+            if not f16:  # the f32-grade joint also meets north_star's ABSOLUTE figure on the two activation gradients
+                _abs_report[name] = max(_abs_report.get(name, 0.0), float(np.abs(got - ref).max()))
+                assert np.abs(got - ref).max() <= 1e-4, (b, name, np.abs(got - ref).max(), np.abs(ref).max())
         dW2_ref, db2_ref = dW2_ref + o["dW2"], db2_ref + o["db2"]
     for name, got, ref in (("dW2", grads_masked[2].cpu().numpy(), dW2_ref), ("db2", grads_masked[3].cpu().numpy(), db2_ref)):
         assert np.abs(got - ref).max() <= gtol * max(1.0, np.abs(ref).max()), (name, np.abs(got - ref).max())
+
+
+_abs_report = {}  # max |d| of d enc_proj / d pred_proj over the f32-grade cases of this file -> gpurun_out/r04_accuracy_fused.json
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _write_abs_report():
+    yield
+    import json
+    import os
+
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "r04_accuracy_fused.json"), "w") as f:
+        json.dump({"fused_f32_max_abs_d_activation_gradients": _abs_report, "bar": 1e-4}, f, indent=1)
 
 
 def check_properties(case, costs, grads, rerun):
@@ -118,7 +136,7 @@ def test_c2_fused_joint_at_bench_size():
 
 def test_c3_joint_shape_at_size():
     """configs[2]'s joint: B=64, T'=300 (600 frames, x2 time reduction), U=100, H=J=320, V=28 -- five 64-wide J slabs,
-    four u-tiles, row splits; through the model-level entry (W1 applied by hipBLASLt, as train steps do)."""
+    four u-tiles, row splits; through the model-level entry (the first Dense layer inside the library too, as train steps do)."""
     B, T, U, H, J, V = 64, 300, 100, 320, 320, 28
     rng = np.random.default_rng(33)
     enc = rng.normal(size=(B, T, H)).astype(np.float32)

@@ -53,9 +53,11 @@ for case in range(n_cases):
             if dg > worst["loss_grad"]:
                 worst_case["loss_grad"] = (str(kind), B, T, U, V, blank, sc)
             worst["loss_cost"], worst["loss_grad"] = max(worst["loss_cost"], dc), max(worst["loss_grad"], dg)
-            # f32 lattice sums: the rounding error of every edge weight grows with its magnitude, so the bar scales with
-            # the logit spread (1e-4 for N(0,1) logits, the tests' setting)
-            if not (dc <= 1e-4 and dg <= 1e-4 * max(1.0, sc)):
+            # FIXED bars, the ones of include/rnnt.h (round 3 scaled the bar by sigma and hid a 1.26e-4 at 4 sigma on a 643-column
+            # lattice): 1e-4 up to 4 sigma on lattices of up to 256 columns and on wider ones with T >= U; 2.5e-4 on wider
+            # lattices with fewer frames than columns and at 4 sigma there; 8 sigma is not drawn here (tests/test_peaky*_gpu.py)
+            bar = 1e-4 if (U <= 256 or (T >= U and sc <= 1.0)) else 2.5e-4
+            if not (dc <= 1e-4 and dg <= bar):
                 fails.append((str(kind), B, T, U, V, blank, sc, dc, dg))
         else:
             f16 = kind == "joint16"
