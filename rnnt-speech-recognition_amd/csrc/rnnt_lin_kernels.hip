@@ -70,6 +70,63 @@ __device__ __forceinline__ void lin_renorm(float (&v)[K], LinState &st, const in
     st_i32_wt(st.tab + (size_t)kc * 64, En);
 }
 
+// The edge probabilities of one diagonal for this lane: K pairs {blank, label} = 8 K contiguous bytes of LDS at a lane stride of
+// 8 K bytes.  Even K: 16-byte reads (a lone wave pays a full issue slot per instruction whatever its width).  Odd K: 8-byte
+// reads -- at K = 3 the 16-byte form would be only 8-byte aligned (lane stride 24); gfx950 serves such reads (unaligned DS
+// access; scripts/probes/probe_lat.hip) but slower: 44.3 against 40.6 us for the sweeps at B32 T600 U150.
+template <int K>
+struct LinRow {
+    static constexpr bool WIDE = (K % 2) == 0;
+    static constexpr int NR = WIDE ? K / 2 : K;  // LDS instructions per row
+    f32x4 q4[WIDE ? K / 2 : 1];
+    f32x2 q2[WIDE ? 1 : K];
+    template <int J>
+    __device__ __forceinline__ float b() const {  // p(blank) of column J
+        if constexpr (WIDE) return q4[J / 2][2 * (J & 1)];
+        else return q2[J][0];
+    }
+    template <int J>
+    __device__ __forceinline__ float l() const {  // p(label) of column J
+        if constexpr (WIDE) return q4[J / 2][2 * (J & 1) + 1];
+        else return q2[J][1];
+    }
+};
+template <int K, int J = 0>
+__device__ __forceinline__ void lin_row_unpack(const LinRow<K> &w, float (&wb)[K], float (&wl)[K]) {
+    if constexpr (J < K) {
+        wb[J] = w.template b<J>(), wl[J] = w.template l<J>();
+        lin_row_unpack<K, J + 1>(w, wb, wl);
+    }
+}
+// Issue the LDS reads of row ROW of the chunk buffer; completion is NOT tracked by the compiler: the caller waits with
+// lds_wait<N>() (LDS returns in order) and nothing may touch the row's registers before that.
+template <int K, int ROW>
+__device__ __forceinline__ void lin_issue_row(LinRow<K> &w, const uint32_t addr) {
+    if constexpr (LinRow<K>::WIDE) {
+#pragma unroll
+        for (int i = 0; i < K / 2; ++i)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w.q4[i]) : "v"(addr), "n"(ROW * 2 * 64 * K * 4 + i * 16));
+    } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(w.q2[j]) : "v"(addr), "n"(ROW * 2 * 64 * K * 4 + j * 8));
+    }
+}
+// (the tail of a sweep reads its rows with ordinary, compiler-tracked loads)
+template <int K>
+__device__ __forceinline__ void lin_load_row(LinRow<K> &w, const float *wrow) {
+    if constexpr (LinRow<K>::WIDE) {
+#pragma unroll
+        for (int i = 0; i < K / 2; ++i) {
+            const f32x2 a = ((const f32x2 *)wrow)[2 * i], c = ((const f32x2 *)wrow)[2 * i + 1];
+            w.q4[i] = (f32x4){a[0], a[1], c[0], c[1]};
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) w.q2[j] = ((const f32x2 *)wrow)[j];
+    }
+}
+
 // One step of the recurrence.  A lone wave issues ONE instruction of any kind (VALU, LDS, VMEM, s_nop) per ~5 clocks, ~8.5 when
 // a VALU instruction consumes the result of the one just before it (scripts/probes/probe_lat.hip; profiles/r04_notes.md): the
 // time of a step is its instruction count.  Two VALU instructions per lattice column plus the hand-over (v_ldexp into the
@@ -81,36 +138,37 @@ __device__ __forceinline__ void lin_renorm(float (&v)[K], LinState &st, const in
 // alpha: diagonal r -> r+1 with the outgoing edge probabilities w[j] = {blank, label} of diagonal r:
 //   a[j] <- a[j] p_blank[j] + a[j-1] p_label[j-1];  what leaves column K-1 is scaled into lane + 1's frame BEFORE the product
 template <int K>
-__device__ __forceinline__ void lin_alpha_step(float (&a)[K], const f32x2 (&w)[K], const int d) {
+__device__ __forceinline__ void lin_alpha_step(float (&a)[K], const LinRow<K> &w, const int d) {
     // ONE asm block: the compiler puts the hand-over product right in front of the DPP move (s_nop 1).  Inputs and outputs are
     // separate registers, so that the new diagonal can land in the register triple the store instruction wants.
     if constexpr (K > 4) {  // wide lattices: left to the compiler (their step is long enough to hide its own latencies)
-        float pr[K];
-        const float hand = ldexp_f(a[K - 1], d) * w[K - 1][1];
+        float pr[K], wb[K], wl[K];
+        lin_row_unpack<K>(w, wb, wl);
+        const float hand = ldexp_f(a[K - 1], d) * wl[K - 1];
 #pragma unroll
-        for (int j = 0; j < K - 1; ++j) pr[j] = a[j] * w[j][1];
+        for (int j = 0; j < K - 1; ++j) pr[j] = a[j] * wl[j];
         const float left = dpp_lower_zero(hand);
 #pragma unroll
-        for (int j = K - 1; j >= 1; --j) a[j] = fmaf(a[j], w[j][0], pr[j - 1]);
-        a[0] = fmaf(a[0], w[0][0], left);
+        for (int j = K - 1; j >= 1; --j) a[j] = fmaf(a[j], wb[j], pr[j - 1]);
+        a[0] = fmaf(a[0], wb[0], left);
     } else {
     float n[K], as, q, pr[K > 1 ? K - 1 : 1];
     if constexpr (K == 1) {
         asm volatile("v_ldexp_f32 %[as], %[a0], %[d]\n\tv_mul_f32 %[as], %[as], %[l0]\n\ts_nop 1\n\tv_mov_b32_dpp %[q], %[as] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fma_f32 %[n0], %[a0], %[b0], %[q]"
                      : [n0] "=&v"(n[0]), [as] "=&v"(as), [q] "=&v"(q)
-                     : [a0] "v"(a[0]), [b0] "v"(w[0][0]), [l0] "v"(w[0][1]), [d] "v"(d));
+                     : [a0] "v"(a[0]), [b0] "v"(w.template b<0>()), [l0] "v"(w.template l<0>()), [d] "v"(d));
     } else if constexpr (K == 2) {
         asm volatile("v_ldexp_f32 %[as], %[a1], %[d]\n\tv_mul_f32 %[p0], %[a0], %[l0]\n\tv_mul_f32 %[as], %[as], %[l1]\n\tv_fma_f32 %[n1], %[a1], %[b1], %[p0]\n\ts_nop 0\n\tv_mov_b32_dpp %[q], %[as] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fma_f32 %[n0], %[a0], %[b0], %[q]"
                      : [n0] "=&v"(n[0]), [n1] "=&v"(n[1]), [as] "=&v"(as), [q] "=&v"(q), [p0] "=&v"(pr[0])
-                     : [a0] "v"(a[0]), [a1] "v"(a[1]), [b0] "v"(w[0][0]), [b1] "v"(w[1][0]), [l0] "v"(w[0][1]), [l1] "v"(w[1][1]), [d] "v"(d));
+                     : [a0] "v"(a[0]), [a1] "v"(a[1]), [b0] "v"(w.template b<0>()), [b1] "v"(w.template b<1>()), [l0] "v"(w.template l<0>()), [l1] "v"(w.template l<1>()), [d] "v"(d));
     } else if constexpr (K == 3) {
         asm volatile("v_ldexp_f32 %[as], %[a2], %[d]\n\tv_mul_f32 %[p0], %[a0], %[l0]\n\tv_mul_f32 %[p1], %[a1], %[l1]\n\tv_mul_f32 %[as], %[as], %[l2]\n\tv_fma_f32 %[n2], %[a2], %[b2], %[p1]\n\tv_fma_f32 %[n1], %[a1], %[b1], %[p0]\n\tv_mov_b32_dpp %[q], %[as] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fma_f32 %[n0], %[a0], %[b0], %[q]"
                      : [n0] "=&v"(n[0]), [n1] "=&v"(n[1]), [n2] "=&v"(n[2]), [as] "=&v"(as), [q] "=&v"(q), [p0] "=&v"(pr[0]), [p1] "=&v"(pr[1])
-                     : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [b0] "v"(w[0][0]), [b1] "v"(w[1][0]), [b2] "v"(w[2][0]), [l0] "v"(w[0][1]), [l1] "v"(w[1][1]), [l2] "v"(w[2][1]), [d] "v"(d));
+                     : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [b0] "v"(w.template b<0>()), [b1] "v"(w.template b<1>()), [b2] "v"(w.template b<2>()), [l0] "v"(w.template l<0>()), [l1] "v"(w.template l<1>()), [l2] "v"(w.template l<2>()), [d] "v"(d));
     } else {
         asm volatile("v_ldexp_f32 %[as], %[a3], %[d]\n\tv_mul_f32 %[p0], %[a0], %[l0]\n\tv_mul_f32 %[p1], %[a1], %[l1]\n\tv_mul_f32 %[p2], %[a2], %[l2]\n\tv_mul_f32 %[as], %[as], %[l3]\n\tv_fma_f32 %[n3], %[a3], %[b3], %[p2]\n\tv_fma_f32 %[n2], %[a2], %[b2], %[p1]\n\tv_fma_f32 %[n1], %[a1], %[b1], %[p0]\n\tv_mov_b32_dpp %[q], %[as] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fma_f32 %[n0], %[a0], %[b0], %[q]"
                      : [n0] "=&v"(n[0]), [n1] "=&v"(n[1]), [n2] "=&v"(n[2]), [n3] "=&v"(n[3]), [as] "=&v"(as), [q] "=&v"(q), [p0] "=&v"(pr[0]), [p1] "=&v"(pr[1]), [p2] "=&v"(pr[2])
-                     : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [b0] "v"(w[0][0]), [b1] "v"(w[1][0]), [b2] "v"(w[2][0]), [b3] "v"(w[3][0]), [l0] "v"(w[0][1]), [l1] "v"(w[1][1]), [l2] "v"(w[2][1]), [l3] "v"(w[3][1]), [d] "v"(d));
+                     : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [b0] "v"(w.template b<0>()), [b1] "v"(w.template b<1>()), [b2] "v"(w.template b<2>()), [b3] "v"(w.template b<3>()), [l0] "v"(w.template l<0>()), [l1] "v"(w.template l<1>()), [l2] "v"(w.template l<2>()), [l3] "v"(w.template l<3>()), [d] "v"(d));
     }
 #pragma unroll
     for (int j = 0; j < K; ++j) a[j] = n[j];
@@ -119,19 +177,20 @@ __device__ __forceinline__ void lin_alpha_step(float (&a)[K], const f32x2 (&w)[K
 // beta: diagonal n+1 -> n with the outgoing edge probabilities of diagonal n:
 //   b[j] <- b[j] p_blank[j] + b[j+1] p_label[j];  what arrives from lane + 1 is scaled into this lane's frame BEFORE the product
 template <int K>
-__device__ __forceinline__ void lin_beta_step(float (&bv)[K], const f32x2 (&w)[K], const int d) {
-    float st[K];
+__device__ __forceinline__ void lin_beta_step(float (&bv)[K], const LinRow<K> &w, const int d) {
+    float st[K], wb[K], wl[K];
+    lin_row_unpack<K>(w, wb, wl);  // (register names only: no instruction)
     float right = dpp_upper_zero(bv[0]);
     LIN_FENCE();
 #pragma unroll
-    for (int j = 0; j < K; ++j) st[j] = bv[j] * w[j][0];
+    for (int j = 0; j < K; ++j) st[j] = bv[j] * wb[j];
     LIN_FENCE();
     right = ldexp_f(right, d);
     LIN_FENCE();
 #pragma unroll
-    for (int j = 0; j < K - 1; ++j) bv[j] = fmaf(bv[j + 1], w[j][1], st[j]);
+    for (int j = 0; j < K - 1; ++j) bv[j] = fmaf(bv[j + 1], wl[j], st[j]);
     LIN_FENCE();
-    bv[K - 1] = fmaf(right, w[K - 1][1], st[K - 1]);
+    bv[K - 1] = fmaf(right, wl[K - 1], st[K - 1]);
     LIN_FENCE();
 }
 
@@ -139,18 +198,18 @@ __device__ __forceinline__ void lin_beta_step(float (&bv)[K], const f32x2 (&w)[K
 // row II + 2 are issued behind the arithmetic of step II (LDS latency ~64 clocks against a step of ~65), and they separate the
 // step's asm block from the diagonal's store (the compiler would otherwise pad with an s_nop).
 template <int K, int G, int II>
-__device__ __forceinline__ void lin_alpha_fast_steps(float (&a)[K], f32x2 (&wq)[3][K], const uint32_t abase, LinState &st,
+__device__ __forceinline__ void lin_alpha_fast_steps(float (&a)[K], LinRow<K> (&wq)[3], const uint32_t abase, LinState &st,
                                                      const int voff, const int lane, const int r0) {
     if constexpr (II < G) {
         constexpr int R = 1 << lin_shift(K);
         if constexpr (LIN_KO != 3) {
             if constexpr (II + 1 < G)
-                lds_wait<K>();  // row II has landed, row II+1 stays in flight
+                lds_wait<LinRow<K>::NR>();  // row II has landed, row II+1 stays in flight
             else
                 lds_wait<0>();
         }
         if constexpr (LIN_KO != 4) lin_alpha_step<K>(a, wq[II % 3], st.d);
-        if constexpr (LIN_KO != 3 && II + 2 < G) lds_issue_row<K, II + 2>(wq[(II + 2) % 3], abase);
+        if constexpr (LIN_KO != 3 && II + 2 < G) lin_issue_row<K, II + 2>(wq[(II + 2) % 3], abase);
         if constexpr (((II + 1) % R) == 0 && LIN_KO != 2) lin_renorm<K, false>(a, st, (r0 + II + 1) >> lin_shift(K));  // (r0 is a multiple of G)
         constexpr int RB = rows_per_base(K);
         if constexpr (LIN_KO != 1) store_diag<K, true, (II % RB) * 64 * K * 4>(st.row, voff, lane, a);
@@ -159,19 +218,19 @@ __device__ __forceinline__ void lin_alpha_fast_steps(float (&a)[K], f32x2 (&wq)[
     }
 }
 template <int K, int G, int II>
-__device__ __forceinline__ void lin_beta_fast_steps(float (&bv)[K], f32x2 (&wq)[3][K], const uint32_t abase, LinState &st,
+__device__ __forceinline__ void lin_beta_fast_steps(float (&bv)[K], LinRow<K> (&wq)[3], const uint32_t abase, LinState &st,
                                                     const int voff, const int lane, const int r0) {
     if constexpr (II < G) {
         constexpr int R = 1 << lin_shift(K);
         constexpr int i = G - 1 - II;  // row inside the chunk (descending)
         if constexpr (LIN_KO != 3) {
             if constexpr (i > 0)
-                lds_wait<K>();
+                lds_wait<LinRow<K>::NR>();
             else
                 lds_wait<0>();
         }
         if constexpr (LIN_KO != 4) lin_beta_step<K>(bv, wq[II % 3], st.d);
-        if constexpr (LIN_KO != 3 && i >= 2) lds_issue_row<K, (i >= 2 ? i - 2 : 0)>(wq[(II + 2) % 3], abase);
+        if constexpr (LIN_KO != 3 && i >= 2) lin_issue_row<K, (i >= 2 ? i - 2 : 0)>(wq[(II + 2) % 3], abase);
         if constexpr ((i % R) == R - 1 && LIN_KO != 2) lin_renorm<K, true>(bv, st, (r0 + i) >> lin_shift(K));
         constexpr int RB = rows_per_base(K);
         if constexpr (LIN_KO != 1) store_diag<K, true, -(II % RB) * 64 * K * 4>(st.row, voff, lane, bv);
@@ -247,18 +306,18 @@ __device__ void lin_alpha_sweep(const LossParams &p, float *bufs, const LdLink l
         timed_out |= !lv.wait(ck);
         const float *cur = bufs + (ck % NB) * chunkf + 2 * u0;
         const int r0 = ck * G;
-        if (K <= 15 && r0 + G <= last_row) {  // (lgkmcnt counts to 15)
+        if (r0 + G <= last_row) {
             const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
-            f32x2 wq[3][K];
-            lds_issue_row<K, 0>(wq[0], abase);
-            lds_issue_row<K, 1>(wq[1], abase);
+            LinRow<K> wq[3];
+            lin_issue_row<K, 0>(wq[0], abase);
+            lin_issue_row<K, 1>(wq[1], abase);
             lin_alpha_fast_steps<K, G, 0>(a, wq, abase, st, voff, lane, r0);
         } else {
             for (int i = 0; i < G; ++i) {
                 const int n = r0 + i + 1;
                 if (n > last_row) break;
-                f32x2 wc[K];
-                load_w<K>(wc, cur + i * 2 * Up);
+                LinRow<K> wc;
+                lin_load_row<K>(wc, cur + i * 2 * Up);
                 lin_alpha_step<K>(a, wc, st.d);
                 if ((n & ((1 << lin_shift(K)) - 1)) == 0) lin_renorm<K, false>(a, st, n >> lin_shift(K));
                 store_diag<K, false>(st.row, voff, lane, a);
@@ -307,19 +366,19 @@ __device__ void lin_beta_sweep(const LossParams &p, float *bufs, const LdLink lk
         timed_out |= !lv.wait(i_ring);
         const float *cur = bufs + (i_ring % NB) * chunkf + 2 * u0;
         const int r0 = ck * G;
-        if (K <= 15 && r0 + G - 1 < last) {
+        if (r0 + G - 1 < last) {
             const uint32_t abase = (uint32_t)(uintptr_t)((lds_void *)cur);
-            f32x2 wq[3][K];
-            lds_issue_row<K, G - 1>(wq[0], abase);
-            lds_issue_row<K, G - 2>(wq[1], abase);
+            LinRow<K> wq[3];
+            lin_issue_row<K, G - 1>(wq[0], abase);
+            lin_issue_row<K, G - 2>(wq[1], abase);
             lin_beta_fast_steps<K, G, 0>(bv, wq, abase, st, voff, lane, r0);
         } else {
             for (int ii = 0; ii < G; ++ii) {
                 const int i = G - 1 - ii;
                 const int n = r0 + i;
                 if (n > last) continue;
-                f32x2 wc[K];
-                load_w<K>(wc, cur + i * 2 * Up);
+                LinRow<K> wc;
+                lin_load_row<K>(wc, cur + i * 2 * Up);
                 lin_beta_step<K>(bv, wc, st.d);
                 if ((n & ((1 << lin_shift(K)) - 1)) == (1 << lin_shift(K)) - 1 || n == last) lin_renorm<K, true>(bv, st, n >> lin_shift(K));
                 store_diag<K, false>(st.row, voff, lane, bv);

@@ -7,6 +7,7 @@
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define REP4(x) x x x x
 #define REP16(x) REP4(x) REP4(x) REP4(x) REP4(x)
 #define REP64(x) REP16(x) REP16(x) REP16(x) REP16(x)
@@ -16,7 +17,7 @@ typedef float f32x3 __attribute__((ext_vector_type(3)));
         __shared__ float lds[4096];                                                        \
         float a = 1.0f + threadIdx.x * 1e-3f, b = 0.999f, c = 1e-3f, d = 1.0f, e = 1.1f, f = 0.9f, g = 1.01f, h = 0.99f;  \
         int sh = 0;                                                                        \
-        unsigned addr = threadIdx.x * 8;                                                   \
+        unsigned addr = threadIdx.x * 8; const unsigned addr3 = threadIdx.x * 24; f32x4 q4 = {1.f, 1.f, 1.f, 1.f};                                                   \
         f32x2 q = {1.f, 1.f}, q2 = {1.f, 1.f}, q3 = {1.f, 1.f}; const f32x2 qc = {b, c}; const f32x3 st3 = {g, h, b};                                                  \
         float *gp = sink + threadIdx.x * 4;                                                \
         for (int i = threadIdx.x; i < 4096; i += 64) lds[i] = 0.f;                         \
@@ -28,7 +29,7 @@ typedef float f32x3 __attribute__((ext_vector_type(3)));
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                        \
         const long long t1 = __builtin_amdgcn_s_memtime();                                 \
         if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;                                   \
-        sink[blockIdx.x * 64 + threadIdx.x] = a + b + c + d + e + f + g + h + q.x + q.y + q2.x + q2.y + q3.x + q3.y + (float)sh + (float)addr; \
+        sink[blockIdx.x * 64 + threadIdx.x] = a + b + c + d + e + f + g + h + q.x + q.y + q2.x + q2.y + q3.x + q3.y + q4.x + q4.w + (float)sh + (float)addr; \
     }                                                                                      \
     static const int NAME##_per = PER;
 
@@ -53,6 +54,9 @@ PROBE(p_pkmul_ind, 2, asm volatile("v_pk_mul_f32 %0, %2, %2\n\tv_pk_mul_f32 %1, 
 // LDS: dependent ds_read_b64 (address from the data: 0) = latency; and issue cost of 3 independent reads + wait
 PROBE(p_lds_lat, 1, asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tv_add_u32 %1, %1, %2" : "=v"(q), "+v"(addr) : "v"(0));)
 PROBE(p_lds_3, 3, asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=v"(q), "=v"(q2), "=v"(q3) : "v"(addr));)
+// the sweep's three 8-byte reads per diagonal as one 16-byte + one 8-byte read at a 24-byte lane stride (8-byte aligned only)
+PROBE(p_lds_b128_b64_unaligned, 2, asm volatile("ds_read_b128 %0, %2 offset:8\n\tds_read_b64 %1, %2 offset:24\n\ts_waitcnt lgkmcnt(0)" : "=v"(q4), "=v"(q2) : "v"(addr3));)
+PROBE(p_lds_3x_b64_stride24, 3, asm volatile("ds_read_b64 %0, %3 offset:8\n\tds_read_b64 %1, %3 offset:16\n\tds_read_b64 %2, %3 offset:24\n\ts_waitcnt lgkmcnt(0)" : "=v"(q), "=v"(q2), "=v"(q3) : "v"(addr3));)
 // store issue: one dwordx3 store + 4 independent fmas
 PROBE(p_store_fma4, 5, asm volatile("global_store_dwordx3 %6, %4, off sc1\n\tv_fma_f32 %0, %0, %7, %8\n\tv_fma_f32 %1, %1, %7, %8\n\tv_fma_f32 %2, %2, %7, %8\n\tv_fma_f32 %3, %3, %7, %8" : "+v"(a), "+v"(d), "+v"(e), "+v"(f) : "v"(st3), "v"(0), "v"(gp), "v"(b), "v"(c) : "memory");)
 PROBE(p_store_only, 1, asm volatile("global_store_dwordx3 %1, %0, off sc1" :: "v"(st3), "v"(gp) : "memory");)
@@ -110,6 +114,8 @@ int main() {
     RUN(p_pkmul_ind);
     RUN(p_lds_lat);
     RUN(p_lds_3);
+    RUN(p_lds_b128_b64_unaligned);
+    RUN(p_lds_3x_b64_stride24);
     RUN(p_store_fma4);
     RUN(p_store_only);
     return 0;
