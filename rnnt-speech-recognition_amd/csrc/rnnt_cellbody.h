@@ -14,7 +14,8 @@ namespace rnnt {
 // LIN: the linear-domain lattice (rnnt_lin.h): edge probabilities instead of log2 weights and no lse store in the lsm pass;
 // in the gradient pass the softmax numerators are recomputed and scaled by occupancies formed from mantissas + frames.
 template <int VP, bool V4, bool GRAD, bool LIN = false, bool SC1 = false>
-__device__ __forceinline__ void cell_body(const LossParams &p, const Cell &cl, const uint32_t c, const float *xs, float *out) {
+__device__ __forceinline__ float cell_body(const LossParams &p, const Cell &cl, const uint32_t c, const float *xs, float *out) {
+    float stat = 0.f;  // LIN lsm: the cell's decay statistic (rnnt_lin.h), else unused
     const int V = p.V;
     if (cl.valid) {
         float x[VP];
@@ -34,7 +35,7 @@ __device__ __forceinline__ void cell_body(const LossParams &p, const Cell &cl, c
         }
 
         if (!GRAD && LIN) {
-            lin_cell_lsm<VP>(p, cl, x, xs);
+            stat = lin_cell_lsm<VP>(p, cl, x, xs);
         } else if (GRAD && LIN) {
             const LinGrad g = lin_grad_setup(p, cl);
             if (g.bad) atomicOr(p.flags + 4 * cl.b + kFlagG, 1);  // (rare) the utterance is redone in the log domain
@@ -108,6 +109,7 @@ __device__ __forceinline__ void cell_body(const LossParams &p, const Cell &cl, c
         for (int i = 0; i < V; ++i) out[i] = 0.f;
     }
 
+    return stat;
 }
 
 }  // namespace rnnt

@@ -73,7 +73,9 @@ struct LossParams {
     float *lik;  // [B][4]: alpha side {mantissa (float), frame (int)}, beta side {mantissa, frame}
     int *flags;  // [B][4]: kFlagA, kFlagB, kFlagG, kFlagState
     int NCl;     // frame blocks per utterance (tables are [NCl][64])
-    int linShift;  // log2 of the diagonals per frame block (rnnt_lin.h lin_shift)
+    float2 *pstat;  // [B][nPstat]: per (patch, wave) of the lsm launch {sum of -log2 max(p_blank, p_label), cells}: how fast mass decays
+    int *lshift;    // [B]: log2 of the diagonals per frame block the sweeps chose for the utterance (rnnt_lin.h)
+    int nPstat;
     int B, T, U, V, blank;
     int b0, nb;  // this launch covers utterances [b0, b0+nb)
     int N, Nr, Up, NC, NG;  // NG = Up/OG offset groups (offset tables are [NC][NG])
@@ -83,8 +85,8 @@ struct LossParams {
 };
 
 struct WsLayout {
-    size_t lse, W, A, Bt, offA, offB, ll, EA, EB, lik, flags, total;
-    int NCl;
+    size_t lse, W, A, Bt, offA, offB, ll, EA, EB, lik, flags, pstat, lshift, total;
+    int NCl, nPstat;
     int N, Nr, Up, NC, NG, OG;
 };
 
@@ -129,6 +131,12 @@ inline WsLayout make_layout(int T, int U, int B) {
     w.EB = take((size_t)B * w.NCl * 64 * sizeof(int));
     w.lik = take((size_t)B * 4 * sizeof(float));
     w.flags = take((size_t)B * 4 * sizeof(int));
+    {
+        const int nu = (U + 31) / 32, UU = (U + nu - 1) / nu, TT = (256 / UU) > T ? T : (256 / UU);  // make_tile's patch geometry
+        w.nPstat = ((T + TT - 1) / TT) * ((U + UU - 1) / UU) * 4;  // four waves per patch workgroup
+    }
+    w.pstat = take((size_t)B * w.nPstat * 2 * sizeof(float));
+    w.lshift = take((size_t)B * sizeof(int));
     w.total = off;
     return w;
 }

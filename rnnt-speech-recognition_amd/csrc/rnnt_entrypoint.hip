@@ -72,7 +72,9 @@ static bool fill_params(LossParams &p, const float *acts, float *grads, const in
     p.lik = (float *)(ws + w.lik);
     p.flags = (int *)(ws + w.flags);
     p.NCl = w.NCl;
-    p.linShift = lin_shift(sweep_K(o.maxU));
+    p.pstat = (float2 *)(ws + w.pstat);
+    p.lshift = (int *)(ws + w.lshift);
+    p.nPstat = w.nPstat;
     p.B = B, p.T = o.maxT, p.U = o.maxU, p.V = V, p.blank = o.blank_label;
     p.b0 = 0, p.nb = B;
     p.tile = make_tile(o.maxT, o.maxU, V);

@@ -160,10 +160,13 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
         }
     };
 
+    // LIN lsm: every wave of every patch leaves {sum of the cells' decay statistic, cells} for the sweeps (rnnt_lin.h)
+    float2 *const pslot = p.pstat + (size_t)b * p.nPstat + ((size_t)tt * tg.tiles_u + tu) * 4 + wave;
     if (rows_valid == 0 || cols_valid == 0) {
         if (GRAD) {  // an all-padding patch: exact zeros, no reads
             for (int r = wave; r < rows_in; r += 4) store_row(r, nullptr);
         }
+        if (!GRAD && LIN && lane == 0) *pslot = make_float2(0.f, 0.f);
         return;
     }
 
@@ -191,11 +194,19 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
     cl.b = b, cl.t = t0 + (int)r, cl.u = u0 + cu, cl.Tb = Tb, cl.Ub = Ub;
     cl.valid = ((int)r < rows_valid) && (cu < cols_valid);
     const uint32_t c = ((uint32_t)(b * p.T + cl.t)) * (uint32_t)p.U + (uint32_t)cl.u;
+    float stat = 0.f;
     if (AL) {
-        if ((GRAD && tid < tg.TT * tg.UU) || cl.valid) cell_body<VP, true, GRAD, LIN>(p, cl, c, lds + tid * V, lds + tid * V);  // (lanes beyond the patch own no LDS)
+        if ((GRAD && tid < tg.TT * tg.UU) || cl.valid) stat = cell_body<VP, true, GRAD, LIN>(p, cl, c, lds + tid * V, lds + tid * V);  // (lanes beyond the patch own no LDS)
     } else if ((int)r < tg.TT) {
         const int a = (int)((patch0 + r * row_f) & 3);
-        if (GRAD || cl.valid) cell_body<VP, false, GRAD, LIN>(p, cl, c, lds + r * row_lds + a + cu * V, lds + r * row_lds + a + cu * V);
+        if (GRAD || cl.valid) stat = cell_body<VP, false, GRAD, LIN>(p, cl, c, lds + r * row_lds + a + cu * V, lds + r * row_lds + a + cu * V);
+    }
+    if (!GRAD && LIN) {  // wave sums by butterfly (no LDS: the patch image is still being read by other waves)
+        float cnt = cl.valid ? 1.f : 0.f;
+        stat = cl.valid ? stat : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) stat += __shfl_xor(stat, off), cnt += __shfl_xor(cnt, off);
+        if (lane == 0) *pslot = make_float2(stat, cnt);
     }
     if (GRAD && !AL) {
         __syncthreads();

@@ -17,15 +17,18 @@
 
 namespace rnnt {
 
-// Diagonals per frame block: a lane renormalises (and the frame tables get a row) every 2^lin_shift(K) diagonals.  Eight, where
-// measured: the renormalisation is ~22 instructions of the sweeping wave (4 us of the sweep at B32 T600 U150 with blocks of four).
-// N(0,1) logits lose ~5 bits per diagonal, i.e. 40 of the 126 bits of room per block; 4 x N(0,1) logits exceed the room and
-// take the log-domain path.  K = 1: blocks of four (mass crosses a lane per diagonal: the frame look-back is 4 lanes deep);
-// K = 12, 16: blocks of four (their LDS chunks are four diagonals long, and a frame spans many columns).
+// Diagonals per frame block: a lane renormalises (and the frame tables get a row) every 2^shift diagonals.  The renormalisation
+// is ~22 instructions of the sweeping wave (4 us of the sweep at B32 T600 U150 with blocks of four), so blocks are EIGHT diagonals
+// long where the mass decays slowly and FOUR where it decays fast -- chosen per utterance by the sweeps from a statistic the lsm
+// pass leaves behind: the mean of -log2 max(p_blank, p_label) over the utterance's cells (bits of mass lost per diagonal along the
+// better edge).  N(0,1) logits: 4.7 bits at 28 symbols, 5.8 at 60 (certificate margin -84 / -72 bits with blocks of eight);
+// trained-like posteriors 0 ... 3; 3 x N(0,1): 7.3 (margin -43 with blocks of eight, -69 with four); 4 x N(0,1): 9.1 (-45 with four).
+// K = 1, 12, 16: always four (K = 1: the frame look-back would be 8 lanes deep; 12, 16: their LDS chunks are four diagonals long).
 #ifndef RNNT_LINSHIFT
 #define RNNT_LINSHIFT 3
 #endif
-__host__ __device__ constexpr int lin_shift(int K) { return (K == 1 || K >= 12) ? 2 : RNNT_LINSHIFT; }
+__host__ __device__ constexpr int lin_shift_max(int K) { return (K == 1 || K >= 12) ? 2 : RNNT_LINSHIFT; }
+constexpr float kLinDecayBits = 6.2f;  // mean bits per diagonal beyond which an utterance gets blocks of four
 constexpr int kLinDrag = 118;            // a lane's frame is at most this far below the lanes mass can reach it from within a block
 constexpr int kFrameNone = -(1 << 28);   // frame of a lane without mass and without a neighbour to copy from
 constexpr int kCertBits = -40;           // per-cell bound (bits) on flush loss x other side / likelihood
@@ -54,8 +57,9 @@ __device__ __forceinline__ bool lin_skip(const LossParams &p, const int b) {
 }
 
 // ---- lsm: one valid cell, its V logits in x[] (registers) and at xs (LDS) ----
+// Returns -log2 max(p_blank, p_label) of the cell (the decay statistic; 200 where an edge had to be refused).
 template <int VP>
-__device__ __forceinline__ void lin_cell_lsm(const LossParams &p, const Cell &cl, const float (&x)[VP], const float *xs) {
+__device__ __forceinline__ float lin_cell_lsm(const LossParams &p, const Cell &cl, const float (&x)[VP], const float *xs) {
     float m = x[0];
 #pragma unroll
     for (int i = 1; i < VP; ++i) m = fmaxf(m, x[i]);
@@ -78,6 +82,8 @@ __device__ __forceinline__ void lin_cell_lsm(const LossParams &p, const Cell &cl
     }
     const size_t wi = ((size_t)cl.b * p.Nr + (cl.t + cl.u)) * p.Up + cl.u;
     ((float2 *)p.W)[wi] = make_float2(pb, pl);
+    const float best = fmaxf(pb, pl);  // (v_max ignores a NaN operand)
+    return (pb != pb || pl != pl) ? 200.f : -lg2(fmaxf(best, 1.0e-37f));
 }
 
 // ---- gradient set-up of one valid cell from mantissas + frames ----
@@ -94,7 +100,8 @@ __device__ __forceinline__ LinGrad lin_grad_setup(const LossParams &p, const Cel
     const int n = cl.t + cl.u;
     const size_t sk = ((size_t)cl.b * p.Nr + n) * p.Up + cl.u;
     const float ma = p.A[sk], mb = p.Bt[sk];
-    const int kc = n >> p.linShift, kc1 = (n + 1) >> p.linShift;
+    const int sh = p.lshift[cl.b];  // the block length the sweeps chose for this utterance
+    const int kc = n >> sh, kc1 = (n + 1) >> sh;
     const int l0 = (int)fdiv((uint32_t)cl.u, p.divOG), l1 = (int)fdiv((uint32_t)cl.u + 1u, p.divOG);
     const size_t tb = (size_t)cl.b * p.NCl * 64;
     const int ea = p.EA[tb + (size_t)kc * 64 + l0], eb = p.EB[tb + (size_t)kc * 64 + l0];

@@ -46,14 +46,14 @@ struct LinState {
 };
 
 // Renormalise a lane's K mantissas against their maximum, choose the frames of the next block, record them.
-template <int K, bool BETA>
+template <int K, bool BETA, int SH>
 __device__ __forceinline__ void lin_renorm(float (&v)[K], LinState &st, const int kc) {
     float m = v[0];
 #pragma unroll
     for (int j = 1; j < K; ++j) m = fmaxf(m, v[j]);
     const int own = (m > 0.f) ? st.E + frexp_e(m) : kFrameNone;  // where this lane's mass is (no mass: no claim)
-    // Within one block mass travels at most 2^lin_shift(K) columns = LOOK lanes: the frame must leave room for what those lanes hold.
-    constexpr int LOOK = ((1 << lin_shift(K)) + K - 1) / K;
+    // Within one block mass travels at most 2^SH columns = LOOK lanes: the frame must leave room for what those lanes hold.
+    constexpr int LOOK = ((1 << SH) + K - 1) / K;
     int nb = own, reach = kFrameNone;
 #pragma unroll
     for (int r = 0; r < LOOK; ++r) {
@@ -197,11 +197,11 @@ __device__ __forceinline__ void lin_beta_step(float (&bv)[K], const LinRow<K> &w
 // Fully unrolled steps of one chunk.  Edge probabilities are read from LDS TWO rows ahead (three register sets): the reads of
 // row II + 2 are issued behind the arithmetic of step II (LDS latency ~64 clocks against a step of ~65), and they separate the
 // step's asm block from the diagonal's store (the compiler would otherwise pad with an s_nop).
-template <int K, int G, int II>
+template <int K, int G, int SH, int II>
 __device__ __forceinline__ void lin_alpha_fast_steps(float (&a)[K], LinRow<K> (&wq)[3], const uint32_t abase, LinState &st,
                                                      const int voff, const int lane, const int r0) {
     if constexpr (II < G) {
-        constexpr int R = 1 << lin_shift(K);
+        constexpr int R = 1 << SH;
         if constexpr (LIN_KO != 3) {
             if constexpr (II + 1 < G)
                 lds_wait<LinRow<K>::NR>();  // row II has landed, row II+1 stays in flight
@@ -210,18 +210,18 @@ __device__ __forceinline__ void lin_alpha_fast_steps(float (&a)[K], LinRow<K> (&
         }
         if constexpr (LIN_KO != 4) lin_alpha_step<K>(a, wq[II % 3], st.d);
         if constexpr (LIN_KO != 3 && II + 2 < G) lin_issue_row<K, II + 2>(wq[(II + 2) % 3], abase);
-        if constexpr (((II + 1) % R) == 0 && LIN_KO != 2) lin_renorm<K, false>(a, st, (r0 + II + 1) >> lin_shift(K));  // (r0 is a multiple of G)
+        if constexpr (((II + 1) % R) == 0 && LIN_KO != 2) lin_renorm<K, false, SH>(a, st, (r0 + II + 1) >> SH);  // (r0 is a multiple of G)
         constexpr int RB = rows_per_base(K);
         if constexpr (LIN_KO != 1) store_diag<K, true, (II % RB) * 64 * K * 4>(st.row, voff, lane, a);
         if constexpr (II % RB == RB - 1 || II == G - 1) st.row += (II % RB + 1) * 64 * K;
-        lin_alpha_fast_steps<K, G, II + 1>(a, wq, abase, st, voff, lane, r0);
+        lin_alpha_fast_steps<K, G, SH, II + 1>(a, wq, abase, st, voff, lane, r0);
     }
 }
-template <int K, int G, int II>
+template <int K, int G, int SH, int II>
 __device__ __forceinline__ void lin_beta_fast_steps(float (&bv)[K], LinRow<K> (&wq)[3], const uint32_t abase, LinState &st,
                                                     const int voff, const int lane, const int r0) {
     if constexpr (II < G) {
-        constexpr int R = 1 << lin_shift(K);
+        constexpr int R = 1 << SH;
         constexpr int i = G - 1 - II;  // row inside the chunk (descending)
         if constexpr (LIN_KO != 3) {
             if constexpr (i > 0)
@@ -231,11 +231,11 @@ __device__ __forceinline__ void lin_beta_fast_steps(float (&bv)[K], LinRow<K> (&
         }
         if constexpr (LIN_KO != 4) lin_beta_step<K>(bv, wq[II % 3], st.d);
         if constexpr (LIN_KO != 3 && i >= 2) lin_issue_row<K, (i >= 2 ? i - 2 : 0)>(wq[(II + 2) % 3], abase);
-        if constexpr ((i % R) == R - 1 && LIN_KO != 2) lin_renorm<K, true>(bv, st, (r0 + i) >> lin_shift(K));
+        if constexpr ((i % R) == R - 1 && LIN_KO != 2) lin_renorm<K, true, SH>(bv, st, (r0 + i) >> SH);
         constexpr int RB = rows_per_base(K);
         if constexpr (LIN_KO != 1) store_diag<K, true, -(II % RB) * 64 * K * 4>(st.row, voff, lane, bv);
         if constexpr (II % RB == RB - 1 || II == G - 1) st.row -= (II % RB + 1) * 64 * K;
-        lin_beta_fast_steps<K, G, II + 1>(bv, wq, abase, st, voff, lane, r0);
+        lin_beta_fast_steps<K, G, SH, II + 1>(bv, wq, abase, st, voff, lane, r0);
     }
 }
 
@@ -272,10 +272,10 @@ struct LandedView {
     }
 };
 
-template <int K, int G, int NB>
+template <int K, int G, int NB, int SH>
 __device__ void lin_alpha_sweep(const LossParams &p, float *bufs, const LdLink lk, const int b, const int lane) {
     constexpr int Up = 64 * K, chunkf = G * 2 * Up;
-    static_assert(G % (1 << lin_shift(K)) == 0, "frame blocks must not straddle chunks");
+    static_assert(G % (1 << SH) == 0, "frame blocks must not straddle chunks");
     const int Tb = length_T(p, b), Ub = length_U(p, b);
     const int Nb = Tb + Ub - 1;
     float *out = p.A + (size_t)b * p.Nr * Up;
@@ -284,6 +284,7 @@ __device__ void lin_alpha_sweep(const LossParams &p, float *bufs, const LdLink l
     if (lane == 0) {  // this forward call owns the utterance's hand-back state from here on
         st_i32_wt(p.flags + 4 * b + kFlagG, 0);
         st_i32_wt(p.flags + 4 * b + kFlagState, 0);
+        st_i32_wt(p.lshift + b, SH);  // the block length this utterance's frame tables are indexed with
     }
     float a[K];
 #pragma unroll
@@ -291,7 +292,7 @@ __device__ void lin_alpha_sweep(const LossParams &p, float *bufs, const LdLink l
     LinState st;
     st.E = 0, st.d = 0;
     st.tab = p.EA + (size_t)b * p.NCl * 64 + lane;
-    lin_renorm<K, false>(a, st, 0);
+    lin_renorm<K, false, SH>(a, st, 0);
     store_diag<K, false>(out, voff, lane, a);
     st.row = out + Up;
     const int last_row = Nb - 1;
@@ -311,7 +312,7 @@ __device__ void lin_alpha_sweep(const LossParams &p, float *bufs, const LdLink l
             LinRow<K> wq[3];
             lin_issue_row<K, 0>(wq[0], abase);
             lin_issue_row<K, 1>(wq[1], abase);
-            lin_alpha_fast_steps<K, G, 0>(a, wq, abase, st, voff, lane, r0);
+            lin_alpha_fast_steps<K, G, SH, 0>(a, wq, abase, st, voff, lane, r0);
         } else {
             for (int i = 0; i < G; ++i) {
                 const int n = r0 + i + 1;
@@ -319,7 +320,7 @@ __device__ void lin_alpha_sweep(const LossParams &p, float *bufs, const LdLink l
                 LinRow<K> wc;
                 lin_load_row<K>(wc, cur + i * 2 * Up);
                 lin_alpha_step<K>(a, wc, st.d);
-                if ((n & ((1 << lin_shift(K)) - 1)) == 0) lin_renorm<K, false>(a, st, n >> lin_shift(K));
+                if ((n & ((1 << SH) - 1)) == 0) lin_renorm<K, false, SH>(a, st, n >> SH);
                 store_diag<K, false>(st.row, voff, lane, a);
                 st.row += Up;
             }
@@ -337,7 +338,7 @@ __device__ void lin_alpha_sweep(const LossParams &p, float *bufs, const LdLink l
     }
 }
 
-template <int K, int G, int NB>
+template <int K, int G, int NB, int SH>
 __device__ void lin_beta_sweep(const LossParams &p, float *bufs, const LdLink lk, const int b, const int lane) {
     constexpr int Up = 64 * K, chunkf = G * 2 * Up;
     const int Tb = length_T(p, b), Ub = length_U(p, b);
@@ -371,7 +372,7 @@ __device__ void lin_beta_sweep(const LossParams &p, float *bufs, const LdLink lk
             LinRow<K> wq[3];
             lin_issue_row<K, G - 1>(wq[0], abase);
             lin_issue_row<K, G - 2>(wq[1], abase);
-            lin_beta_fast_steps<K, G, 0>(bv, wq, abase, st, voff, lane, r0);
+            lin_beta_fast_steps<K, G, SH, 0>(bv, wq, abase, st, voff, lane, r0);
         } else {
             for (int ii = 0; ii < G; ++ii) {
                 const int i = G - 1 - ii;
@@ -380,7 +381,7 @@ __device__ void lin_beta_sweep(const LossParams &p, float *bufs, const LdLink lk
                 LinRow<K> wc;
                 lin_load_row<K>(wc, cur + i * 2 * Up);
                 lin_beta_step<K>(bv, wc, st.d);
-                if ((n & ((1 << lin_shift(K)) - 1)) == (1 << lin_shift(K)) - 1 || n == last) lin_renorm<K, true>(bv, st, n >> lin_shift(K));
+                if ((n & ((1 << SH) - 1)) == (1 << SH) - 1 || n == last) lin_renorm<K, true, SH>(bv, st, n >> SH);
                 store_diag<K, false>(st.row, voff, lane, bv);
                 st.row -= Up;
             }
@@ -416,10 +417,47 @@ __global__ __launch_bounds__(64 * (1 + kLinLoaders)) void lin_sweep_kernel(const
         else
             sweep_loader<K, G, NB, false, kLinLoaderZero, kLinLoaders>(p, lds, mine, b, lane, wave - 1);
     } else {
+        // Block length of this utterance (rnnt_lin.h): the mean decay statistic of its cells, from the per-(patch, wave) sums the
+        // lsm launch left (a fixed-order sum: both directions arrive at the same choice; the loads overlap with the loader
+        // wave's first chunk, which this wave has to wait for anyway).
+        constexpr int SHmax = lin_shift_max(K);
+        int sh = SHmax;
+#ifndef RNNT_LIN_NOSTAT  // (dev builds: blocks of 2^RNNT_LINSHIFT diagonals whatever the logits look like)
+        if constexpr (SHmax > 2) {
+            // (a sample is enough: wave 0's slot of every patch = the first quarter of the patch's lanes; eight loads in flight
+            // per lane -- read one after the other the 1,500 slots of a 600 x 150 lattice cost the sweep 9 us)
+            float sum = 0.f, cnt = 0.f;
+            const float2 *ps = p.pstat + (size_t)b * p.nPstat;
+            const int npatch = p.nPstat >> 2;
+            for (int i0 = 0; i0 < npatch; i0 += 512) {
+                float2 q[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + 64 * k + lane;
+                    q[k] = (i < npatch) ? ps[4 * i] : make_float2(0.f, 0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sum += q[k].x, cnt += q[k].y;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off), cnt += __shfl_xor(cnt, off);
+            sh = (sum > kLinDecayBits * cnt) ? 2 : SHmax;  // (NaN statistics: the comparison is false, the certificate decides)
+            sh = __builtin_amdgcn_readfirstlane(sh);
+        }
+#endif
+        if constexpr (SHmax > 2) {
+            if (sh == 2) {
+                if (beta)
+                    lin_beta_sweep<K, G, NB, 2>(p, lds, lk, b, lane);
+                else
+                    lin_alpha_sweep<K, G, NB, 2>(p, lds, lk, b, lane);
+                return;
+            }
+        }
         if (beta)
-            lin_beta_sweep<K, G, NB>(p, lds, lk, b, lane);
+            lin_beta_sweep<K, G, NB, SHmax>(p, lds, lk, b, lane);
         else
-            lin_alpha_sweep<K, G, NB>(p, lds, lk, b, lane);
+            lin_alpha_sweep<K, G, NB, SHmax>(p, lds, lk, b, lane);
     }
 }
 

@@ -2,7 +2,9 @@
 produces, as opposed to the N(0,1) logits of the headline bench.  Through the C ABI, against the float64 oracle on 8 of the
 32 utterances per case.
 
-  sigma4 / sigma8   logits = 4 / 8 * N(0,1): incoherent peaks (no dominant alignment), costs of 4,000 / 7,500 nats
+  sigma4 / sigma8   logits = 4 / 8 * N(0,1): incoherent peaks (no dominant alignment), costs of 4,000 / 7,500 nats (round 4: 4 sigma
+                    stays on the linear lattice with frame blocks of four diagonals unless a cell fails the certificate; 8 sigma is
+                    handed back to the log-domain kernels)
   trained           one dominant symbol per cell along a monotone alignment (bonus 10 nats on blank before the cell's label
                     is due, on the label afterwards); half of the utterances emit all labels in the last 40 % of the frames
                     (alignments far from the lattice's straight diagonal), costs of a few nats

@@ -2,7 +2,7 @@
 mantissas x 2^(integer frame per sweep lane and block of R diagonals), the gradient set-up from mantissas and frames, and the
 per-cell range certificate that decides whether an utterance stays on this path or is redone in the log domain.
 
-  python tests/tools/emulate_linear.py [T,U,V] [R]
+  python tests/tools/emulate_linear.py [T,U,V] [R]     (R = diagonals per frame block; omitted: chosen as the sweeps choose it)
 
 Prints, per input family: cost error, max|dgrad| against the float64 oracle, and the certificate margin (worst of the three
 per-cell terms, in bits: <= CERT_BITS passes).  Follows csrc/rnnt_lin_kernels.hip closely enough for error LEVELS (not
@@ -198,29 +198,41 @@ def grad_lin(x, labels, e, s, mA, mB, EA, EB, lik, K, R, blank=0):
     return g, worst
 
 
+DECAY_BITS = 6.2  # (csrc/rnnt_lin.h kLinDecayBits) mean -log2 max(p_blank, p_label) beyond which the sweeps take blocks of four
+
+
+def decay_statistic(pb, pl):
+    """What the lsm pass leaves for the sweeps: mean over the cells of -log2 of the better edge's probability."""
+    with np.errstate(divide="ignore"):
+        return float((-np.log2(np.maximum(np.maximum(pb, pl), F(1e-37)))).mean())
+
+
 def run(kind, T, U, V, seed, K, R):
     rng = np.random.default_rng(seed)
     x, labels = make_inputs(kind, T, U, V, rng)
     c_ref, g_ref, _, _, _ = orc.utterance_cost_and_grad(x, labels)
     pb, pl, e, s, tiny = edge_probs(x, labels)
+    stat = decay_statistic(pb, pl)
+    if R == 0:  # the kernels' own choice
+        R = 4 if (K == 1 or K >= 12 or stat > DECAY_BITS) else 8
     mA, mB, EA, EB, lik, likb = sweep_lin(pb, pl, K, R)
     g, worst = grad_lin(x.astype(F), labels, e, s, mA, mB, EA, EB, lik, K, R)
     cost = -(np.log2(lik[0]) + lik[1]) * np.log(2.0)
     costb = -(np.log2(likb[0]) + likb[1]) * np.log(2.0)
     return dict(cost=c_ref, dcost=abs(cost - c_ref) / max(1.0, abs(c_ref)), dab=abs(cost - costb) / max(1.0, abs(c_ref)),
-                dgrad=float(np.abs(g - g_ref).max()), cert=worst, tiny=tiny)
+                dgrad=float(np.abs(g - g_ref).max()), cert=worst, tiny=tiny, stat=stat, R=R)
 
 
 if __name__ == "__main__":
     T, U, V = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "600,150,28").split(","))
-    R = int(sys.argv[2]) if len(sys.argv) > 2 else (4 if (U + 63) // 64 == 1 else 8)  # csrc/rnnt_lin.h lin_shift
+    R = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # 0: chosen per utterance from the decay statistic, as the sweeps do
     k = (U + 63) // 64
     K = next(a for a in (1, 2, 3, 4, 6, 8, 12, 16) if k <= a)
     kinds = ["sigma1", "sigma4", "sigma8", "trained10", "trained10late", "trained20late"]
-    print(f"T={T} U={U} V={V} K={K} R={R}: linear-domain lattice vs the float64 oracle")
+    print(f"T={T} U={U} V={V} K={K} R={R or 'auto'}: linear-domain lattice vs the float64 oracle")
     for kind in kinds:
         for seed in (1, 2):
             r = run(kind, T, U, V, seed, K, R)
-            print(f"{kind:14s} seed {seed} cost {r['cost']:10.2f} dcost {r['dcost']:.1e} |a-b| {r['dab']:.1e} "
+            print(f"{kind:14s} seed {seed} decay {r['stat']:5.2f} bits -> blocks of {r['R']}  cost {r['cost']:10.2f} dcost {r['dcost']:.1e} |a-b| {r['dab']:.1e} "
                   f"dgrad {r['dgrad']:.2e} cert {r['cert']:7.1f} bits {'PASS' if r['cert'] <= CERT_BITS and not r['tiny'] else 'LOG-DOMAIN'}"
                   f"{' (tiny edge)' if r['tiny'] else ''}")
