@@ -120,3 +120,37 @@ def test_invalid_shapes_are_rejected_at_the_boundary():
     scale = np.full(2, 0.5)
     costs, grads = run(case, scale, "auto")
     check_vs_oracle(case, scale, costs, grads)
+
+
+def test_backward_only_call_on_a_workspace_someone_else_touched_fails_loudly():
+    """compute_rnnt_joint_net_loss_bwd trusts the workspace its _fwd left (tables by the dense layer's epilogue, W2 images: nothing is
+    rebuilt).  If another library call has used that workspace in between, the state word is gone and the gradients come back NaN --
+    not numbers computed from somebody else's tables."""
+    from rnnt_speech_recognition_amd import _lib
+
+    dev = torch.device("cuda:0")
+    B, T, U, H, J, V = 2, 9, 5, 32, 64, 28
+    case = make_case(B, T, U, H, J, V, seed=5)
+    t = lambda x: torch.tensor(x, device=dev)
+    enc, pred, W1, b1, W2, b2, labels, il, ll = case
+
+    def forward():
+        ps = [t(x).requires_grad_(True) for x in (enc, pred, W1, b1, W2, b2)]
+        return ps, pkg.rnnt_joint_loss(*ps, t(labels), t(il), t(ll), first_layer="engine")
+
+    ps, costs = forward()  # undisturbed: finite gradients
+    costs.sum().backward()
+    assert all(bool(torch.isfinite(p.grad).all()) for p in ps)
+    ps, costs = forward()
+    ws = costs.grad_fn.saved_tensors[-1]  # the workspace the backward call will be handed
+    assert ws.dtype == torch.uint8
+    lib = _lib.load()
+    ep, pp = torch.randn(B, T, J, device=dev), torch.randn(B, U, J, device=dev)
+    out = torch.empty(B, T, U, V, device=dev)
+    opts = _lib.make_options(torch.cuda.current_stream().cuda_stream, 0, T, U)
+    st = lib.compute_rnnt_joint_logits(ep.data_ptr(), pp.data_ptr(), t(W2).data_ptr(), t(b2).data_ptr(), J, V, B, out.data_ptr(), 0,
+                                       ws.data_ptr(), opts)  # another call on the same workspace (a decoder's, say)
+    _lib.check(st, "compute_rnnt_joint_logits")
+    costs.sum().backward()
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(ps[1].grad).all()), "the backward-only call used a workspace whose state word was gone"
