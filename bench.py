@@ -747,7 +747,7 @@ def main():
                   "lengths": "T_b ~ U{T/2..T}, L_b ~ U{(U-1)/2..U-1}, one full-length utterance (SURVEY.md 8d)"}
 
     # ---- fused joint + loss (SURVEY.md 8d "P2"): reported beside the headline, not as `value` ----
-    fused = fused_full = fused_c5 = op_c5 = fused_dp = None
+    fused = fused_full = fused_c5 = fused_mid = op_c5 = fused_dp = None
     headline_shape = (B, T, U, V) == (32, 600, 150, 28)
     if not a.no_fused:
         nf = max(3, min(a.steps, 10))
@@ -783,6 +783,10 @@ def main():
             torch.cuda.empty_cache()
             fused_c5 = bench_fused_joint(lib, _lib, dev, 16, 1500, 300, 1024, 640, stream, 3)
             torch.cuda.empty_cache()
+            # a mid-sized vocabulary (vocab_size and joint_net_size are free hyper-parameters, hparams.py:4,23): V = 128 word pieces
+            # at the headline lattice, native since round 4 (before: padded to 512 columns)
+            fused_mid = bench_fused_joint(lib, _lib, dev, B, T, U, 128, 640, stream, 5)
+            torch.cuda.empty_cache()
             try:
                 op_c5 = bench_op_shape(lib, _lib, dev, 16, 1500, 300, 1024, stream, 3)
             except Exception as e:
@@ -815,7 +819,7 @@ def main():
             "warm_value": world * cells * a.steps / dt_warm,
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "roofline": roof, "cpu_baseline": cpu, "ragged_batch": ragged, "fused_joint": fused,
-            "fused_joint_full": fused_full, "fused_joint_config5": fused_c5, "op_config5": op_c5,
+            "fused_joint_full": fused_full, "fused_joint_config5": fused_c5, "fused_joint_v128": fused_mid, "op_config5": op_c5,
             "fused_dp_step": fused_dp, "e2e_train_step": e2e,
         }
         if world > 1:

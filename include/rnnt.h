@@ -179,8 +179,8 @@ RNNT_API rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, cons
  *                                    accumulation; when some |W2| leaves the binary16 range the library switches, on the device, to
  *                                    plain f32 MFMA kernels with no such limit), small vocabularies: alphabet_size <= 32 (the
  *                                    reference's character set), joint_size a multiple of 64 (<= 704).
- *                                1 = f16 MFMA, large vocabularies: alphabet_size a multiple of 512 (<= 8192),
- *                                    joint_size in {128, 256, 512, 640}.  h = tanh(.) and W2 are rounded to binary16
+ *                                1 = f16 MFMA, larger vocabularies: alphabet_size a multiple of 128 (128 ... 8192),
+ *                                    joint_size a multiple of 128 (128 ... 640).  h = tanh(.) and W2 are rounded to binary16
  *                                    (round-to-nearest-even) before the products, accumulation is f32; the loss gradient
  *                                    w.r.t. the logits is scaled by 2^(14 - ceil(log2 max|cost_scale|)) and rounded to
  *                                    binary16 before dh = dl.W2^T and dW2 = h^T.dl.  The lattice (log-softmax, alpha,
@@ -279,7 +279,7 @@ RNNT_API rnntStatus_t compute_rnnt_joint_net_loss_bwd(const float *enc, const fl
  *   joint_dtype 0  f32-grade split-precision products (and the same device-side switch to plain f32 MFMAs): alphabet_size <= 32,
  *                  joint_size a multiple of 64 (<= 704);
  *   joint_dtype 1  operands rounded to binary16, f32 accumulation (the reference's default vocabulary of 4096 word pieces,
- *                  hparams.py:4): alphabet_size a multiple of 512 (<= 8192), joint_size in {128, 256, 512, 640}; logits 16-byte aligned.
+ *                  hparams.py:4): alphabet_size a multiple of 128 (128 ... 8192), joint_size a multiple of 128 (128 ... 640); logits 16-byte aligned.
  * maxU <= 1024; a greedy decoder calls it with maxT = maxU = 1 and minibatch = the number of hypotheses.
  * workspace: get_joint_workspace_size(maxT, maxU, minibatch, joint_size, alphabet_size) bytes, 256-byte aligned. */
 RNNT_API rnntStatus_t compute_rnnt_joint_logits(const float *enc_proj, const float *pred_proj,

@@ -257,8 +257,9 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
                 if (k * 64 + lane < KS * 4)
                     lds_dma16(erow + 4 * (k * 64 + lane), Eimg + wave * (KS * 64) + k * 1024);
             if (b2_in_lds)
-                for (int i = wave; i < (V >> 8); i += 8)
-                    lds_dma16(b2tab + i * 256 + lane * 4, smem + jp.b2_lds_off + i * 1024);
+                for (int i = wave; i < ((V + 255) >> 8); i += 8)
+                    if (i * 256 + lane * 4 < V)  // (V is a multiple of 128: the last piece may be half full)
+                        lds_dma16(b2tab + i * 256 + lane * 4, smem + jp.b2_lds_off + i * 1024);
         }
         wait_vm();
         __syncthreads();
@@ -594,11 +595,11 @@ constexpr int kK2Span = JH_K2_SPAN;  // 16-byte pieces per workgroup (16 KB; 8 K
 constexpr int kK2Per = kK2Span / 256;   // ... per thread
 __global__ __launch_bounds__(256) void jh_dlogits_kernel(const JhParams jp) {
     if (jp.state[0] != 1) return;  // no parked values: the recompute kernel (MODE 2) does this call's work
-    __shared__ float4 sset[32];    // per cell of the span: factor scale * S, c0, blank value, label value
-    __shared__ int slab[32];       // ... the label column to patch (-1: none), -2: the cell is not written at all
+    __shared__ float4 sset[64];    // per cell of the span: factor scale * S, c0, blank value, label value
+    __shared__ int slab[64];       // ... the label column to patch (-1: none), -2: the cell is not written at all
     const LossParams &p = jp.lp;
     const int V = p.V, tid = threadIdx.x;
-    const int ppc = V >> 3, cw = kK2Span / ppc;  // pieces per cell, cells per workgroup (1 .. 16)
+    const int ppc = V >> 3, cw = kK2Span / ppc;  // pieces per cell, cells per workgroup (1 at V = 8192 .. 64 at V = 128)
     const uint32_t cell_lo = (uint32_t)p.b0 * (uint32_t)(p.T * p.U), cell_hi = cell_lo + (uint32_t)p.nb * (uint32_t)(p.T * p.U);
     const uint32_t c0w = cell_lo + blockIdx.x * (uint32_t)cw;  // first cell of this workgroup
     h8 v[kK2Per];
@@ -919,7 +920,11 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
 // A work unit is (utterance, u-tile of 32, kTQ lattice rows); one lattice row (32 cells = 2 MFMA k-steps) per step.
 // LDS per stage (three stages): dl rows [32 cells][kDRow B] (row-major, read transposed) | h^T fragments
 // [2 ks][4 jb][2][32][8]; plus four 512-byte enc_proj row slices
+// PARTIAL: V is not a multiple of 512 -- the last V tile holds 128, 256 or 384 columns; the waves of the empty 128-column
+// groups keep the workgroup's barriers, DMA pieces and h^T staging and skip their products (a separate instantiation: the
+// schedule of the full-tile kernel is left as it was tuned).
 // ---------------------------------------------------------------------------------------------
+template <bool PARTIAL>
 __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LossParams &p = jp.lp;
@@ -930,10 +935,12 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
     constexpr int kDBytes = 32 * kDRow, kHBytes = 2 * 4 * 32 * 32, kStage = kDBytes + kHBytes;
 
     uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int n_vt = V >> 9, n_tiles = (J >> 7) * n_vt;
+    const int n_vt = (V + 511) >> 9, n_tiles = (J >> 7) * n_vt;
     const int tile = (int)(bid % (uint32_t)n_tiles), range = (int)(bid / (uint32_t)n_tiles);
     const int vt = tile % n_vt, jt = tile / n_vt;
     const int j0 = jt * 128, v0 = vt * 512;
+    const int vw = PARTIAL ? min(512, V - v0) : 512;  // columns of this V tile (a multiple of 128)
+    const bool wv_live = !PARTIAL || wv * 128 < vw;   // wave-uniform: this wave's 128 columns exist
     const int unit_lo = (int)((long long)jp.n_units * range / jp.n_ranges);
     const int unit_hi = (int)((long long)jp.n_units * (range + 1) / jp.n_ranges);
 
@@ -986,14 +993,14 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
                 const int i = wave + 8 * k;
                 const f16 *src = (u0 + i < p.U) ? jp.dl + ((size_t)(b * p.T + t) * p.U + u0 + i) * V + v0 + lane * 8
                                                 : jp.zrow + lane * 8;
-                lds_dma16(src, st + i * kDRow);
+                if (!PARTIAL || lane * 8 < vw) lds_dma16(src, st + i * kDRow);
             }
         };
         auto dma_d_piece = [&](const int s, char *st, const int k) {  // piece k (0..3) of the same
             const int t = t_begin + s, i = wave + 8 * k;
             const f16 *src = (u0 + i < p.U) ? jp.dl + ((size_t)(b * p.T + t) * p.U + u0 + i) * V + v0 + lane * 8
                                             : jp.zrow + lane * 8;
-            lds_dma16(src, st + i * kDRow);
+            if (!PARTIAL || lane * 8 < vw) lds_dma16(src, st + i * kDRow);
         };
         auto build_h = [&](const int s, char *st) {
             const float ej = ((const float *)(ebuf + (s & 3) * 512))[jl];
@@ -1056,18 +1063,20 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
             // of stage s+2 between them
             h8 a[2][2];
             h4 blo[2][4], bhi[2][4];
+            if (wv_live) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+                for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int jb = 0; jb < 2; ++jb)
-                    a[ks][jb] = *(const h8 *)(H + ((ks * 4 + wj * 2 + jb) * 64 + lane) * 16);
-                const int row0 = ks * 16 + 8 * (g4 >> 1) + (pl >> 2);
+                    for (int jb = 0; jb < 2; ++jb)
+                        a[ks][jb] = *(const h8 *)(H + ((ks * 4 + wj * 2 + jb) * 64 + lane) * 16);
+                    const int row0 = ks * 16 + 8 * (g4 >> 1) + (pl >> 2);
 #pragma unroll
-                for (int vb = 0; vb < 4; ++vb) {
-                    const int col = wv * 128 + vb * 32 + 16 * (g4 & 1) + 4 * (pl & 3);
-                    const char *ad = D + row0 * kDRow + col * 2;
-                    blo[ks][vb] = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)ad));
-                    bhi[ks][vb] = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(ad + 4 * kDRow)));
+                    for (int vb = 0; vb < 4; ++vb) {
+                        const int col = wv * 128 + vb * 32 + 16 * (g4 & 1) + 4 * (pl & 3);
+                        const char *ad = D + row0 * kDRow + col * 2;
+                        blo[ks][vb] = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)ad));
+                        bhi[ks][vb] = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(ad + 4 * kDRow)));
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1076,9 +1085,11 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
 #pragma unroll
                 for (int vb = 0; vb < 4; ++vb) {
                     const h4 lo4 = blo[ks][vb], hi4 = bhi[ks][vb];
-                    const h8 bf = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
-                    acc[0][vb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][0], bf, acc[0][vb], 0, 0, 0);
-                    acc[1][vb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][1], bf, acc[1][vb], 0, 0, 0);
+                    if (wv_live) {
+                        const h8 bf = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[0][vb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][0], bf, acc[0][vb], 0, 0, 0);
+                        acc[1][vb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][1], bf, acc[1][vb], 0, 0, 0);
+                    }
                     if (pf) {
                         if (ks == 0) {
                             if (vb == 0 && s + 3 < nsteps) dma_e(s + 3);
@@ -1094,7 +1105,7 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
                             }
                         }
                     }
-                    if (do_db) {
+                    if (do_db && wv_live) {
                         float sdb = dbacc[vb];
                         sdb = __builtin_amdgcn_fdot2(__builtin_shufflevector(lo4, lo4, 0, 1), ones, sdb, false);
                         sdb = __builtin_amdgcn_fdot2(__builtin_shufflevector(lo4, lo4, 2, 3), ones, sdb, false);
@@ -1115,6 +1126,7 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
     }
     const float invS = jp.scal[1];
     float *out = jp.dWpart + (size_t)range * J * V;
+    if (!wv_live) return;
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
@@ -1142,7 +1154,9 @@ struct JhLayout {
 };
 
 bool joint_f16_supported(int J, int V) {
-    return (J == 128 || J == 256 || J == 512 || J == 640) && V >= 512 && (V % 512) == 0 && V <= 8192;
+    // J: whole 128-unit tiles of K3 / K4 (K1 is instantiated per J); V: whole 128-column groups (four 32-column chunks share one
+    // 8-byte reference word in K1; a wave of K4 owns 128 columns -- its 512-wide tile may be partly empty)
+    return (J == 128 || J == 256 || J == 384 || J == 512 || J == 640) && V >= 128 && (V % 128) == 0 && V <= 8192;
 }
 
 static JhLayout make_jh_layout(int T, int U, int B, int J, int V) {
@@ -1155,7 +1169,7 @@ static JhLayout make_jh_layout(int T, int U, int B, int J, int V) {
     L.n_ts = (T + L.TS - 1) / L.TS;
     L.n_tq = (T + kTQ - 1) / kTQ;
     L.n_units = B * L.n_ut * L.n_tq;
-    const int n_tiles = (J / 128) * (V / 512);
+    const int n_tiles = (J / 128) * ((V + 511) / 512);
     // K4: one workgroup per CU -- as many ranges of cell units as fill the 256 CUs with n_tiles workgroups each
     // (config 5: 25 ranges x 10 tiles = 250 workgroups; 24 x 10, XCD-aligned, measured 4 % slower)
     L.n_ranges = 256 / n_tiles;
@@ -1213,9 +1227,10 @@ static hipError_t launch_logits_mode(const JhParams &jp, unsigned grid, hipStrea
     if (shm < images) shm = images;
     JhParams jq = jp;
     jq.b2_lds_off = -1;
-    if (shm + (size_t)jp.lp.V * 4 <= 160 * 1024) {
+    const size_t b2_bytes = (size_t)((jp.lp.V + 255) / 256 * 256) * 4;  // whole 1 KB pieces
+    if (shm + b2_bytes <= 160 * 1024) {
         jq.b2_lds_off = (int)shm;
-        shm += (size_t)jp.lp.V * 4;
+        shm += b2_bytes;
     }
     hipError_t e;
     if (jq.b2_lds_off >= 0) {
@@ -1234,6 +1249,7 @@ static hipError_t jh_launch_logits_for_J(const JhParams &jp, int J, int mode, un
     switch (J) {
         case 128: return launch_logits<8>(jp, mode, tiles, s);
         case 256: return launch_logits<16>(jp, mode, tiles, s);
+        case 384: return launch_logits<24>(jp, mode, tiles, s);
         case 512: return launch_logits<32>(jp, mode, tiles, s);
         case 640: return launch_logits<40>(jp, mode, tiles, s);
     }
@@ -1383,9 +1399,14 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     if ((e = set_state(2)) != hipSuccess) return e;
     {
         const size_t shm = 3 * (size_t)(32 * kDRow + 2 * 4 * 32 * 32) + 4 * 512;
-        if ((e = set_lds_f16(jh_dw_kernel, shm)) != hipSuccess) return e;
-        const unsigned grid = (unsigned)L.n_ranges * (J / 128) * (V / 512);
-        hipLaunchKernelGGL(jh_dw_kernel, dim3(grid), dim3(512), shm, s, jp);
+        const unsigned grid = (unsigned)L.n_ranges * (J / 128) * ((V + 511) / 512);
+        if (V % 512 == 0) {
+            if ((e = set_lds_f16(jh_dw_kernel<false>, shm)) != hipSuccess) return e;
+            hipLaunchKernelGGL(jh_dw_kernel<false>, dim3(grid), dim3(512), shm, s, jp);
+        } else {
+            if ((e = set_lds_f16(jh_dw_kernel<true>, shm)) != hipSuccess) return e;
+            hipLaunchKernelGGL(jh_dw_kernel<true>, dim3(grid), dim3(512), shm, s, jp);
+        }
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if ((e = launch_reduce_enc(d_enc_proj, jp.dApart, L.n_ut, jp.lp, J, s, hooks ? hooks->dmax_enc : nullptr)) != hipSuccess) return e;

@@ -176,7 +176,7 @@ def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_leng
     joint_dtype: arithmetic of the J x V product.  "f32": f32-grade products (binary16 hi + lo operands on the f16 MFMA units, f32 accumulation), small vocabularies (V <= 32, the reference's
     character set).  "f16": operands rounded to binary16, f32 accumulation, for large vocabularies -- the counterpart
     of the reference's `mixed_float16` policy (run_rnnt.py:96-99); the lattice stays f32 either way.  "auto" picks by V.
-    Shapes the kernels do not take natively (f16: V a multiple of 512, J in {128, 256, 512, 640}; f32: J a multiple of
+    Shapes the kernels do not take natively (f16: V a multiple of 128, J a multiple of 128 up to 640; f32: J a multiple of
     64) are padded up exactly (zero units / zero-probability symbols).
 
     first_layer: where the first Dense layer (enc @ W1 + b1, pred @ W1, and dW1 / db1 / d enc / d pred) runs.  "engine": inside
@@ -278,7 +278,7 @@ def joint_logits(enc, pred, W1, b1, W2, b2, joint_dtype: str = "auto", reuse_buf
 
 
 _PAD_BIAS = -1.0e4
-_F16_J = (128, 256, 512, 640)
+_F16_J = (128, 256, 384, 512, 640)
 
 
 def padded_joint_shape(J: int, V: int, joint_dtype: str):
@@ -293,7 +293,7 @@ def padded_joint_shape(J: int, V: int, joint_dtype: str):
     Jp = next((j for j in _F16_J if j >= J), None)
     if Jp is None:
         raise ValueError("rnnt_joint_loss: the f16 joint takes joint sizes of at most 640")
-    Vp = (V + 511) // 512 * 512
+    Vp = max(128, (V + 127) // 128 * 128)
     if Vp > 8192:
         raise ValueError("rnnt_joint_loss: the f16 joint takes vocabularies of at most 8192 symbols")
     return Jp, Vp

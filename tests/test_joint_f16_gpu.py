@@ -59,6 +59,12 @@ SHAPES = [
     (1, 9, 5, 32, 640, 512),      # the BASELINE joint width
     (3, 17, 12, 8, 512, 1536),    # three V tiles
     (4, 64, 64, 16, 128, 1024),   # 16.8 M logits, eight row tiles x two column tiles per utterance
+    # mid-sized vocabularies and joint widths (round 4): V any multiple of 128, J any multiple of 128 up to 640
+    (2, 19, 9, 16, 128, 128),     # one 128-column group: three of the dW2 kernel's four column waves have no tile
+    (2, 40, 37, 24, 384, 256),    # J = 384 (three 128-unit tiles), half a dW2 tile, bias table = exactly one 1 KB piece
+    (3, 13, 33, 16, 640, 384),    # the BASELINE joint width on 384 symbols: bias table = one and a half pieces
+    (2, 21, 11, 8, 256, 640),     # one full 512-column dW2 tile + a 128-column one
+    (1, 70, 35, 16, 384, 1152),   # two full tiles + 128 columns, row splits
 ]
 
 
@@ -163,8 +169,8 @@ def test_joint_f16_is_deterministic():
 
 
 def test_joint_f16_odd_shapes_are_padded_exactly():
-    """V = 1000 (not a multiple of 512) and J = 320 (BASELINE configs 3/4's joint width): the host layer pads to the
-    kernels' shapes with zero units / zero-probability symbols; results equal the oracle on the UNPADDED problem."""
+    """V = 1000 (not a multiple of 128) and J = 320 (BASELINE configs 3/4's joint width): the host layer pads to the
+    kernels' shapes (1024, 384) with zero units / zero-probability symbols; results equal the oracle on the UNPADDED problem."""
     case = make(2, 12, 7, 16, 320, 1000, True, seed=21)
     scale = np.array([1.0, 0.5])
     costs, grads = run(case, scale)
