@@ -63,7 +63,7 @@ for case in range(n_cases):
             f16 = kind == "joint16"
             B, T, U, H = int(rng.integers(1, 4)), int(rng.integers(1, 40)), int(rng.integers(1, 45)), int(rng.integers(4, 24))
             if f16:
-                J, V = int(rng.choice([128, 200, 256, 320])), int(rng.choice([512, 600, 1024, 1100]))
+                J, V = int(rng.choice([128, 200, 256, 320, 384, 500])), int(rng.choice([40, 128, 200, 384, 512, 600, 640, 1024, 1100]))
             else:
                 J, V = int(rng.choice([64, 100, 128, 192, 250])), int(rng.integers(2, 33))
             enc = rng.normal(size=(B, T, H)).astype(np.float32)
