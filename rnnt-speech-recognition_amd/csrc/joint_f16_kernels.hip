@@ -90,7 +90,6 @@ constexpr float kRefLimit = 30000.0f;  // chunk references are kept as int16
 #define JH_TQ 128
 #endif
 constexpr int kTQ = JH_TQ;         // lattice rows per K4 work unit
-constexpr int kDRow = 1088;        // bytes per dl row in K4's LDS image (1024 + 64: conflict-free transposed reads)
 
 struct JhParams {
     LossParams lp;  // lattice workspace, labels, lengths, costs, cost_scale (acts / grads unused)
@@ -918,40 +917,51 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
 // K4: dW2 = h^T . dl / S (and db2 = sum dl / S).  workgroup = (range of work units, 128-wide J tile, 512-wide V tile);
 // 8 waves as 2 (64 joint units) x 4 (128 vocabulary columns), 2 x 4 accumulator tiles each.
 // A work unit is (utterance, u-tile of 32, kTQ lattice rows); one lattice row (32 cells = 2 MFMA k-steps) per step.
-// LDS per stage (three stages): dl rows [32 cells][kDRow B] (row-major, read transposed) | h^T fragments
+// LDS per stage (three stages): dl rows [32 cells][2 VT + 64 B] (row-major, read transposed) | h^T fragments
 // [2 ks][4 jb][2][32][8]; plus four 512-byte enc_proj row slices
 // PARTIAL: V is not a multiple of 512 -- the last V tile holds 128, 256 or 384 columns; the waves of the empty 128-column
 // groups keep the workgroup's barriers, DMA pieces and h^T staging and skip their products (a separate instantiation: the
 // schedule of the full-tile kernel is left as it was tuned).
 // ---------------------------------------------------------------------------------------------
-template <bool PARTIAL>
-__global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
+#ifndef JH_K4_W256
+#define JH_K4_W256 4  // waves per SIMD the 256-column instantiation is compiled for (4 = two workgroups per CU)
+#endif
+template <bool PARTIAL, int VT>
+__global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(const JhParams jp) {
+    // VT = columns of a workgroup's V tile: 512 (one workgroup per CU, 126 KB of LDS) or 256 (TWO per CU at 80 KB each: while one
+    // sits in its barrier / fragment-read phase the other has the matrix pipe)
+    constexpr int VB = VT / 128;       // 32-column accumulator blocks per wave
+    constexpr int WCOL = VT / 4;       // columns per wave
+    constexpr int kRow = 2 * VT + 64;  // bytes per dl row in LDS (+64: conflict-free transposed reads)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LossParams &p = jp.lp;
     const int J = jp.J, V = p.V;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, n = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wj = wave & 1, wv = wave >> 1;
-    constexpr int kDBytes = 32 * kDRow, kHBytes = 2 * 4 * 32 * 32, kStage = kDBytes + kHBytes;
+    constexpr int kDBytes = 32 * kRow, kHBytes = 2 * 4 * 32 * 32, kStage = kDBytes + kHBytes;
 
     uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int n_vt = (V + 511) >> 9, n_tiles = (J >> 7) * n_vt;
+    const int n_vt = (V + VT - 1) / VT, n_tiles = (J >> 7) * n_vt;
     const int tile = (int)(bid % (uint32_t)n_tiles), range = (int)(bid / (uint32_t)n_tiles);
     const int vt = tile % n_vt, jt = tile / n_vt;
-    const int j0 = jt * 128, v0 = vt * 512;
-    const int vw = PARTIAL ? min(512, V - v0) : 512;  // columns of this V tile (a multiple of 128)
-    const bool wv_live = !PARTIAL || wv * 128 < vw;   // wave-uniform: this wave's 128 columns exist
+    const int j0 = jt * 128, v0 = vt * VT;
+    const int vw = PARTIAL ? min(VT, V - v0) : VT;     // columns of this V tile (a multiple of 128)
+    const bool wv_live = !PARTIAL || wv * WCOL < vw;   // wave-uniform: this wave's columns exist
+    constexpr bool kAllLanes = !PARTIAL && VT == 512;  // a dl row piece fills all 64 lanes of its LDS-DMA instruction
     const int unit_lo = (int)((long long)jp.n_units * range / jp.n_ranges);
     const int unit_hi = (int)((long long)jp.n_units * (range + 1) / jp.n_ranges);
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][VB];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < VB; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][q][r] = 0.f;
-    float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+    float dbacc[VB];
+#pragma unroll
+    for (int q = 0; q < VB; ++q) dbacc[q] = 0.f;
     const bool do_db = (jt == 0) && (wj == 0);
     const int jl = tid & 127, cg = tid >> 7;  // h generation: this thread's joint unit and group of 8 cells
     const h2 ones = {(f16)1.0f, (f16)1.0f};
@@ -993,14 +1003,14 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
                 const int i = wave + 8 * k;
                 const f16 *src = (u0 + i < p.U) ? jp.dl + ((size_t)(b * p.T + t) * p.U + u0 + i) * V + v0 + lane * 8
                                                 : jp.zrow + lane * 8;
-                if (!PARTIAL || lane * 8 < vw) lds_dma16(src, st + i * kDRow);
+                if (kAllLanes || lane * 8 < vw) lds_dma16(src, st + i * kRow);
             }
         };
         auto dma_d_piece = [&](const int s, char *st, const int k) {  // piece k (0..3) of the same
             const int t = t_begin + s, i = wave + 8 * k;
             const f16 *src = (u0 + i < p.U) ? jp.dl + ((size_t)(b * p.T + t) * p.U + u0 + i) * V + v0 + lane * 8
                                             : jp.zrow + lane * 8;
-            if (!PARTIAL || lane * 8 < vw) lds_dma16(src, st + i * kDRow);
+            if (kAllLanes || lane * 8 < vw) lds_dma16(src, st + i * kRow);
         };
         auto build_h = [&](const int s, char *st) {
             const float ej = ((const float *)(ebuf + (s & 3) * 512))[jl];
@@ -1062,7 +1072,7 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
             // all fragment reads of the step first (2 x (2 A + 8 transposed B)), then MFMA pairs with the staging work
             // of stage s+2 between them
             h8 a[2][2];
-            h4 blo[2][4], bhi[2][4];
+            h4 blo[2][VB], bhi[2][VB];
             if (wv_live) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -1071,11 +1081,11 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
                         a[ks][jb] = *(const h8 *)(H + ((ks * 4 + wj * 2 + jb) * 64 + lane) * 16);
                     const int row0 = ks * 16 + 8 * (g4 >> 1) + (pl >> 2);
 #pragma unroll
-                    for (int vb = 0; vb < 4; ++vb) {
-                        const int col = wv * 128 + vb * 32 + 16 * (g4 & 1) + 4 * (pl & 3);
-                        const char *ad = D + row0 * kDRow + col * 2;
+                    for (int vb = 0; vb < VB; ++vb) {
+                        const int col = wv * WCOL + vb * 32 + 16 * (g4 & 1) + 4 * (pl & 3);
+                        const char *ad = D + row0 * kRow + col * 2;
                         blo[ks][vb] = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)ad));
-                        bhi[ks][vb] = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(ad + 4 * kDRow)));
+                        bhi[ks][vb] = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(ad + 4 * kRow)));
                     }
                 }
             }
@@ -1083,7 +1093,7 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int vb = 0; vb < 4; ++vb) {
+                for (int vb = 0; vb < VB; ++vb) {
                     const h4 lo4 = blo[ks][vb], hi4 = bhi[ks][vb];
                     if (wv_live) {
                         const h8 bf = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -1091,17 +1101,19 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
                         acc[1][vb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][1], bf, acc[1][vb], 0, 0, 0);
                     }
                     if (pf) {
+                        constexpr int PP = 4 / VB, HP = 8 / VB;  // DMA pieces / h values per MFMA pair
                         if (ks == 0) {
                             if (vb == 0 && s + 3 < nsteps) dma_e(s + 3);
-                            dma_d_piece(s + 2, stn, vb);
+#pragma unroll
+                            for (int k = 0; k < PP; ++k) dma_d_piece(s + 2, stn, vb * PP + k);
                         } else {
-                            // two of this thread's eight h values of row s+2
+                            // this thread's eight h values of row s+2, spread over the MFMA pairs of the second k-step
                             if (!slow) {
-                                hh[2 * vb] = htanh2(ejn, pv[2 * vb]);
-                                hh[2 * vb + 1] = htanh2(ejn, pv[2 * vb + 1]);
+#pragma unroll
+                                for (int e = vb * HP; e < (vb + 1) * HP; ++e) hh[e] = htanh2(ejn, pv[e]);
                             } else {
-                                hh[2 * vb] = htanh(ejn + pv[2 * vb]);
-                                hh[2 * vb + 1] = htanh(ejn + pv[2 * vb + 1]);
+#pragma unroll
+                                for (int e = vb * HP; e < (vb + 1) * HP; ++e) hh[e] = htanh(ejn + pv[e]);
                             }
                         }
                     }
@@ -1130,16 +1142,16 @@ __global__ __launch_bounds__(512) void jh_dw_kernel(const JhParams jp) {
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-        for (int vb = 0; vb < 4; ++vb)
+        for (int vb = 0; vb < VB; ++vb)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                out[(size_t)(j0 + wj * 64 + jb * 32 + cdrow(r, half)) * V + v0 + wv * 128 + vb * 32 + n] = acc[jb][vb][r] * invS;
+                out[(size_t)(j0 + wj * 64 + jb * 32 + cdrow(r, half)) * V + v0 + wv * WCOL + vb * 32 + n] = acc[jb][vb][r] * invS;
     if (do_db) {
 #pragma unroll
-        for (int vb = 0; vb < 4; ++vb) {
+        for (int vb = 0; vb < VB; ++vb) {
             float s = dbacc[vb];
             s += __shfl_xor(s, 32);
-            if (lane < 32) jp.dbpart[(size_t)range * V + v0 + wv * 128 + vb * 32 + n] = s * invS;
+            if (lane < 32) jp.dbpart[(size_t)range * V + v0 + wv * WCOL + vb * 32 + n] = s * invS;
         }
     }
 }
@@ -1152,6 +1164,11 @@ struct JhLayout {
     size_t W2Tp, W2h, dl, pref, xbl, scal, expE, expP, b2l, dApart, dCpart, zrow, dWpart, dbpart, total;
     int n_ut, n_tt, n_ts, TS, n_tq, n_units, n_ranges;
 };
+
+// Columns of K4's V tile: 512 = one workgroup per CU, 256 = two (see jh_dw_kernel).  Measured (profiles/r04_notes.md): 256-column
+// tiles win while they are the only tile (V = 128: 4.97 -> 4.31 ms, V = 256: 4.40 -> 3.83 ms at B32 T600 U150) and lose beyond
+// (V = 384: 7.89 -> 8.77 ms; config 5, V = 1024: K4 11.3 -> 15.5 ms -- every tile rebuilds the h^T image).
+static int k4_vt(int V) { return V <= 256 ? 256 : 512; }
 
 bool joint_f16_supported(int J, int V) {
     // J: whole 128-unit tiles of K3 / K4 (K1 is instantiated per J); V: whole 128-column groups (four 32-column chunks share one
@@ -1169,10 +1186,10 @@ static JhLayout make_jh_layout(int T, int U, int B, int J, int V) {
     L.n_ts = (T + L.TS - 1) / L.TS;
     L.n_tq = (T + kTQ - 1) / kTQ;
     L.n_units = B * L.n_ut * L.n_tq;
-    const int n_tiles = (J / 128) * ((V + 511) / 512);
-    // K4: one workgroup per CU -- as many ranges of cell units as fill the 256 CUs with n_tiles workgroups each
+    const int vt = k4_vt(V), n_tiles = (J / 128) * ((V + vt - 1) / vt);
+    // K4: one workgroup per CU (two with 256-column tiles) -- as many ranges of cell units as fill the 256 CUs with n_tiles workgroups each
     // (config 5: 25 ranges x 10 tiles = 250 workgroups; 24 x 10, XCD-aligned, measured 4 % slower)
-    L.n_ranges = 256 / n_tiles;
+    L.n_ranges = (vt == 512 ? 256 : 512) / n_tiles;
     if (L.n_ranges < 1) L.n_ranges = 1;
     if (L.n_ranges > L.n_units) L.n_ranges = L.n_units;
     size_t off = L.w.total;
@@ -1398,15 +1415,18 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     }
     if ((e = set_state(2)) != hipSuccess) return e;
     {
-        const size_t shm = 3 * (size_t)(32 * kDRow + 2 * 4 * 32 * 32) + 4 * 512;
-        const unsigned grid = (unsigned)L.n_ranges * (J / 128) * ((V + 511) / 512);
-        if (V % 512 == 0) {
-            if ((e = set_lds_f16(jh_dw_kernel<false>, shm)) != hipSuccess) return e;
-            hipLaunchKernelGGL(jh_dw_kernel<false>, dim3(grid), dim3(512), shm, s, jp);
-        } else {
-            if ((e = set_lds_f16(jh_dw_kernel<true>, shm)) != hipSuccess) return e;
-            hipLaunchKernelGGL(jh_dw_kernel<true>, dim3(grid), dim3(512), shm, s, jp);
-        }
+        const int vt = k4_vt(V);
+        const size_t shm = 3 * (size_t)(32 * (2 * vt + 64) + 2 * 4 * 32 * 32) + 4 * 512;
+        const unsigned grid = (unsigned)L.n_ranges * (J / 128) * ((V + vt - 1) / vt);
+        auto go = [&](auto kernel) -> hipError_t {
+            hipError_t e2 = set_lds_f16(kernel, shm);
+            if (e2 != hipSuccess) return e2;
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), shm, s, jp);
+            return hipGetLastError();
+        };
+        if (vt == 256) e = (V % 256 == 0) ? go(jh_dw_kernel<false, 256>) : go(jh_dw_kernel<true, 256>);
+        else e = (V % 512 == 0) ? go(jh_dw_kernel<false, 512>) : go(jh_dw_kernel<true, 512>);
+        if (e != hipSuccess) return e;
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if ((e = launch_reduce_enc(d_enc_proj, jp.dApart, L.n_ut, jp.lp, J, s, hooks ? hooks->dmax_enc : nullptr)) != hipSuccess) return e;
