@@ -78,6 +78,7 @@ struct LossParams {
     int nPstat;
     int B, T, U, V, blank;
     int b0, nb;  // this launch covers utterances [b0, b0+nb)
+    int precise;  // 1: the log-domain sweeps carry their recurrence in float64 (rnnt_sweep.h alpha_sweep_pr); lattices of 8+ columns per lane always do
     int N, Nr, Up, NC, NG;  // NG = Up/OG offset groups (offset tables are [NC][NG])
     uint32_t cells;  // B*T*U
     FastDiv divU, divT, divV, divOG;  // divOG: lattice column -> offset group

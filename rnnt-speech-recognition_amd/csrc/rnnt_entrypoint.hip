@@ -77,6 +77,7 @@ static bool fill_params(LossParams &p, const float *acts, float *grads, const in
     p.nPstat = w.nPstat;
     p.B = B, p.T = o.maxT, p.U = o.maxU, p.V = V, p.blank = o.blank_label;
     p.b0 = 0, p.nb = B;
+    p.precise = 0;
     p.tile = make_tile(o.maxT, o.maxU, V);
     p.N = w.N, p.Nr = w.Nr, p.Up = w.Up, p.NC = w.NC, p.NG = w.NG;
     p.cells = (uint32_t)cells;
@@ -134,6 +135,7 @@ static rnntStatus_t run_forward(LossParams &p, const WsLayout &w, hipStream_t s)
     // the patch kernels write the log-zero part of W themselves; the wave-per-cell kernels (large or unaligned vocabularies)
     // rely on a pre-filled W
     if (!tile_path_ok(p, false) && launch_fill(p.W, kFillByte, w.A - w.W, s) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
+    p.precise = 1;  // the op's contract is 1e-4 on every input: float64 recurrence (the fused joints keep the float32 one up to 6 columns per lane)
     hipError_t e = launch_lsm(p, s);
     if (e != hipSuccess) return from_hip(e);
     return from_hip(launch_sweeps(p, s));

@@ -343,6 +343,11 @@ __global__ __launch_bounds__(128) void sweep_ld_kernel(const LossParams p) {
             sweep_loader<K, G, NB, true>(p, lds, lk, b, lane);
         else
             sweep_loader<K, G, NB, false>(p, lds, lk, b, lane);
+    } else if (K >= 8 || p.precise) {  // the float64 recurrence (rnnt_sweep.h): the loss op, and every lattice of 8+ columns per lane (wider than 384 columns)
+        if (beta)
+            beta_sweep_pr<K, G, NB>(p, lds, lk, b, lane);
+        else
+            alpha_sweep_pr<K, G, NB>(p, lds, lk, b, lane);
     } else {
         if (beta)
             beta_sweep_ld<K, G, NB>(p, lds, lk, b, lane);
@@ -367,91 +372,112 @@ static hipError_t launch_sweep_ld(const LossParams &p, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // Wide sweep (1024 < maxU <= 8192; upstream has no such limit, label sequences this long are rare): one workgroup of 1024
 // threads per (utterance, direction), the previous diagonal in LDS, one barrier per diagonal -- the plain formulation, an
-// order of magnitude slower per diagonal than the register-resident sweeps, with the SAME arithmetic (log2 domain, finite
-// log zero, integer re-basing against the straight-line ridge cell every kRebase diagonals; one offset per block, copied to
-// every 64-column group of the offset tables) and the same outputs, so the gradient pass does not know which sweep ran.
+// order of magnitude slower per diagonal than the register-resident sweeps.  Same arithmetic as the precise sweeps of
+// rnnt_sweep.h (alpha / beta as TRUE log2 values in float64, the log2(1 + 2^-|d|) term on the float32 units) and the same
+// outputs, so the gradient pass does not know which sweep ran: float32 residues against one integer offset per block of
+// kRebase diagonals and group of 64 columns (the group's largest value, rounded; a group without mass copies the neighbour
+// the mass will come from), offsets in the tables.  (Round 3 carried float32 residues against ONE offset per block -- the
+// straight-line ridge cell -- for all columns: 1.4e-4 of relative cost error on a trained-like 1200 x 1100 lattice.)
 // ---------------------------------------------------------------------------------------------
 template <bool BETA>
 __global__ __launch_bounds__(1024) void sweep_wide_kernel(const LossParams p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    const int tid = threadIdx.x, lane = tid & 63;
     const int b = p.b0 + (int)blockIdx.x;
-    const int Up = p.Up;
+    const int Up = p.Up;  // a multiple of 64: every wave iteration covers one whole offset group
     const int Tb = length_T(p, b), Ub = length_U(p, b);
     const int Nb = Tb + Ub - 1, last = Nb - 1;
-    const RidgeLine ridge = make_ridge(Ub, Nb);
     const float2 *Wb = (const float2 *)p.W + (size_t)b * p.Nr * Up;
     float *out = (BETA ? p.Bt : p.A) + (size_t)b * p.Nr * Up;
     float *offs = (BETA ? p.offB : p.offA) + (size_t)b * p.NC * p.NG;
-    float *cur = lds, *nxt = lds + Up;
-    float off = 0.f;  // cumulative integer offset (every thread tracks the same value)
+    double *cur = ldsd, *nxt = ldsd + Up;
+    float *gm = (float *)(ldsd + 2 * Up);  // [NG] the groups' rounded maxima of the row being re-based (NaN: no mass)
+    constexpr int kIter = kMaxU / 1024;    // column iterations per thread at most
+    float goff[kIter];                     // offset in force for this thread's column of iteration i (its 64-column group)
+#pragma unroll
+    for (int i = 0; i < kIter; ++i) goff[i] = 0.f;
     const bool bad = lengths_invalid(p, b);
-    auto record = [&](const int kc) {
-        for (int g = tid; g < p.NG; g += 1024) offs[(size_t)kc * p.NG + g] = off;
+    const double negd = (double)kNeg;
+    // new offsets of the complete, visible row `row` for block kc; ends with a barrier
+    auto reoffset = [&](const double *row, const int kc) {
+#pragma unroll
+        for (int i = 0; i < kIter; ++i) {
+            const int u = tid + 1024 * i;
+            if (u < Up) {
+                float m = (float)row[u];
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft));
+                if (lane == 0) gm[u >> 6] = (m > kNegTest) ? rintf(m) : NAN;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kIter; ++i) {
+            const int u = tid + 1024 * i;
+            if (u < Up) {
+                const int g = u >> 6, gn = BETA ? min(g + 1, p.NG - 1) : max(g - 1, 0);
+                const float own = gm[g], nb = gm[gn];
+                goff[i] = (own == own) ? own : ((nb == nb) ? nb : goff[i]);
+                if (lane == 0) offs[(size_t)kc * p.NG + g] = goff[i];
+            }
+        }
+        __syncthreads();
     };
-    auto rebase_row = [&](float *row, const int n) {  // row is complete and visible; afterwards so is the re-based row
-        const float mi = rintf(row[ridge.u_at(n)]);
-        __syncthreads();
-        for (int u = tid; u < Up; u += 1024) row[u] -= mi;
-        off += mi;
-        __syncthreads();
+    auto store_row = [&](const double *row, const int n) {
+#pragma unroll
+        for (int i = 0; i < kIter; ++i) {
+            const int u = tid + 1024 * i;
+            if (u < Up) out[(size_t)n * Up + u] = (row[u] > (double)kNegTest) ? (float)(row[u] - (double)goff[i]) : kNeg;
+        }
     };
     if (!BETA) {
-        for (int u = tid; u < Up; u += 1024) {
-            cur[u] = (u == 0) ? 0.f : kNeg;
-            out[u] = cur[u];
-        }
-        record(0);
+        for (int u = tid; u < Up; u += 1024) cur[u] = (u == 0) ? 0.0 : negd;
         __syncthreads();
+        reoffset(cur, 0);
+        store_row(cur, 0);
         for (int n = 1; n <= last; ++n) {  // diagonal n from diagonal n - 1 and the edge weights leaving diagonal n - 1
             const float2 *wrow = Wb + (size_t)(n - 1) * Up;
             for (int u = tid; u < Up; u += 1024) {
-                const float stay = cur[u] + wrow[u].x;                             // blank: (t-1, u) -> (t, u)
-                const float emit = (u > 0) ? cur[u - 1] + wrow[u - 1].y : kNeg;    // label: (t, u-1) -> (t, u)
-                nxt[u] = lse2(stay, emit);
+                const double stay = cur[u] + (double)wrow[u].x;                           // blank: (t-1, u) -> (t, u)
+                const double emit = (u > 0) ? cur[u - 1] + (double)wrow[u - 1].y : negd;  // label: (t, u-1) -> (t, u)
+                nxt[u] = lse2_pr(stay, emit);
             }
             __syncthreads();
-            if ((n & (kRebase - 1)) == 0) {
-                rebase_row(nxt, n);
-                record(n / kRebase);
-            }
-            for (int u = tid; u < Up; u += 1024) out[(size_t)n * Up + u] = nxt[u];
-            float *t = cur;
+            if ((n & (kRebase - 1)) == 0) reoffset(nxt, n / kRebase);
+            store_row(nxt, n);
+            double *t = cur;
             cur = nxt, nxt = t;
         }
         if (tid == 0) {
-            const double ll2 = bad ? (double)NAN : (double)off + (double)cur[Ub - 1] + (double)Wb[(size_t)last * Up + Ub - 1].x;
+            const double ll2 = bad ? (double)NAN : cur[Ub - 1] + (double)Wb[(size_t)last * Up + Ub - 1].x;
             p.ll[2 * b] = ll2;
             p.costs[b] = (float)(-ll2 * 0.6931471805599453);
         }
     } else {
-        for (int u = tid; u < Up; u += 1024) cur[u] = (u == Ub - 1) ? 0.f : kNeg;  // the virtual terminal node (T_b, U_b - 1)
+        for (int u = tid; u < Up; u += 1024) cur[u] = (u == Ub - 1) ? 0.0 : negd;  // the virtual terminal node (T_b, U_b - 1)
         __syncthreads();
         for (int n = last; n >= 0; --n) {  // diagonal n from diagonal n + 1 and the edge weights leaving diagonal n
             const float2 *wrow = Wb + (size_t)n * Up;
             for (int u = tid; u < Up; u += 1024) {
-                const float stay = cur[u] + wrow[u].x;
-                const float emit = ((u + 1 < Up) ? cur[u + 1] : kNeg) + wrow[u].y;
-                nxt[u] = lse2(stay, emit);
+                const double stay = cur[u] + (double)wrow[u].x;
+                const double emit = ((u + 1 < Up) ? cur[u + 1] : negd) + (double)wrow[u].y;
+                nxt[u] = lse2_pr(stay, emit);
             }
             __syncthreads();
-            if ((n & (kRebase - 1)) == kRebase - 1 || n == last) {
-                rebase_row(nxt, n);
-                record(n / kRebase);
-            }
-            for (int u = tid; u < Up; u += 1024) out[(size_t)n * Up + u] = nxt[u];
-            float *t = cur;
+            if ((n & (kRebase - 1)) == kRebase - 1 || n == last) reoffset(nxt, n / kRebase);
+            store_row(nxt, n);
+            double *t = cur;
             cur = nxt, nxt = t;
         }
         if (tid == 0) {
-            p.ll[2 * b + 1] = bad ? (double)NAN : (double)off + (double)cur[0];
+            p.ll[2 * b + 1] = bad ? (double)NAN : cur[0];
             if (bad) p.costs[b] = NAN;
         }
     }
 }
 
 static hipError_t launch_sweep_wide(const LossParams &p, hipStream_t s) {
-    const size_t shm = (size_t)2 * p.Up * sizeof(float);
+    const size_t shm = (size_t)2 * p.Up * sizeof(double) + (size_t)p.NG * sizeof(float);  // two diagonals in float64 + the groups' maxima
     hipError_t e;
     if (shm > 64 * 1024) {
         if ((e = hipFuncSetAttribute((const void *)sweep_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)) != hipSuccess) return e;

@@ -544,14 +544,14 @@ __global__ __launch_bounds__(kRedoThreads) void lin_redo_kernel(const LossParams
         if (wave == 1)
             sweep_loader<K, G, NB, false>(p, lds, lk, b, lane);
         else if (wave == 0)
-            alpha_sweep_ld<K, G, NB>(p, lds, lk, b, lane);
+            alpha_sweep_pr<K, G, NB>(p, lds, lk, b, lane);  // the float64 recurrence: whatever failed the certificate is a hard input
         __syncthreads();
         if (tid < 2) ctr[tid] = 0;
         __syncthreads();
         if (wave == 1)
             sweep_loader<K, G, NB, true>(p, lds, lk, b, lane);
         else if (wave == 0)
-            beta_sweep_ld<K, G, NB>(p, lds, lk, b, lane);
+            beta_sweep_pr<K, G, NB>(p, lds, lk, b, lane);
         redo_phase_sync();
         if (tid == 0) st_i32_wt(fl + kFlagState, 2);
     }

@@ -537,4 +537,172 @@ __device__ void beta_sweep_ld(const LossParams &p, float *bufs, const LdLink lk,
     if (timed_out && lane == 0 && p.costs) st_f32_wt(p.costs + b, NAN);  // the alpha side may have finished normally
 }
 
+// ---------------------------------------------------------------------------------------------
+// PRECISE sweeps: the same recurrence carried in float64, for the inputs the float32 one is not good enough for.
+// The float32 sweeps round every log-add at the magnitude of its residue (up to hundreds of bits below the lane's reference
+// at 4 ... 8 x N(0,1) logits): ~1e-5 bits per step, a random walk of ~3e-4 bits over the ~1,000 steps of a path through a wide
+// lattice -- that, not the re-basing granularity, is where 2 ... 5e-4 of gradient error on such inputs came from
+// (tests/tools/emulate_sweep.py: per-column offsets and per-diagonal re-basing do not remove it, a float64 recurrence on the
+// same float32 edge weights does: 5e-6).  Here: alpha / beta are TRUE log2 values in float64 registers (no frames in the
+// recurrence, hence no offset differences at lane crossings either), the transcendental part of a log-add -- log2(1 + 2^-|d|),
+// in (0, 1] -- stays on the float32 units (absolute error ~1e-7, not accumulated at the residue's magnitude), and the outputs
+// keep their format: float32 residues against the lane's integer offset of the block (one rounding at the store, not carried
+// forward), offsets in the tables, ll in float64.  ~3x the instructions of the float32 step; used by the linear lattice's
+// hand-back kernel (utterances whose range certificate failed: peaked posteriors) and for lattices of 8 and more columns per lane.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dpp64_from_lower_lane(const double x, const double fill) {
+    const long long xi = __double_as_longlong(x), fi = __double_as_longlong(fill);
+    const int lo = __builtin_amdgcn_update_dpp((int)fi, (int)xi, 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(fi >> 32), (int)(xi >> 32), 0x138, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double dpp64_from_upper_lane(const double x, const double fill) {
+    const long long xi = __double_as_longlong(x), fi = __double_as_longlong(fill);
+    const int lo = __builtin_amdgcn_update_dpp((int)fi, (int)xi, 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(fi >> 32), (int)(xi >> 32), 0x130, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double lse2_pr(const double u, const double l) {
+    const double M = fmax(u, l);
+    const float d = (float)(fmin(u, l) - M);  // <= 0 (0 for two log zeros: the result stays a log zero)
+    return M + (double)lg2(1.0f + ex2(d));
+}
+// The lane's integer offset of a block = its largest value, rounded; a lane without mass copies the lane the mass will come
+// from (as rebase_lane does).  Values are NOT re-based in registers.
+template <int K, bool BETA>
+__device__ __forceinline__ void offset_lane_pr(const double (&v)[K], SweepState &st, const int kc) {
+    double m = v[0];
+#pragma unroll
+    for (int j = 1; j < K; ++j) m = fmax(m, v[j]);
+    const bool fin = m > (double)kNegTest;
+    float off = fin ? rintf((float)m) : st.off;
+    constexpr int R = (kRebase + K - 1) / K;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float nb = BETA ? dpp_from_upper_lane(off, off) : dpp_from_lower_lane(off, off);
+        off = fin ? off : nb;
+    }
+    st.off = off;
+    st_f32_wt(st.tab + (size_t)kc * 64, off);
+}
+template <int K>
+__device__ __forceinline__ void store_diag_pr(float *row, const int lane, const double (&v)[K], const float off) {
+    float *dst = row + lane * K;
+#pragma unroll
+    for (int j = 0; j < K; ++j) st_f32_wt(dst + j, v[j] > (double)kNegTest ? (float)(v[j] - (double)off) : kNeg);
+}
+
+template <int K, int G, int NB>
+__device__ void alpha_sweep_pr(const LossParams &p, float *bufs, const LdLink lk, const int b, const int lane) {
+    constexpr int Up = 64 * K, chunkf = G * 2 * Up;
+    const int Tb = length_T(p, b), Ub = length_U(p, b);
+    const int Nb = Tb + Ub - 1;
+    float *out = p.A + (size_t)b * p.Nr * Up;
+    const int u0 = lane * K;
+    double a[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = (u0 + j == 0) ? 0.0 : (double)kNeg;
+    SweepState st;
+    st.off = 0.f, st.dlt = 0.f, st.edge = kNeg;
+    st.tab = p.offA + (size_t)b * p.NC * p.NG + lane;
+    st_f32_wt(st.tab, 0.f);  // block 0
+    store_diag_pr<K>(out, lane, a, 0.f);
+    st.row = out + Up;
+    const int last_row = Nb - 1;
+    const int nchunks = last_row / G + 1;
+    int have = 0;
+    bool timed_out = lengths_invalid(p, b);
+    for (int ck = 0; ck < nchunks; ++ck) {
+        if (have < ck + 1) {
+            have = lds_wait_ge(lk.landed, ck + 1);
+            timed_out |= have < ck + 1;
+        }
+        const float *cur = bufs + (ck % NB) * chunkf + 2 * u0;
+        const int r0 = ck * G;
+#pragma unroll 1
+        for (int i = 0; i < G; ++i) {
+            const int n = r0 + i + 1;
+            if (n > last_row) break;
+            f32x2 w[K];
+            load_w<K>(w, cur + i * 2 * Up);
+            double emit[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) emit[j] = a[j] + (double)w[j][1];  // (t, u) -> (t, u + 1)
+            const double from_left = dpp64_from_lower_lane(emit[K - 1], (double)kNeg);
+#pragma unroll
+            for (int j = 0; j < K; ++j) a[j] = lse2_pr(a[j] + (double)w[j][0], (j == 0) ? from_left : emit[j - 1]);
+            if ((n & (kRebase - 1)) == 0) offset_lane_pr<K, false>(a, st, n / kRebase);
+            store_diag_pr<K>(st.row, lane, a, st.off);
+            st.row += Up;
+        }
+        if (ck + 1 < nchunks) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read of this chunk's buffer has returned
+            if (lane == 0) lds_post(lk.consumed, ck + 1);
+        }
+    }
+    {
+        const float *wrow = bufs + ((nchunks - 1) % NB) * chunkf + (last_row % G) * 2 * Up + 2 * u0;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (u0 + j == Ub - 1) {
+                const double ll2 = timed_out ? (double)NAN : a[j] + (double)wrow[2 * j];
+                st_f64_wt(p.ll + 2 * b, ll2);
+                if (p.costs) st_f32_wt(p.costs + b, (float)(-ll2 * 0.6931471805599453));
+            }
+    }
+}
+
+template <int K, int G, int NB>
+__device__ void beta_sweep_pr(const LossParams &p, float *bufs, const LdLink lk, const int b, const int lane) {
+    constexpr int Up = 64 * K, chunkf = G * 2 * Up;
+    const int Tb = length_T(p, b), Ub = length_U(p, b);
+    const int Nb = Tb + Ub - 1;
+    float *out = p.Bt + (size_t)b * p.Nr * Up;
+    const int u0 = lane * K;
+    double bv[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) bv[j] = (u0 + j == Ub - 1) ? 0.0 : (double)kNeg;
+    const int last = Nb - 1;
+    const int ckl = last / G;
+    SweepState st;
+    st.off = 0.f, st.dlt = 0.f, st.edge = kNeg;
+    st.tab = p.offB + (size_t)b * p.NC * p.NG + lane;
+    st.row = out + (size_t)last * Up;
+    int have = 0;
+    bool timed_out = lengths_invalid(p, b);
+    for (int ck = ckl; ck >= 0; --ck) {
+        const int i_ring = ckl - ck;  // the loader's chunk index
+        if (have < i_ring + 1) {
+            have = lds_wait_ge(lk.landed, i_ring + 1);
+            timed_out |= have < i_ring + 1;
+        }
+        const float *cur = bufs + (i_ring % NB) * chunkf + 2 * u0;
+        const int r0 = ck * G;
+#pragma unroll 1
+        for (int ii = 0; ii < G; ++ii) {
+            const int i = G - 1 - ii;
+            const int n = r0 + i;
+            if (n > last) continue;
+            f32x2 w[K];
+            load_w<K>(w, cur + i * 2 * Up);
+            const double from_right = dpp64_from_upper_lane(bv[0], (double)kNeg);
+            double nv[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                nv[j] = lse2_pr(bv[j] + (double)w[j][0], ((j == K - 1) ? from_right : bv[j + 1]) + (double)w[j][1]);
+#pragma unroll
+            for (int j = 0; j < K; ++j) bv[j] = nv[j];
+            if (((n & (kRebase - 1)) == kRebase - 1) || n == last) offset_lane_pr<K, true>(bv, st, n / kRebase);
+            store_diag_pr<K>(st.row, lane, bv, st.off);
+            st.row -= Up;
+        }
+        if (ck > 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) lds_post(lk.consumed, i_ring + 1);
+        }
+    }
+    if (lane == 0) st_f64_wt(p.ll + 2 * b + 1, timed_out ? (double)NAN : bv[0]);
+    if (timed_out && lane == 0 && p.costs) st_f32_wt(p.costs + b, NAN);  // the alpha side may have finished normally
+}
+
 }  // namespace rnnt

@@ -31,7 +31,7 @@ t_start = time.time()
 for case in range(n_cases):
     kind = rng.choice(kinds)
     try:
-        if kind in ("loss", "loss_wide"):
+        if kind in ("loss", "loss_wide", "loss_wide4"):  # loss_wide4: the wide lattices at 4 sigma only (the tail of the widest bar)
             if kind == "loss":
                 B, T, U = int(rng.integers(1, 6)), int(rng.integers(1, 80)), int(rng.integers(1, 90))
                 V = int(rng.choice([2, 3, 5, 8, 12, 28, 29, 31, 32, 33, 47, 60, 61, 64, 100, 257]))
@@ -40,7 +40,7 @@ for case in range(n_cases):
                 T = int(rng.integers(20, max(21, 60000 // U)))
                 V = int(rng.choice([4, 7, 8]))
             blank = int(rng.integers(0, V)) if rng.random() < 0.3 else 0
-            sc = float(rng.choice([0.5, 1.0, 4.0]))
+            sc = 4.0 if kind == "loss_wide4" else float(rng.choice([0.5, 1.0, 4.0]))
             acts = (rng.normal(size=(B, T, U, V)) * sc).astype(np.float32)
             pool = [v for v in range(V) if v != blank]
             labels = rng.choice(pool, size=(B, max(U - 1, 1))).astype(np.int32)[:, : max(U - 1, 0)]
