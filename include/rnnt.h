@@ -89,22 +89,25 @@ RNNT_API rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool
  * frame is flushed; whether that mattered is decided per lattice cell by the gradient pass (what a flush can have cost, times
  * the other side's mass, over the likelihood, must stay below 2^-40) and per utterance by the sweeps (likelihood zero /
  * non-finite, alpha-side vs beta-side likelihood, an edge probability below 2^-100).  An utterance that fails is redone by the
- * LOG-domain kernels (float32 log2 values with exact integer re-basing per sweep lane, float64 where offsets are combined) --
- * slower by a millisecond per utterance, exact for any range -- so results never depend on the shortcut.  N(0,1) logits and
- * trained-like posteriors (one dominant symbol per cell along any monotone alignment) stay on the linear lattice, and so do
- * unstructured logits up to about 4 x N(0,1) (the sweeps shorten their frame blocks from 8 to 4 diagonals where the lsm pass saw the
- * mass decay fast); beyond that utterances are handed back.  Everything else (larger vocabularies, unaligned tensors, more than
- * 1024 columns, the fused joints) runs on the log-domain kernels throughout.
+ * LOG-domain kernels -- slower by a millisecond per utterance, exact for any range -- so results never depend on the shortcut.
+ * N(0,1) logits and trained-like posteriors (one dominant symbol per cell along any monotone alignment) stay on the linear
+ * lattice, and so do unstructured logits up to about 4 x N(0,1) (the sweeps shorten their frame blocks from 8 to 4 diagonals where
+ * the lsm pass saw the mass decay fast); beyond that utterances are handed back.  Everything else (larger vocabularies, unaligned
+ * tensors, more than 1024 columns, the fused joints) runs on the log-domain kernels throughout.
+ * The log-domain kernels keep alpha / beta as log2 values.  Wherever THIS op uses them (the hand-back, vocabularies above 60
+ * symbols, unaligned tensors, more than 1024 columns) the recurrence is carried in float64 registers -- the log2(1 + 2^-|d|) term
+ * of a log-add, in (0, 1], on the float32 units -- and only the stored lattice is float32 (residues against an integer offset per
+ * block of 8 diagonals and sweep lane / group of 64 columns): a float32 recurrence rounds every log-add at the magnitude of its
+ * residue, a random walk that reached 1e-4 ... 5e-4 of gradient error over the ~1,000-step paths of peaked or wide lattices
+ * (rounds 1-3; tests/tools/emulate_sweep.py).  The fused joints keep the float32 recurrence up to 6 columns per lane (maxU <= 384)
+ * and use the float64 one beyond.
  * Bars, against a float64 evaluation of the same logits, all tested with FIXED bars (tests/test_lin_gpu.py,
- * tests/test_peaky_gpu.py, tests/test_peaky_wide_gpu.py; measured values in profiles/r04_accuracy*.json):
- *   costs      within 1e-4 max(1, |cost|) everywhere;
- *   gradients  within 1e-4 absolute for N(0,1) ... 4 x N(0,1) logits and trained-like posteriors on lattices of up to 256
- *              columns (measured 2e-7 ... 8.5e-5 at B=32 T=600 U=150 V=28) and on wider lattices with at least as many frames
- *              as columns; within 2.5e-4 for 8 x N(0,1) logits there (costs of ~7,500 nats: the float32 representation of the
- *              log-probabilities themselves limits the result) and, on lattices wider than 256 columns, for 4 x N(0,1) logits
- *              and for unstructured logits when there are FEWER frames than columns (every path emits several labels per
- *              frame; a sweep lane's 12-16 columns then span hundreds of bits, measured 1.2e-4 ... 1.8e-4); within 5e-4 for
- *              8 x N(0,1) logits on those lattices (measured 3.7e-4).
+ * tests/test_peaky_gpu.py, tests/test_peaky_wide_gpu.py, tests/test_loss_gpu.py; measured values in profiles/r04_accuracy*.json):
+ *   costs      within 1e-4 max(1, |cost|) everywhere (measured <= 6e-6);
+ *   gradients  within 1e-4 absolute on every input: N(0,1), 4 x N(0,1), 8 x N(0,1) logits and trained-like posteriors, lattices
+ *              of up to 8192 columns, every vocabulary size (measured: linear lattice 1e-7 ... 4e-6; log-domain paths 4e-6 at
+ *              4 x N(0,1) and 1.1e-5 at 8 x N(0,1) at B=32 T=600 U=150 V=28, up to 4.4e-5 at 8 x N(0,1) on 1000-column lattices,
+ *              5.5e-5 at T=1500 U=300 V=1024; 5,000 random shapes up to 1000 columns, half of them at 4 x N(0,1): 3.0e-5).
  * Out-of-range per-utterance lengths (T_b < 1, T_b > maxT, L_b < 0, L_b > maxU-1) are device data and cannot be
  * checked at enqueue time: the kernels clamp them into the tensor (no out-of-bounds access) and report that
  * utterance with a NaN cost and NaN gradients.  Labels outside [0, alphabet_size) are clamped into range. */

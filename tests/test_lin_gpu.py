@@ -163,7 +163,7 @@ def test_peaked_logits_are_handed_back(sigma):
     acts, labels, il, ll = _case(2, 60, 150, 28, seed=11, sigma=sigma)
     k = Call(acts, labels, il, ll, poison=True)
     c, g = k.full()
-    worst = _check(c, g, acts, labels, il, ll, gtol=2.5e-4)
+    worst = _check(c, g, acts, labels, il, ll, gtol=1e-4)  # (the hand-back kernel's recurrence runs in float64: measured ~1e-5)
     # handed back -- or the certificate held (short lattices at 8 sigma with blocks of four) and the result is linear-lattice grade
     assert k.flags()[:, :3].any() or worst <= 1e-5
     assert sigma < 16 or k.flags()[:, :3].any()
@@ -189,7 +189,7 @@ def test_split_calls_and_repeated_backward():
     c = k.fwd()
     g1 = k.bwd()
     g2 = k.bwd()
-    _check(c, g1, acts, labels, il, ll, gtol=2.5e-4)
+    _check(c, g1, acts, labels, il, ll, gtol=1e-4)
     np.testing.assert_array_equal(g1, g2)
     f = k.flags()
     assert f[1, 3] == 2 and f[0, 3] == 0 and f[2, 3] == 0
@@ -208,7 +208,7 @@ def test_cost_scale_on_both_routes():
     scale = torch.tensor([0.5, -2.0, 3.0], device=DEV)
     c, g = k.full(scale)
     c_ref, g_ref = orc.rnnt_loss_and_grad(acts, labels, il, ll)
-    assert np.abs(g - g_ref * scale.cpu().numpy()[:, None, None, None]).max() <= 7.5e-4
+    assert np.abs(g - g_ref * scale.cpu().numpy()[:, None, None, None]).max() <= 3e-4  # 1e-4 x the largest |cost_scale|
     np.testing.assert_array_less(np.abs(c - c_ref), 1e-4 * np.maximum(1.0, np.abs(c_ref)))
 
 

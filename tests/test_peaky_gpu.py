@@ -4,18 +4,18 @@ produces, as opposed to the N(0,1) logits of the headline bench.  Through the C 
 
   sigma4 / sigma8   logits = 4 / 8 * N(0,1): incoherent peaks (no dominant alignment), costs of 4,000 / 7,500 nats (round 4: 4 sigma
                     stays on the linear lattice with frame blocks of four diagonals unless a cell fails the certificate; 8 sigma is
-                    handed back to the log-domain kernels)
+                    handed back to the log-domain kernels, whose recurrence runs in float64 there)
   trained           one dominant symbol per cell along a monotone alignment (bonus 10 nats on blank before the cell's label
                     is due, on the label afterwards); half of the utterances emit all labels in the last 40 % of the frames
                     (alignments far from the lattice's straight diagonal), costs of a few nats
   fused x5 / x10    the f32-grade fused joint with glorot W2 scaled by 5 / 10 (logit spread ~4 / ~8)
 
 Bars (north_star "within 1e-4 fp32"): costs |d| <= 1e-4 max(1, |cost|); gradients max|d| <= 1e-4 (P1: absolute, gradients
-live in [-1, 1]; fused: relative to max(1, max|ref|)) -- except the two 8-sigma cases, whose bar is 2.5e-4: there the error is
-set by the float32 REPRESENTATION of the lattice's inputs, not by the recurrences.  Measured with tests/tools/debug_peaky.py
-(the sweep re-run in float64 over the GPU's own f32 edge weights): at 8 sigma the rounding of the log2-probabilities to f32
-(|log2 p| up to ~100, costs of 7,500 nats) alone moves alpha by up to 1.4e-4 nats at cells that carry posterior mass, the
-sweeps add 0.7-1.0e-4 (per-lane re-basing; 2-3e-4 with one offset per diagonal).  include/rnnt.h states this bound.
+live in [-1, 1]; fused: relative to max(1, max|ref|)) -- except the 8-sigma case of the FUSED joint, whose bar is 2.5e-4: its
+sweeps keep the float32 recurrence (rounding every log-add at the magnitude of its residue: ~1e-5 bits per step, a random walk
+over the ~750 steps of a path).  The loss op's hand-back kernel carries the recurrence in float64 since round 4: 4.3e-6 at
+4 sigma, 1.1e-5 at 8 sigma (round 3: 8.5e-5 / 1.6e-4 with a 2.5e-4 bar at 8 sigma -- then attributed to the float32
+representation of the log-probabilities; it was the recurrence).
 The measured maxima are written to gpurun_out/r04_accuracy.json (copied to profiles/ by hand)."""
 import json
 import math
@@ -101,7 +101,7 @@ def test_p1_peaked_logits_at_c2_size(kind):
     _report[f"p1_{kind}"] = {"utterances": picks, "max_rel_dcost": max(dc), "max_abs_dgrad": max(dg),
                              "cost_range_nats": [float(min(r[0] for r in refs)), float(max(r[0] for r in refs))]}
     assert max(dc) <= CTOL, (kind, dc)
-    assert max(dg) <= (2.5e-4 if kind == "sigma8" else GTOL), (kind, dg)
+    assert max(dg) <= GTOL, (kind, dg)
 
 
 def _fused_oracle(args):

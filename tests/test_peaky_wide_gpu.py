@@ -3,16 +3,14 @@ sweep lane; the linear-domain lattice where its certificate holds, else the log-
 the op at BASELINE.json configs[4]'s shape at full size.
 
 Wide lattices: (B, T, U, V) = (2, 36, 643, 8) [12 columns per lane], (1, 24, 1000, 4) [16], (2, 300, 500, 28) [8],
-(1, 700, 600, 8) [12, more frames than columns], logits
+(1, 700, 600, 8) [12, more frames than columns], (1, 30, 1100, 4) and (1, 1200, 1100, 4) [more than 1024 columns: the wide sweep],
+plus two vocabularies the patch kernels do not take ((2, 120, 60, 64), (1, 60, 300, 1024): wave-per-cell kernels), logits
 N(0,1), 4 x N(0,1), 8 x N(0,1) and trained-like (one dominant symbol per cell along a monotone alignment), every utterance
-against the float64 oracle.  The bars are the FIXED ones of include/rnnt.h (round 3's fuzz scaled its bar by sigma and hid a
-1.26e-4 at (2, 36, 643, 8), 4 sigma):
-    costs |d| <= 1e-4 max(1, |cost|) everywhere;
-    gradients max|d| <= 1e-4 for trained-like posteriors and for N(0,1) logits on lattices with at least as many frames as
-    label columns; <= 2.5e-4 for 4 x N(0,1) and for N(0,1) on lattices with FEWER frames than label columns (T < U: every
-    path emits several labels per frame, a lane's 12-16 columns span hundreds of bits and the log-domain sweeps round there);
-    <= 5e-4 for 8 x N(0,1) on these lattices
-    (up to 256 columns the figures are 1e-4 / 1e-4 / 2.5e-4: tests/test_peaky_gpu.py, tests/test_lin_gpu.py).
+against the float64 oracle.  FIXED bars, the ones of include/rnnt.h: costs |d| <= 1e-4 max(1, |cost|), gradients max|d| <= 1e-4
+on EVERY case (round 3's fuzz scaled its bar by sigma and hid a 1.26e-4 at (2, 36, 643, 8); round 4 first narrowed the header to
+2.5e-4 / 5e-4 on these lattices, then found the cause -- the float32 recurrence of the log-domain sweeps, a random walk of
+rounding errors over ~1,000-step paths -- and moved that recurrence to float64 wherever the loss op falls back to the log domain:
+measured 2e-7 ... 4.4e-5 here).
 configs[4]'s shape (T = 1500, U = 300, V = 1024, the wave-per-cell kernels): one full-length utterance and three ragged
 ones against a float64 evaluation streamed over row chunks (450,000 cells x 1,024 symbols do not fit a dense float64 oracle).
 The measured maxima go to gpurun_out/r04_accuracy_wide.json (copied to profiles/ by hand)."""
@@ -30,7 +28,7 @@ from oracle import rnnt_oracle as orc
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _report = {}
-GBAR = {"sigma1": 1e-4, "trained": 1e-4, "sigma4": 2.5e-4, "sigma8": 5e-4}
+GBAR = 1e-4
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -69,7 +67,8 @@ def _oracle(args):
 
 
 @pytest.mark.parametrize("kind", ["sigma1", "sigma4", "sigma8", "trained"])
-@pytest.mark.parametrize("B,T,U,V", [(2, 36, 643, 8), (1, 24, 1000, 4), (2, 300, 500, 28), (1, 700, 600, 8)])
+@pytest.mark.parametrize("B,T,U,V", [(2, 36, 643, 8), (1, 24, 1000, 4), (2, 300, 500, 28), (1, 700, 600, 8), (1, 30, 1100, 4), (1, 1200, 1100, 4),
+                                     (2, 120, 60, 64), (1, 60, 300, 1024)])
 def test_wide_lattices_fixed_bars(B, T, U, V, kind):
     x, labels, il, ll = make_logits(kind, B, T, U, V, seed=T + U + len(kind))
     dev = torch.device("cuda:0")
@@ -83,7 +82,7 @@ def test_wide_lattices_fixed_bars(B, T, U, V, kind):
         refs = list(ex.map(_oracle, [(x[b], labels[b]) for b in range(B)]))
     dc = max(abs(c[b] - refs[b][0]) / max(1.0, abs(refs[b][0])) for b in range(B))
     dg = max(float(np.abs(g[b] - refs[b][1]).max()) for b in range(B))
-    bar = 2.5e-4 if (kind == "sigma1" and T < U) else (1e-4 if (kind == "sigma4" and T >= U) else (2.5e-4 if (kind == "sigma8" and T >= U) else GBAR[kind]))
+    bar = GBAR
     _report[f"p1_{kind}_B{B}_T{T}_U{U}_V{V}"] = {"max_rel_dcost": dc, "max_abs_dgrad": dg, "cost_nats": [float(r[0]) for r in refs],
                                                  "bar_dgrad": bar}
     assert dc <= 1e-4, (kind, dc)

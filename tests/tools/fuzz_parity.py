@@ -53,10 +53,10 @@ for case in range(n_cases):
             if dg > worst["loss_grad"]:
                 worst_case["loss_grad"] = (str(kind), B, T, U, V, blank, sc)
             worst["loss_cost"], worst["loss_grad"] = max(worst["loss_cost"], dc), max(worst["loss_grad"], dg)
-            # FIXED bars, the ones of include/rnnt.h (round 3 scaled the bar by sigma and hid a 1.26e-4 at 4 sigma on a 643-column
-            # lattice): 1e-4 up to 4 sigma on lattices of up to 256 columns and on wider ones with T >= U; 2.5e-4 on wider
-            # lattices with fewer frames than columns and at 4 sigma there; 8 sigma is not drawn here (tests/test_peaky*_gpu.py)
-            bar = 1e-4 if (U <= 256 or (T >= U and sc <= 1.0)) else 2.5e-4
+            # FIXED bar, the one of include/rnnt.h: 1e-4 on every input (round 3 scaled the bar by sigma and hid a 1.26e-4 at 4 sigma
+            # on a 643-column lattice; 5,500 draws of 'loss_wide4' then showed up to 4.7e-4 on 760 ... 1000-column lattices: the
+            # float32 recurrence of the log-domain sweeps, in float64 since)
+            bar = 1e-4
             if not (dc <= 1e-4 and dg <= bar):
                 fails.append((str(kind), B, T, U, V, blank, sc, dc, dg))
         else:
