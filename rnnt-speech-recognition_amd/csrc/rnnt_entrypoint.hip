@@ -7,6 +7,7 @@
 #include "../../include/rnnt.h"
 #include "rnnt_common.h"
 #include "rnnt_lin.h"
+#include <cstdlib>
 
 using namespace rnnt;
 
@@ -77,7 +78,10 @@ static bool fill_params(LossParams &p, const float *acts, float *grads, const in
     p.nPstat = w.nPstat;
     p.B = B, p.T = o.maxT, p.U = o.maxU, p.V = V, p.blank = o.blank_label;
     p.b0 = 0, p.nb = B;
-    p.precise = 0;
+    {  // dev switch: RNNT_PRECISE_ALL=1 gives the fused joints the float64 recurrence too (timing / accuracy experiments)
+        static const int all = [] { const char *e = getenv("RNNT_PRECISE_ALL"); return e ? atoi(e) : 0; }();
+        p.precise = all;
+    }
     p.tile = make_tile(o.maxT, o.maxU, V);
     p.N = w.N, p.Nr = w.Nr, p.Up = w.Up, p.NC = w.NC, p.NG = w.NG;
     p.cells = (uint32_t)cells;
