@@ -10,7 +10,7 @@
 // Fixed frames can lose mass that falls more than 126 bits below its lane's frame.  Whether that mattered is decided per cell
 // by the gradient pass (lin_certificate below: what a flush can have cost, times the other side's mass, over the likelihood)
 // and per utterance by the sweeps (non-finite / zero likelihood, alpha-side vs beta-side likelihood).  An utterance that fails
-// is redone in the log domain by lin_redo_kernel (rnnt_lin_kernels.hip) -- the round-3 kernels, exact for any range -- so the
+// is redone in the log domain by lin_redo_kernel (rnnt_lin_kernels.hip) -- log2 values, recurrence in float64 (rnnt_sweep.h alpha_sweep_pr), any range -- so the
 // results never depend on the shortcut.  tests/tools/emulate_linear.py restates all of it in NumPy.
 #pragma once
 #include "rnnt_sweep.h"
