@@ -48,7 +48,7 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv f) {
 // Patch geometry of the small-vocabulary tile kernels (TT*UU <= 256 lattice cells per workgroup).
 struct TileGeom {
     int TT, UU, tiles_t, tiles_u, cpr;  // cpr = 16-byte chunks per patch row = UU*V/4
-    FastDiv div_tu, div_tt, divUU, div_cpr;
+    FastDiv div_tu, div_tt, divUU, div_cpr, divTT;
 };
 
 struct LossParams {
@@ -154,6 +154,7 @@ inline TileGeom make_tile(int T, int U, int V) {
     g.div_tu = make_fastdiv((uint32_t)g.tiles_u);
     g.div_tt = make_fastdiv((uint32_t)g.tiles_t);
     g.divUU = make_fastdiv((uint32_t)g.UU);
+    g.divTT = make_fastdiv((uint32_t)(g.TT > 0 ? g.TT : 1));
     g.div_cpr = make_fastdiv((uint32_t)(g.cpr > 0 ? g.cpr : 1));
     return g;
 }

@@ -207,6 +207,29 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) stat += __shfl_xor(stat, off), cnt += __shfl_xor(cnt, off);
         if (lane == 0) *pslot = make_float2(stat, cnt);
+        // The edge probabilities, from the cells' LDS slots to the skewed array DIAGONAL by diagonal: thread j takes row j % TT of
+        // patch diagonal j / TT, so TT consecutive lanes store TT consecutive (descending) positions of one row of W -- 64-byte
+        // runs at TT = 8 -- where a lane per cell scattered every wave-store over 64 rows (2.9 M 8-byte requests per step at
+        // B32 T600 U150: ~10 us of the lsm pass).
+#if RNNT_LSM_DIAG
+        __syncthreads();
+        float2 *const Wp = (float2 *)p.W + ((size_t)b * p.Nr + t0 + u0) * p.Up + u0;  // cell (r, c) of the patch: Wp[(r + c) Up + c]
+        const uint32_t total = (uint32_t)(tg.TT + tg.UU - 1) * (uint32_t)tg.TT;
+        for (uint32_t j = tid; j < total; j += 256) {
+            const uint32_t d = fdiv(j, tg.divTT);
+            const int rr = (int)(j - d * (uint32_t)tg.TT), cc = (int)d - rr;
+            if (rr < rows_valid && cc >= 0 && cc < cols_valid) {
+                float2 v;
+                if (AL) {
+                    v = *(const float2 *)(lds + (rr * tg.UU + cc) * V);
+                } else {
+                    const float *src = lds + rr * row_lds + (int)((patch0 + rr * row_f) & 3) + cc * V;
+                    v = make_float2(src[0], src[1]);
+                }
+                Wp[(size_t)(rr + cc) * p.Up + cc] = v;
+            }
+        }
+#endif
     }
     if (GRAD && !AL) {
         __syncthreads();

@@ -40,6 +40,9 @@ constexpr float kTinyEdge = 7.8886091e-31f;  // 2^-100: an edge the lattice owns
 #define RNNT_LIN_ZERO 0  // (needs RNNT_LIN_LOADERS = 1)
 #endif
 constexpr bool kLinLoaderZero = RNNT_LIN_ZERO != 0;
+#ifndef RNNT_LSM_DIAG
+#define RNNT_LSM_DIAG 1  // lsm pass: edge probabilities leave through LDS, diagonal by diagonal (0: one scattered store per cell)
+#endif
 
 // per-utterance words in LossParams::flags
 enum { kFlagA = 0, kFlagB = 1, kFlagG = 2, kFlagState = 3 };  // state: 0 linear lattice, 2 log-domain lattice ready (after a redo)
@@ -56,7 +59,7 @@ __device__ __forceinline__ bool lin_skip(const LossParams &p, const int b) {
     return (fl[kFlagA] | fl[kFlagB]) != 0 || fl[kFlagState] == 2;
 }
 
-// ---- lsm: one valid cell, its V logits in x[] (registers) and at xs (LDS) ----
+// ---- lsm: one valid cell, its V logits in x[] (registers) and at xs (its slot of the patch image in LDS) ----
 // Returns -log2 max(p_blank, p_label) of the cell (the decay statistic; 200 where an edge had to be refused).
 template <int VP>
 __device__ __forceinline__ float lin_cell_lsm(const LossParams &p, const Cell &cl, const float (&x)[VP], const float *xs) {
@@ -80,8 +83,15 @@ __device__ __forceinline__ float lin_cell_lsm(const LossParams &p, const Cell &c
         pl = ex2(fmaf(xs[lab], kLog2e, nml)) * inv;
         if (!(pl >= kTinyEdge)) pl = NAN;
     }
-    const size_t wi = ((size_t)cl.b * p.Nr + (cl.t + cl.u)) * p.Up + cl.u;
-    ((float2 *)p.W)[wi] = make_float2(pb, pl);
+    // The two edge probabilities go into the first two floats of the cell's own LDS slot (nobody else reads it); the patch kernel
+    // writes them to the skewed edge array diagonal by diagonal afterwards (rnnt_kernels.hip: consecutive lanes then store
+    // consecutive positions of one diagonal's row -- written from here, a lane per cell, every store of a wave went to 64 rows).
+#if RNNT_LSM_DIAG
+    float *const xo = const_cast<float *>(xs);
+    xo[0] = pb, xo[1] = pl;
+#else
+    ((float2 *)p.W)[((size_t)cl.b * p.Nr + (cl.t + cl.u)) * p.Up + cl.u] = make_float2(pb, pl);
+#endif
     const float best = fmaxf(pb, pl);  // (v_max ignores a NaN operand)
     return (pb != pb || pl != pl) ? 200.f : -lg2(fmaxf(best, 1.0e-37f));
 }
