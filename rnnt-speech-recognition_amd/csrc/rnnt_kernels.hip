@@ -83,29 +83,52 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int V = p.V;
     const TileGeom &tg = p.tile;
-    // The lsm launch carries extra workgroups behind its patches that write "log zero" into the W positions no lattice cell
-    // writes (the sweeps read whole rows of the skewed array): kFillRows diagonals of one utterance each.  This replaces a
-    // 37 MB memset in front of the launch (7.5 us at C2) by ~14 MB of stores that overlap with the patches.
+    // The lsm launch carries extra workgroups that write "log zero" into the W positions no lattice cell writes (the sweeps
+    // read whole rows of the skewed array): kFillRows diagonals of one utterance each.  This replaces a 37 MB memset in front of
+    // the launch (7.5 us at C2) by ~14 MB of stores.  They are INTERLEAVED with the patch workgroups -- every P-th group of eight
+    // consecutive block indices (one per XCD) is a fill group -- so that their stores run under the patches' reads; appended behind
+    // the patches (rounds 2-3) they formed a write-only tail of the launch (~4.7 us of 68 at B32 T600 U150).
     const uint32_t n_patch_wg = (uint32_t)p.nb * (uint32_t)tg.tiles_t * (uint32_t)tg.tiles_u;
-    if (!GRAD && blockIdx.x >= n_patch_wg) {
-        const uint32_t f = blockIdx.x - n_patch_wg, per = (uint32_t)p.Nr / kFillRows;
-        const int fb = p.b0 + (int)(f / per), chunk = (int)(f % per);
-        const int Tf = length_T(p, fb), Uf = length_U(p, fb);
-        const int Nf = Tf + Uf - 1;
-        float2 *Wb = (float2 *)p.W + (size_t)fb * p.Nr * p.Up;
-        const float2 z = LIN ? make_float2(0.f, 0.f) : make_float2(kNeg, kNeg);  // linear lattice: probability zero
-        for (int idx = tid; idx < kFillRows * p.Up; idx += 256) {
-            const int rr = idx / p.Up, u = idx - rr * p.Up;
-            const int n = chunk * kFillRows + rr;
-            // lattice cells of diagonal n: u in [lo, hi]; diagonals past the lattice are never read by the sweeps
-            if (n < Nf && (u < max(0, n - Tf + 1) || u > min(n, Uf - 1))) Wb[(size_t)n * p.Up + u] = z;
+    uint32_t vblock = blockIdx.x;  // index among the patch workgroups
+    if (!GRAD && !(LIN && kLinLoaderZero)) {
+        const uint32_t per = (uint32_t)p.Nr / kFillRows, n_fill = (uint32_t)p.nb * per;
+        const uint32_t pgs = (n_patch_wg + 7u) >> 3, fgs = (n_fill + 7u) >> 3, P = (pgs + fgs) / fgs;
+        const uint32_t g = blockIdx.x >> 3, l8 = blockIdx.x & 7u;
+#ifdef RNNT_FILL_TAIL  // dev switch: the fill groups behind the patch groups, as in rounds 2-3 (A/B timing)
+        const uint32_t k = g >= pgs ? g - pgs : 0u;
+        const bool is_fill = g >= pgs;
+        (void)P;
+#else
+        const uint32_t k = g / P;
+        const bool is_fill = g - k * P == P - 1u && k < fgs;  // fill groups sit at positions P - 1, 2 P - 1, ..., fgs P - 1
+#endif
+        if (is_fill) {
+            const uint32_t f = k * 8u + l8;
+            if (f >= n_fill) return;
+            const int fb = p.b0 + (int)(f / per), chunk = (int)(f % per);
+            const int Tf = length_T(p, fb), Uf = length_U(p, fb);
+            const int Nf = Tf + Uf - 1;
+            float2 *Wb = (float2 *)p.W + (size_t)fb * p.Nr * p.Up;
+            const float2 z = LIN ? make_float2(0.f, 0.f) : make_float2(kNeg, kNeg);  // linear lattice: probability zero
+            for (int idx = tid; idx < kFillRows * p.Up; idx += 256) {
+                const int rr = idx / p.Up, u = idx - rr * p.Up;
+                const int n = chunk * kFillRows + rr;
+                // lattice cells of diagonal n: u in [lo, hi]; diagonals past the lattice are never read by the sweeps
+                if (n < Nf && (u < max(0, n - Tf + 1) || u > min(n, Uf - 1))) Wb[(size_t)n * p.Up + u] = z;
+            }
+            return;
         }
-        return;
+#ifdef RNNT_FILL_TAIL
+        vblock = blockIdx.x;
+#else
+        vblock = (g - min(k, fgs)) * 8u + l8;  // fill groups in front of group g: min(g / P, fgs)
+#endif
+        if (vblock >= n_patch_wg) return;
     }
     // XCD-aware remap: hand each XCD (blockIdx % 8) a contiguous range of patches (bijective form)
     uint32_t bid;
     {
-        const uint32_t nwg = n_patch_wg, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+        const uint32_t nwg = n_patch_wg, xcd = vblock & 7u, idx = vblock >> 3;
         const uint32_t q = nwg >> 3, r = nwg & 7u;
         bid = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
         // The gradient pass walks each XCD's range backwards: the logits the lsm pass read LAST are the ones most
@@ -312,7 +335,10 @@ static hipError_t launch_cell(const LossParams &p, hipStream_t s) {
     if (tile_path_ok(p, GRAD)) {
         // (the lsm launch fills the log-zero part of W itself: see cell_tile_kernel)
         // (rnnt_lin.h kLinLoaderZero: the linear lattice's loader waves can write probability zero over the unowned positions in LDS instead)
-        const unsigned blocks = (unsigned)p.nb * p.tile.tiles_t * p.tile.tiles_u + ((GRAD || (LIN && kLinLoaderZero)) ? 0u : (unsigned)p.nb * (unsigned)(p.Nr / kFillRows));
+        const unsigned n_patch = (unsigned)p.nb * p.tile.tiles_t * p.tile.tiles_u;
+        unsigned blocks = n_patch;
+        if (!(GRAD || (LIN && kLinLoaderZero)))  // + the fill workgroups, in groups of eight among the patch groups (cell_tile_kernel)
+            blocks = (((n_patch + 7u) >> 3) + (((unsigned)p.nb * (unsigned)(p.Nr / kFillRows) + 7u) >> 3)) * 8u;
         // the patch image: TT x UU cells (<= 256) of V floats, to the byte.  Sized by the patch, not by the 256 lanes, and without
         // padding: at V = 28 that is 26,880 B -- six workgroups per CU instead of five (gradient pass 115 -> 110.5 us); at V = 32
         // 30,720 B instead of 32,832 B -- five instead of four (146 -> 140 us)
