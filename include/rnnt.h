@@ -89,7 +89,7 @@ RNNT_API rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool
  * frame is flushed; whether that mattered is decided per lattice cell by the gradient pass (what a flush can have cost, times
  * the other side's mass, over the likelihood, must stay below 2^-40) and per utterance by the sweeps (likelihood zero /
  * non-finite, alpha-side vs beta-side likelihood, an edge probability below 2^-100).  An utterance that fails is redone by the
- * LOG-domain kernels -- one workgroup per utterance, ~3 ms at T=600 U=150 (a whole batch of such inputs: 2.7 - 3.3 ms per step against
+ * LOG-domain kernels -- one workgroup per utterance, ~2 ms at T=600 U=150 (a whole batch of such inputs: 1.9 - 2.3 ms per step against
  * 0.23 ms), exact for any range -- so results never depend on the shortcut.
  * N(0,1) logits and trained-like posteriors (one dominant symbol per cell along any monotone alignment) stay on the linear
  * lattice, and so do unstructured logits up to about 4 x N(0,1) (the sweeps shorten their frame blocks from 8 to 4 diagonals where

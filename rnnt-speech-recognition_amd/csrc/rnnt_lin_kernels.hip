@@ -466,12 +466,17 @@ __global__ __launch_bounds__(64 * (1 + kLinLoaders)) void lin_sweep_kernel(const
 // utterance is fine reads two 16-byte words and returns).  An utterance is redone when a sweep flagged it (kFlagA / kFlagB),
 // when the two likelihoods disagree, when the gradient pass's certificate failed for one of its cells (kFlagG), or when
 // `force` is set (a gradient buffer the patch kernels cannot write): the workgroup rebuilds the utterance's edge weights in the
-// log2 domain from the logits (one lattice cell per thread, straight from global memory), runs the round-3 log-domain sweeps
-// (exact for any range; two of its eight waves) and, if gradients are wanted, writes all of the utterance's gradients (again a
-// cell per thread).  Slow -- about a millisecond for a 600 x 150 lattice -- and rare.  Afterwards the utterance's state word
+// log2 domain from the logits (one lattice cell per thread, staged through LDS), runs the log-domain sweeps with the float64
+// recurrence (any range; two of its sixteen waves) and, if gradients are wanted, writes all of the utterance's gradients (again a
+// cell per thread).  Slow -- the better part of a millisecond for a 600 x 150 lattice -- and rare.  Afterwards the utterance's state word
 // says that its lattice is in the log format, so that a later backward-only call goes straight to the gradient stage here.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRedoThreads = 512;
+constexpr int kRedoThreads = 1024;
+#ifdef RNNT_REDO_TRACE  // dev builds: s_memtime stamps of the hand-back's phases (utterance 0), printed by the kernel
+#define RT(i) do { if (tid == 0 && b == p.b0) rt[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RT(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ void redo_phase_sync() {
     __threadfence();  // this workgroup's global stores are visible device-wide ...
@@ -479,26 +484,53 @@ __device__ __forceinline__ void redo_phase_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ... and nothing stale is served from this CU's vector L1
 }
 
-// The cells [c0, c1) of one utterance, one per thread, logits and gradients in global memory.
+// The cells [c0, c1) of one utterance, one per thread.  With 16-byte-aligned rows the logits are staged through LDS in chunks of
+// up to kRedoThreads cells (the workgroup's chunk ring is idle during the cell phases) and the gradients leave the same way:
+// every global access is a coalesced 16-byte piece.  (A lane per cell straight from global memory made every load / store
+// instruction of a wave touch 56 cache lines: 0.6 ms for the lsm phase and 1.8 ms for the gradients of a 600 x 150 lattice on
+// the one CU the workgroup has.)  Otherwise (V % 4 != 0 or unaligned tensors): straight from / to global memory.
 template <bool GRAD>
-__device__ __forceinline__ void redo_cells(const LossParams &p, const uint32_t c0, const uint32_t c1, const int tid) {
+__device__ __forceinline__ void redo_cells(const LossParams &p, const uint32_t c0, const uint32_t c1, const int tid, float *lds,
+                                           const int lds_floats) {
     const bool v4 = (p.V % 4) == 0 && (((uintptr_t)p.acts | (uintptr_t)p.grads) & 15) == 0;
+    const int V = p.V;
+    if (v4) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const uint32_t CH = (uint32_t)min(kRedoThreads, lds_floats / V);  // cells per chunk
+        for (uint32_t cs = c0; cs < c1; cs += CH) {
+            const uint32_t n = min(CH, c1 - cs), nq = n * (uint32_t)V / 4u;
+            const v4f *src = (const v4f *)(p.acts + (size_t)cs * V);
+            for (uint32_t i = tid; i < nq; i += kRedoThreads) ((v4f *)lds)[i] = src[i];
+            __syncthreads();
+            if ((uint32_t)tid < n) {
+                const uint32_t c = cs + (uint32_t)tid;
+                const Cell cl = decode(p, c);
+                float *xs = lds + (size_t)tid * V;
+                if (GRAD || cl.valid) {
+                    if (V <= 32)
+                        cell_body<32, true, GRAD, false, true>(p, cl, c, xs, xs);
+                    else
+                        cell_body<64, true, GRAD, false, true>(p, cl, c, xs, xs);
+                }
+            }
+            __syncthreads();
+            if (GRAD) {
+                v4f *dst = (v4f *)(p.grads + (size_t)cs * V);
+                for (uint32_t i = tid; i < nq; i += kRedoThreads) __builtin_nontemporal_store(((const v4f *)lds)[i], dst + i);
+                __syncthreads();
+            }
+        }
+        return;
+    }
     for (uint32_t c = c0 + (uint32_t)tid; c < c1; c += kRedoThreads) {
         const Cell cl = decode(p, c);
         const float *xs = p.acts + (size_t)c * p.V;
         float *out = GRAD ? p.grads + (size_t)c * p.V : nullptr;
         if (!GRAD && !cl.valid) continue;
-        if (p.V <= 32) {
-            if (v4)
-                cell_body<32, true, GRAD, false, true>(p, cl, c, xs, out);
-            else
-                cell_body<32, false, GRAD, false, true>(p, cl, c, xs, out);
-        } else {
-            if (v4)
-                cell_body<64, true, GRAD, false, true>(p, cl, c, xs, out);
-            else
-                cell_body<64, false, GRAD, false, true>(p, cl, c, xs, out);
-        }
+        if (p.V <= 32)
+            cell_body<32, false, GRAD, false, true>(p, cl, c, xs, out);
+        else
+            cell_body<64, false, GRAD, false, true>(p, cl, c, xs, out);
     }
 }
 
@@ -525,15 +557,21 @@ __global__ __launch_bounds__(kRedoThreads) void lin_redo_kernel(const LossParams
     } else if (!p.grads) {
         return;
     }
+#ifdef RNNT_REDO_TRACE
+    long long rt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     const uint32_t c0 = (uint32_t)b * (uint32_t)p.T * (uint32_t)p.U, c1 = c0 + (uint32_t)p.T * (uint32_t)p.U;
+    RT(0);
     if (redo) {
         // ---- log2-domain edge weights of this utterance: log zero everywhere, then the cells ----
         uint32_t *Wb = (uint32_t *)(p.W + (size_t)b * p.Nr * 2 * p.Up);
         const uint32_t lz = (uint32_t)kFillByte * 0x01010101u;
         for (size_t i = tid; i < (size_t)p.Nr * 2 * p.Up; i += kRedoThreads) Wb[i] = lz;
         redo_phase_sync();
-        redo_cells<false>(p, c0, c1, tid);
+        RT(1);
+        redo_cells<false>(p, c0, c1, tid, lds, NB * chunkf);
         redo_phase_sync();
+        RT(2);
         // ---- the log-domain sweeps, one after the other, by waves 0 (sweeping) and 1 (loading) ----
         int *ctr = (int *)(lds + NB * chunkf);
         LdLink lk;
@@ -546,6 +584,7 @@ __global__ __launch_bounds__(kRedoThreads) void lin_redo_kernel(const LossParams
         else if (wave == 0)
             alpha_sweep_pr<K, G, NB>(p, lds, lk, b, lane);  // the float64 recurrence: whatever failed the certificate is a hard input
         __syncthreads();
+        RT(3);
         if (tid < 2) ctr[tid] = 0;
         __syncthreads();
         if (wave == 1)
@@ -553,9 +592,14 @@ __global__ __launch_bounds__(kRedoThreads) void lin_redo_kernel(const LossParams
         else if (wave == 0)
             beta_sweep_pr<K, G, NB>(p, lds, lk, b, lane);
         redo_phase_sync();
+        RT(4);
         if (tid == 0) st_i32_wt(fl + kFlagState, 2);
     }
-    if (p.grads) redo_cells<true>(p, c0, c1, tid);
+    if (p.grads) redo_cells<true>(p, c0, c1, tid, lds, NB * chunkf);
+    RT(5);
+#ifdef RNNT_REDO_TRACE
+    if (tid == 0 && b == p.b0) printf("redo trace (clocks): fill %lld lsm %lld alpha %lld beta %lld grad %lld\n", rt[1] - rt[0], rt[2] - rt[1], rt[3] - rt[2], rt[4] - rt[3], rt[5] - rt[4]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
