@@ -4,6 +4,8 @@ re-basing every kRebase diagonals, offsets on the side, gradient from f32 residu
 enough to reproduce the error LEVELS the GPU shows (not bit-exact: hardware exp2/log2 differ in the last ulp).
 
   python tests/tools/emulate_sweep.py            # table: max|dgrad| per input family and reference rule
+Rules: "ridge" / "follow" (one offset per block of diagonals), "laneK" (one integer offset per K columns, float32 recurrence),
+"laneKf64" (the float64 recurrence the loss op uses wherever it falls back to the log domain since round 4).
 """
 import os
 import re
@@ -115,6 +117,25 @@ def sweep(wb, wl, rule, kreb=KREB):
         cur = np.concatenate([nxt, [NEG]]).astype(F)
     # offsets are per BLOCK of kreb diagonals in the kernels: offA[n] as recorded here changes only at block starts
     return A, Bt, offA, offB, ll2
+
+
+def sweep_lane_f64(wb, wl, K=16, kreb=KREB, store_bits=17):
+    """The float64 recurrence of csrc/rnnt_sweep.h alpha_sweep_pr / beta_sweep_pr: the SAME float32 edge weights, alpha / beta
+    carried as true log2 values in float64 (here: sweep_lane with float64 registers), stored as float32 residues against the
+    lane's integer offset -- emulated by rounding the stored values to 2^-store_bits (the ulp of a residue of ~64).  The
+    log2(1 + 2^-|d|) term is float64 here and float32 on the GPU (absolute error ~1e-7 per step, not accumulated at the
+    residue's magnitude)."""
+    global F, NEG
+    F_old, NEG_old = F, NEG
+    F, NEG = np.float64, np.float64(-1.0e30)
+    try:
+        A, Bt, ll2 = sweep_lane(wb.astype(np.float64), wl.astype(np.float64), K, kreb)
+    finally:
+        F, NEG = F_old, NEG_old
+    q = 2.0 ** -store_bits
+    A = np.where(np.isfinite(A), np.round(A / q) * q, A)
+    Bt = np.where(np.isfinite(Bt), np.round(Bt / q) * q, Bt)
+    return A, Bt, ll2
 
 
 def sweep_lane(wb, wl, K=3, kreb=KREB):
@@ -295,7 +316,10 @@ def run(kind, T, U, V, seed, rules=("ridge+s64", "follow+s64", "lane3", "lane1")
     out = {}
     for rule in rules:
         if rule.startswith("lane"):
-            A, Bt, ll2 = sweep_lane(wb, wl, int(rule[4:] or 3), kreb)
+            if rule.endswith("f64"):  # e.g. "lane16f64": the float64 recurrence, 16 columns per lane
+                A, Bt, ll2 = sweep_lane_f64(wb, wl, int(rule[4:-3] or 16), kreb)
+            else:
+                A, Bt, ll2 = sweep_lane(wb, wl, int(rule[4:] or 3), kreb)
             g = grad_from_true(x, labels, A, Bt, ll2, lse)
             cost = -ll2 * np.log(2.0)
             out[rule] = (abs(cost - c_ref) / max(1.0, abs(c_ref)), float(np.abs(g - g_ref).max()))
