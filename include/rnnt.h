@@ -100,8 +100,8 @@ RNNT_API rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool
  * of a log-add, in (0, 1], on the float32 units -- and only the stored lattice is float32 (residues against an integer offset per
  * block of 8 diagonals and sweep lane / group of 64 columns): a float32 recurrence rounds every log-add at the magnitude of its
  * residue, a random walk that reached 1e-4 ... 5e-4 of gradient error over the ~1,000-step paths of peaked or wide lattices
- * (rounds 1-3; tests/tools/emulate_sweep.py).  The fused joints keep the float32 recurrence up to 6 columns per lane (maxU <= 384)
- * and use the float64 one beyond.
+ * (rounds 1-3; tests/tools/emulate_sweep.py).  The f32-grade fused joint (joint_dtype 0) uses the float64 recurrence as well; the f16
+ * joint (joint_dtype 1: binary16 roundings set its error) keeps the float32 one up to 6 columns per lane (maxU <= 384).
  * Bars, against a float64 evaluation of the same logits, all tested with FIXED bars (tests/test_lin_gpu.py,
  * tests/test_peaky_gpu.py, tests/test_peaky_wide_gpu.py, tests/test_loss_gpu.py; measured values in profiles/r04_accuracy*.json):
  *   costs      within 1e-4 max(1, |cost|) everywhere (measured <= 6e-6);

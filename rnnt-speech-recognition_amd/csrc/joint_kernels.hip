@@ -2141,7 +2141,12 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
         }
         hipLaunchKernelGGL(joint_phase1_kernel, dim3(g1 < kFallbackGrid ? g1 : kFallbackGrid), dim3(kP1Waves * 64), shm1, s, jp, g1);
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        if ((e = launch_sweeps(jp.lp, s)) != hipSuccess) return e;
+        // f32-GRADE joint: the sweeps' recurrence in float64 too (rnnt_sweep.h alpha_sweep_pr) -- with float32 sweeps they, not the
+        // split-precision products, set this path's error under peaked logits (W2 x 10: 1.2e-4 relative -> 1.4e-6; W2 x 5: 2.9e-5 ->
+        // 1.0e-6) for +0.08 ms of a 2.1 ms step at B32 T600 U150.  (The f16 joint keeps the float32 sweeps: binary16 sets its error.)
+        LossParams lpp = jp.lp;
+        lpp.precise = 1;
+        if ((e = launch_sweeps(lpp, s)) != hipSuccess) return e;
     }
     if (!(phases & 2) || !d_enc_proj) return hipSuccess;  // score only
 

@@ -563,9 +563,29 @@ __device__ __forceinline__ double dpp64_from_upper_lane(const double x, const do
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 __device__ __forceinline__ double lse2_pr(const double u, const double l) {
-    const double M = fmax(u, l);
-    const float d = (float)(fmin(u, l) - M);  // <= 0 (0 for two log zeros: the result stays a log zero)
-    return M + (double)lg2(1.0f + ex2(d));
+    const float d = (float)(u - l);  // (0 for two log zeros: the result stays a log zero)
+    return fmax(u, l) + (double)lg2(1.0f + ex2(-fabsf(d)));
+}
+// K independent log-adds, stage by stage (a lone wave stalls on every instruction that consumes the result of the one just
+// before it: every consumer is K instructions behind its producer, as in lse2_staged)
+template <int K>
+__device__ __forceinline__ void lse2_pr_staged(double (&out)[K], const double (&u)[K], const double (&l)[K]) {
+    float d[K];
+    double m[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) d[j] = (float)(u[j] - l[j]);
+    SWEEP_FENCE();
+#pragma unroll
+    for (int j = 0; j < K; ++j) d[j] = ex2(-fabsf(d[j]));
+    SWEEP_FENCE();
+#pragma unroll
+    for (int j = 0; j < K; ++j) m[j] = fmax(u[j], l[j]);
+    SWEEP_FENCE();
+#pragma unroll
+    for (int j = 0; j < K; ++j) d[j] = lg2(1.0f + d[j]);
+    SWEEP_FENCE();
+#pragma unroll
+    for (int j = 0; j < K; ++j) out[j] = m[j] + (double)d[j];
 }
 // The lane's integer offset of a block = its largest value, rounded; a lane without mass copies the lane the mass will come
 // from (as rebase_lane does).  Values are NOT re-based in registers.
@@ -589,7 +609,7 @@ template <int K>
 __device__ __forceinline__ void store_diag_pr(float *row, const int lane, const double (&v)[K], const float off) {
     float *dst = row + lane * K;
 #pragma unroll
-    for (int j = 0; j < K; ++j) st_f32_wt(dst + j, v[j] > (double)kNegTest ? (float)(v[j] - (double)off) : kNeg);
+    for (int j = 0; j < K; ++j) st_f32_wt(dst + j, (float)(v[j] - (double)off));  // (a log zero, <= -1e30, stays one: readers test against kNegTest)
 }
 
 template <int K, int G, int NB>
@@ -619,18 +639,21 @@ __device__ void alpha_sweep_pr(const LossParams &p, float *bufs, const LdLink lk
         }
         const float *cur = bufs + (ck % NB) * chunkf + 2 * u0;
         const int r0 = ck * G;
-#pragma unroll 1
+#pragma unroll 4
         for (int i = 0; i < G; ++i) {
             const int n = r0 + i + 1;
             if (n > last_row) break;
             f32x2 w[K];
             load_w<K>(w, cur + i * 2 * Up);
-            double emit[K];
+            double emit[K], stay[K], left[K];
 #pragma unroll
-            for (int j = 0; j < K; ++j) emit[j] = a[j] + (double)w[j][1];  // (t, u) -> (t, u + 1)
+            for (int j = K - 1; j >= 0; --j) emit[j] = a[j] + (double)w[j][1];  // (t, u) -> (t, u + 1); last column first: the DPP moves wait for it
+            SWEEP_FENCE();
             const double from_left = dpp64_from_lower_lane(emit[K - 1], (double)kNeg);
 #pragma unroll
-            for (int j = 0; j < K; ++j) a[j] = lse2_pr(a[j] + (double)w[j][0], (j == 0) ? from_left : emit[j - 1]);
+            for (int j = 0; j < K; ++j) stay[j] = a[j] + (double)w[j][0], left[j] = (j == 0) ? from_left : emit[j - 1];
+            SWEEP_FENCE();
+            lse2_pr_staged<K>(a, stay, left);
             if ((n & (kRebase - 1)) == 0) offset_lane_pr<K, false>(a, st, n / kRebase);
             store_diag_pr<K>(st.row, lane, a, st.off);
             st.row += Up;
@@ -678,7 +701,7 @@ __device__ void beta_sweep_pr(const LossParams &p, float *bufs, const LdLink lk,
         }
         const float *cur = bufs + (i_ring % NB) * chunkf + 2 * u0;
         const int r0 = ck * G;
-#pragma unroll 1
+#pragma unroll 4
         for (int ii = 0; ii < G; ++ii) {
             const int i = G - 1 - ii;
             const int n = r0 + i;
@@ -686,12 +709,12 @@ __device__ void beta_sweep_pr(const LossParams &p, float *bufs, const LdLink lk,
             f32x2 w[K];
             load_w<K>(w, cur + i * 2 * Up);
             const double from_right = dpp64_from_upper_lane(bv[0], (double)kNeg);
-            double nv[K];
+            double stay[K], emit[K];
 #pragma unroll
             for (int j = 0; j < K; ++j)
-                nv[j] = lse2_pr(bv[j] + (double)w[j][0], ((j == K - 1) ? from_right : bv[j + 1]) + (double)w[j][1]);
-#pragma unroll
-            for (int j = 0; j < K; ++j) bv[j] = nv[j];
+                stay[j] = bv[j] + (double)w[j][0], emit[j] = ((j == K - 1) ? from_right : bv[j + 1]) + (double)w[j][1];
+            SWEEP_FENCE();
+            lse2_pr_staged<K>(bv, stay, emit);
             if (((n & (kRebase - 1)) == kRebase - 1) || n == last) offset_lane_pr<K, true>(bv, st, n / kRebase);
             store_diag_pr<K>(st.row, lane, bv, st.off);
             st.row -= Up;

@@ -11,11 +11,11 @@ produces, as opposed to the N(0,1) logits of the headline bench.  Through the C 
   fused x5 / x10    the f32-grade fused joint with glorot W2 scaled by 5 / 10 (logit spread ~4 / ~8)
 
 Bars (north_star "within 1e-4 fp32"): costs |d| <= 1e-4 max(1, |cost|); gradients max|d| <= 1e-4 (P1: absolute, gradients
-live in [-1, 1]; fused: relative to max(1, max|ref|)) -- except the 8-sigma case of the FUSED joint, whose bar is 2.5e-4: its
-sweeps keep the float32 recurrence (rounding every log-add at the magnitude of its residue: ~1e-5 bits per step, a random walk
-over the ~750 steps of a path).  The loss op's hand-back kernel carries the recurrence in float64 since round 4: 4.3e-6 at
-4 sigma, 1.1e-5 at 8 sigma (round 3: 8.5e-5 / 1.6e-4 with a 2.5e-4 bar at 8 sigma -- then attributed to the float32
-representation of the log-probabilities; it was the recurrence).
+live in [-1, 1]; fused: relative to max(1, max|ref|)) on every case.  The log-domain sweeps behind the hand-back kernel and behind the
+f32-grade fused joint carry their recurrence in float64 since round 4 (a float32 recurrence rounds every log-add at the magnitude of its
+residue: ~1e-5 bits per step, a random walk over the ~750 steps of a path): P1 4 sigma 8.5e-5 -> 4.3e-6, 8 sigma 1.6e-4 -> 1.1e-5 (round 3's
+bar there was 2.5e-4, attributed to the float32 representation of the log-probabilities; it was the recurrence); fused W2 x 5
+2.9e-5 -> 1.0e-6, W2 x 10 1.2e-4 -> 1.4e-6.
 The measured maxima are written to gpurun_out/r04_accuracy.json (copied to profiles/ by hand)."""
 import json
 import math
@@ -153,4 +153,4 @@ def test_fused_f32_joint_peaked_at_c2_size(gain):
     _report[f"fused_f32_w2x{gain:g}"] = {"utterances": picks, "max_rel_dcost": max(dc), "max_rel_dgrad": max(dg),
                                          "cost_range_nats": [float(min(r["cost"] for r in refs)), float(max(r["cost"] for r in refs))]}
     assert max(dc) <= CTOL, dc
-    assert max(dg) <= (2.5e-4 if gain >= 10 else GTOL), dg
+    assert max(dg) <= GTOL, dg
