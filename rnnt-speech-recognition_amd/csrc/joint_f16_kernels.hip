@@ -746,12 +746,6 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
     };
     set_arow();
     auto dma_piece = [&](const int k) {  // piece k (0..5) of the chunk under the prefetch cursor
-#ifdef JH_K3_NOB
-        if (k >= 4) return;  // timing experiment: no W2 tile traffic (results wrong)
-#endif
-#ifdef JH_K3_NODMA
-        return;  // timing experiment: no L2 -> LDS traffic at all (results wrong)
-#endif
         const f16 *src = (k < 4 ? arowP[k] : jp.W2h) + doff[k] + kp * 64;
         lds_dma16(src, smem + sp * kStage + (wave + 8 * k) * 1024);
     };
@@ -1363,11 +1357,7 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     // Park the softmax numerators in the forward pass when a backward pass will use them: this call's own, or (phases bit 2,
     // the _fwd entry points) a later backward-only call on the same workspace.
     const bool want_bwd = (phases & 2) && d_enc_proj;
-#ifdef JH_RECOMPUTE
-    const bool park = false;  // dev builds: the round-2 route (the product twice), for A/B timing
-#else
     const bool park = (phases & 1) && (want_bwd || (phases & 4));
-#endif
     // the binary16 weight copies and the scale are rebuilt by whichever phase runs (cheap; W2 or cost_scale may differ)
     if (launch_fill(jp.scal, 0, 32, s) != hipSuccess) return hipErrorUnknown;
     hipLaunchKernelGGL(jh_prep_kernel, dim3(1024), dim3(256), 0, s, jp);

@@ -1,4 +1,4 @@
-// joint_kernels.hip -- joint network fused with the transducer loss (gfx950, f32 MFMA).
+// joint_kernels.hip -- joint network fused with the transducer loss (gfx950): f32-GRADE products on the f16 MFMA units.
 //
 // Replaces, for the hot path, the tail of the reference model and everything TF autodiff does
 // behind it:
@@ -7,25 +7,29 @@
 //   model.py:165-166  y  = h @ W2 + b2                         -> logits [B,T,U,V]
 //   run_rnnt.py:284   tape.gradient(...) through those three ops
 // The first Dense layer is factored exactly (W1^T(e+p)+b1 = (W1^T e + b1) + W1^T p), so the kernels
-// take the two small projections  enc_proj [B,T,J], pred_proj [B,U,J]  (library GEMMs on the host
+// take the two small projections  enc_proj [B,T,J], pred_proj [B,U,J]  (dense_kernels.hip, or library GEMMs on the host
 // side) and never materialise the [B,T,U,J] or [B,T,U,V] tensors:
 //
-//   phase 1  (joint_phase1_kernel)  logits tile = tanh(A_t + C_u) . W2 + b2 on v_mfma_f32_32x32x2_f32
-//            forward  epilogue: softmax denominator + lattice edge weights  (same outputs as the
-//                               lsm pass of rnnt_kernels.hip -> the alpha/beta sweeps run unchanged)
-//                               and parks the logits tile (V <= 32 floats per cell) in the workspace
-//   dl       (joint_dl_kernel)      backward: logits tile -> dlogits in place (per-cell, memory-bound) + db2 partials
-//   phase 2  (joint_phase2_kernel)  dh = dl . W2^T,  dz = dh * (1-h^2),  d enc_proj = sum_u dz,
-//            d pred_proj = sum_t dz,  dW2 = h^T . dl   -- the "gradient scatter back through the joint".
-//            h is recomputed in the MFMA C/D register layout, which is at the same time a valid
-//            A-operand layout for dW2 (the K-slot <-> lattice-column assignment of a dot product is
-//            free), so no data moves between the three products.
+//   forward   (joint_fwd_kernel, J <= 640; joint_phase1s_kernel for 640 < J <= 704)
+//             logits tile = tanh(A_t + C_u) . W2 + b2 as a split-precision product on v_mfma_f32_32x32x16_f16 (both operands
+//             as binary16 hi + lo parts, f32 accumulation; W2 scaled by a power of two into binary16's range first), softmax
+//             epilogue in registers: the lattice's edge PROBABILITIES for the linear-domain sweeps (round 5: rnnt_lin.h,
+//             lin_sweep_kernel -- the lattice the loss op runs on) and the parked logits tile (V <= 32 floats per cell)
+//   backward  (joint_cellrec_kernel + joint_bwd_kernel; joint_dl_kernel + joint_phase2s_kernel for the wide joint)
+//             per-cell gradient set-up from the lattice (mantissas + frames, range certificate; log-domain values for an
+//             utterance that was handed back), then dlogits, dh = dl . W2^T, dz = dh * (1-h^2), d enc_proj = sum_u dz,
+//             d pred_proj = sum_t dz, dW2 = h^T . dl in one persistent producer / consumer kernel.  h is recomputed in the
+//             MFMA C/D register layout, which is at the same time a valid A-operand layout for dW2 (the K-slot <-> lattice
+//             column assignment of a dot product is free), so no data moves between the three products.
+//   hand-back (joint_redo_kernel) utterances the linear lattice cannot represent are redone in the log domain from the parked
+//             logits by a team of workgroups (rnnt_redo.h), exactly as in the loss op.
 //   reductions over u-tiles / row splits / blocks go through partial buffers summed in a fixed
-//   order (deterministic; no floating-point atomics).
+//   order (deterministic; no floating-point atomics), one launch for all four outputs.
 //
-// Limits of this round (checked at the boundary): V <= 32 (one MFMA column tile), J % 64 == 0.
+// Limits (checked at the boundary): V <= 32 (one MFMA column tile), J % 64 == 0, J <= 704.
 #include "rnnt_common.h"
 #include "rnnt_cell.h"
+#include "rnnt_redo.h"
 
 #include <math.h>
 #ifdef JH_TRACE
@@ -58,7 +62,6 @@ __device__ __forceinline__ float tanh_from_exp(float ea, float ec) {
 // saturation behaviour: 0 for an overflowing product, 1 for an underflowing one)
 __device__ __forceinline__ float r_from_exp(float ea, float ec) { return __builtin_amdgcn_rcpf(fmaf(ea, ec, 1.0f)); }
 __device__ __forceinline__ float fast_r(float x) { return __builtin_amdgcn_rcpf(1.0f + jex2(x * 2.8853900817779268f)); }
-constexpr float kSplitLimit = 60000.0f;  // |W2| beyond this leaves binary16's range (65504): no hi/lo split
 // row of the 32x32 MFMA C/D tile held in register `reg` of a lane in half `half` (= lane >> 5)
 __device__ __forceinline__ constexpr int cd_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
@@ -86,9 +89,11 @@ struct JointParams {
     float *d_enc_proj, *d_pred_proj, *dW2, *db2;
     float *expE, *expP;  // [B][T][J], [B][U][J]  e^{2 x} tables of the two projections
     float *tflag;        // [0] != 0: some |projection| exceeds kExpTabLimit, use the raw projections + fast_tanh
-                         // [1] != 0: some |W2| is outside the binary16 range: the plain f32 MFMA kernels run instead of the
-                         //           split-precision ones (both are enqueued; the one the flag does not select exits at once)
-    jf16 *W2s;           // [J/16][2 (hi, lo)][64 lanes][8]: W2 as binary16 hi + lo parts in MFMA B-fragment order (phase 1s)
+                         // [1] != 0: some |W2| exceeds kRFormLimit: joint_fwd_kernel accumulates h = tanh(.) instead of r = (1 - h) / 2
+                         // [2] = 1 / s2: W2 enters every product as s2 W2, s2 the power of two that puts max |W2| into
+                         //       [2^13, 2^14) (binary16 hi + lo parts then carry 22 significand bits whatever W2's magnitude)
+                         // [3] == 1: the workspace holds the state of a whole-network forward call (JointHooks::prep_mode)
+    jf16 *W2s;           // [J/16][2 (hi, lo)][64 lanes][8]: s2 W2 as binary16 hi + lo parts in MFMA fragment order
     float *b2s;          // [2][32]: b2[v] + sum_j W2[j][v] as an f32 hi + lo pair (-1e30 / 0 beyond V), for joint_fwd_kernel
 #ifdef JH_TRACE
     long long *trace;    // dev builds only: s_memtime stamps of one workgroup of phase 1 and one of phase 2
@@ -96,8 +101,11 @@ struct JointParams {
     int J, n_ut, TR, n_tr, TS, n_ts;
     int tables_ready; // the e^{2x} tables and tflag[0] were written by the caller (the dense layer's epilogue): prep does W2 only
     int logits_only;  // compute_rnnt_joint_logits: full lengths written by the prep kernel, only the parked logits are kept
-    int single_bwd;  // 1: joint_bwd_kernel does the backward; joint_dl_kernel only runs for the f32 fallback (tflag[1])
+    int nblk;         // workgroups per J group of joint_bwd_kernel (sizes what the reduction reads of the partial buffers)
+    int need_state;   // backward-only whole-network call: the reductions return NaN unless tflag[3] says the state is there
 };
+
+constexpr float kRFormLimit = 4096.0f;  // largest |W2| the forward kernel's r = (1 - h) / 2 accumulation is used for (joint_prep_kernel)
 
 // tables for tanh_from_exp + the overflow flag (zeroed before the launch)
 __global__ __launch_bounds__(256) void joint_prep_kernel(const JointParams jp) {
@@ -135,228 +143,84 @@ __global__ __launch_bounds__(256) void joint_prep_kernel(const JointParams jp) {
             const_cast<int *>(p.input_lengths)[b] = p.T;
             const_cast<int *>(p.label_lengths)[b] = p.U - 1;
         }
-    if (blockIdx.x == 0) {  // joint_fwd_kernel accumulates r = (1 - h) / 2: logits = (b2 + sum_j W2) - 2 W2^T r
-        __shared__ double part[8][32];
-        const int v = threadIdx.x & 31, q = threadIdx.x >> 5;
-        double sum = 0.0;
-        if (v < p.V) {  // 32 loads in flight per thread: the block is alone on its CU and waits out a full memory latency per
-                        // round (with 8 per round, ten rounds at J = 640, this block alone made the kernel 28 us long)
-            constexpr int kRound = 32;
-            float w[kRound];
-            for (int j0 = q; j0 < jp.J; j0 += 8 * kRound) {
+    // W2 = hi + lo with both parts binary16, laid out as the fragments of v_mfma_f32_32x32x16_f16: lane l of k-step ks holds
+    // s2 W2[16 ks + 8 (l >> 5) + 0..7][l & 31] (zero beyond V).  s2 = the power of two that puts max |W2| into [2^13, 2^14):
+    // hi and lo are then both normal binary16 numbers for every weight within 2^-13 of the largest (22 significand bits
+    // together; without the scale the lo part of a weight below 2^-3 sat in binary16's subnormals), and weights beyond
+    // binary16's range (65504) need no other kernels.  Every block that builds fragments finds max |W2| itself (J V <= 22,528
+    // floats out of L2); block 0 publishes 1 / s2.  A non-finite weight gives s2 = 1 and NaN results, as it should.
+    const int nfrag = (jp.J / 16) * 64;
+    if ((int)blockIdx.x * 256 < nfrag) {
+        __shared__ float wred[4];
+        const int nW = jp.J * p.V;
+        float wmax = 0.f;
+        for (int i0 = 0; i0 < nW; i0 += 256 * 16) {
+            float w[16];
 #pragma unroll
-                for (int k = 0; k < kRound; ++k) w[k] = (j0 + 8 * k < jp.J) ? jp.W2[(size_t)(j0 + 8 * k) * p.V + v] : 0.f;
+            for (int k = 0; k < 16; ++k) {
+                const int i = i0 + 256 * k + (int)threadIdx.x;
+                w[k] = (i < nW) ? fabsf(jp.W2[i]) : 0.f;
+            }
 #pragma unroll
-                for (int k = 0; k < kRound; ++k) sum += (double)w[k];
+            for (int k = 0; k < 16; ++k) wmax = fmaxf(wmax, w[k]);  // (a NaN operand is ignored: handled below)
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
+        if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = wmax;
+        __syncthreads();
+        wmax = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+        float s2 = 1.0f, inv2 = 1.0f;
+        if (wmax > 0.f && wmax < 3.0e38f) {
+            const int e = ilogbf(wmax);  // wmax in [2^e, 2^(e+1))
+            s2 = ldexpf(1.0f, 13 - e), inv2 = ldexpf(1.0f, e - 13);
+        }
+        // r form or h form?  The r form forms every logit as (b2 + sum_j W2[j]) - 2 sum_j W2[j] r_j: fine while those sums are of the
+        // order of the logits, a cancellation of two numbers of the magnitude of the LARGEST weight otherwise (a unit with h = 0
+        // and a weight of 1e5 then costs 4e-3 of absolute logit error in f32 accumulators).  Beyond kRFormLimit: accumulate h.
+        const bool hform = !(wmax <= kRFormLimit);
+        if (blockIdx.x == 0 && threadIdx.x == 0) jp.tflag[2] = inv2, jp.tflag[1] = hform ? 1.0f : 0.f;
+        if (blockIdx.x == 0) {  // joint_fwd_kernel accumulates r = (1 - h) / 2: logits = (b2 + sum_j W2) - 2 W2^T r (h form: b2 alone)
+            __shared__ double part[8][32];
+            const int v = threadIdx.x & 31, q = threadIdx.x >> 5;
+            double sum = 0.0;
+            if (v < p.V && !hform) {  // 32 loads in flight per thread: the block is alone on its CU and waits out a full memory latency per
+                            // round (with 8 per round, ten rounds at J = 640, this block alone made the kernel 28 us long)
+                constexpr int kRound = 32;
+                float w[kRound];
+                for (int j0 = q; j0 < jp.J; j0 += 8 * kRound) {
+#pragma unroll
+                    for (int k = 0; k < kRound; ++k) w[k] = (j0 + 8 * k < jp.J) ? jp.W2[(size_t)(j0 + 8 * k) * p.V + v] : 0.f;
+#pragma unroll
+                    for (int k = 0; k < kRound; ++k) sum += (double)w[k];
+                }
+            }
+            part[q][v] = sum;
+            __syncthreads();
+            if (threadIdx.x < 32) {
+                sum = (v < p.V) ? (double)jp.b2[v] : -1.0e30;
+                for (int k = 0; k < 8; ++k) sum += part[k][v];
+                const float hi = (float)sum;
+                jp.b2s[v] = hi, jp.b2s[32 + v] = (v < p.V) ? (float)(sum - (double)hi) : 0.f;
             }
         }
-        part[q][v] = sum;
-        __syncthreads();
-        if (threadIdx.x < 32) {
-            sum = (v < p.V) ? (double)jp.b2[v] : -1.0e30;
-            for (int k = 0; k < 8; ++k) sum += part[k][v];
-            const float hi = (float)sum;
-            jp.b2s[v] = hi, jp.b2s[32 + v] = (v < p.V) ? (float)(sum - (double)hi) : 0.f;
-        }
-    }
-    // W2 = hi + lo with both parts binary16 (22 significand bits together), laid out as the B fragments of
-    // v_mfma_f32_32x32x16_f16: lane l of k-step ks holds W2[16 ks + 8 (l >> 5) + 0..7][l & 31] (zero beyond V)
-    const int nfrag = (jp.J / 16) * 64;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nfrag; i += gridDim.x * 256) {
-        const int ks = i >> 6, l = i & 63, v = l & 31;
-        jh8 hi, lo;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < nfrag; i += gridDim.x * 256) {
+            const int ks = i >> 6, l = i & 63, v = l & 31;
+            jh8 hi, lo;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int j = 16 * ks + 8 * (l >> 5) + e;
-            const float w = (v < p.V) ? jp.W2[(size_t)j * p.V + v] : 0.f;
-            if (!(fabsf(w) <= kSplitLimit)) jp.tflag[1] = 1.0f;  // also catches NaN / inf
-            hi[e] = (jf16)w;
-            lo[e] = (jf16)(w - (float)hi[e]);
+            for (int e = 0; e < 8; ++e) {
+                const int j = 16 * ks + 8 * (l >> 5) + e;
+                const float w = (v < p.V) ? jp.W2[(size_t)j * p.V + v] * s2 : 0.f;
+                hi[e] = (jf16)w;
+                lo[e] = (jf16)(w - (float)hi[e]);
+            }
+            *(jh8 *)(jp.W2s + ((size_t)(ks * 2 + 0) * 64 + l) * 8) = hi;
+            *(jh8 *)(jp.W2s + ((size_t)(ks * 2 + 1) * 64 + l) * 8) = lo;
         }
-        *(jh8 *)(jp.W2s + ((size_t)(ks * 2 + 0) * 64 + l) * 8) = hi;
-        *(jh8 *)(jp.W2s + ((size_t)(ks * 2 + 1) * 64 + l) * 8) = lo;
     }
 }
 
 constexpr int kP1Waves = 8;    // phase-1 workgroup = 8 waves (2 per SIMD: one wave's tanh VALU hides the other's MFMA issue)
 constexpr int kStagePad = 33;  // row stride of the per-wave 32x32 staging tiles (bank-conflict free both ways)
-
-// ---------------------------------------------------------------------------------------------
-// phase 1 (forward): one lattice row (32 cells of one u-tile) per wave per iteration.
-// LDS: Ct [J][32] (pred_proj tile, transposed) | W2c [2][32][32] | Arow [8][J] | stage [8][32][33]
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void joint_phase1_kernel_body(const JointParams &jp, const unsigned block_id) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const LossParams &p = jp.lp;
-    const int J = jp.J, V = p.V;
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float *Ct = lds;                       // [J][32]
-    float *W2c = Ct + J * 32;              // [2][32][32]
-    float *Arow = W2c + 2 * 32 * 32;       // [kP1Waves][J]
-    float *stage = Arow + kP1Waves * J;    // [kP1Waves][32][kStagePad]
-    float *my_arow = Arow + wave * J;
-    float *my_stage = stage + wave * 32 * kStagePad;
-    if (jp.tflag[1] == 0.f) return;  // W2 fits binary16 hi + lo parts: joint_phase1s_kernel does this launch's work
-    const bool slow = jp.tflag[0] != 0.f;  // kernel-uniform
-    const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
-
-    int bid = block_id;
-    const int tr = bid % jp.n_tr;
-    bid /= jp.n_tr;
-    const int ut = bid % jp.n_ut;
-    const int b = bid / jp.n_ut;
-    const int u0 = ut * 32;
-    const int Tb = length_T(p, b), Ub = length_U(p, b);
-    const int t_begin = tr * jp.TR, t_end = min(min(t_begin + jp.TR, p.T), Tb);
-    const bool tile_live = (t_begin < t_end) && (u0 < Ub);
-
-    if (tile_live) {
-        // ---- C^T tile: Ct[j][u] = pred_proj[b][u0+u][j]  (lanes run along u: conflict-free LDS writes)
-        for (int idx = tid; idx < 32 * (J / 4); idx += kP1Waves * 64) {
-            const int u = idx & 31, j4 = idx >> 5;
-            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u0 + u < p.U) c4 = *(const float4 *)(Ptab + ((size_t)b * p.U + u0 + u) * J + j4 * 4);
-            Ct[(j4 * 4 + 0) * 32 + u] = c4.x;
-            Ct[(j4 * 4 + 1) * 32 + u] = c4.y;
-            Ct[(j4 * 4 + 2) * 32 + u] = c4.z;
-            Ct[(j4 * 4 + 3) * 32 + u] = c4.w;
-        }
-    }
-    const int n_iter = tile_live ? (t_end - t_begin + kP1Waves - 1) / kP1Waves : 0;
-#ifdef JH_TRACE
-    long long *trc = (block_id == 1201) ? jp.trace + wave * 64 : nullptr;
-#endif
-    JT1(0);
-    for (int it = 0; it < n_iter; ++it) {
-        if (it < 5) JT1(1 + 4 * it);
-        const int t = t_begin + it * kP1Waves + wave;
-        const bool active = t < t_end;  // wave-uniform
-        // enc_proj row, de-interleaved per 32-wide chunk as [half][16] so that a lane's 16 A-side addends of a
-        // chunk (j = jc*32 + 2*kk + half) are 16 consecutive words: four broadcast ds_read_b128 per chunk.
-        if (active)
-            for (int j = lane; j < J; j += 64) {
-                const int jc = j >> 5, r = j & 31;
-                my_arow[jc * 32 + (r & 1) * 16 + (r >> 1)] = Etab[((size_t)b * p.T + t) * J + j];
-            }
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        // W2 streams through LDS in [32 j][32 v] chunks (zero-padded beyond V), staged ONCE per workgroup and shared
-        // by its 8 waves.  Chunk jc+1 is fetched into registers BEFORE chunk jc's 16 MFMA steps and parked in the other
-        // LDS buffer after them: the L2 latency hides under the matrix work, one barrier per chunk.
-        // (Measured alternative: every wave pulling its B operands straight from L2 -- 3.1 ms instead of 2.0 ms.)
-        constexpr int kWPT = 1024 / (kP1Waves * 64);  // W2 chunk words per thread
-        auto w2_fetch = [&](const int jc, float (&w)[kWPT]) {
-#pragma unroll
-            for (int q = 0; q < kWPT; ++q) {
-                const int e = tid + q * (kP1Waves * 64), jj = e >> 5, v = e & 31;
-                w[q] = (v < V) ? jp.W2[(size_t)(jc * 32 + jj) * V + v] : 0.f;
-            }
-        };
-        auto w2_park = [&](const int jc, const float (&w)[kWPT]) {
-            float *wb = W2c + (jc & 1) * 1024;
-#pragma unroll
-            for (int q = 0; q < kWPT; ++q) wb[tid + q * (kP1Waves * 64)] = w[q];
-        };
-        float wreg[kWPT];
-        w2_fetch(0, wreg);
-        w2_park(0, wreg);
-        __syncthreads();  // chunk 0 (and, first time round, Ct / Arow) visible
-        const int nchunk = J / 32;
-        for (int jc = 0; jc < nchunk; ++jc) {
-            const float *wbuf = W2c + (jc & 1) * 1024;
-            if (jc + 1 < nchunk) w2_fetch(jc + 1, wreg);
-            if (active) {
-                float av[16];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 a4 = *(const float4 *)(my_arow + jc * 32 + half * 16 + q * 4);
-                    av[4 * q] = a4.x, av[4 * q + 1] = a4.y, av[4 * q + 2] = a4.z, av[4 * q + 3] = a4.w;
-                }
-                if (!slow) {
-#pragma unroll
-                    for (int kk = 0; kk < 16; ++kk) {
-                        const int jl = 2 * kk + half;
-                        const float h = tanh_from_exp(av[kk], Ct[(jc * 32 + jl) * 32 + l31]);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h, wbuf[jl * 32 + l31], acc, 0, 0, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int kk = 0; kk < 16; ++kk) {
-                        const int jl = 2 * kk + half;
-                        const float h = fast_tanh(av[kk] + Ct[(jc * 32 + jl) * 32 + l31]);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h, wbuf[jl * 32 + l31], acc, 0, 0, 0);
-                    }
-                }
-            }
-            if (jc + 1 < nchunk) w2_park(jc + 1, wreg);
-            __syncthreads();  // next chunk visible; everyone is done with the buffer it will overwrite after that
-        }
-        if (it < 5) JT1(2 + 4 * it);
-        // ---- epilogue: logits tile -> LDS, then one lattice cell per lane (lanes 0..31)
-        if (active) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) my_stage[cd_row(r, half) * kStagePad + l31] = acc[r];
-        }
-        __syncthreads();
-        if (active && lane < 32) {
-            Cell cl;
-            cl.b = b, cl.t = t, cl.u = u0 + lane, cl.Tb = Tb, cl.Ub = Ub;
-            cl.valid = cl.u < Ub;
-            float *xs = my_stage + lane * kStagePad;
-            if (cl.valid) {
-                const uint32_t c = ((uint32_t)(b * p.T + t)) * (uint32_t)p.U + (uint32_t)cl.u;
-                float m = -INFINITY;
-                for (int v = 0; v < V; ++v) {
-                    xs[v] += jp.b2[v];
-                    m = fmaxf(m, xs[v]);
-                }
-                float s = 0.f;
-                const float nml = -m * kLog2e;
-                for (int v = 0; v < V; ++v) s += jex2(fmaf(xs[v], kLog2e, nml));
-                const float lg2s = jlg2(s);
-                const float lse = m + kLn2 * lg2s;
-                const bool blank_stays = (cl.t < Tb - 1) || (cl.u == Ub - 1);
-                const float ob = blank_stays ? fmaf(xs[p.blank] - m, kLog2e, -lg2s) : kNeg;
-                float ol = kNeg;
-                if (cl.u < Ub - 1) {
-                    const int lab = min(max(p.labels[(size_t)b * (p.U - 1) + cl.u], 0), V - 1);
-                    ol = fmaf(xs[lab] - m, kLog2e, -lg2s);
-                }
-                p.lse[c] = lse;
-                const size_t wi = ((size_t)b * p.Nr + (cl.t + cl.u)) * p.Up + cl.u;
-                ((float2 *)p.W)[wi] = make_float2(ob, ol);
-            }
-
-        }
-        if (it < 5) JT1(3 + 4 * it);
-        {
-            // park the logits tile (bias included) in the workspace: V <= 32 floats per cell.  The backward pass turns
-            // it into dlogits in place instead of re-running this whole MFMA pass.
-            __syncthreads();
-            if (active)
-                for (int e = lane; e < 1024; e += 64) {
-                    const int uu = e >> 5, v = e & 31;
-                    if (u0 + uu < Ub) {
-                        const size_t c = ((size_t)(b * p.T + t)) * p.U + u0 + uu;
-                        jp.dl[c * 32 + v] = my_stage[uu * kStagePad + v];
-                    }
-                }
-        }
-        __syncthreads();  // staging tiles and Arow are rewritten by the next iteration
-        if (it < 5) JT1(4 + 4 * it);
-    }
-}
-// The launch: a FEW workgroups that walk the body's block indices (this kernel is the fallback of its faster twin and exits on
-// the workspace's range flag in every ordinary call: a full grid of workgroups that start only to return cost 4.9 us each).
-__global__ __launch_bounds__(kP1Waves * 64) void joint_phase1_kernel(const JointParams jp, const unsigned n_blocks) {
-    if (jp.tflag[1] == 0.f) return;  // W2 fits binary16 hi + lo parts: the split-precision forward does this launch's work
-    for (unsigned bid = blockIdx.x; bid < n_blocks; bid += gridDim.x) {
-        joint_phase1_kernel_body(jp, bid);
-        __syncthreads();  // the next block's LDS image must not overtake this block's readers
-    }
-}
 
 typedef _Float16 jh2 __attribute__((ext_vector_type(2)));
 // x -> binary16 hi (round to nearest even) and lo = binary16(x - hi).  The residual is one v_fma_mix_f32 per value: it reads
@@ -419,8 +283,8 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1s_kernel(const Join
     float *stage = Arow + kP1Waves * J;               // [kP1Waves][32][kStagePad]
     float *my_arow = Arow + wave * J;
     float *my_stage = stage + wave * 32 * kStagePad;
-    if (jp.tflag[1] != 0.f) return;  // some |W2| outside the binary16 range: joint_phase1_kernel (plain f32 MFMAs) runs instead
     const bool slow = jp.tflag[0] != 0.f;  // kernel-uniform
+    const float w2inv = jp.tflag[2];       // the W2 images hold s2 W2 (joint_prep_kernel)
     const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
 
     int bid = blockIdx.x;
@@ -490,7 +354,8 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1s_kernel(const Join
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's piece of the next chunk has landed
             __syncthreads();  // next chunk visible; everyone is done with the buffer it will overwrite after that
         }
-        // ---- epilogue: identical to joint_phase1_kernel (logits tile -> LDS, one lattice cell per lane, park the tile)
+        // ---- epilogue: logits tile -> LDS, one lattice cell per lane (log2-domain edge weights + lse: the wide joint stays on
+        //      the log-domain sweeps), park the tile
         if (active) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) my_stage[cd_row(r, half) * kStagePad + l31] = acc[r];
@@ -505,7 +370,7 @@ __global__ __launch_bounds__(kP1Waves * 64) void joint_phase1s_kernel(const Join
                 const uint32_t c = ((uint32_t)(b * p.T + t)) * (uint32_t)p.U + (uint32_t)cl.u;
                 float m = -INFINITY;
                 for (int v = 0; v < V; ++v) {
-                    xs[v] += jp.b2[v];
+                    xs[v] = fmaf(xs[v], w2inv, jp.b2[v]);
                     m = fmaxf(m, xs[v]);
                 }
                 float ssum = 0.f;
@@ -559,7 +424,7 @@ template <int E>
 __device__ __forceinline__ float row_bcast(const float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + E /*row_newbcast:E*/, 0xf, 0xf, true));
 }
-template <int E, bool SLOW>
+template <int E, bool SLOW, bool HFORM>
 __device__ __forceinline__ void fwd_h_pair(const float ea0, const float ea1, const float ec, float &h0, float &h1) {
     const float a0 = row_bcast<E>(ea0), a1 = row_bcast<E>(ea1);
     if (!SLOW) {  // r = (1 - h) / 2, see fwd_row_epilogue
@@ -567,6 +432,7 @@ __device__ __forceinline__ void fwd_h_pair(const float ea0, const float ea1, con
     } else {
         h0 = fast_r(a0 + ec), h1 = fast_r(a1 + ec);
     }
+    if (HFORM) h0 = fmaf(h0, -2.0f, 1.0f), h1 = fmaf(h1, -2.0f, 1.0f);  // h itself (huge weights: see joint_prep_kernel)
 }
 // The J-long product of one row pair: acc += W2^T . r^T, A = W2 fragments (row = symbol), B = r (column = cell), with
 // r = (1 - h) / 2 = 1 / (1 + e^{2(a + c)}) (see fwd_row_epilogue).  Measured alternatives (profiles/r02_notes.md): building
@@ -602,7 +468,7 @@ __device__ __forceinline__ FwdAddends fwd_spread(const float x) {
     f.y[2] = __uint_as_float(y23[0]), f.y[3] = __uint_as_float(y23[1]);
     return f;
 }
-template <bool SLOW>
+template <bool SLOW, bool HFORM>
 __device__ __forceinline__ void fwd_row_pair(const int J, const float *e0, const float *e1, const char *ct_row, const uint32_t ct_swz,
                                              const char *wlane, const int half, const int lane, f32x16 &acc0, f32x16 &acc1) {
     const int n = J / 16;
@@ -614,17 +480,17 @@ __device__ __forceinline__ void fwd_row_pair(const int J, const float *e0, const
         const jh8 wl = *(const jh8 *)(wlane + (size_t)(ks * 2 + 1) * 1024);
         FwdFrags f;
         float x0[2], x1[2];
-        fwd_h_pair<0, SLOW>(a0, a1, c4a.x, x0[0], x1[0]);
-        fwd_h_pair<1, SLOW>(a0, a1, c4a.y, x0[1], x1[1]);
+        fwd_h_pair<0, SLOW, HFORM>(a0, a1, c4a.x, x0[0], x1[0]);
+        fwd_h_pair<1, SLOW, HFORM>(a0, a1, c4a.y, x0[1], x1[1]);
         fwd_split_quad<0>(x0, x1, f);
-        fwd_h_pair<2, SLOW>(a0, a1, c4a.z, x0[0], x1[0]);
-        fwd_h_pair<3, SLOW>(a0, a1, c4a.w, x0[1], x1[1]);
+        fwd_h_pair<2, SLOW, HFORM>(a0, a1, c4a.z, x0[0], x1[0]);
+        fwd_h_pair<3, SLOW, HFORM>(a0, a1, c4a.w, x0[1], x1[1]);
         fwd_split_quad<2>(x0, x1, f);
-        fwd_h_pair<4, SLOW>(a0, a1, c4b.x, x0[0], x1[0]);
-        fwd_h_pair<5, SLOW>(a0, a1, c4b.y, x0[1], x1[1]);
+        fwd_h_pair<4, SLOW, HFORM>(a0, a1, c4b.x, x0[0], x1[0]);
+        fwd_h_pair<5, SLOW, HFORM>(a0, a1, c4b.y, x0[1], x1[1]);
         fwd_split_quad<4>(x0, x1, f);
-        fwd_h_pair<6, SLOW>(a0, a1, c4b.z, x0[0], x1[0]);
-        fwd_h_pair<7, SLOW>(a0, a1, c4b.w, x0[1], x1[1]);
+        fwd_h_pair<6, SLOW, HFORM>(a0, a1, c4b.z, x0[0], x1[0]);
+        fwd_h_pair<7, SLOW, HFORM>(a0, a1, c4b.w, x0[1], x1[1]);
         fwd_split_quad<6>(x0, x1, f);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, f.hi0, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, f.hi1, acc1, 0, 0, 0);
@@ -658,23 +524,28 @@ __device__ __forceinline__ float half_swap_sum(const float v) {
 }
 
 // lsm outputs + parked logits of one lattice row held in the transposed C/D layout (lane = cell u0 + l31, register r = symbol
-// cd_row(r, half)).  `acc` holds W2^T r with r = (1 - h) / 2 = 1 / (1 + e^{2(a + c)}): the main loop saves the multiply-add that
-// turns the reciprocal into tanh, and logits = (b2 + sum_j W2[j]) - 2 acc with the first term tabulated by joint_prep_kernel as an
-// f32 hi + lo pair (-1e30 for the pad symbols).  Rounding: the split products bound the error of acc by ~2^-22 sum_j |W2[j][v]| r_j
+// cd_row(r, half)).  `acc` holds (s2 W2)^T r with r = (1 - h) / 2 = 1 / (1 + e^{2(a + c)}): the main loop saves the multiply-add that
+// turns the reciprocal into tanh, and logits = (b2 + sum_j W2[j]) - (2 / s2) acc with the first term tabulated by joint_prep_kernel
+// as an f32 hi + lo pair (-1e30 for the pad symbols).  (With weights beyond kRFormLimit the kernel accumulates h itself and the
+// table holds b2 alone: the r form would form the logits as the difference of two sums of the magnitude of the largest weight.)  Rounding: the split products bound the error of acc by ~2^-22 sum_j |W2[j][v]| r_j
 // -- at most twice the bound of the h form, and of the order of an f32 matrix product's.  `rsel_b` / `rsel_l`: the register
 // that holds this lane's blank / label logit, or -1 when it lives in the other half (or there is no label edge).
-__device__ __forceinline__ void fwd_row_epilogue(const JointParams &jp, const f32x16 &acc,
-                                                 const int rsel_b, const int rsel_l, const int b, const int t,
-                                                 const int u, const int Tb, const int Ub, const int half) {
+// Round 5: the lattice's edges leave as PROBABILITIES {p(blank), p(label)} = e_i / sum for the linear-domain sweeps (rnnt_lin.h:
+// zero where an edge leaves the lattice, NaN -- the utterance is handed back -- where an edge the lattice owns is below 2^-100);
+// lse is still stored (the backward's per-cell set-up needs the denominator and does not re-read the tile).
+// Returns the cell's decay statistic -log2 max(p_blank, p_label) (rnnt_lin.h; 0 for lanes that own no cell, half 1 included).
+__device__ __forceinline__ float fwd_row_epilogue(const JointParams &jp, const f32x16 &acc, const float m2inv,
+                                                  const int rsel_b, const int rsel_l, const int b, const int t,
+                                                  const int u, const int Tb, const int Ub, const int half) {
     const LossParams &p = jp.lp;
     float x[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {  // registers 4g .. 4g+3 are the four consecutive symbols 8g + 4 half + 0..3
         const float4 bh = *(const float4 *)(jp.b2s + 8 * g + 4 * half), bl = *(const float4 *)(jp.b2s + 32 + 8 * g + 4 * half);
-        x[4 * g + 0] = fmaf(acc[4 * g + 0], -2.0f, bh.x) + bl.x;
-        x[4 * g + 1] = fmaf(acc[4 * g + 1], -2.0f, bh.y) + bl.y;
-        x[4 * g + 2] = fmaf(acc[4 * g + 2], -2.0f, bh.z) + bl.z;
-        x[4 * g + 3] = fmaf(acc[4 * g + 3], -2.0f, bh.w) + bl.w;
+        x[4 * g + 0] = fmaf(acc[4 * g + 0], m2inv, bh.x) + bl.x;
+        x[4 * g + 1] = fmaf(acc[4 * g + 1], m2inv, bh.y) + bl.y;
+        x[4 * g + 2] = fmaf(acc[4 * g + 2], m2inv, bh.z) + bl.z;
+        x[4 * g + 3] = fmaf(acc[4 * g + 3], m2inv, bh.w) + bl.w;
     }
     float m = x[0];
 #pragma unroll
@@ -693,17 +564,26 @@ __device__ __forceinline__ void fwd_row_epilogue(const JointParams &jp, const f3
     }
     xb = half_swap_max(xb);
     xl = half_swap_max(xl);
+    float stat = 0.f;
     if (u < Ub) {
         const size_t c = ((size_t)(b * p.T + t)) * p.U + u;
         if (half == 0) {
-            const float lg2s = jlg2(ssum);
+            const float inv = __builtin_amdgcn_rcpf(ssum);
             const bool blank_stays = (t < Tb - 1) || (u == Ub - 1);
-            const float ob = blank_stays ? fmaf(xb - m, kLog2e, -lg2s) : kNeg;
-            const float ol = (u < Ub - 1) ? fmaf(xl - m, kLog2e, -lg2s) : kNeg;
-            p.lse[c] = m + kLn2 * lg2s;
+            float pb = 0.f, pl = 0.f;
+            if (blank_stays) {
+                pb = jex2(fmaf(xb, kLog2e, nml)) * inv;
+                if (!(pb >= kTinyEdge)) pb = NAN;  // (also a NaN logit): not representable on the linear lattice
+            }
+            if (u < Ub - 1) {
+                pl = jex2(fmaf(xl, kLog2e, nml)) * inv;
+                if (!(pl >= kTinyEdge)) pl = NAN;
+            }
+            p.lse[c] = m + kLn2 * jlg2(ssum);
             const size_t wi = ((size_t)b * p.Nr + (t + u)) * p.Up + u;
-            ((float2 *)p.W)[wi] = make_float2(ob, ol);
+            ((float2 *)p.W)[wi] = make_float2(pb, pl);
             jp.xbl[c] = make_float2(xb, xl);  // what the backward's per-cell records need of the logits tile (8 of its 128 bytes)
+            stat = (pb != pb || pl != pl) ? 200.f : -jlg2(fmaxf(fmaxf(pb, pl), 1.0e-37f));
         }
         // park the logits (bias included): registers 4g .. 4g+3 are the four consecutive symbols 8g + 4 half + 0..3
         float *dst = jp.dl + c * 32 + 4 * half;
@@ -711,6 +591,18 @@ __device__ __forceinline__ void fwd_row_epilogue(const JointParams &jp, const f3
         for (int g = 0; g < 4; ++g)
             *(float4 *)(dst + 8 * g) = make_float4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
     }
+    return stat;
+}
+
+// {sum of the decay statistic, cells} of one wave's row pair -> its slot of the utterance's statistic table (what the linear
+// sweeps choose their frame-block length from: rnnt_lin.h; slot = u-tile * ceil(T / 2) + row pair, LossParams::pstatStride 1)
+__device__ __forceinline__ void fwd_put_stat(const JointParams &jp, const int b, const int ut, const int t0, float stat, float cnt,
+                                             const int lane) {
+    const LossParams &p = jp.lp;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) stat += __shfl_xor(stat, off), cnt += __shfl_xor(cnt, off);
+    if (lane == 0 && t0 < p.T)
+        p.pstat[(size_t)b * p.nPstat + (size_t)ut * ((p.T + 1) >> 1) + (t0 >> 1)] = make_float2(stat, cnt);
 }
 
 __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointParams jp) {
@@ -719,8 +611,10 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
     const int J = jp.J, V = p.V;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (jp.tflag[1] != 0.f) return;  // some |W2| outside the binary16 range: joint_phase1_kernel (plain f32 MFMAs) runs instead
     const bool slow = jp.tflag[0] != 0.f;  // kernel-uniform
+    // the W2 image holds s2 W2.  r form: logits = (b2 + sum_j W2) - (2 / s2) acc;  h form (huge weights): logits = b2 + acc / s2
+    const bool hform = jp.tflag[1] != 0.f;  // kernel-uniform
+    const float m2inv = hform ? jp.tflag[2] : -2.0f * jp.tflag[2];
     const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
     char *Ct = (char *)lds;                 // [32 u][J] floats, 16-byte chunk c of row u stored at chunk c ^ (u & 15)
     char *Wimg = Ct + (size_t)J * 128;      // [J/16][hi, lo][64 lanes][16 B]
@@ -748,7 +642,11 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
         const int u0 = ut * 32;
         const int Tb = length_T(p, b), Ub = length_U(p, b);
         const int t_begin = tr * kFwdRows, t_end = min(min(t_begin + kFwdRows, p.T), Tb);
-        if (t_begin >= t_end || u0 >= Ub) continue;  // workgroup-uniform
+        const int t0 = t_begin + 2 * wave;
+        if (t_begin >= t_end || u0 >= Ub) {  // workgroup-uniform: no lattice cell here -- the statistic slots still get their zeros
+            fwd_put_stat(jp, b, ut, t0, 0.f, 0.f, lane);
+            continue;
+        }
         const int u = u0 + l31;
         if (ct_owner != bu) {
             ct_owner = bu;
@@ -768,8 +666,10 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        const int t0 = t_begin + 2 * wave;
-        if (t0 >= t_end) continue;  // wave-uniform (no barrier below)
+        if (t0 >= t_end) {  // wave-uniform (no barrier below)
+            fwd_put_stat(jp, b, ut, t0, 0.f, 0.f, lane);
+            continue;
+        }
         const bool two = t0 + 1 < t_end;  // wave-uniform
         const float *e0 = Etab + ((size_t)b * p.T + t0) * J;
         const float *e1 = two ? e0 + J : e0;
@@ -777,26 +677,37 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
         const char *ct_row = Ct + (size_t)ct_lane * 16, *wlane = Wimg + lane * 16;
-        if (!slow)
-            fwd_row_pair<false>(J, e0, e1, ct_row, ct_swz, wlane, half, lane, acc0, acc1);
-        else
-            fwd_row_pair<true>(J, e0, e1, ct_row, ct_swz, wlane, half, lane, acc0, acc1);
-        fwd_row_epilogue(jp, acc0, rsel_b, rsel_l, b, t0, u, Tb, Ub, half);
-        if (two) fwd_row_epilogue(jp, acc1, rsel_b, rsel_l, b, t0 + 1, u, Tb, Ub, half);
+        if (hform) {  // (kernel-uniform branches: four straight-line instantiations of the product loop)
+            if (!slow)
+                fwd_row_pair<false, true>(J, e0, e1, ct_row, ct_swz, wlane, half, lane, acc0, acc1);
+            else
+                fwd_row_pair<true, true>(J, e0, e1, ct_row, ct_swz, wlane, half, lane, acc0, acc1);
+        } else if (!slow) {
+            fwd_row_pair<false, false>(J, e0, e1, ct_row, ct_swz, wlane, half, lane, acc0, acc1);
+        } else {
+            fwd_row_pair<true, false>(J, e0, e1, ct_row, ct_swz, wlane, half, lane, acc0, acc1);
+        }
+        float stat = fwd_row_epilogue(jp, acc0, m2inv, rsel_b, rsel_l, b, t0, u, Tb, Ub, half);
+        float cnt = (half == 0 && u < Ub) ? 1.f : 0.f;
+        if (two) {
+            stat += fwd_row_epilogue(jp, acc1, m2inv, rsel_b, rsel_l, b, t0 + 1, u, Tb, Ub, half);
+            cnt += cnt;
+        }
+        fwd_put_stat(jp, b, ut, t0, stat, cnt, lane);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward, step 1: dlogits from the parked logits tile (one lattice cell per lane, 128 B in / 128 B out, in place)
-// plus this workgroup's share of db2 = sum_cells dl.  Replaces a second run of phase 1.
+// backward of the WIDE joint (640 < J <= 704), step 1: dlogits from the parked logits tile (one lattice cell per lane, 128 B
+// in / 128 B out) plus this workgroup's share of db2 = sum_cells dl.  Replaces a second run of phase 1.
 // ---------------------------------------------------------------------------------------------
 constexpr int kDlChunks = 8;  // 256-cell chunks per workgroup (fewer, fatter db2 partials)
 
-__device__ __forceinline__ void joint_dl_kernel_body(const JointParams &jp, const unsigned block_id) {
+__global__ __launch_bounds__(256) void joint_dl_kernel(const JointParams jp) {
     __shared__ float red[256][33];
     const LossParams &p = jp.lp;
     const int V = p.V, tid = threadIdx.x;
-    if (jp.single_bwd && jp.tflag[1] == 0.f) return;  // joint_bwd_kernel forms dlogits itself
+    const unsigned block_id = blockIdx.x;
     float colsum[32];
 #pragma unroll
     for (int v = 0; v < 32; ++v) colsum[v] = 0.f;
@@ -870,198 +781,10 @@ __device__ __forceinline__ void joint_dl_kernel_body(const JointParams &jp, cons
         jp.dbpart[(size_t)block_id * 32 + tid] = s;
     }
 }
-// The launch: a FEW workgroups that walk the body's block indices (this kernel is the fallback of its faster twin and exits on
-// the workspace's range flag in every ordinary call: a full grid of workgroups that start only to return cost 4.9 us each).
-__global__ __launch_bounds__(256) void joint_dl_kernel(const JointParams jp, const unsigned n_blocks) {
-    if (jp.single_bwd && jp.tflag[1] == 0.f) return;  // joint_bwd_kernel forms dlogits itself
-    for (unsigned bid = blockIdx.x; bid < n_blocks; bid += gridDim.x) {
-        joint_dl_kernel_body(jp, bid);
-        __syncthreads();  // the next block's LDS image must not overtake this block's readers
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// phase 2: block = (utterance, u-tile, 64-wide J slab, row split); one lattice row per wave per iteration.
-// LDS: Cs [64 j][36] (32 u + pad) | W2s [64 j][33] | dlr [4][32 u][33] | red [4][32][33]
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void joint_phase2_kernel_body(const JointParams &jp, const unsigned block_id) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const LossParams &p = jp.lp;
-    const int J = jp.J, V = p.V;
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int kCs = 36;                     // row stride of Cs: 16-byte aligned and conflict-free for b128 reads
-    float *Cs = lds;                            // [64][kCs]
-    float *W2s = Cs + 64 * kCs;                 // [64][kStagePad]
-    float *dlr = W2s + 64 * kStagePad;          // [4][32][kStagePad]
-    float *red = dlr + 4 * 32 * kStagePad;      // [4][32][kStagePad]
-    float *my_dl = dlr + wave * 32 * kStagePad;
-    if (jp.tflag[1] == 0.f) return;  // joint_phase2s_kernel does this launch's work
-    const bool slow = jp.tflag[0] != 0.f;  // kernel-uniform
-    const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
-
-    int bid = block_id;
-    const int ts = bid % jp.n_ts;
-    bid /= jp.n_ts;
-    const int js = bid % (J / 64);
-    bid /= (J / 64);
-    const int ut = bid % jp.n_ut;
-    const int b = bid / jp.n_ut;
-    const int u0 = ut * 32, j0 = js * 64;
-    const int Tb = length_T(p, b), Ub = length_U(p, b);
-    const int t_begin = ts * jp.TS, t_end = min(min(t_begin + jp.TS, p.T), Tb);
-    const bool tile_live = (t_begin < t_end) && (u0 < Ub);
-
-    f32x16 accC[2], accW[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accC[q][r] = 0.f, accW[q][r] = 0.f;
-
-    if (tile_live) {
-        for (int idx = tid; idx < 32 * 16; idx += 256) {  // C slab, transposed: Cs[j][u]
-            const int u = idx & 31, j4 = idx >> 5;
-            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u0 + u < p.U) c4 = *(const float4 *)(Ptab + ((size_t)b * p.U + u0 + u) * J + j0 + j4 * 4);
-            Cs[(j4 * 4 + 0) * kCs + u] = c4.x;
-            Cs[(j4 * 4 + 1) * kCs + u] = c4.y;
-            Cs[(j4 * 4 + 2) * kCs + u] = c4.z;
-            Cs[(j4 * 4 + 3) * kCs + u] = c4.w;
-        }
-        for (int e = tid; e < 64 * 32; e += 256) {  // W2 slab [64 j][32 v], zero-padded beyond V
-            const int jj = e >> 5, v = e & 31;
-            W2s[jj * kStagePad + v] = (v < V) ? jp.W2[(size_t)(j0 + jj) * V + v] : 0.f;
-        }
-    }
-    __syncthreads();
-
-    // B-operands of dh = dl . W2^T do not depend on the row: W2[j0 + jt*32 + l31][2s + half], 16 per J tile
-    float w2op[2][16];
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int sidx = 0; sidx < 16; ++sidx) w2op[jt][sidx] = W2s[(jt * 32 + l31) * kStagePad + 2 * sidx + half];
-    const int n_iter = tile_live ? (t_end - t_begin + 3) / 4 : 0;
-    // this wave's dlogits tile of row t: 1024 floats = 16 per lane, fetched one row ahead into registers
-    auto dl_fetch = [&](const int t, float (&d)[16]) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int e = lane + q * 64, uu = e >> 5, v = e & 31;
-            d[q] = (t < t_end && u0 + uu < p.U) ? jp.dlg[(((size_t)(b * p.T + t)) * p.U + u0 + uu) * 32 + v] : 0.f;
-        }
-    };
-    float dnext[16];
-    if (n_iter > 0) dl_fetch(t_begin + wave, dnext);
-#ifdef JH_TRACE
-    long long *trc = (block_id == 3001) ? jp.trace + 512 + wave * 64 : nullptr;
-#endif
-    for (int it = 0; it < n_iter; ++it) {
-        const int t = t_begin + it * 4 + wave;
-        if (it < 20) JT1(3 * it);
-        if (t < t_end) {  // wave-uniform; no workgroup barrier inside: the dl row buffer is wave-private
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int e = lane + q * 64;
-                my_dl[(e >> 5) * kStagePad + (e & 31)] = dnext[q];
-            }
-            dl_fetch(t + 4, dnext);  // next row of this wave: latency hides under this row's MFMAs
-            if (it < 20) JT1(3 * it + 1);
-            const float *arow = Etab + ((size_t)b * p.T + t) * J + j0;
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt) {
-                // h tile in C/D layout: rows = lattice columns u, column = joint unit j = jt*32 + l31
-                const float aj = arow[jt * 32 + l31];
-                float h[16];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 c4 = *(const float4 *)(Cs + (jt * 32 + l31) * kCs + 8 * g + 4 * half);
-                    if (!slow) {
-                        h[4 * g + 0] = tanh_from_exp(aj, c4.x);
-                        h[4 * g + 1] = tanh_from_exp(aj, c4.y);
-                        h[4 * g + 2] = tanh_from_exp(aj, c4.z);
-                        h[4 * g + 3] = tanh_from_exp(aj, c4.w);
-                    } else {
-                        h[4 * g + 0] = fast_tanh(aj + c4.x);
-                        h[4 * g + 1] = fast_tanh(aj + c4.y);
-                        h[4 * g + 2] = fast_tanh(aj + c4.z);
-                        h[4 * g + 3] = fast_tanh(aj + c4.w);
-                    }
-                }
-                // dh[u][j] = sum_v dl[u][v] * W2[j][v]
-                f32x16 dh;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dh[r] = 0.f;
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int v = 2 * s + half;
-                    dh = __builtin_amdgcn_mfma_f32_32x32x2f32(my_dl[l31 * kStagePad + v], w2op[jt][s], dh, 0, 0, 0);
-                }
-                // dz = dh * (1 - h^2);  sum over u -> d enc_proj partial;  running sum over t -> d pred_proj
-                float colsum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float dz = dh[r] * (1.0f - h[r] * h[r]);
-                    accC[jt][r] += dz;
-                    colsum += dz;
-                }
-                colsum += __shfl_xor(colsum, 32);
-                if (lane < 32)
-                    jp.dApart[(((size_t)ut * p.B + b) * p.T + t) * J + j0 + jt * 32 + lane] = colsum;
-                // dW2[j][v] += sum_u h[u][j] * dl[u][v]   (K-slot (s, half) <-> lattice column cd_row(s, half))
-#pragma unroll
-                for (int s = 0; s < 16; ++s)
-                    accW[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[s], my_dl[cd_row(s, half) * kStagePad + l31],
-                                                                    accW[jt], 0, 0, 0);
-            }
-        }
-    }
-    JT1(60);
-    // rows of this u-tile / J slab that no block visits (t >= T_b, or a dead tile) must read as zero
-    // in the partial buffers: they are zero-filled before the launch (launch_fill).
-
-    // ---- deterministic cross-wave reductions, then the partial buffers
-    if (!tile_live) return;
-    const int wid = (b * jp.n_ut + ut) * jp.n_ts + ts;
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-        // d pred_proj partial: accC[jt] is [u rows][j col]
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[(wave * 32 + cd_row(r, half)) * kStagePad + l31] = accC[jt][r];
-        __syncthreads();
-        for (int e = tid; e < 1024; e += 256) {
-            const int uu = e >> 5, j = e & 31;
-            float s = 0.f;
-            for (int w = 0; w < 4; ++w) s += red[(w * 32 + uu) * kStagePad + j];
-            if (u0 + uu < p.U) jp.dCpart[(((size_t)ts * p.B + b) * p.U + u0 + uu) * J + j0 + jt * 32 + j] = s;
-        }
-        // dW2 partial: accW[jt] is [j rows][v col]
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[(wave * 32 + cd_row(r, half)) * kStagePad + l31] = accW[jt][r];
-        __syncthreads();
-        for (int e = tid; e < 1024; e += 256) {
-            const int jj = e >> 5, v = e & 31;
-            float s = 0.f;
-            for (int w = 0; w < 4; ++w) s += red[(w * 32 + jj) * kStagePad + v];
-            jp.dWpart[((size_t)wid * J + j0 + jt * 32 + jj) * 32 + v] = s;
-        }
-    }
-}
-// The launch: a FEW workgroups that walk the body's block indices (this kernel is the fallback of its faster twin and exits on
-// the workspace's range flag in every ordinary call: a full grid of workgroups that start only to return cost 4.9 us each).
-__global__ __launch_bounds__(256) void joint_phase2_kernel(const JointParams jp, const unsigned n_blocks) {
-    if (jp.tflag[1] == 0.f) return;  // joint_phase2s_kernel / joint_bwd_kernel does this launch's work
-    for (unsigned bid = blockIdx.x; bid < n_blocks; bid += gridDim.x) {
-        joint_phase2_kernel_body(jp, bid);
-        __syncthreads();  // the next block's LDS image must not overtake this block's readers
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// phase 2, split-precision form (default): same block decomposition, partial buffers and reductions as
-// joint_phase2_kernel, with both products on v_mfma_f32_32x32x16_f16 and every operand as binary16 hi + lo parts
-// (three MFMAs per 16-wide k-step, see joint_phase1s_kernel):
+// phase 2 of the WIDE joint (640 < J <= 704; joint_bwd_kernel below is the default): block = (utterance, u-tile, 64-wide J slab,
+// row split), one lattice row per wave per iteration; both products on v_mfma_f32_32x32x16_f16 with every operand as binary16
+// hi + lo parts (three MFMAs per 16-wide k-step, see joint_phase1s_kernel):
 //   dh[u][j]   = sum_v dl[u][v] W2[j][v]   A = dl rows (k = v, 8 consecutive per lane), B = W2^T fragments kept in registers
 //   dW2[j][v] += sum_u h[u][j] dl[u][v]    A = h straight from the C/D layout of the h tile: the k-slots of a k-step are
 //                                          assigned to the lattice columns cd_row(8 ks + e, half), and dl is gathered in the
@@ -1085,8 +808,8 @@ __global__ __launch_bounds__(256, P2S_WG_PER_CU) void joint_phase2s_kernel(const
     float *red = dlr + 4 * 32 * kCs;            // [4][32][kStagePad]
     jh8 *wfrag = (jh8 *)(red + 4 * 32 * kStagePad);  // [jt 2][ks 2][hi, lo][64 lanes]: B fragments of dh (8 KB)
     float *my_dl = dlr + wave * 32 * kCs;
-    if (jp.tflag[1] != 0.f) return;  // joint_phase2_kernel (plain f32 MFMAs) runs instead
     const bool slow = jp.tflag[0] != 0.f;  // kernel-uniform
+    const float w2inv = jp.tflag[2], s2 = 1.0f / w2inv;  // W2 enters the products as s2 W2 (powers of two: exact)
     const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
 
     int bid = blockIdx.x;
@@ -1136,7 +859,7 @@ __global__ __launch_bounds__(256, P2S_WG_PER_CU) void joint_phase2s_kernel(const
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int v = 16 * ks + 8 * half + e;
-            w[e] = (v < V) ? jp.W2[(size_t)(j0 + jt * 32 + l31) * V + v] : 0.f;
+            w[e] = (v < V) ? jp.W2[(size_t)(j0 + jt * 32 + l31) * V + v] * s2 : 0.f;
         }
         jh8 hi, lo;
         split_h8(w, hi, lo);
@@ -1210,7 +933,7 @@ __global__ __launch_bounds__(256, P2S_WG_PER_CU) void joint_phase2s_kernel(const
                 float colsum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float dz = dh[r] * invS * (1.0f - h[r] * h[r]);
+                    const float dz = dh[r] * (invS * w2inv) * (1.0f - h[r] * h[r]);
                     accC[jt][r] += dz;
                     colsum += dz;
                 }
@@ -1229,7 +952,7 @@ __global__ __launch_bounds__(256, P2S_WG_PER_CU) void joint_phase2s_kernel(const
             }
         }
     }
-    // ---- deterministic cross-wave reductions, then the partial buffers (as in joint_phase2_kernel)
+    // ---- deterministic cross-wave reductions, then the partial buffers
     if (!tile_live) return;
     const int wid = (b * jp.n_ut + ut) * jp.n_ts + ts;
 #pragma unroll
@@ -1338,8 +1061,9 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
     const int J = jp.J, V = p.V;
     const int half = lane >> 5, l31 = lane & 31;
     const float *Ptab = SLOW ? jp.pred_proj : jp.expP;
+    const float w2inv = jp.tflag[2], s2 = 1.0f / w2inv;  // W2 enters the products as s2 W2 (joint_prep_kernel; powers of two: exact)
     // B fragments of dh = dl . W2^T for this wave's 32 joint units: lane (j = j0 + l31, half), k-step ks holds
-    // W2[j][16 ks + 8 half + 0..7] as binary16 hi + lo parts; row-independent, kept in registers
+    // s2 W2[j][16 ks + 8 half + 0..7] as binary16 hi + lo parts; row-independent, kept in registers
     jh8 wf[2][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -1347,7 +1071,7 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int v = 16 * ks + 8 * half + e;
-            w[e] = (v < V) ? jp.W2[(size_t)(j0 + l31) * V + v] : 0.f;
+            w[e] = (v < V) ? jp.W2[(size_t)(j0 + l31) * V + v] * s2 : 0.f;
         }
         split_h8(w, wf[ks][0], wf[ks][1]);
     }
@@ -1376,7 +1100,7 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
         for (int r = 0; r < 16; ++r) {
             const int u = cur_u0 + cd_row(r, half);
             if (u < p.U)
-                jp.dCpart[(((size_t)cur_slot * p.B + cur_b) * p.U + u) * J + j0 + l31] = poisoned ? NAN : accC[r] * invS;
+                jp.dCpart[(((size_t)cur_slot * p.B + cur_b) * p.U + u) * J + j0 + l31] = poisoned ? NAN : accC[r] * (invS * w2inv);
             accC[r] = 0.f;
         }
     };
@@ -1481,7 +1205,7 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
             colsum = half_swap_sum(colsum);
             BT(5);
             if (lane < 32)
-                jp.dApart[(((size_t)it.ut * p.B + it.b) * p.T + t) * J + j0 + lane] = poisoned ? NAN : colsum * invS;
+                jp.dApart[(((size_t)it.ut * p.B + it.b) * p.T + t) * J + j0 + lane] = poisoned ? NAN : colsum * (invS * w2inv);
         }
     }
     flush_C();
@@ -1493,17 +1217,68 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
 
 // Per-cell gradient set-up, once per lattice cell, by the whole chip in parallel (a chain of dependent gathers from the
 // diagonal-major lattice arrays: latency-bound for a single wave, so it is NOT done by the backward kernel's producers):
-//   rec[c] = { c0 = alpha + beta - ll - lse (log2 domain; add x log2e), sS = cost_scale S_b,
+//   rec[c] = { c0 = log2(alpha beta / L) - lse log2e (add x log2e: log2 of softmax x occupancy), sS = cost_scale S_b,
 //              corr_b, corr_l = the blank / label corrections, already scaled by sS }    lab[c] = label of the cell or -1
 // The producers of joint_bwd_kernel turn a row of these plus the parked logits into the dlogits fragments.
+// Round 5: the lattice is the LINEAR one (mantissas + integer frames, rnnt_lin.h) unless the utterance was handed back
+// (state word 2: log2 values + offsets, as before); on the linear lattice the kernel also evaluates the per-cell range
+// certificate and raises the utterance's flag (joint_redo_kernel then redoes it and rewrites its records).
 // Workgroup = a patch of 8 lattice rows x 32 columns.  The lattice state is diagonal-major (row n = t + u of the skewed
 // arrays): the patch touches 40 diagonals and, on each, a window of at most 10 consecutive columns -- staged through LDS with
 // window-contiguous loads (a lane-per-cell gather touches a different 64-byte sector for every lane: 4 x 64 sectors per wave).
+__device__ __forceinline__ void rec_from_log(const JointParams &jp, const CellGrad &g, const float2 xx, const float S, float4 &rec,
+                                             int &lab) {
+    const float sS = g.scale * S;
+    rec.x = g.c0, rec.y = sS;
+    if (g.has_blank_corr) rec.z = sS * jex2(fmaf(xx.x, kLog2e, g.nl) + g.cb);
+    if (g.has_label) lab = g.lab, rec.w = sS * jex2(fmaf(xx.y, kLog2e, g.nl) + g.cl);
+}
+// The same record from the linear lattice: ma = alpha^(t,u), mb = beta^(t,u), m_t1 = beta^(t+1,u), m_u1 = beta^(t,u+1) as
+// mantissas relative to the frame tables (the last two are only looked at where that neighbour exists).  Returns false when
+// the cell fails the range certificate (rnnt_lin.h lin_grad_setup: what a flush can have cost x the other side's mass, over the
+// likelihood, must stay below 2^kCertBits).
+__device__ __forceinline__ bool rec_from_lin(const LossParams &p, const Cell &cl, const uint32_t c, const float ma, const float mb,
+                                             const float m_t1, const float m_u1, const float2 xx, const float S, float4 &rec,
+                                             int &lab) {
+    const int n = cl.t + cl.u;
+    const int sh = p.lshift[cl.b];  // the block length the sweeps chose for this utterance
+    const int kc = n >> sh, kc1 = (n + 1) >> sh;
+    const int l0 = (int)fdiv((uint32_t)cl.u, p.divOG), l1 = (int)fdiv((uint32_t)cl.u + 1u, p.divOG);
+    const size_t tb = (size_t)cl.b * p.NCl * 64;
+    const int ea = p.EA[tb + (size_t)kc * 64 + l0], eb = p.EB[tb + (size_t)kc * 64 + l0];
+    const float mL = p.lik[4 * cl.b];
+    const int EL = ((const int *)p.lik)[4 * cl.b + 1];
+    const float scale = p.cost_scale ? p.cost_scale[cl.b] : 1.0f;
+    const float sS = scale * S;
+    const float nl = -p.lse[c] * kLog2e;
+    // alpha / L as (qa, base): mantissas may sit anywhere in the f32 range (a dragged frame), so split before multiplying
+    const int xa = frexp_e(ma), xb = frexp_e(mb);
+    const float qa = frexp_m(ma) * __builtin_amdgcn_rcpf(mL);
+    const int base = ea + xa - EL;
+    // log2 of the occupancy alpha beta / L: log2 of a mantissa product in [1/4, 2) plus an integer (-inf for a cell without mass)
+    rec.x = (jlg2(qa * frexp_m(mb)) + (float)(base + eb + xb)) + nl;
+    rec.y = sS;
+    if (cl.t < cl.Tb - 1) {
+        const float occ = ldexp_f(qa * frexp_m(m_t1), base + p.EB[tb + (size_t)kc1 * 64 + l0] + frexp_e(m_t1));
+        rec.z = sS * occ * jex2(fmaf(xx.x, kLog2e, nl));
+    } else if (cl.u == cl.Ub - 1) {
+        rec.z = sS * ldexp_f(qa, base) * jex2(fmaf(xx.x, kLog2e, nl));  // the terminal transition: beta of the virtual end node is 1
+    }
+    if (cl.u < cl.Ub - 1) {
+        lab = clamp_label(p.labels[(size_t)cl.b * (p.U - 1) + cl.u], p.V);
+        const float occ = ldexp_f(qa * frexp_m(m_u1), base + p.EB[tb + (size_t)kc1 * 64 + l1] + frexp_e(m_u1));
+        rec.w = sS * occ * jex2(fmaf(xx.y, kLog2e, nl));
+    }
+    int worst = ea + eb - 252 - EL;
+    if (mb != 0.f) worst = max(worst, ea - 126 + eb + xb - EL);
+    if (ma != 0.f) worst = max(worst, eb - 126 + ea + xa - EL);
+    return !(worst > kCertBits || !(ma <= FLT_MAX) || !(mb <= FLT_MAX) || !(ma >= 0.f) || !(mb >= 0.f));
+}
+
 constexpr int kRecRows = 8, kRecDiags = kRecRows + 32, kRecWin = 10;
 __global__ __launch_bounds__(256) void joint_cellrec_kernel(const JointParams jp) {
     __shared__ float As[kRecDiags][kRecWin], Bs[kRecDiags][kRecWin];
     const LossParams &p = jp.lp;
-    if (jp.tflag[1] != 0.f) return;  // joint_dl_kernel + joint_phase2_kernel (plain f32 MFMAs) run instead
     const int tid = threadIdx.x;
     const int n_tt = (p.T + kRecRows - 1) / kRecRows;
     int bid = blockIdx.x;
@@ -1514,6 +1289,7 @@ __global__ __launch_bounds__(256) void joint_cellrec_kernel(const JointParams jp
     const int t0 = tt * kRecRows, u0 = ut * 32;
     const int Tb = length_T(p, b), Ub = length_U(p, b);
     const bool live = (t0 < Tb) && (u0 < Ub);  // workgroup-uniform
+    const bool lin = !lin_skip(p, b);          // the utterance's lattice is in the linear format (workgroup-uniform)
     if (live) {
         const size_t base = (size_t)b * p.Nr;
         for (int e = tid; e < 2 * kRecDiags * kRecWin; e += 256) {
@@ -1538,17 +1314,64 @@ __global__ __launch_bounds__(256) void joint_cellrec_kernel(const JointParams jp
         const int w0 = max(0, n - kRecRows), w1 = max(0, n1 - kRecRows);
         float S, invS;
         bwd_scale(p, b, S, invS);
-        const CellGrad g = cell_grad_from(p, cl, c, As[n][cu - w0], Bs[n][cu - w0], Bs[n1][cu - w1], Bs[n1][cu + 1 - w1]);
         // blank / label logits from the forward kernel's compact copy (gathering them out of the parked tiles read two
         // sectors of every cell's 128-byte row: the whole 369 MB at C2 for 23 MB of payload)
         const float2 xx = jp.xbl[c];
-        const float sS = g.scale * S;
-        rec.x = g.c0, rec.y = sS;
-        if (g.has_blank_corr) rec.z = sS * jex2(fmaf(xx.x, kLog2e, g.nl) + g.cb);
-        if (g.has_label) lab = g.lab, rec.w = sS * jex2(fmaf(xx.y, kLog2e, g.nl) + g.cl);
+        if (lin) {
+            if (!rec_from_lin(p, cl, c, As[n][cu - w0], Bs[n][cu - w0], Bs[n1][cu - w1], Bs[n1][cu + 1 - w1], xx, S, rec, lab))
+                atomicOr(p.flags + 4 * b + kFlagG, 1);  // (rare) the utterance is redone in the log domain
+        } else {
+            const CellGrad g = cell_grad_from(p, cl, c, As[n][cu - w0], Bs[n][cu - w0], Bs[n1][cu - w1], Bs[n1][cu + 1 - w1]);
+            rec_from_log(jp, g, xx, S, rec, lab);
+        }
     }
     jp.rec[c] = rec;
     jp.reclab[c] = lab;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The hand-back of the fused joint (rnnt_redo.h; the loss op's is lin_redo_kernel): grid = utterances x team, a workgroup whose
+// utterance is fine reads its flag words and the two likelihoods and returns.  A flagged utterance (a sweep's flag, the two
+// likelihoods apart, the certificate of joint_cellrec_kernel) is redone in the log domain from its PARKED logits tile -- `q` is
+// the loss parameters with acts = the [cells][32] tile (pad symbols at -1e30: probability zero) -- and, when the backward
+// wants them, its per-cell records are rewritten from the log-domain lattice.  Its state word then says "log-domain lattice".
+// ---------------------------------------------------------------------------------------------
+template <int K, int G, int NB>
+__global__ __launch_bounds__(kRedoThreads) void joint_redo_kernel(const JointParams jp, const LossParams q, const int want_rec,
+                                                                  const int team) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const LossParams &p = jp.lp;
+    const int tid = threadIdx.x;
+    const int ub = (int)blockIdx.x / team;
+    const int b = p.b0 + ub;
+    RedoTeam tm;
+    tm.k = (int)blockIdx.x - ub * team, tm.n = team, tm.bar = p.bar + b, tm.ok = true;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const i32x4 fw = __builtin_nontemporal_load((const i32x4 *)(p.flags + 4 * b));
+    const f64x2 lw = __builtin_nontemporal_load((const f64x2 *)(p.ll + 2 * b));
+    if (fw[kFlagState] == 2) return;  // already redone (its records come from joint_cellrec_kernel's log-domain branch)
+    const bool agree = fabs(lw[0] - lw[1]) * 0.6931471805599453 <= 2e-5 + 1e-8 * fabs(lw[0]);
+    if ((fw[kFlagA] | fw[kFlagB] | fw[kFlagG]) == 0 && agree) return;
+    redo_lattice<K, G, NB>(q, b, tm, lds, tid);
+    if (!tm.ok && q.costs && tm.k == 0 && tid == 0) st_f32_wt(q.costs + b, NAN);
+    if (!want_rec) return;
+    uint32_t lo, hi;
+    redo_cell_range(p, b, tm, lo, hi);
+    float S, invS;
+    bwd_scale(p, b, S, invS);
+    for (uint32_t c = lo + (uint32_t)tid; c < hi; c += kRedoThreads) {
+        const Cell cl = decode(p, c);
+        float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+        int lab = -1;
+        if (cl.valid) {
+            const CellGrad g = cell_grad_setup<true>(p, cl, c);
+            rec_from_log(jp, g, jp.xbl[c], S, rec, lab);
+            if (!tm.ok) rec.x = NAN;
+        }
+        jp.rec[c] = rec;
+        jp.reclab[c] = lab;
+    }
 }
 
 // dlogits fragments of one lattice row tile (32 cells x 32 symbols), 8 KB: pieces 0..3 = A fragments of dh ([ks][hi, lo],
@@ -1721,7 +1544,6 @@ __global__ __launch_bounds__(768) void joint_bwd_kernel(const JointParams jp) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_groups = (jp.J / 32 + kBwdMaxCons - 1) / kBwdMaxCons;
     const int n_cons = jp.J / 32 / n_groups;
-    if (jp.tflag[1] != 0.f) return;  // joint_dl_kernel + joint_phase2_kernel (plain f32 MFMAs) run instead
     const bool slow = jp.tflag[0] != 0.f;  // kernel-uniform
     char *ring = (char *)lds;                                    // [kBwdRing][10 KB] dlogits fragments + enc addends of a row
     float *scratch = (float *)(ring + kBwdRing * kBwdSlotBytes); // [2 producers][32 cells][8]
@@ -1755,7 +1577,7 @@ __device__ __forceinline__ unsigned absbits4(const float4 v) {
     return max(max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu),
                max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu));
 }
-__device__ __forceinline__ void store_block_max(unsigned m, unsigned *blockmax) {
+__device__ __forceinline__ void store_block_max(unsigned m, unsigned *slot) {  // slot = this block's entry
     __shared__ unsigned red[4];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
@@ -1763,24 +1585,18 @@ __device__ __forceinline__ void store_block_max(unsigned m, unsigned *blockmax) 
     __syncthreads();
     // (write-through: the consumer's loads are agent-scope too, dense_kernels.hip dense_max_of)
     if (threadIdx.x == 0)
-        __hip_atomic_store(blockmax + blockIdx.x, max(max(red[0], red[1]), max(red[2], red[3])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot, max(max(red[0], red[1]), max(red[2], red[3])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// out[i] = sum_p in[p*n + i]  (fixed order)
-// `flag` (nullable): when flag[1] != 0 the fallback kernels produced the partials and there are `nparts_fb` of them
-// `blockmax` (nullable): [gridDim.x] abs-max bit patterns of the block's outputs
-__global__ __launch_bounds__(256) void reduce_partials_kernel(float *out, const float *in, int nparts, size_t n,
-                                                              const float *flag = nullptr, int nparts_fb = 0,
-                                                              unsigned *blockmax = nullptr, int need_state = 0) {
-    if (flag && flag[1] != 0.f) nparts = nparts_fb;
-    // a backward-only call that trusted the workspace (prep_mode 2) on a workspace some other call has touched since: NaN, loudly
-    const float poison = (need_state && flag && flag[3] != 1.0f) ? NAN : 0.f;
+// Block `blk` of `nblk` of: out[i] = poison + sum_q in[q*n + i]  (fixed order q = 0, 1, ...: deterministic; 16-byte accesses, up
+// to four partials in flight per thread).  `bmslot` (nullable): where this block's abs-max bit pattern goes.
+__device__ __forceinline__ void reduce_partials_body(float *out, const float *in, const int nparts, const size_t n, const unsigned blk,
+                                                     const unsigned nblk, unsigned *bmslot, const float poison) {
     unsigned bm = 0u;
-    // fixed order q = 0, 1, ... for every element (deterministic); 16-byte accesses, up to four partials in flight per thread
     if ((n & 3) == 0 && (((uintptr_t)out | (uintptr_t)in) & 15) == 0) {
         const size_t n4 = n >> 2;
         const float4 *in4 = (const float4 *)in;
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        for (size_t i = (size_t)blk * 256 + threadIdx.x; i < n4; i += (size_t)nblk * 256) {
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
             int q = 0;
             for (; q + 4 <= nparts; q += 4) {
@@ -1797,42 +1613,47 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(float *out, const 
             ((float4 *)out)[i] = s;
             bm = max(bm, absbits4(s));
         }
-        if (blockmax) store_block_max(bm, blockmax);
+        if (bmslot) store_block_max(bm, bmslot);
         return;
     }
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    for (size_t i = (size_t)blk * 256 + threadIdx.x; i < n; i += (size_t)nblk * 256) {
         float s = 0.f;
         for (int q = 0; q < nparts; ++q) s += in[(size_t)q * n + i];
         s += poison;
         out[i] = s;
         bm = max(bm, __float_as_uint(s) & 0x7fffffffu);
     }
-    if (blockmax) store_block_max(bm, blockmax);
+    if (bmslot) store_block_max(bm, bmslot);
 }
+__global__ __launch_bounds__(256) void reduce_partials_kernel(float *out, const float *in, int nparts, size_t n, unsigned *blockmax) {
+    reduce_partials_body(out, in, nparts, n, blockIdx.x, gridDim.x, blockmax ? blockmax + blockIdx.x : nullptr, 0.f);
+}
+
 // d enc_proj[b][t][:] = sum over the u-tiles of their partial rows, in u-tile order.  Every backward kernel writes the row
 // (ut, b, t) exactly when the u-tile starts inside the utterance's label range and t < T_b, and never otherwise: the reduction
 // reads only those rows (and writes zeros for t >= T_b), so the 4 n_ut B T J bytes of partials need no zero-fill.
-__global__ __launch_bounds__(256) void reduce_enc_kernel(float *out, const float *in, int n_ut, const LossParams p, int J,
-                                                         unsigned *blockmax = nullptr) {
+__device__ __forceinline__ void reduce_enc_body(float *out, const float *in, const int n_ut, const LossParams &p, const int J,
+                                                const unsigned blk, const unsigned nblk, unsigned *bmslot, const float poison) {
     const uint32_t J4 = (uint32_t)J >> 2, n4 = (uint32_t)p.B * (uint32_t)p.T * J4;
     const float4 *in4 = (const float4 *)in;
     unsigned bm = 0u;
     if (((uintptr_t)out & 15) != 0) {  // a caller's gradient buffer off the 16-byte grid (the partials are workspace: aligned)
         const uint32_t n = n4 * 4u;
-        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        for (uint32_t i = blk * 256u + threadIdx.x; i < n; i += nblk * 256u) {
             const uint32_t row = i / (uint32_t)J, b = row / (uint32_t)p.T, t = row - b * (uint32_t)p.T;
             float s = 0.f;
             if ((int)t < length_T(p, (int)b)) {
                 const int nv = min(n_ut, (length_U(p, (int)b) + 31) >> 5);
                 for (int q = 0; q < nv; ++q) s += in[(size_t)q * n + i];
             }
+            s += poison;
             out[i] = s;
             bm = max(bm, __float_as_uint(s) & 0x7fffffffu);
         }
-        if (blockmax) store_block_max(bm, blockmax);
+        if (bmslot) store_block_max(bm, bmslot);
         return;
     }
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+    for (uint32_t i = blk * 256u + threadIdx.x; i < n4; i += nblk * 256u) {
         const uint32_t row = i / J4, b = row / (uint32_t)p.T, t = row - b * (uint32_t)p.T;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((int)t < length_T(p, (int)b)) {
@@ -1849,20 +1670,71 @@ __global__ __launch_bounds__(256) void reduce_enc_kernel(float *out, const float
                 s.x += a.x, s.y += a.y, s.z += a.z, s.w += a.w;
             }
         }
+        s.x += poison, s.y += poison, s.z += poison, s.w += poison;
         ((float4 *)out)[i] = s;
         bm = max(bm, absbits4(s));
     }
-    if (blockmax) store_block_max(bm, blockmax);
+    if (bmslot) store_block_max(bm, bmslot);
 }
-// Deterministic tree: out[i] = sum_p in[p*stride_p + map(i)], 256 threads = 32 outputs x 8 partial lanes.
+__global__ __launch_bounds__(256) void reduce_enc_kernel(float *out, const float *in, int n_ut, const LossParams p, int J,
+                                                         unsigned *blockmax) {
+    reduce_enc_body(out, in, n_ut, p, J, blockIdx.x, gridDim.x, blockmax ? blockmax + blockIdx.x : nullptr, 0.f);
+}
+
+// d pred_proj[b][u][:] from the partial slabs of joint_bwd_kernel: an (utterance, u-tile) is written by the workgroups of a J
+// group whose item ranges hold one of its live row tiles -- consecutive workgroups, slab index = distance from the first --
+// and by nobody when the u-tile starts beyond the utterance's labels.  The reduction recomputes that count from the item
+// partition (bwd_consumer's cur_slot) and reads only slabs that were written: the partial buffers need no zero-fill.
+__device__ __forceinline__ void reduce_pred_body(float *out, const float *in, const JointParams &jp, const unsigned blk,
+                                                 const unsigned nblk, unsigned *bmslot, const float poison) {
+    const LossParams &p = jp.lp;
+    const int J = jp.J;
+    const uint32_t n = (uint32_t)p.B * (uint32_t)p.U * (uint32_t)J;
+    const bool vec = (((uintptr_t)out) & 15) == 0;
+    const uint32_t step = vec ? 4u : 1u, nq = n / step, Jq = (uint32_t)J / step;
+    const int n_tr = (p.T + kBwdRows - 1) / kBwdRows;
+    const long long n_items = (long long)n_tr * p.B * jp.n_ut;
+    unsigned bm = 0u;
+    for (uint32_t i = blk * 256u + threadIdx.x; i < nq; i += nblk * 256u) {
+        const uint32_t row = i / Jq, b = row / (uint32_t)p.U, u = row - b * (uint32_t)p.U;
+        const int ut = (int)(u >> 5);
+        int ns = 0;
+        if (ut * 32 < length_U(p, (int)b)) {
+            const long long first = ((long long)b * jp.n_ut + ut) * n_tr;
+            const int n_live = (length_T(p, (int)b) + kBwdRows - 1) / kBwdRows;
+            const int blk_first = (int)(((first + 1) * jp.nblk - 1) / n_items);
+            const int blk_last = (int)(((first + n_live) * jp.nblk - 1) / n_items);
+            ns = min(blk_last - blk_first + 1, kBwdSlots);
+        }
+        if (vec) {
+            const float4 *in4 = (const float4 *)in;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < ns; ++q) {
+                const float4 a = in4[(size_t)q * nq + i];
+                s.x += a.x, s.y += a.y, s.z += a.z, s.w += a.w;
+            }
+            s.x += poison, s.y += poison, s.z += poison, s.w += poison;
+            ((float4 *)out)[i] = s;
+            bm = max(bm, absbits4(s));
+        } else {
+            float s = 0.f;
+            for (int q = 0; q < ns; ++q) s += in[(size_t)q * n + i];
+            s += poison;
+            out[i] = s;
+            bm = max(bm, __float_as_uint(s) & 0x7fffffffu);
+        }
+    }
+    if (bmslot) store_block_max(bm, bmslot);
+}
+
+// Deterministic tree: out[i] = poison + sum_p in[p*stride_p + map(i)], 256 threads = 32 outputs x 8 partial lanes.
 // Each partial lane sums its strided share in a fixed order, then the 8 lanes are combined in order.
 template <bool W2MAP>
-__global__ __launch_bounds__(256) void reduce_small_kernel(float *out, const float *in, int nparts, int n, int J, int V,
-                                                           const float *flag = nullptr, int nparts_fb = 0) {
+__device__ __forceinline__ void reduce_small_body(float *out, const float *in, const int nparts, const int n, const int J, const int V,
+                                                  const unsigned blk, const float poison) {
     __shared__ float sm[8][33];
-    if (flag && flag[1] != 0.f) nparts = nparts_fb;
     const int o = threadIdx.x & 31, pl = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + o;
+    const int i = (int)blk * 32 + o;
     float s = 0.f;
     if (i < n) {
         size_t base, stride;
@@ -1879,9 +1751,36 @@ __global__ __launch_bounds__(256) void reduce_small_kernel(float *out, const flo
     sm[pl][o] = s;
     __syncthreads();
     if (pl == 0 && i < n) {
-        float t = 0.f;
+        float t = poison;
         for (int k = 0; k < 8; ++k) t += sm[k][o];
         out[i] = t;
+    }
+}
+
+// All four outputs of the fused joint's backward in ONE launch (round 5; four launches before): blocks [0, kHookBlocks) d enc_proj,
+// [kHookBlocks, 2 kHookBlocks) d pred_proj, then ceil(J V / 32) blocks of dW2, then one block of db2.  `single`: the partials
+// come from joint_bwd_kernel (jp.nblk workgroups per J group), else from the wide joint's two-kernel backward (nC / nW / nDb
+// zero-filled partials).  A backward-only whole-network call on a workspace whose state word is not the forward's (need_state)
+// returns NaN in every output, loudly, instead of numbers from someone else's tables.
+__global__ __launch_bounds__(256) void joint_reduce_kernel(const JointParams jp, const int single, const int nC, const int nW,
+                                                           const int nDb, unsigned *dmax_enc, unsigned *dmax_pred) {
+    const LossParams &p = jp.lp;
+    const float poison = (jp.need_state && jp.tflag[3] != 1.0f) ? NAN : 0.f;
+    const unsigned blk = blockIdx.x;
+    const unsigned nWblk = (unsigned)(jp.J * p.V + 31) / 32u;
+    if (blk < (unsigned)kHookBlocks) {
+        reduce_enc_body(jp.d_enc_proj, jp.dApart, jp.n_ut, p, jp.J, blk, kHookBlocks, dmax_enc ? dmax_enc + blk : nullptr, poison);
+    } else if (blk < 2u * kHookBlocks) {
+        const unsigned k = blk - kHookBlocks;
+        if (single)
+            reduce_pred_body(jp.d_pred_proj, jp.dCpart, jp, k, kHookBlocks, dmax_pred ? dmax_pred + k : nullptr, poison);
+        else
+            reduce_partials_body(jp.d_pred_proj, jp.dCpart, nC, (size_t)p.B * p.U * jp.J, k, kHookBlocks,
+                                 dmax_pred ? dmax_pred + k : nullptr, poison);
+    } else if (blk < 2u * kHookBlocks + nWblk) {
+        reduce_small_body<true>(jp.dW2, jp.dWpart, single ? jp.nblk : nW, jp.J * p.V, jp.J, p.V, blk - 2u * kHookBlocks, poison);
+    } else {
+        reduce_small_body<false>(jp.db2, jp.dbpart, single ? 2 * jp.nblk : nDb, p.V, jp.J, p.V, 0u, poison);
     }
 }
 
@@ -1890,13 +1789,15 @@ __global__ __launch_bounds__(256) void reduce_small_kernel(float *out, const flo
 // ---------------------------------------------------------------------------------------------
 struct JointLayout {
     WsLayout w;
-    size_t dl, dlg, rec, reclab, xbl, dApart, dCpart, dWpart, dbpart, expE, expP, tflag, W2s, total;
-    int n_ut, TR, n_tr, TS, n_ts, nC, nW, nDb;
+    size_t dl, dlg, rec, reclab, xbl, dApart, dCpart, dWpart, dbpart, expE, expP, tflag, W2s, pstat, total;
+    int n_ut, TR, n_tr, TS, n_ts, nC, nW, nDb, nPstat;
+    bool wide;  // 640 < J <= 704: W2 streams through the LDS (joint_phase1s_kernel), two-kernel backward, log-domain sweeps
 };
 
 static JointLayout make_joint_layout(int T, int U, int B, int J) {
     JointLayout L;
     L.w = make_layout(T, U, B);
+    L.wide = (size_t)J * 256 > 160 * 1024;  // the forward's two resident tables no longer fit the LDS together
     L.n_ut = (U + 31) / 32;
     L.TR = 40;  // rows per phase-1 block (amortises the 128*J-byte C^T tile)
     L.n_tr = (T + L.TR - 1) / L.TR;
@@ -1910,17 +1811,17 @@ static JointLayout make_joint_layout(int T, int U, int B, int J) {
         return o;
     };
     L.dl = take((size_t)B * T * U * 32 * sizeof(float));
-    L.dlg = take((size_t)B * T * U * 32 * sizeof(float));  // touched only by the two-kernel backward (J outside the single-kernel domain, W2 outside binary16)
+    L.dlg = take(L.wide ? (size_t)B * T * U * 32 * sizeof(float) : 0);  // dlogits of the wide joint's two-kernel backward
     L.rec = take((size_t)B * T * U * sizeof(float4));
     L.reclab = take((size_t)B * T * U * sizeof(int));
     L.xbl = take((size_t)B * T * U * sizeof(float2));
     L.dApart = take((size_t)L.n_ut * B * T * J * sizeof(float));
-    // partial buffers are shared by the single-kernel backward and the two-kernel (f32 fallback / wide J) backward: sized for
-    // whichever needs more, zero-filled before every backward, and always reduced over the larger count
-    L.nC = L.n_ts > kBwdSlots ? L.n_ts : kBwdSlots;
-    L.nW = B * L.n_ut * L.n_ts > kBwdMaxBlocks ? B * L.n_ut * L.n_ts : kBwdMaxBlocks;
+    // partial buffers: what joint_bwd_kernel writes (kBwdSlots slabs of d pred_proj, one dW2 / two db2 partials per workgroup of a
+    // J group; no zero-fill: the reduction knows what exists), or what the wide joint's two-kernel backward writes (zero-filled)
     const size_t gdl = ((size_t)B * T * U + 256 * kDlChunks - 1) / (256 * kDlChunks);
-    L.nDb = (int)(gdl > 2 * (size_t)kBwdMaxBlocks ? gdl : 2 * (size_t)kBwdMaxBlocks);
+    L.nC = L.wide ? L.n_ts : kBwdSlots;
+    L.nW = L.wide ? B * L.n_ut * L.n_ts : kBwdMaxBlocks;
+    L.nDb = L.wide ? (int)gdl : 2 * kBwdMaxBlocks;
     L.dCpart = take((size_t)L.nC * B * U * J * sizeof(float));
     L.dWpart = take((size_t)L.nW * J * 32 * sizeof(float));
     L.dbpart = take((size_t)L.nDb * 32 * sizeof(float));
@@ -1928,11 +1829,11 @@ static JointLayout make_joint_layout(int T, int U, int B, int J) {
     L.expP = take((size_t)B * U * J * sizeof(float));
     L.tflag = take(512);  // flags (zeroed per call) + the b2s table
     L.W2s = take((size_t)J * 32 * 2 * sizeof(jf16));
+    L.nPstat = L.n_ut * ((T + 1) / 2);  // decay statistic of the forward kernel: one slot per (u-tile, row pair) (fwd_put_stat)
+    L.pstat = take((size_t)B * L.nPstat * sizeof(float2));
     L.total = off;
     return L;
 }
-
-constexpr unsigned kFallbackGrid = 512;  // workgroups of a fallback launch (two per CU when it does run)
 
 static bool joint_supported(int J, int V) {
     // J <= 704: the streaming forward (640 < J) keeps the whole C^T tile (128 J bytes), a row of enc_proj per wave (32 J) and
@@ -1959,7 +1860,7 @@ hipError_t launch_reduce_enc(float *out, const float *in, int n_ut, const LossPa
 hipError_t launch_reduce_partials(float *out, const float *in, int nparts, size_t n, hipStream_t s, unsigned *blockmax) {
     // (a consumer of `blockmax` reads kHookBlocks entries: the grid is then exactly that, whatever n is)
     const unsigned grid = blockmax ? (unsigned)kHookBlocks : (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, s, out, in, nparts, n, nullptr, 0, blockmax);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, s, out, in, nparts, n, blockmax);
     return hipGetLastError();
 }
 
@@ -1972,8 +1873,27 @@ hipError_t joint_aux_pointers(void *workspace, int T, int U, int B, int J, int V
     return hipSuccess;
 }
 
+// What every forward call of the f32-grade joint needs in front of its kernels, in ONE launch: the edge array pre-filled
+// (probability zero for the linear lattice; the finite "log zero" for the wide joint's log-domain sweeps) and the flag words
+// zeroed.  A caller that raises the table-range flag itself (the dense layer's epilogue, JointHooks::prep_mode 1) calls this
+// in front of its own launches and says so (JointHooks::prefilled).
+hipError_t launch_joint_prefill(void *workspace, int T, int U, int B, int J, int V, hipStream_t s) {
+    if (!joint_supported(J, V) || sweep_K(U) == 0) return hipErrorInvalidValue;
+    const JointLayout L = make_joint_layout(T, U, B, J);
+    char *ws = (char *)workspace;
+    return launch_fill2(ws + L.w.W, L.wide ? kFillByte : 0, L.w.A - L.w.W, ws + L.tflag, 0, 256, s);
+}
+
+// does the joint of the requested arithmetic take this shape?  (checked before anything is enqueued: the workspace layout is
+// chosen by the vocabulary -- the two domains are disjoint -- and must be the one the requested kernels expect)
+bool joint_dtype_supported(int joint_dtype, int J, int V) {
+    if (joint_dtype == 0) return joint_supported(J, V);
+    if (joint_dtype == 1) return V > 32 && joint_f16_supported(J, V);
+    return false;
+}
+
 hipError_t joint_workspace_bytes(int T, int U, int B, int J, int V, size_t *bytes) {
-    // the two joint paths have disjoint shape domains (V <= 32: f32 MFMA; V % 512 == 0: f16 MFMA), so the
+    // the two joint paths have disjoint shape domains (V <= 32: f32-grade; V % 128 == 0: f16 MFMA), so the
     // workspace query needs no dtype argument; it returns the size for whichever path accepts (J, V)
     if (V > 32) return joint_f16_workspace_bytes(T, U, B, J, V, bytes);
     if (!joint_supported(J, V) || sweep_K(U) == 0) return hipErrorInvalidValue;
@@ -2009,9 +1929,45 @@ __global__ __launch_bounds__(256) void joint_logits_copy_kernel(float *out, cons
     }
 }
 
-// Joint logits only (decoding: utils/decoding.py:6-18): the forward kernels of launch_joint_loss -- the same tables, the same
-// split-precision products, the same device-side choice between them -- with every lattice cell live; what they park in the
-// workspace is copied out as [B, T, U, V].
+// everything of JointParams that depends only on the workspace layout
+static void joint_bind(JointParams &jp, const JointLayout &L, char *ws) {
+    jp.dl = (float *)(ws + L.dl);
+    jp.dlg = (float *)(ws + L.dlg);
+    jp.rec = (float4 *)(ws + L.rec);
+    jp.reclab = (int *)(ws + L.reclab);
+    jp.xbl = (float2 *)(ws + L.xbl);
+    jp.dApart = (float *)(ws + L.dApart);
+    jp.dCpart = (float *)(ws + L.dCpart);
+    jp.dWpart = (float *)(ws + L.dWpart);
+    jp.dbpart = (float *)(ws + L.dbpart);
+    jp.expE = (float *)(ws + L.expE), jp.expP = (float *)(ws + L.expP), jp.tflag = (float *)(ws + L.tflag);
+    jp.b2s = jp.tflag + 64;
+    jp.W2s = (jf16 *)(ws + L.W2s);
+    jp.n_ut = L.n_ut, jp.TR = L.TR, jp.n_tr = L.n_tr, jp.TS = L.TS, jp.n_ts = L.n_ts;
+    jp.nblk = 0, jp.need_state = 0;
+    // the forward kernel's decay statistic (instead of the lsm launch's per-patch slots)
+    jp.lp.pstat = (float2 *)(ws + L.pstat), jp.lp.nPstat = L.nPstat, jp.lp.pstatStride = 1;
+}
+
+static hipError_t launch_joint_fwd(const JointParams &jp, const JointLayout &L, int B, int T, hipStream_t s) {
+    const int J = jp.J;
+    hipError_t e;
+    if (!L.wide) {
+        const size_t shm_fwd = (size_t)J * 256;  // Ct tile + W2 fragment image, both resident
+        if ((e = set_lds(joint_fwd_kernel, shm_fwd)) != hipSuccess) return e;
+        const int n_items = ((T + kFwdRows - 1) / kFwdRows) * B * L.n_ut;
+        const int ncu = device_cu_count();
+        hipLaunchKernelGGL(joint_fwd_kernel, dim3(n_items < ncu ? n_items : ncu), dim3(kFwdWaves * 64), shm_fwd, s, jp);
+    } else {  // J > 640: the two tables do not fit the LDS together; W2 streams through it in chunks instead
+        const size_t shm1s = (size_t)J * 32 * sizeof(float) + 2 * 8192 + (kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
+        if ((e = set_lds(joint_phase1s_kernel, shm1s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(joint_phase1s_kernel, dim3((unsigned)B * L.n_ut * L.n_tr), dim3(kP1Waves * 64), shm1s, s, jp);
+    }
+    return hipGetLastError();
+}
+
+// Joint logits only (decoding: utils/decoding.py:6-18): the forward kernel of launch_joint_loss -- the same tables, the same
+// split-precision products -- with every lattice cell live; what it parks in the workspace is copied out as [B, T, U, V].
 hipError_t launch_joint_logits(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2, int J, int V,
                                int B, int T, int U, float *logits, void *workspace, hipStream_t s) {
     if (!joint_supported(J, V) || sweep_K(U) == 0) return hipErrorInvalidValue;
@@ -2025,45 +1981,51 @@ hipError_t launch_joint_logits(const float *enc_proj, const float *pred_proj, co
     if (!fill_loss_params(jp.lp, nullptr, nullptr, labels, ll, il, nullptr, V, B, nullptr, workspace, T, U, 0))
         return hipErrorInvalidValue;
     jp.enc_proj = enc_proj, jp.pred_proj = pred_proj, jp.W2 = W2, jp.b2 = b2;
-    jp.dl = (float *)(ws + L.dl);
-    jp.dlg = (float *)(ws + L.dlg);
-    jp.rec = nullptr, jp.reclab = nullptr;
-    jp.xbl = (float2 *)(ws + L.xbl);
-    jp.dApart = jp.dCpart = jp.dWpart = jp.dbpart = nullptr;
+    jp.J = J;
+    joint_bind(jp, L, ws);
     jp.d_enc_proj = jp.d_pred_proj = jp.dW2 = jp.db2 = nullptr;
-    jp.expE = (float *)(ws + L.expE), jp.expP = (float *)(ws + L.expP), jp.tflag = (float *)(ws + L.tflag);
-    jp.b2s = jp.tflag + 64;
-    jp.W2s = (jf16 *)(ws + L.W2s);
 #ifdef JH_TRACE
     jp.trace = nullptr;
 #endif
-    jp.J = J, jp.n_ut = L.n_ut, jp.TR = L.TR, jp.n_tr = L.n_tr, jp.TS = L.TS, jp.n_ts = L.n_ts;
-    jp.logits_only = 1, jp.single_bwd = 0, jp.tables_ready = 0;
+    jp.logits_only = 1, jp.tables_ready = 0;
     hipError_t e;
-    if (launch_fill(jp.tflag, 0, 256, s) != hipSuccess) return hipErrorUnknown;
-    if (U > 1 && launch_fill(labels, 0, (size_t)B * (U - 1) * sizeof(int), s) != hipSuccess) return hipErrorUnknown;
+    if ((e = launch_fill2(jp.tflag, 0, 256, labels, 0, U > 1 ? (size_t)B * (U - 1) * sizeof(int) : 0, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(joint_prep_kernel, dim3(1024), dim3(256), 0, s, jp);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    const unsigned g1 = (unsigned)B * L.n_ut * L.n_tr;
-    const size_t shm_fwd = (size_t)J * 256;
-    if (shm_fwd <= 160 * 1024) {
-        if ((e = set_lds(joint_fwd_kernel, shm_fwd)) != hipSuccess) return e;
-        const int n_items = ((T + kFwdRows - 1) / kFwdRows) * B * L.n_ut;
-        const int ncu = device_cu_count();
-        hipLaunchKernelGGL(joint_fwd_kernel, dim3(n_items < ncu ? n_items : ncu), dim3(kFwdWaves * 64), shm_fwd, s, jp);
-    } else {
-        const size_t shm1s = (size_t)J * 32 * sizeof(float) + 2 * 8192 + (kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
-        if ((e = set_lds(joint_phase1s_kernel, shm1s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(joint_phase1s_kernel, dim3(g1), dim3(kP1Waves * 64), shm1s, s, jp);
-    }
-    const size_t shm1 = ((size_t)J * 32 + 2 * 1024 + kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
-    if ((e = set_lds(joint_phase1_kernel, shm1)) != hipSuccess) return e;
-    hipLaunchKernelGGL(joint_phase1_kernel, dim3(g1 < kFallbackGrid ? g1 : kFallbackGrid), dim3(kP1Waves * 64), shm1, s, jp, g1);  // exits at once unless W2 left binary16
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = launch_joint_fwd(jp, L, B, T, s)) != hipSuccess) return e;
     const size_t n = (size_t)jp.lp.cells * V;
     const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(joint_logits_copy_kernel, dim3(grid), dim3(256), 0, s, logits, jp.dl, jp.lp.cells, V);
     return hipGetLastError();
+}
+
+// the hand-back launch of the fused joint (joint_redo_kernel) with the chunk geometry of the utterance's sweeps
+template <int K, int G>
+static hipError_t launch_joint_redo_k(const JointParams &jp, const LossParams &q, const bool want_rec, hipStream_t s) {
+    constexpr int NB = ((size_t)4 * G * 2 * 64 * K * sizeof(float) + 16 <= 128 * 1024) ? 4 : 3;
+    constexpr size_t shm = (size_t)NB * G * 2 * 64 * K * sizeof(float) + 16;
+    hipError_t e = set_lds(joint_redo_kernel<K, G, NB>, shm);
+    if (e != hipSuccess) return e;
+    const int team = redo_team_size(jp.lp.nb, jp.lp.T, jp.lp.U);
+    hipLaunchKernelGGL((joint_redo_kernel<K, G, NB>), dim3(jp.lp.nb * team), dim3(kRedoThreads), shm, s, jp, q, want_rec ? 1 : 0, team);
+    return hipGetLastError();
+}
+static hipError_t launch_joint_redo(const JointParams &jp, const bool want_rec, hipStream_t s) {
+    // the loss parameters of the redo: the parked tile [cells][32] as the logits (pad symbols hold -1e30: probability zero)
+    LossParams q = jp.lp;
+    q.acts = jp.dl, q.grads = nullptr, q.V = 32;
+    q.divV = make_fastdiv(32u);
+    switch (sweep_K(jp.lp.U)) {
+        case 1: return launch_joint_redo_k<1, 16>(jp, q, want_rec, s);
+        case 2: return launch_joint_redo_k<2, 16>(jp, q, want_rec, s);
+        case 3: return launch_joint_redo_k<3, 16>(jp, q, want_rec, s);
+        case 4: return launch_joint_redo_k<4, 16>(jp, q, want_rec, s);
+        case 6: return launch_joint_redo_k<6, 8>(jp, q, want_rec, s);
+        case 8: return launch_joint_redo_k<8, 8>(jp, q, want_rec, s);
+        case 12: return launch_joint_redo_k<12, 4>(jp, q, want_rec, s);
+        case 16: return launch_joint_redo_k<16, 4>(jp, q, want_rec, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2,
@@ -2076,7 +2038,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     if (joint_dtype == 1)
         return launch_joint_loss_f16(enc_proj, pred_proj, W2, b2, labels, label_lengths, input_lengths, cost_scale, J, V,
                                      B, T, U, blank, costs, d_enc_proj, d_pred_proj, dW2, db2, phases, workspace, s, hooks);
-    if (!joint_supported(J, V) || joint_dtype != 0) return hipErrorInvalidValue;
+    if (!joint_supported(J, V) || joint_dtype != 0 || sweep_K(U) == 0) return hipErrorInvalidValue;
     if (((uintptr_t)enc_proj & 15) || ((uintptr_t)pred_proj & 15)) return hipErrorInvalidValue;
     // the reductions over the [B][T][J] / [B][U][J] arrays index with 32 bits (B*T*U < 2^31 alone does not bound B*T*J)
     if ((unsigned long long)B * T * J >= (1ull << 32) || (unsigned long long)B * U * J >= (1ull << 32)) return hipErrorInvalidValue;
@@ -2087,19 +2049,9 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
         return hipErrorInvalidValue;
     char *ws = (char *)workspace;
     jp.enc_proj = enc_proj, jp.pred_proj = pred_proj, jp.W2 = W2, jp.b2 = b2;
-    jp.dl = (float *)(ws + L.dl);
-    jp.dlg = (float *)(ws + L.dlg);
-    jp.rec = (float4 *)(ws + L.rec);
-    jp.reclab = (int *)(ws + L.reclab);
-    jp.xbl = (float2 *)(ws + L.xbl);
-    jp.dApart = (float *)(ws + L.dApart);
-    jp.dCpart = (float *)(ws + L.dCpart);
-    jp.dWpart = (float *)(ws + L.dWpart);
-    jp.dbpart = (float *)(ws + L.dbpart);
+    jp.J = J;
+    joint_bind(jp, L, ws);
     jp.d_enc_proj = d_enc_proj, jp.d_pred_proj = d_pred_proj, jp.dW2 = dW2, jp.db2 = db2;
-    jp.expE = (float *)(ws + L.expE), jp.expP = (float *)(ws + L.expP), jp.tflag = (float *)(ws + L.tflag);
-    jp.b2s = jp.tflag + 64;
-    jp.W2s = (jf16 *)(ws + L.W2s);
 #ifdef JH_TRACE
     static long long *trace_dev = nullptr;
     const size_t trace_bytes = 1024 * sizeof(long long);
@@ -2107,61 +2059,44 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     (void)hipMemsetAsync(trace_dev, 0, trace_bytes, s);
     jp.trace = trace_dev;
 #endif
-    jp.J = J, jp.n_ut = L.n_ut, jp.TR = L.TR, jp.n_tr = L.n_tr, jp.TS = L.TS, jp.n_ts = L.n_ts;
     jp.logits_only = 0;
     const int prep_mode = hooks ? hooks->prep_mode : 0;
     jp.tables_ready = prep_mode == 1;
+    jp.need_state = prep_mode == 2;
+    const bool fwd = (phases & 1) != 0, bwd = (phases & 2) != 0 && d_enc_proj != nullptr;
 
-    const size_t shm1 = ((size_t)J * 32 + 2 * 1024 + kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
-    const size_t shm2 = ((size_t)64 * 36 + 64 * kStagePad + 2 * 4 * 32 * kStagePad) * sizeof(float);
     hipError_t e;
-    if ((e = set_lds(joint_phase1_kernel, shm1)) != hipSuccess) return e;
-
-    const unsigned g1 = (unsigned)B * L.n_ut * L.n_tr;
+    // flag words (rebuilt by whichever phase runs the prep kernel) and, for a forward, the edge array's pre-fill: one launch
+    if (!(hooks && hooks->prefilled)) {
+        if (fwd)
+            e = launch_fill2(jp.lp.W, L.wide ? kFillByte : 0, L.w.A - L.w.W, jp.tflag, 0, prep_mode == 0 ? 256 : 0, s);
+        else
+            e = prep_mode == 0 ? launch_fill(jp.tflag, 0, 256, s) : hipSuccess;
+        if (e != hipSuccess) return e;
+    }
     // tanh tables + W2 images (rebuilt by whichever phase runs: the projections may have changed -- unless the caller vouches
     // for the workspace, JointHooks::prep_mode)
-    if (prep_mode == 0 && launch_fill(jp.tflag, 0, 256, s) != hipSuccess) return hipErrorUnknown;
     if (prep_mode != 2) hipLaunchKernelGGL(joint_prep_kernel, dim3(jp.tables_ready ? 64 : 1024), dim3(256), 0, s, jp);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (phases & 1) {
-        // forward: edge weights (W pre-filled with log zero) -> sweeps -> costs
-        if (launch_fill(jp.lp.W, kFillByte, L.w.A - L.w.W, s) != hipSuccess) return hipErrorUnknown;
-        // Both forms are enqueued; the prep kernel's range flag (tflag[1], device data) decides which one works and which one
-        // exits at once: split-precision f16 MFMAs whenever W2 fits binary16 hi + lo parts, plain f32 MFMAs otherwise.
-        const size_t shm_fwd = (size_t)J * 256;  // Ct tile + W2 fragment image, both resident
-        if (shm_fwd <= 160 * 1024) {
-            if ((e = set_lds(joint_fwd_kernel, shm_fwd)) != hipSuccess) return e;
-            const int n_items = ((T + kFwdRows - 1) / kFwdRows) * B * L.n_ut;
-            const int ncu = device_cu_count();
-            hipLaunchKernelGGL(joint_fwd_kernel, dim3(n_items < ncu ? n_items : ncu), dim3(kFwdWaves * 64), shm_fwd, s, jp);
-        } else {  // J > 640: the two tables do not fit the LDS together; W2 streams through it in chunks instead
-            const size_t shm1s = (size_t)J * 32 * sizeof(float) + 2 * 8192 + (kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
-            if ((e = set_lds(joint_phase1s_kernel, shm1s)) != hipSuccess) return e;
-            hipLaunchKernelGGL(joint_phase1s_kernel, dim3(g1), dim3(kP1Waves * 64), shm1s, s, jp);
+    if (fwd) {
+        if ((e = launch_joint_fwd(jp, L, B, T, s)) != hipSuccess) return e;
+        if (!L.wide) {
+            // the linear-domain lattice of the loss op (rnnt_lin.h: multiply / add sweeps on mantissas x 2^frame, 43 us at
+            // B32 T600 U150 where the float64 log-domain recurrence this path used before took 138), with its hand-back:
+            // in a forward-only call right here (costs), otherwise behind the backward's per-cell pass (certificate)
+            if ((e = launch_sweeps_lin(jp.lp, s)) != hipSuccess) return e;
+            if (!bwd && (e = launch_joint_redo(jp, false, s)) != hipSuccess) return e;
+        } else {
+            LossParams lpp = jp.lp;
+            lpp.precise = 1;  // f32-GRADE joint: the log-domain recurrence in float64 (rnnt_sweep.h alpha_sweep_pr)
+            if ((e = launch_sweeps(lpp, s)) != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(joint_phase1_kernel, dim3(g1 < kFallbackGrid ? g1 : kFallbackGrid), dim3(kP1Waves * 64), shm1, s, jp, g1);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        // f32-GRADE joint: the sweeps' recurrence in float64 too (rnnt_sweep.h alpha_sweep_pr) -- with float32 sweeps they, not the
-        // split-precision products, set this path's error under peaked logits (W2 x 10: 1.2e-4 relative -> 1.4e-6; W2 x 5: 2.9e-5 ->
-        // 1.0e-6) for +0.08 ms of a 2.1 ms step at B32 T600 U150.  (The f16 joint keeps the float32 sweeps: binary16 sets its error.)
-        LossParams lpp = jp.lp;
-        lpp.precise = 1;
-        if ((e = launch_sweeps(lpp, s)) != hipSuccess) return e;
     }
-    if (!(phases & 2) || !d_enc_proj) return hipSuccess;  // score only
+    if (!bwd) return hipSuccess;  // score only
 
-    // backward.  Partial buffers first: zero (rows / slots / workgroups a path does not write must read as zero)
-    // (the d enc_proj partials need none: reduce_enc_kernel knows which of their rows exist)
-    if (launch_fill(jp.dCpart, 0, (L.dbpart - L.dCpart) + (size_t)L.nDb * 32 * sizeof(float), s) != hipSuccess) return hipErrorUnknown;
-    const int n_groups = bwd_groups(J);
-    const bool single = (J / 32) % n_groups == 0 && J <= 640;  // consumers per group must come out even; LDS / wave budget
-    jp.single_bwd = single ? 1 : 0;
-    const unsigned gdl = (jp.lp.cells + 256u * kDlChunks - 1u) / (256u * kDlChunks);
-    hipLaunchKernelGGL(joint_dl_kernel, dim3(single ? (gdl < kFallbackGrid ? gdl : kFallbackGrid) : gdl), dim3(256), 0, s, jp, gdl);  // exits at once when joint_bwd_kernel does its work
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    const unsigned g2 = (unsigned)B * L.n_ut * (J / 64) * L.n_ts;
-    int bwd_nblk = 0;
-    if (single) {
+    int nC = 0, nW = 0, nDb = 0;
+    if (!L.wide) {
+        const int n_groups = bwd_groups(J);
         const int n_cons = J / 32 / n_groups;
         const int n_items = ((T + kBwdRows - 1) / kBwdRows) * B * L.n_ut;
         int nblk = device_cu_count() / n_groups;
@@ -2169,28 +2104,29 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
         if (nblk > n_items) nblk = n_items;
         if (nblk > kBwdMaxBlocks) nblk = kBwdMaxBlocks;
         if (nblk < 1) nblk = 1;
-        bwd_nblk = nblk;
+        jp.nblk = nblk;
         hipLaunchKernelGGL(joint_cellrec_kernel, dim3((unsigned)B * L.n_ut * ((T + kRecRows - 1) / kRecRows)), dim3(256), 0, s, jp);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = launch_joint_redo(jp, true, s)) != hipSuccess) return e;
         const size_t shm_bwd = (size_t)kBwdRing * kBwdSlotBytes + 2 * 32 * 8 * sizeof(float) + 2 * kBwdRing * sizeof(int);
         if ((e = set_lds(joint_bwd_kernel, shm_bwd)) != hipSuccess) return e;
         hipLaunchKernelGGL(joint_bwd_kernel, dim3(nblk * n_groups), dim3((n_cons + 2) * 64), shm_bwd, s, jp);
     } else {
+        // the wide joint: dlogits by their own kernel, then the block-per-tile products; partial buffers zero-filled (rows /
+        // workgroups that path does not write must read as zero; the d enc_proj partials need none)
+        if (launch_fill(jp.dCpart, 0, (L.dbpart - L.dCpart) + (size_t)L.nDb * 32 * sizeof(float), s) != hipSuccess) return hipErrorUnknown;
+        const unsigned gdl = (jp.lp.cells + 256u * kDlChunks - 1u) / (256u * kDlChunks);
+        hipLaunchKernelGGL(joint_dl_kernel, dim3(gdl), dim3(256), 0, s, jp);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        const unsigned g2 = (unsigned)B * L.n_ut * (J / 64) * L.n_ts;
         const size_t shm2s = ((size_t)64 * 36 + 4 * 32 * 36 + 4 * 32 * kStagePad) * sizeof(float) + 8192;
         hipLaunchKernelGGL(joint_phase2s_kernel, dim3(g2), dim3(256), shm2s, s, jp);
+        nC = L.n_ts, nW = B * L.n_ut * L.n_ts, nDb = (int)gdl;
     }
-    hipLaunchKernelGGL(joint_phase2_kernel, dim3(g2 < kFallbackGrid ? g2 : kFallbackGrid), dim3(256), shm2, s, jp, g2);  // exits at once unless tflag[1] is set
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    const size_t nC = (size_t)B * U * J;
-    // partial counts: what the single-kernel backward wrote, or (flag set / wide J) what the two-kernel backward wrote
-    const int nC_fb = L.n_ts, nW_fb = B * L.n_ut * L.n_ts, nDb_fb = (int)gdl;
-    const int nC_s = single ? kBwdSlots : nC_fb, nW_s = single ? bwd_nblk : nW_fb, nDb_s = single ? 2 * bwd_nblk : nDb_fb;
-    hipLaunchKernelGGL(reduce_enc_kernel, dim3(kHookBlocks), dim3(256), 0, s, d_enc_proj, jp.dApart, L.n_ut, jp.lp, J,
-                       hooks ? hooks->dmax_enc : (unsigned *)nullptr);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(kHookBlocks), dim3(256), 0, s, d_pred_proj, jp.dCpart, nC_s, nC, jp.tflag, nC_fb,
-                       hooks ? hooks->dmax_pred : (unsigned *)nullptr, prep_mode == 2 ? 1 : 0);
-    hipLaunchKernelGGL((reduce_small_kernel<true>), dim3((J * V + 31) / 32), dim3(256), 0, s, dW2, jp.dWpart, nW_s, J * V, J, V,
-                       jp.tflag, nW_fb);
-    hipLaunchKernelGGL((reduce_small_kernel<false>), dim3(1), dim3(256), 0, s, db2, jp.dbpart, nDb_s, V, J, V, jp.tflag, nDb_fb);
+    const unsigned nWblk = (unsigned)(J * V + 31) / 32u;
+    hipLaunchKernelGGL(joint_reduce_kernel, dim3(2u * kHookBlocks + nWblk + 1u), dim3(256), 0, s, jp, L.wide ? 0 : 1, nC, nW, nDb,
+                       hooks ? hooks->dmax_enc : (unsigned *)nullptr, hooks ? hooks->dmax_pred : (unsigned *)nullptr);
 #ifdef JH_TRACE
     {
         (void)hipStreamSynchronize(s);

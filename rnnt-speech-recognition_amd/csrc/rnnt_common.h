@@ -23,10 +23,7 @@ constexpr float kNeg = -1.0e30f;      // "log zero" that survives additions with
 constexpr float kNegTest = -1.0e29f;  // anything below this is "log zero"
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
-#ifndef RNNT_REBASE
-#define RNNT_REBASE 8
-#endif
-constexpr int kRebase = RNNT_REBASE;  // diagonals per precision block (alpha~/beta~ are re-based each block)
+constexpr int kRebase = 8;  // diagonals per precision block (alpha~/beta~ are re-based each block)
 
 // Unsigned division by a launch-constant for n < 2^31 (Granlund-Montgomery, add-shift form).
 struct FastDiv {
@@ -75,7 +72,9 @@ struct LossParams {
     int NCl;     // frame blocks per utterance (tables are [NCl][64])
     float2 *pstat;  // [B][nPstat]: per (patch, wave) of the lsm launch {sum of -log2 max(p_blank, p_label), cells}: how fast mass decays
     int *lshift;    // [B]: log2 of the diagonals per frame block the sweeps chose for the utterance (rnnt_lin.h)
+    int *bar;       // [B]: phase counter of the utterance's hand-back team (rnnt_redo.h), zeroed by the forward sweeps
     int nPstat;
+    int pstatStride;  // the sweeps sample slot pstatStride * i, i < nPstat / pstatStride (4: wave 0 of every patch of the lsm launch)
     int B, T, U, V, blank;
     int b0, nb;  // this launch covers utterances [b0, b0+nb)
     int precise;  // 1: the log-domain sweeps carry their recurrence in float64 (rnnt_sweep.h alpha_sweep_pr); lattices of 8+ columns per lane always do
@@ -86,7 +85,7 @@ struct LossParams {
 };
 
 struct WsLayout {
-    size_t lse, W, A, Bt, offA, offB, ll, EA, EB, lik, flags, pstat, lshift, total;
+    size_t lse, W, A, Bt, offA, offB, ll, EA, EB, lik, flags, pstat, lshift, bar, total;
     int NCl, nPstat;
     int N, Nr, Up, NC, NG, OG;
 };
@@ -138,6 +137,7 @@ inline WsLayout make_layout(int T, int U, int B) {
     }
     w.pstat = take((size_t)B * w.nPstat * 2 * sizeof(float));
     w.lshift = take((size_t)B * sizeof(int));
+    w.bar = take((size_t)B * sizeof(int));
     w.total = off;
     return w;
 }
@@ -176,6 +176,7 @@ struct JointHooks {
     int prep_mode;        // 0: full prep kernel.  1: the e^{2x} tables of the projections and tflag[0] (zeroed, then raised by the
                           //    table writer) are already in the workspace: the prep kernel only does the W2 images.  2: the
                           //    workspace still holds the state of the forward call with the same inputs: no prep at all.
+    int prefilled;        // 1: the caller has already run joint_prefill (edge array + flag words) in front of its own launches
     unsigned *dmax_enc;   // nullable: [kHookBlocks] per-block abs-max bit patterns of d enc_proj, written by its reduction
     unsigned *dmax_pred;  // nullable: the same for d pred_proj
 };
@@ -183,18 +184,12 @@ struct JointHooks {
 // LDS-DMA (global -> LDS, 16 bytes per lane, lane l lands at lds + 16 l; `lds` wave-uniform).
 // The compiler models the builtin as a FLAT access that may touch LDS: from then on every wait for a plain ds_read is
 // `s_waitcnt lgkmcnt(0)` ("pending flat"), so an MFMA loop that prefetches its LDS fragments exposes one LDS latency per DMA
-// instruction.  -DRNNT_DMA_ASM issues the instruction as inline assembly instead (the waits become lgkmcnt(N) again; the
-// callers already order the DMA with `s_waitcnt vmcnt` themselves).  Measured at config 5 (round 3): K1's chunk period drops
-// from 4830 to 4210 shader clocks and its run time does not move (the kernels are power-limited: the clock drops instead),
-// and K3 + K4 lose 3 ms (the asm statement is a barrier for the compiler's own LDS scheduling): the builtin stays.
+// instruction.  Issued as inline assembly instead the waits become lgkmcnt(N) again -- measured at config 5 (round 3): K1's chunk
+// period drops from 4830 to 4210 shader clocks and its run time does not move (the kernels are power-limited: the clock drops
+// instead), and K3 + K4 lose 3 ms (the asm statement is a barrier for the compiler's own LDS scheduling): the builtin stays.
 #ifdef __HIPCC__
 __device__ __forceinline__ void lds_dma16(const void *global, void *lds) {
-#ifdef RNNT_DMA_ASM
-    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(global), "s"(a) : "memory", "m0");
-#else
     __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void *)global, (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
-#endif
 }
 #endif
 
@@ -203,6 +198,8 @@ __device__ __forceinline__ void lds_dma16(const void *global, void *lds) {
 // fused paths survived it only because positions no lattice cell owns are never a source of probability mass.
 // `bytes` must be a multiple of 4, `dst` 4-byte aligned; `byte` is replicated into every byte.
 hipError_t launch_fill(void *dst, int byte, size_t bytes, hipStream_t s);
+// the same for two regions in ONE launch
+hipError_t launch_fill2(void *dst0, int byte0, size_t bytes0, void *dst1, int byte1, size_t bytes1, hipStream_t s);
 
 // kernel launchers (rnnt_kernels.hip); return hipError_t from the launch
 bool tile_path_ok(const LossParams &p, bool grad);

@@ -7,7 +7,6 @@
 #include "../../include/rnnt.h"
 #include "rnnt_common.h"
 #include "rnnt_lin.h"
-#include <cstdlib>
 
 using namespace rnnt;
 
@@ -20,6 +19,8 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
                              float *d_enc_proj, float *d_pred_proj, float *dW2, float *db2, int joint_dtype,
                              int phases, void *workspace, hipStream_t s, const JointHooks *hooks);
 hipError_t joint_aux_pointers(void *workspace, int T, int U, int B, int J, int V, float **expE, float **expP, float **tflag);
+hipError_t launch_joint_prefill(void *workspace, int T, int U, int B, int J, int V, hipStream_t s);
+bool joint_dtype_supported(int joint_dtype, int J, int V);
 // dense_kernels.hip (the joint's first Dense layer)
 bool dense_supported(int H, int J);
 hipError_t dense_workspace_bytes(int B, int T, int U, int H, int J, size_t base, size_t *bytes);
@@ -75,13 +76,12 @@ static bool fill_params(LossParams &p, const float *acts, float *grads, const in
     p.NCl = w.NCl;
     p.pstat = (float2 *)(ws + w.pstat);
     p.lshift = (int *)(ws + w.lshift);
+    p.bar = (int *)(ws + w.bar);
     p.nPstat = w.nPstat;
+    p.pstatStride = 4;
     p.B = B, p.T = o.maxT, p.U = o.maxU, p.V = V, p.blank = o.blank_label;
     p.b0 = 0, p.nb = B;
-    {  // dev switch: RNNT_PRECISE_ALL=1 gives the fused joints the float64 recurrence too (timing / accuracy experiments)
-        static const int all = [] { const char *e = getenv("RNNT_PRECISE_ALL"); return e ? atoi(e) : 0; }();
-        p.precise = all;
-    }
+    p.precise = 0;
     p.tile = make_tile(o.maxT, o.maxU, V);
     p.N = w.N, p.Nr = w.Nr, p.Up = w.Up, p.NC = w.NC, p.NG = w.NG;
     p.cells = (uint32_t)cells;
@@ -251,6 +251,7 @@ static rnntStatus_t joint_call(const float *enc_proj, const float *pred_proj, co
     if (st != RNNT_STATUS_SUCCESS) return st;
     if (options.blank_label >= alphabet_size) return RNNT_STATUS_INVALID_VALUE;
     if (options.maxU > 1024) return RNNT_STATUS_INVALID_VALUE;  // the fused joint paths are built on the register-resident sweeps
+    if (!joint_dtype_supported(joint_dtype, joint_size, alphabet_size)) return RNNT_STATUS_INVALID_VALUE;
     const bool any_grad = d_enc_proj || d_pred_proj || dW2 || db2;
     if (any_grad && !(d_enc_proj && d_pred_proj && dW2 && db2)) return RNNT_STATUS_INVALID_VALUE;
     if ((phases & 2) && !(phases & 1) && !any_grad) return RNNT_STATUS_INVALID_VALUE;
@@ -321,6 +322,7 @@ static rnntStatus_t joint_net_call(const float *enc, const float *pred, const fl
     if (any_grad && ((((uintptr_t)dW1 | (uintptr_t)db1 | (uintptr_t)d_enc | (uintptr_t)d_pred) & 15) != 0)) return RNNT_STATUS_INVALID_VALUE;  // 16-byte stores
     if ((((uintptr_t)enc | (uintptr_t)pred | (uintptr_t)W1 | (uintptr_t)b1) & 15) != 0) return RNNT_STATUS_INVALID_VALUE;
     if ((phases & 2) && !(phases & 1) && !any_grad) return RNNT_STATUS_INVALID_VALUE;
+    if (!joint_dtype_supported(joint_dtype, joint_size, alphabet_size)) return RNNT_STATUS_INVALID_VALUE;  // before anything is enqueued
     const int B = minibatch, T = options.maxT, U = options.maxU;
     hipStream_t s = (hipStream_t)options.stream;
     size_t base = 0;
@@ -332,6 +334,7 @@ static rnntStatus_t joint_net_call(const float *enc, const float *pred, const fl
     // their per-block abs-max entries for the backward GEMMs' operand scales.
     JointHooks hooks;
     hooks.prep_mode = 0;
+    hooks.prefilled = 0;
     dense_hook_pointers(workspace, B, T, U, hidden_size, joint_size, base, &hooks.dmax_enc, &hooks.dmax_pred);
     float *expE = nullptr, *expP = nullptr, *tflag = nullptr;
     if (joint_dtype == 0) {
@@ -339,7 +342,10 @@ static rnntStatus_t joint_net_call(const float *enc, const float *pred, const fl
         hooks.prep_mode = (phases & 1) ? 1 : 2;
     }
     if (phases & 1) {
-        if (tflag && launch_fill(tflag, 0, 256, s) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
+        if (tflag) {  // the joint's edge-array pre-fill and its flag words (the GEMM epilogue raises one of them) in ONE launch
+            if (launch_joint_prefill(workspace, T, U, B, joint_size, alphabet_size, s) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
+            hooks.prefilled = 1;
+        }
         if ((e = launch_dense_fwd(enc, pred, W1, b1, B, T, U, hidden_size, joint_size, workspace, base, expE, expP, tflag, s)) != hipSuccess)
             return from_hip(e);
     }
@@ -392,6 +398,7 @@ rnntStatus_t compute_rnnt_joint_logits(const float *enc_proj, const float *pred_
     if (st != RNNT_STATUS_SUCCESS) return st;
     if (options.maxU > 1024) return RNNT_STATUS_INVALID_VALUE;
     if (((uintptr_t)workspace & 255) != 0) return RNNT_STATUS_INVALID_VALUE;
+    if (!joint_dtype_supported(joint_dtype, joint_size, alphabet_size)) return RNNT_STATUS_INVALID_VALUE;
     hipStream_t s = (hipStream_t)options.stream;
     if (joint_dtype == 1)
         return from_hip(launch_joint_logits_f16(enc_proj, pred_proj, W2, b2, joint_size, alphabet_size, minibatch, options.maxT,
@@ -413,6 +420,7 @@ rnntStatus_t compute_rnnt_joint_net_logits(const float *enc, const float *pred, 
     if (options.maxU > 1024) return RNNT_STATUS_INVALID_VALUE;
     if (((uintptr_t)workspace & 255) != 0 || !dense_supported(hidden_size, joint_size)) return RNNT_STATUS_INVALID_VALUE;
     if ((((uintptr_t)enc | (uintptr_t)pred | (uintptr_t)W1 | (uintptr_t)b1) & 15) != 0) return RNNT_STATUS_INVALID_VALUE;
+    if (!joint_dtype_supported(joint_dtype, joint_size, alphabet_size)) return RNNT_STATUS_INVALID_VALUE;  // before the GEMM is enqueued
     const int B = minibatch, T = options.maxT, U = options.maxU;
     hipStream_t s = (hipStream_t)options.stream;
     size_t base = 0;

@@ -34,29 +34,10 @@
 namespace rnnt {
 
 
-// Dev variants (scripts/build_variant.sh): cache policy of the gradient pass's 16-byte stores / of its logit loads.
-#ifndef RNNT_GSTORE
-#define RNNT_GSTORE 0  // 0 nt (shipped), 1 plain, 2 sc1, 3 sc0 sc1, 4 sc1 nt, 5 sc0 sc1 nt
-#endif
-#ifndef RNNT_GLOAD
-#define RNNT_GLOAD 0   // aux bits of the gradient pass's global_load_lds (0 default policy, 2 nt)
-#endif
+// The gradient pass's 16-byte stores: non-temporal (written once, never re-read by this op).  Measured alternatives (round 3):
+// plain, sc1, sc0 sc1, sc1 nt, sc0 sc1 nt stores and non-temporal logit LOADS were all slower or equal.
 typedef float gs_v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void grad_store16(gs_v4f *dst, const gs_v4f v) {
-#if RNNT_GSTORE == 0
-    __builtin_nontemporal_store(v, dst);
-#elif RNNT_GSTORE == 1
-    *dst = v;
-#elif RNNT_GSTORE == 2
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
-#elif RNNT_GSTORE == 3
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
-#elif RNNT_GSTORE == 4
-    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(dst), "v"(v) : "memory");
-#else
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(v) : "memory");
-#endif
-}
+__device__ __forceinline__ void grad_store16(gs_v4f *dst, const gs_v4f v) { __builtin_nontemporal_store(v, dst); }
 
 // ---------------------------------------------------------------------------------------------
 // Small-vocabulary TILE path (V % 4 == 0): a workgroup owns a TT x UU patch of one utterance's
@@ -70,9 +51,6 @@ __device__ __forceinline__ void grad_store16(gs_v4f *dst, const gs_v4f v) {
 // (a = start & 3, per row) into a 16-byte-aligned LDS row; cells read their logits with scalar LDS reads, and the gradient
 // rows go back with float4 stores for the aligned interior and single floats at the two ragged ends.  Needs B*T*U*V % 4 == 0
 // (then no aligned span reaches past the tensor).
-#ifndef RNNT_TILE_LDS_PAD
-#define RNNT_TILE_LDS_PAD 0  // dev builds: extra LDS bytes per patch workgroup (occupancy experiments)
-#endif
 constexpr int kFillRows = 16;  // W diagonals per fill workgroup of the lsm launch
 
 template <int VP, bool GRAD, bool AL = true, bool LIN = false>
@@ -90,18 +68,12 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
     // the patches (rounds 2-3) they formed a write-only tail of the launch (~4.7 us of 68 at B32 T600 U150).
     const uint32_t n_patch_wg = (uint32_t)p.nb * (uint32_t)tg.tiles_t * (uint32_t)tg.tiles_u;
     uint32_t vblock = blockIdx.x;  // index among the patch workgroups
-    if (!GRAD && !(LIN && kLinLoaderZero)) {
+    if (!GRAD) {
         const uint32_t per = (uint32_t)p.Nr / kFillRows, n_fill = (uint32_t)p.nb * per;
         const uint32_t pgs = (n_patch_wg + 7u) >> 3, fgs = (n_fill + 7u) >> 3, P = (pgs + fgs) / fgs;
         const uint32_t g = blockIdx.x >> 3, l8 = blockIdx.x & 7u;
-#ifdef RNNT_FILL_TAIL  // dev switch: the fill groups behind the patch groups, as in rounds 2-3 (A/B timing)
-        const uint32_t k = g >= pgs ? g - pgs : 0u;
-        const bool is_fill = g >= pgs;
-        (void)P;
-#else
         const uint32_t k = g / P;
         const bool is_fill = g - k * P == P - 1u && k < fgs;  // fill groups sit at positions P - 1, 2 P - 1, ..., fgs P - 1
-#endif
         if (is_fill) {
             const uint32_t f = k * 8u + l8;
             if (f >= n_fill) return;
@@ -118,11 +90,7 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
             }
             return;
         }
-#ifdef RNNT_FILL_TAIL
-        vblock = blockIdx.x;
-#else
         vblock = (g - min(k, fgs)) * 8u + l8;  // fill groups in front of group g: min(g / P, fgs)
-#endif
         if (vblock >= n_patch_wg) return;
     }
     // XCD-aware remap: hand each XCD (blockIdx % 8) a contiguous range of patches (bijective form)
@@ -204,7 +172,7 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
             const int q = q0 + lane;
             if (q < nq) {
                 // default cache policy: non-temporal loads lose the Infinity-Cache reuse between the two cell passes
-                __builtin_amdgcn_global_load_lds((glb_void *)(src + q * 4), (lds_void *)(dst + q0 * 4), 16, 0, GRAD ? RNNT_GLOAD : 0);
+                __builtin_amdgcn_global_load_lds((glb_void *)(src + q * 4), (lds_void *)(dst + q0 * 4), 16, 0, 0);
             }
         }
     }
@@ -234,7 +202,6 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
         // patch diagonal j / TT, so TT consecutive lanes store TT consecutive (descending) positions of one row of W -- 64-byte
         // runs at TT = 8 -- where a lane per cell scattered every wave-store over 64 rows (2.9 M 8-byte requests per step at
         // B32 T600 U150: ~10 us of the lsm pass).
-#if RNNT_LSM_DIAG
         __syncthreads();
         float2 *const Wp = (float2 *)p.W + ((size_t)b * p.Nr + t0 + u0) * p.Up + u0;  // cell (r, c) of the patch: Wp[(r + c) Up + c]
         const uint32_t total = (uint32_t)(tg.TT + tg.UU - 1) * (uint32_t)tg.TT;
@@ -252,7 +219,6 @@ __global__ __launch_bounds__(256) void cell_tile_kernel(const LossParams p) {
                 Wp[(size_t)(rr + cc) * p.Up + cc] = v;
             }
         }
-#endif
     }
     if (GRAD && !AL) {
         __syncthreads();
@@ -287,31 +253,58 @@ __global__ __launch_bounds__(256) void cell_wave_kernel(const LossParams p) {
 // fills (see launch_fill in rnnt_common.h)
 // ---------------------------------------------------------------------------------------------
 // One contiguous 16 KB span per workgroup (four 16-byte stores per thread), no grid stride.
-__global__ __launch_bounds__(256) void fill_kernel(uint32_t *dst, const uint32_t word, const size_t nwords) {
+__device__ __forceinline__ void fill_span(uint32_t *dst, const uint32_t word, const size_t nwords, const unsigned blk) {
     if ((((uintptr_t)dst) & 15) == 0) {
         const size_t n4 = nwords >> 2;
         const uint4 q = make_uint4(word, word, word, word);
-        const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+        const size_t base = (size_t)blk * 1024 + threadIdx.x;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (base + 256 * k < n4) ((uint4 *)dst)[base + 256 * k] = q;
-        if (blockIdx.x == 0 && threadIdx.x < (nwords & 3)) dst[n4 * 4 + threadIdx.x] = word;
+        if (blk == 0 && threadIdx.x < (nwords & 3)) dst[n4 * 4 + threadIdx.x] = word;
     } else {
-        const size_t base = (size_t)blockIdx.x * 4096 + threadIdx.x;
+        const size_t base = (size_t)blk * 4096 + threadIdx.x;
 #pragma unroll
         for (int k = 0; k < 16; ++k)
             if (base + 256 * k < nwords) dst[base + 256 * k] = word;
     }
 }
+__global__ __launch_bounds__(256) void fill_kernel(uint32_t *dst, const uint32_t word, const size_t nwords) {
+    fill_span(dst, word, nwords, blockIdx.x);
+}
+// two regions in one launch (the fused joints zero their flag words with the same launch that pre-fills the edge array)
+__global__ __launch_bounds__(256) void fill2_kernel(uint32_t *dst0, const uint32_t word0, const size_t nwords0, const unsigned grid0,
+                                                    uint32_t *dst1, const uint32_t word1, const size_t nwords1) {
+    if (blockIdx.x < grid0)
+        fill_span(dst0, word0, nwords0, blockIdx.x);
+    else
+        fill_span(dst1, word1, nwords1, blockIdx.x - grid0);
+}
+
+static inline uint32_t fill_word(int byte) {
+    const uint32_t b = (uint32_t)(byte & 0xff);
+    return b | (b << 8) | (b << 16) | (b << 24);
+}
 
 hipError_t launch_fill(void *dst, int byte, size_t bytes, hipStream_t s) {
     if (bytes == 0) return hipSuccess;
     if ((bytes & 3) != 0 || (((uintptr_t)dst) & 3) != 0) return hipErrorInvalidValue;
-    const uint32_t b = (uint32_t)(byte & 0xff), word = b | (b << 8) | (b << 16) | (b << 24);
     const size_t nwords = bytes >> 2;
     const size_t grid = (nwords + 4095) / 4096;  // 16 KB per workgroup
     if (grid > 0x7fffffffu) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)grid), dim3(256), 0, s, (uint32_t *)dst, word, nwords);
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)grid), dim3(256), 0, s, (uint32_t *)dst, fill_word(byte), nwords);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill2(void *dst0, int byte0, size_t bytes0, void *dst1, int byte1, size_t bytes1, hipStream_t s) {
+    if (bytes0 == 0) return launch_fill(dst1, byte1, bytes1, s);
+    if (bytes1 == 0) return launch_fill(dst0, byte0, bytes0, s);
+    if (((bytes0 | bytes1) & 3) != 0 || ((((uintptr_t)dst0) | ((uintptr_t)dst1)) & 3) != 0) return hipErrorInvalidValue;
+    const size_t n0 = bytes0 >> 2, n1 = bytes1 >> 2;
+    const size_t g0 = (n0 + 4095) / 4096, g1 = (n1 + 4095) / 4096;
+    if (g0 + g1 > 0x7fffffffu) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fill2_kernel, dim3((unsigned)(g0 + g1)), dim3(256), 0, s, (uint32_t *)dst0, fill_word(byte0), n0, (unsigned)g0,
+                       (uint32_t *)dst1, fill_word(byte1), n1);
     return hipGetLastError();
 }
 
@@ -334,15 +327,14 @@ static hipError_t launch_cell(const LossParams &p, hipStream_t s) {
     if (LIN && !tile_path_ok(p, GRAD)) return hipErrorInvalidValue;
     if (tile_path_ok(p, GRAD)) {
         // (the lsm launch fills the log-zero part of W itself: see cell_tile_kernel)
-        // (rnnt_lin.h kLinLoaderZero: the linear lattice's loader waves can write probability zero over the unowned positions in LDS instead)
         const unsigned n_patch = (unsigned)p.nb * p.tile.tiles_t * p.tile.tiles_u;
         unsigned blocks = n_patch;
-        if (!(GRAD || (LIN && kLinLoaderZero)))  // + the fill workgroups, in groups of eight among the patch groups (cell_tile_kernel)
+        if (!GRAD)  // + the fill workgroups, in groups of eight among the patch groups (cell_tile_kernel)
             blocks = (((n_patch + 7u) >> 3) + (((unsigned)p.nb * (unsigned)(p.Nr / kFillRows) + 7u) >> 3)) * 8u;
         // the patch image: TT x UU cells (<= 256) of V floats, to the byte.  Sized by the patch, not by the 256 lanes, and without
         // padding: at V = 28 that is 26,880 B -- six workgroups per CU instead of five (gradient pass 115 -> 110.5 us); at V = 32
         // 30,720 B instead of 32,832 B -- five instead of four (146 -> 140 us)
-        const size_t shm = (size_t)p.tile.TT * p.tile.UU * p.V * sizeof(float) + RNNT_TILE_LDS_PAD;
+        const size_t shm = (size_t)p.tile.TT * p.tile.UU * p.V * sizeof(float);
         if ((p.V % 4) != 0) {
             const size_t pitch = (size_t)((p.tile.UU * p.V + 3 + 3) & ~3);
             size_t shmu = (size_t)p.tile.TT * pitch * sizeof(float);

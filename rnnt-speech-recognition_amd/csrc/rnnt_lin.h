@@ -24,25 +24,12 @@ namespace rnnt {
 // better edge).  N(0,1) logits: 4.7 bits at 28 symbols, 5.8 at 60 (certificate margin -84 / -72 bits with blocks of eight);
 // trained-like posteriors 0 ... 3; 3 x N(0,1): 7.3 (margin -43 with blocks of eight, -69 with four); 4 x N(0,1): 9.1 (-45 with four).
 // K = 1, 12, 16: always four (K = 1: the frame look-back would be 8 lanes deep; 12, 16: their LDS chunks are four diagonals long).
-#ifndef RNNT_LINSHIFT
-#define RNNT_LINSHIFT 3
-#endif
-__host__ __device__ constexpr int lin_shift_max(int K) { return (K == 1 || K >= 12) ? 2 : RNNT_LINSHIFT; }
+__host__ __device__ constexpr int lin_shift_max(int K) { return (K == 1 || K >= 12) ? 2 : 3; }
 constexpr float kLinDecayBits = 6.2f;  // mean bits per diagonal beyond which an utterance gets blocks of four
 constexpr int kLinDrag = 118;            // a lane's frame is at most this far below the lanes mass can reach it from within a block
 constexpr int kFrameNone = -(1 << 28);   // frame of a lane without mass and without a neighbour to copy from
 constexpr int kCertBits = -40;           // per-cell bound (bits) on flush loss x other side / likelihood
 constexpr float kTinyEdge = 7.8886091e-31f;  // 2^-100: an edge the lattice owns below this goes to the log-domain path (NaN in W)
-
-// Positions of the skewed edge array that no lattice cell owns: 1 = nobody fills them in HBM, the sweeps' loader waves write
-// probability zero over them in LDS (rnnt_sweep.h sweep_loader ZERO); 0 = the lsm launch carries fill workgroups for them.
-#ifndef RNNT_LIN_ZERO
-#define RNNT_LIN_ZERO 0  // (needs RNNT_LIN_LOADERS = 1)
-#endif
-constexpr bool kLinLoaderZero = RNNT_LIN_ZERO != 0;
-#ifndef RNNT_LSM_DIAG
-#define RNNT_LSM_DIAG 1  // lsm pass: edge probabilities leave through LDS, diagonal by diagonal (0: one scattered store per cell)
-#endif
 
 // per-utterance words in LossParams::flags
 enum { kFlagA = 0, kFlagB = 1, kFlagG = 2, kFlagState = 3 };  // state: 0 linear lattice, 2 log-domain lattice ready (after a redo)
@@ -86,12 +73,8 @@ __device__ __forceinline__ float lin_cell_lsm(const LossParams &p, const Cell &c
     // The two edge probabilities go into the first two floats of the cell's own LDS slot (nobody else reads it); the patch kernel
     // writes them to the skewed edge array diagonal by diagonal afterwards (rnnt_kernels.hip: consecutive lanes then store
     // consecutive positions of one diagonal's row -- written from here, a lane per cell, every store of a wave went to 64 rows).
-#if RNNT_LSM_DIAG
     float *const xo = const_cast<float *>(xs);
     xo[0] = pb, xo[1] = pl;
-#else
-    ((float2 *)p.W)[((size_t)cl.b * p.Nr + (cl.t + cl.u)) * p.Up + cl.u] = make_float2(pb, pl);
-#endif
     const float best = fmaxf(pb, pl);  // (v_max ignores a NaN operand)
     return (pb != pb || pl != pl) ? 200.f : -lg2(fmaxf(best, 1.0e-37f));
 }

@@ -17,10 +17,7 @@
 #include "rnnt_cellwave.h"
 #include "rnnt_lin.h"
 #include "rnnt_cellbody.h"
-
-#ifndef LIN_KO
-#define LIN_KO 0  // dev builds (timing only, wrong results): 1 no diagonal stores, 2 no renormalisation, 3 no LDS reads, 4 no step arithmetic
-#endif
+#include "rnnt_redo.h"
 
 namespace rnnt {
 
@@ -202,17 +199,15 @@ __device__ __forceinline__ void lin_alpha_fast_steps(float (&a)[K], LinRow<K> (&
                                                      const int voff, const int lane, const int r0) {
     if constexpr (II < G) {
         constexpr int R = 1 << SH;
-        if constexpr (LIN_KO != 3) {
-            if constexpr (II + 1 < G)
-                lds_wait<LinRow<K>::NR>();  // row II has landed, row II+1 stays in flight
-            else
-                lds_wait<0>();
-        }
-        if constexpr (LIN_KO != 4) lin_alpha_step<K>(a, wq[II % 3], st.d);
-        if constexpr (LIN_KO != 3 && II + 2 < G) lin_issue_row<K, II + 2>(wq[(II + 2) % 3], abase);
-        if constexpr (((II + 1) % R) == 0 && LIN_KO != 2) lin_renorm<K, false, SH>(a, st, (r0 + II + 1) >> SH);  // (r0 is a multiple of G)
+        if constexpr (II + 1 < G)
+            lds_wait<LinRow<K>::NR>();  // row II has landed, row II+1 stays in flight
+        else
+            lds_wait<0>();
+        lin_alpha_step<K>(a, wq[II % 3], st.d);
+        if constexpr (II + 2 < G) lin_issue_row<K, II + 2>(wq[(II + 2) % 3], abase);
+        if constexpr (((II + 1) % R) == 0) lin_renorm<K, false, SH>(a, st, (r0 + II + 1) >> SH);  // (r0 is a multiple of G)
         constexpr int RB = rows_per_base(K);
-        if constexpr (LIN_KO != 1) store_diag<K, true, (II % RB) * 64 * K * 4>(st.row, voff, lane, a);
+        store_diag<K, true, (II % RB) * 64 * K * 4>(st.row, voff, lane, a);
         if constexpr (II % RB == RB - 1 || II == G - 1) st.row += (II % RB + 1) * 64 * K;
         lin_alpha_fast_steps<K, G, SH, II + 1>(a, wq, abase, st, voff, lane, r0);
     }
@@ -223,17 +218,15 @@ __device__ __forceinline__ void lin_beta_fast_steps(float (&bv)[K], LinRow<K> (&
     if constexpr (II < G) {
         constexpr int R = 1 << SH;
         constexpr int i = G - 1 - II;  // row inside the chunk (descending)
-        if constexpr (LIN_KO != 3) {
-            if constexpr (i > 0)
-                lds_wait<LinRow<K>::NR>();
-            else
-                lds_wait<0>();
-        }
-        if constexpr (LIN_KO != 4) lin_beta_step<K>(bv, wq[II % 3], st.d);
-        if constexpr (LIN_KO != 3 && i >= 2) lin_issue_row<K, (i >= 2 ? i - 2 : 0)>(wq[(II + 2) % 3], abase);
-        if constexpr ((i % R) == R - 1 && LIN_KO != 2) lin_renorm<K, true, SH>(bv, st, (r0 + i) >> SH);
+        if constexpr (i > 0)
+            lds_wait<LinRow<K>::NR>();
+        else
+            lds_wait<0>();
+        lin_beta_step<K>(bv, wq[II % 3], st.d);
+        if constexpr (i >= 2) lin_issue_row<K, (i >= 2 ? i - 2 : 0)>(wq[(II + 2) % 3], abase);
+        if constexpr ((i % R) == R - 1) lin_renorm<K, true, SH>(bv, st, (r0 + i) >> SH);
         constexpr int RB = rows_per_base(K);
-        if constexpr (LIN_KO != 1) store_diag<K, true, -(II % RB) * 64 * K * 4>(st.row, voff, lane, bv);
+        store_diag<K, true, -(II % RB) * 64 * K * 4>(st.row, voff, lane, bv);
         if constexpr (II % RB == RB - 1 || II == G - 1) st.row -= (II % RB + 1) * 64 * K;
         lin_beta_fast_steps<K, G, SH, II + 1>(bv, wq, abase, st, voff, lane, r0);
     }
@@ -252,10 +245,7 @@ __device__ __forceinline__ void lin_record(const LossParams &p, const int b, con
     if (side == 0 && p.costs) st_f32_wt(p.costs + b, (float)(-ll2 * 0.6931471805599453));
 }
 
-#ifndef RNNT_LIN_LOADERS
-#define RNNT_LIN_LOADERS 1
-#endif
-constexpr int kLinLoaders = RNNT_LIN_LOADERS;  // loader waves per sweep workgroup (rnnt_sweep.h sweep_loader); measured: two loaders that split every chunk give the same sweep time (41.9 vs 40.6 us at B32 T600 U150) -- the sweeping wave is not waiting for data
+constexpr int kLinLoaders = 1;  // loader waves per sweep workgroup (rnnt_sweep.h sweep_loader); measured: two loaders that split every chunk give the same sweep time (41.9 vs 40.6 us at B32 T600 U150) -- the sweeping wave is not waiting for data
 
 // Chunk i of the loading order has landed when EVERY loader has counted i + 1 chunks (each brings its share of the pieces).
 struct LandedView {
@@ -285,6 +275,7 @@ __device__ void lin_alpha_sweep(const LossParams &p, float *bufs, const LdLink l
         st_i32_wt(p.flags + 4 * b + kFlagG, 0);
         st_i32_wt(p.flags + 4 * b + kFlagState, 0);
         st_i32_wt(p.lshift + b, SH);  // the block length this utterance's frame tables are indexed with
+        st_i32_wt(p.bar + b, 0);      // phase counter of the utterance's hand-back team (rnnt_redo.h)
     }
     float a[K];
 #pragma unroll
@@ -413,28 +404,27 @@ __global__ __launch_bounds__(64 * (1 + kLinLoaders)) void lin_sweep_kernel(const
         LdLink mine = lk;
         mine.landed = lk.landed + 8u * (uint32_t)(wave - 1);
         if (beta)
-            sweep_loader<K, G, NB, true, kLinLoaderZero, kLinLoaders>(p, lds, mine, b, lane, wave - 1);
+            sweep_loader<K, G, NB, true, kLinLoaders>(p, lds, mine, b, lane, wave - 1);
         else
-            sweep_loader<K, G, NB, false, kLinLoaderZero, kLinLoaders>(p, lds, mine, b, lane, wave - 1);
+            sweep_loader<K, G, NB, false, kLinLoaders>(p, lds, mine, b, lane, wave - 1);
     } else {
         // Block length of this utterance (rnnt_lin.h): the mean decay statistic of its cells, from the per-(patch, wave) sums the
         // lsm launch left (a fixed-order sum: both directions arrive at the same choice; the loads overlap with the loader
         // wave's first chunk, which this wave has to wait for anyway).
         constexpr int SHmax = lin_shift_max(K);
         int sh = SHmax;
-#ifndef RNNT_LIN_NOSTAT  // (dev builds: blocks of 2^RNNT_LINSHIFT diagonals whatever the logits look like)
         if constexpr (SHmax > 2) {
             // (a sample is enough: wave 0's slot of every patch = the first quarter of the patch's lanes; eight loads in flight
             // per lane -- read one after the other the 1,500 slots of a 600 x 150 lattice cost the sweep 9 us)
             float sum = 0.f, cnt = 0.f;
             const float2 *ps = p.pstat + (size_t)b * p.nPstat;
-            const int npatch = p.nPstat >> 2;
+            const int stride = p.pstatStride, npatch = p.nPstat / stride;
             for (int i0 = 0; i0 < npatch; i0 += 512) {
                 float2 q[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int i = i0 + 64 * k + lane;
-                    q[k] = (i < npatch) ? ps[4 * i] : make_float2(0.f, 0.f);
+                    q[k] = (i < npatch) ? ps[(size_t)stride * i] : make_float2(0.f, 0.f);
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) sum += q[k].x, cnt += q[k].y;
@@ -444,7 +434,6 @@ __global__ __launch_bounds__(64 * (1 + kLinLoaders)) void lin_sweep_kernel(const
             sh = (sum > kLinDecayBits * cnt) ? 2 : SHmax;  // (NaN statistics: the comparison is false, the certificate decides)
             sh = __builtin_amdgcn_readfirstlane(sh);
         }
-#endif
         if constexpr (SHmax > 2) {
             if (sh == 2) {
                 if (beta)
@@ -462,85 +451,25 @@ __global__ __launch_bounds__(64 * (1 + kLinLoaders)) void lin_sweep_kernel(const
 }
 
 // ---------------------------------------------------------------------------------------------
-// The hand-back: ONE small launch at the end of every call of the linear path (grid = utterances; a workgroup whose
+// The hand-back: ONE small launch at the end of every call of the linear path (grid = utterances x team; a workgroup whose
 // utterance is fine reads two 16-byte words and returns).  An utterance is redone when a sweep flagged it (kFlagA / kFlagB),
 // when the two likelihoods disagree, when the gradient pass's certificate failed for one of its cells (kFlagG), or when
-// `force` is set (a gradient buffer the patch kernels cannot write): the workgroup rebuilds the utterance's edge weights in the
-// log2 domain from the logits (one lattice cell per thread, staged through LDS), runs the log-domain sweeps with the float64
-// recurrence (any range; two of its sixteen waves) and, if gradients are wanted, writes all of the utterance's gradients (again a
-// cell per thread).  Slow -- the better part of a millisecond for a 600 x 150 lattice -- and rare.  Afterwards the utterance's state word
-// says that its lattice is in the log format, so that a later backward-only call goes straight to the gradient stage here.
+// `force` is set (a gradient buffer the patch kernels cannot write): its team of workgroups (rnnt_redo.h) rebuilds the
+// utterance's edge weights in the log2 domain from the logits (one lattice cell per thread, staged through LDS), runs the
+// log-domain sweeps with the float64 recurrence (any range; alpha and beta side by side on two members) and, if gradients are
+// wanted, writes all of the utterance's gradients (again a cell per thread, split over the team).  Afterwards the utterance's
+// state word says that its lattice is in the log format, so that a later backward-only call goes straight to the gradient
+// stage here.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRedoThreads = 1024;
-#ifdef RNNT_REDO_TRACE  // dev builds: s_memtime stamps of the hand-back's phases (utterance 0), printed by the kernel
-#define RT(i) do { if (tid == 0 && b == p.b0) rt[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define RT(i) do { } while (0)
-#endif
-
-__device__ __forceinline__ void redo_phase_sync() {
-    __threadfence();  // this workgroup's global stores are visible device-wide ...
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ... and nothing stale is served from this CU's vector L1
-}
-
-// The cells [c0, c1) of one utterance, one per thread.  With 16-byte-aligned rows the logits are staged through LDS in chunks of
-// up to kRedoThreads cells (the workgroup's chunk ring is idle during the cell phases) and the gradients leave the same way:
-// every global access is a coalesced 16-byte piece.  (A lane per cell straight from global memory made every load / store
-// instruction of a wave touch 56 cache lines: 0.6 ms for the lsm phase and 1.8 ms for the gradients of a 600 x 150 lattice on
-// the one CU the workgroup has.)  Otherwise (V % 4 != 0 or unaligned tensors): straight from / to global memory.
-template <bool GRAD>
-__device__ __forceinline__ void redo_cells(const LossParams &p, const uint32_t c0, const uint32_t c1, const int tid, float *lds,
-                                           const int lds_floats) {
-    const bool v4 = (p.V % 4) == 0 && (((uintptr_t)p.acts | (uintptr_t)p.grads) & 15) == 0;
-    const int V = p.V;
-    if (v4) {
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        const uint32_t CH = (uint32_t)min(kRedoThreads, lds_floats / V);  // cells per chunk
-        for (uint32_t cs = c0; cs < c1; cs += CH) {
-            const uint32_t n = min(CH, c1 - cs), nq = n * (uint32_t)V / 4u;
-            const v4f *src = (const v4f *)(p.acts + (size_t)cs * V);
-            for (uint32_t i = tid; i < nq; i += kRedoThreads) ((v4f *)lds)[i] = src[i];
-            __syncthreads();
-            if ((uint32_t)tid < n) {
-                const uint32_t c = cs + (uint32_t)tid;
-                const Cell cl = decode(p, c);
-                float *xs = lds + (size_t)tid * V;
-                if (GRAD || cl.valid) {
-                    if (V <= 32)
-                        cell_body<32, true, GRAD, false, true>(p, cl, c, xs, xs);
-                    else
-                        cell_body<64, true, GRAD, false, true>(p, cl, c, xs, xs);
-                }
-            }
-            __syncthreads();
-            if (GRAD) {
-                v4f *dst = (v4f *)(p.grads + (size_t)cs * V);
-                for (uint32_t i = tid; i < nq; i += kRedoThreads) __builtin_nontemporal_store(((const v4f *)lds)[i], dst + i);
-                __syncthreads();
-            }
-        }
-        return;
-    }
-    for (uint32_t c = c0 + (uint32_t)tid; c < c1; c += kRedoThreads) {
-        const Cell cl = decode(p, c);
-        const float *xs = p.acts + (size_t)c * p.V;
-        float *out = GRAD ? p.grads + (size_t)c * p.V : nullptr;
-        if (!GRAD && !cl.valid) continue;
-        if (p.V <= 32)
-            cell_body<32, false, GRAD, false, true>(p, cl, c, xs, out);
-        else
-            cell_body<64, false, GRAD, false, true>(p, cl, c, xs, out);
-    }
-}
-
 template <int K, int G, int NB>
-__global__ __launch_bounds__(kRedoThreads) void lin_redo_kernel(const LossParams p, const int force) {
+__global__ __launch_bounds__(kRedoThreads) void lin_redo_kernel(const LossParams p, const int force, const int team) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int chunkf = G * 2 * 64 * K;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = p.b0 + (int)blockIdx.x;
+    const int tid = threadIdx.x;
+    const int ub = (int)blockIdx.x / team;
+    const int b = p.b0 + ub;
+    RedoTeam tm;
+    tm.k = (int)blockIdx.x - ub * team, tm.n = team, tm.bar = p.bar + b, tm.ok = true;
     int *fl = p.flags + 4 * b;
     // one round trip: the four flag words and the two likelihoods (both written write-through by the sweeps / the gradient pass)
     typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -557,49 +486,15 @@ __global__ __launch_bounds__(kRedoThreads) void lin_redo_kernel(const LossParams
     } else if (!p.grads) {
         return;
     }
-#ifdef RNNT_REDO_TRACE
-    long long rt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    const uint32_t c0 = (uint32_t)b * (uint32_t)p.T * (uint32_t)p.U, c1 = c0 + (uint32_t)p.T * (uint32_t)p.U;
-    RT(0);
-    if (redo) {
-        // ---- log2-domain edge weights of this utterance: log zero everywhere, then the cells ----
-        uint32_t *Wb = (uint32_t *)(p.W + (size_t)b * p.Nr * 2 * p.Up);
-        const uint32_t lz = (uint32_t)kFillByte * 0x01010101u;
-        for (size_t i = tid; i < (size_t)p.Nr * 2 * p.Up; i += kRedoThreads) Wb[i] = lz;
-        redo_phase_sync();
-        RT(1);
-        redo_cells<false>(p, c0, c1, tid, lds, NB * chunkf);
-        redo_phase_sync();
-        RT(2);
-        // ---- the log-domain sweeps, one after the other, by waves 0 (sweeping) and 1 (loading) ----
-        int *ctr = (int *)(lds + NB * chunkf);
-        LdLink lk;
-        lk.landed = (uint32_t)(uintptr_t)((lds_void *)ctr);
-        lk.consumed = lk.landed + 4u;
-        if (tid < 2) ctr[tid] = 0;
-        __syncthreads();
-        if (wave == 1)
-            sweep_loader<K, G, NB, false>(p, lds, lk, b, lane);
-        else if (wave == 0)
-            alpha_sweep_pr<K, G, NB>(p, lds, lk, b, lane);  // the float64 recurrence: whatever failed the certificate is a hard input
-        __syncthreads();
-        RT(3);
-        if (tid < 2) ctr[tid] = 0;
-        __syncthreads();
-        if (wave == 1)
-            sweep_loader<K, G, NB, true>(p, lds, lk, b, lane);
-        else if (wave == 0)
-            beta_sweep_pr<K, G, NB>(p, lds, lk, b, lane);
-        redo_phase_sync();
-        RT(4);
-        if (tid == 0) st_i32_wt(fl + kFlagState, 2);
+    if (redo) redo_lattice<K, G, NB>(p, b, tm, lds, tid);
+    uint32_t lo, hi;
+    redo_cell_range(p, b, tm, lo, hi);
+    if (p.grads) redo_cells<true>(p, lo, hi, tid, lds, NB * chunkf);
+    if (!tm.ok) {  // a team member never arrived (bounded spin): the utterance's results must not look valid
+        if (p.costs && tm.k == 0 && tid == 0) st_f32_wt(p.costs + b, NAN);
+        if (p.grads)
+            for (size_t i = (size_t)lo * p.V + tid; i < (size_t)hi * p.V; i += kRedoThreads) p.grads[i] = NAN;
     }
-    if (p.grads) redo_cells<true>(p, c0, c1, tid, lds, NB * chunkf);
-    RT(5);
-#ifdef RNNT_REDO_TRACE
-    if (tid == 0 && b == p.b0) printf("redo trace (clocks): fill %lld lsm %lld alpha %lld beta %lld grad %lld\n", rt[1] - rt[0], rt[2] - rt[1], rt[3] - rt[2], rt[4] - rt[3], rt[5] - rt[4]);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -608,7 +503,8 @@ __global__ __launch_bounds__(kRedoThreads) void lin_redo_kernel(const LossParams
 // The linear path covers what the patch kernels cover (V <= 60, 16-byte-aligned logits) on every lattice the register-resident
 // sweeps cover (up to 1024 columns).  One frame per lane spans up to 16 columns there: lattices on which that is too coarse
 // (more label columns than frames, unstructured logits) fail the certificate and are redone in the log domain.
-bool lin_path_ok(const LossParams &p) { return sweep_K(p.U) >= 1 && tile_path_ok(p, false); }
+// (V >= 2: the lsm pass parks a cell's two edge probabilities in the cell's own LDS slot of V floats)
+bool lin_path_ok(const LossParams &p) { return p.V >= 2 && sweep_K(p.U) >= 1 && tile_path_ok(p, false); }
 
 template <int K, int G>
 static hipError_t launch_lin_sweep(const LossParams &p, hipStream_t s) {
@@ -630,7 +526,8 @@ static hipError_t launch_lin_redo(const LossParams &p, const bool force, hipStre
         hipError_t e = hipFuncSetAttribute((const void *)lin_redo_kernel<K, G, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((lin_redo_kernel<K, G, NB>), dim3(p.nb), dim3(kRedoThreads), shm, s, p, force ? 1 : 0);
+    const int team = redo_team_size(p.nb, p.T, p.U);
+    hipLaunchKernelGGL((lin_redo_kernel<K, G, NB>), dim3(p.nb * team), dim3(kRedoThreads), shm, s, p, force ? 1 : 0, team);
     return hipGetLastError();
 }
 

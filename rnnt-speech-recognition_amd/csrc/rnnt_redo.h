@@ -1,0 +1,173 @@
+// rnnt_redo.h -- the hand-back of the linear-domain lattice (rnnt_lin.h): device code shared by the loss op's hand-back launch
+// (rnnt_lin_kernels.hip lin_redo_kernel) and the fused joint's (joint_kernels.hip joint_redo_kernel).
+//
+// An utterance the linear lattice cannot represent (a sweep flagged it, the two likelihoods disagree, the gradient pass's range
+// certificate failed) is redone in the LOG domain from its logits: edge weights (a lattice cell per thread), the log2 recurrence
+// in float64 registers (rnnt_sweep.h alpha_sweep_pr / beta_sweep_pr), then whatever the caller forms per cell from that lattice.
+// Replaces the same stages of warp-transducer's GPU path as the kernels it falls back to (SURVEY.md 2.1, 8a-6 ... a-9; call
+// site utils/loss.py:34-35), which has no such fast path and hence no hand-back.
+//
+// Round 5: a TEAM of workgroups per utterance.  One workgroup -- one CU's worth of exponentials -- took ~2 ms for a 600 x 150
+// lattice, a 10x cliff for a step that holds one such utterance.  The launch now carries `team` workgroups per utterance (all of
+// them read the utterance's flag words and return at once when it is fine); a flagged utterance's cell phases are split over
+// the team, the alpha and beta sweeps run side by side on two of its members, and the phases are separated by a counter in the
+// workspace (one agent-scope add per workgroup and phase, bounded spin, NaN results on a timeout -- never a hang).  Members of
+// a team have consecutive block indices; workgroups are dispatched in block order, so the members of the oldest unfinished team
+// are always resident or next in line and a waiting team cannot starve the one it waits for.
+#pragma once
+#include "rnnt_sweep.h"
+#include "rnnt_lin.h"
+#include "rnnt_cellbody.h"
+
+namespace rnnt {
+
+constexpr int kRedoThreads = 1024;
+
+struct RedoTeam {
+    int k, n;   // this workgroup's index in the team, team size
+    int *bar;   // the utterance's phase counter (LossParams::bar; zeroed by the forward sweeps)
+    bool ok;    // false once a bounded spin gave up: the caller poisons its outputs
+};
+
+// Workgroups per flagged utterance: the whole chip for a small batch, at least ~1024 lattice cells per member.
+inline int redo_team_size(int nb, int T, int U) {
+#ifdef RNNT_REDO_TEAM  // dev builds: fixed team size (timing experiments)
+    (void)nb, (void)T, (void)U;
+    return RNNT_REDO_TEAM;
+#else
+    int t = 256 / (nb > 0 ? nb : 1);
+    const long long cells = (long long)T * U;
+    if ((long long)t * 1024 > cells) t = (int)(cells / 1024);
+    return t < 1 ? 1 : (t > 16 ? 16 : t);
+#endif
+}
+
+// Phase boundary of a team: everything this workgroup wrote is visible device-wide, then wait until `phase * n` arrivals.
+__device__ __forceinline__ void team_sync(RedoTeam &tm, const int phase, const int tid) {
+    __shared__ int team_ok;
+    __threadfence();  // this workgroup's global stores are visible device-wide ...
+    __syncthreads();
+    if (tm.n > 1) {
+        if (tid == 0) {
+            __hip_atomic_fetch_add(tm.bar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const int need = phase * tm.n;
+            int ok = 0;
+            for (int spin = 0; spin < (1 << 19); ++spin) {
+                if (__hip_atomic_load(tm.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= need) {
+                    ok = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            team_ok = ok;
+        }
+        __syncthreads();
+        if (!team_ok) tm.ok = false;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ... and nothing stale is served from this CU's vector L1 / this XCD's L2
+}
+
+// The cells [c0, c1) of one utterance, one per thread.  With 16-byte-aligned rows the logits are staged through LDS in chunks of
+// up to kRedoThreads cells (the workgroup's chunk ring is idle during the cell phases) and the gradients leave the same way:
+// every global access is a coalesced 16-byte piece.  (A lane per cell straight from global memory made every load / store
+// instruction of a wave touch 56 cache lines: 0.6 ms for the lsm phase and 1.8 ms for the gradients of a 600 x 150 lattice on
+// the one CU a workgroup has.)  Otherwise (V % 4 != 0 or unaligned tensors): straight from / to global memory.
+template <bool GRAD>
+__device__ __forceinline__ void redo_cells(const LossParams &p, const uint32_t c0, const uint32_t c1, const int tid, float *lds,
+                                           const int lds_floats) {
+    const bool v4 = (p.V % 4) == 0 && (((uintptr_t)p.acts | (uintptr_t)p.grads) & 15) == 0;
+    const int V = p.V;
+    if (v4) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const uint32_t CH = (uint32_t)min(kRedoThreads, lds_floats / V);  // cells per chunk
+        for (uint32_t cs = c0; cs < c1; cs += CH) {
+            const uint32_t n = min(CH, c1 - cs), nq = n * (uint32_t)V / 4u;
+            const v4f *src = (const v4f *)(p.acts + (size_t)cs * V);
+            for (uint32_t i = tid; i < nq; i += kRedoThreads) ((v4f *)lds)[i] = src[i];
+            __syncthreads();
+            if ((uint32_t)tid < n) {
+                const uint32_t c = cs + (uint32_t)tid;
+                const Cell cl = decode(p, c);
+                float *xs = lds + (size_t)tid * V;
+                if (GRAD || cl.valid) {
+                    if (V <= 32)
+                        cell_body<32, true, GRAD, false, true>(p, cl, c, xs, xs);
+                    else
+                        cell_body<64, true, GRAD, false, true>(p, cl, c, xs, xs);
+                }
+            }
+            __syncthreads();
+            if (GRAD) {
+                v4f *dst = (v4f *)(p.grads + (size_t)cs * V);
+                for (uint32_t i = tid; i < nq; i += kRedoThreads) __builtin_nontemporal_store(((const v4f *)lds)[i], dst + i);
+                __syncthreads();
+            }
+        }
+        return;
+    }
+    for (uint32_t c = c0 + (uint32_t)tid; c < c1; c += kRedoThreads) {
+        const Cell cl = decode(p, c);
+        const float *xs = p.acts + (size_t)c * p.V;
+        float *out = GRAD ? p.grads + (size_t)c * p.V : nullptr;
+        if (!GRAD && !cl.valid) continue;
+        if (p.V <= 32)
+            cell_body<32, false, GRAD, false, true>(p, cl, c, xs, out);
+        else
+            cell_body<64, false, GRAD, false, true>(p, cl, c, xs, out);
+    }
+}
+
+// This member's share of the utterance's cells: the same split in every phase (a member re-reads what it wrote itself)
+__device__ __forceinline__ void redo_cell_range(const LossParams &p, const int b, const RedoTeam &tm, uint32_t &lo, uint32_t &hi) {
+    const uint32_t c0 = (uint32_t)b * (uint32_t)p.T * (uint32_t)p.U, n = (uint32_t)p.T * (uint32_t)p.U;
+    lo = c0 + (uint32_t)((unsigned long long)n * (unsigned)tm.k / (unsigned)tm.n);
+    hi = c0 + (uint32_t)((unsigned long long)n * (unsigned)(tm.k + 1) / (unsigned)tm.n);
+}
+
+// The log-domain lattice of utterance b from the logits at p.acts ([cells][p.V]): log2 edge weights (W), lse, alpha~ / beta~
+// with their offset tables, ll (and the cost when p.costs is set).  Called by every workgroup of the utterance's team;
+// `lds` = the sweep workgroup's chunk ring (NB chunks + the two counters).  Ends with the team in step (a phase boundary).
+template <int K, int G, int NB>
+__device__ __forceinline__ void redo_lattice(const LossParams &p, const int b, RedoTeam &tm, float *lds, const int tid) {
+    constexpr int chunkf = G * 2 * 64 * K;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- log zero everywhere, then the cells ----
+    uint32_t *Wb = (uint32_t *)(p.W + (size_t)b * p.Nr * 2 * p.Up);
+    const uint32_t lz = (uint32_t)kFillByte * 0x01010101u;
+    const size_t nW = (size_t)p.Nr * 2 * p.Up;
+    for (size_t i = (size_t)tm.k * kRedoThreads + tid; i < nW; i += (size_t)tm.n * kRedoThreads) Wb[i] = lz;
+    team_sync(tm, 1, tid);
+    uint32_t lo, hi;
+    redo_cell_range(p, b, tm, lo, hi);
+    redo_cells<false>(p, lo, hi, tid, lds, NB * chunkf);
+    team_sync(tm, 2, tid);
+    // ---- the log-domain sweeps (float64 recurrence: whatever failed the certificate is a hard input): alpha by member 0,
+    //      beta by member 1 (a team of one: one after the other); waves 0 (sweeping) and 1 (loading) ----
+    int *ctr = (int *)(lds + NB * chunkf);
+    LdLink lk;
+    lk.landed = (uint32_t)(uintptr_t)((lds_void *)ctr);
+    lk.consumed = lk.landed + 4u;
+    const int kbeta = tm.n > 1 ? 1 : 0;
+    if (tm.k == 0) {
+        if (tid < 2) ctr[tid] = 0;
+        __syncthreads();
+        if (wave == 1)
+            sweep_loader<K, G, NB, false>(p, lds, lk, b, lane);
+        else if (wave == 0)
+            alpha_sweep_pr<K, G, NB>(p, lds, lk, b, lane);
+        __syncthreads();
+    }
+    if (tm.k == kbeta) {
+        if (tid < 2) ctr[tid] = 0;
+        __syncthreads();
+        if (wave == 1)
+            sweep_loader<K, G, NB, true>(p, lds, lk, b, lane);
+        else if (wave == 0)
+            beta_sweep_pr<K, G, NB>(p, lds, lk, b, lane);
+    }
+    team_sync(tm, 3, tid);
+    if (tm.k == 0 && tid == 0) st_i32_wt(p.flags + 4 * b + kFlagState, 2);  // "log-domain lattice ready": later calls honour it
+}
+
+}  // namespace rnnt

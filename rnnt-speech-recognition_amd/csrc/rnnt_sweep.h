@@ -368,49 +368,29 @@ struct LdLink {
     uint32_t landed, consumed;  // LDS byte addresses of the two counters
 };
 
-// ZERO (the linear-domain lattice): positions of the skewed array that no lattice cell owns are never written in HBM -- nobody
-// fills them -- and the loader writes probability zero over them in LDS before it publishes the chunk (a few masked 8-byte LDS
-// writes per diagonal; whatever the caller's workspace held there, NaN bit patterns included, never reaches the sweeping wave).
-template <int K, int G, int NB, bool BETA, bool ZERO = false, int NL = 1>
+template <int K, int G, int NB, bool BETA, int NL = 1>
 __device__ void sweep_loader(const LossParams &p, float *bufs, const LdLink lk, const int b, const int lane, const int w = 0) {
     // NL loader waves share EVERY chunk: loader w issues the LDS-DMA pieces w, w + NL, ... of it and counts the chunks whose
     // pieces of its own have landed in its own `landed` word (lk.landed of the LdLink it is handed); a chunk is complete when
     // every loader has counted it.  An LDS-DMA piece costs the issuing wave 60-100 clocks: at 24 pieces per 16 diagonals one
-    // loader keeps pace with a sweeping wave that needs ~120 clocks per diagonal, and no longer with the linear-domain one.
+    // loader keeps pace with either sweeping wave (two that split every chunk: 41.9 against 40.6 us -- the sweeper is not waiting
+    // for data; a loader that also zeroes the positions no lattice cell owns, instead of fill workgroups in the lsm launch:
+    // 103 us -- measured in round 4 and removed).
     constexpr int Up = 64 * K, chunkf = G * 2 * Up, n16 = chunkf / 4, pieces = n16 / 64;
     static_assert(n16 % 64 == 0 && pieces <= 63 && pieces % NL == 0, "chunk must be whole wave-instructions within the vmcnt range");
     const int Tb = length_T(p, b), Ub = length_U(p, b);
     const int nchunks = (Tb + Ub - 2) / G + 1;
     const float *Wb = p.W + (size_t)b * p.Nr * 2 * Up;
-    auto zero_outside = [&](const int i) {  // chunk i of the loading order has landed in ring slot i % NB
-        const int ck = BETA ? nchunks - 1 - i : i;
-        f32x2 *buf = (f32x2 *)(bufs + (i % NB) * chunkf);
-#pragma unroll 1
-        for (int r = w; r < G; r += NL) {  // (the loaders split the rows; each zeroes what EVERY loader's pieces brought: see the barrier note)
-            const int n = ck * G + r;
-            if (n > Tb + Ub - 2) break;  // diagonals past the lattice are never read
-            const int lo = max(0, n - Tb + 1), hi = min(n, Ub - 1);  // the lattice cells of diagonal n: columns lo .. hi
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                if (64 * k >= lo && 64 * k + 63 <= hi) continue;  // (wave-uniform) all 64 columns are lattice cells
-                const int c = lane + 64 * k;
-                if (c < lo || c > hi) buf[r * Up + c] = (f32x2){0.f, 0.f};
-            }
-        }
-    };
-    static_assert(!ZERO || NL == 1, "zeroing a row needs every loader's pieces of it to have landed: one loader only");
     for (int i = 0; i < nchunks; ++i) {
         const int ck = BETA ? nchunks - 1 - i : i;
         if (i >= NB) lds_wait_ge(lk.consumed, i - NB + 1);  // ring slot i % NB is free again
         dma_rows(Wb + (size_t)ck * chunkf, bufs + (i % NB) * chunkf, n16, lane, w, NL);
         if (i > 0) {
             wait_vm_counted<pieces / NL>();  // loads return in order: everything but the pieces just issued has landed
-            if (ZERO) zero_outside(i - 1);
             if (lane == 0) lds_post(lk.landed, i);
         }
     }
     wait_vm0();
-    if (ZERO) zero_outside(nchunks - 1);
     if (lane == 0) lds_post(lk.landed, nchunks);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }

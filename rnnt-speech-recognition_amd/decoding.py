@@ -53,7 +53,8 @@ def greedy_decode(model, mel_specs: torch.Tensor, max_length: Optional[int] = No
                 break
             f = enc[:, i : i + 1, :]
             while True:
-                logits = joint.cell_logits(f, g)[0, 0, 0]  # [V]
+                # (consumed by the argmax below before the next call: the engine may hand out its cached buffer)
+                logits = joint.cell_logits(f, g, reuse_buffers=True)[0, 0, 0]  # [V]
                 k = int(torch.argmax(torch.log_softmax(logits, dim=-1)).item())
                 if k == joint.blank_label:
                     break

@@ -226,7 +226,11 @@ def joint_logits(enc, pred, W1, b1, W2, b2, joint_dtype: str = "auto", reuse_buf
     f32-grade; "f16": binary16 operands, up to 8192 symbols -- the reference's default 4096 word pieces; "auto" picks by V), so a
     decoder sees the logits the loss was trained on.  The first Dense layer runs in the library too (compute_rnnt_joint_net_logits)
     when the hidden size is a multiple of 32, else through torch.matmul in front of compute_rnnt_joint_logits.  Joint sizes /
-    vocabularies the kernels do not take natively are padded exactly as in rnnt_joint_loss."""
+    vocabularies the kernels do not take natively are padded exactly as in rnnt_joint_loss.
+
+    reuse_buffers=True returns a VIEW OF A CACHED BUFFER (one workspace + output pair per device, stream and shape, at most
+    eight pairs): the next call with the same shape on the same stream overwrites it.  Only for callers that consume the result
+    before they call again (the greedy decoder asks for one lattice cell per emitted symbol); the default allocates."""
     lib = _lib.load()
     for name, x in (("enc", enc), ("pred", pred), ("W1", W1), ("W2", W2)):
         if not x.is_cuda:
@@ -246,8 +250,8 @@ def joint_logits(enc, pred, W1, b1, W2, b2, joint_dtype: str = "auto", reuse_buf
         b2 = torch.nn.functional.pad(b2, (0, Vp - V), value=_PAD_BIAS)
     dev = enc.device
     engine_first_layer = H % 32 == 0 and max(H, Jp) <= 4096
-    key = (dev, engine_first_layer, T, U, B, H, Jp, Vp)
     with torch.cuda.device(dev):
+        key = (dev, torch.cuda.current_stream().cuda_stream, engine_first_layer, T, U, B, H, Jp, Vp)
         if reuse_buffers and key in _LOGITS_CACHE:
             ws, out = _LOGITS_CACHE[key]
         else:
@@ -323,15 +327,16 @@ class JointLoss(torch.nn.Module):
         z = enc.unsqueeze(2) + pred.unsqueeze(1)
         return torch.tanh(z @ self.W1 + self.b1) @ self.W2 + self.b2
 
-    def cell_logits(self, enc, pred):
+    def cell_logits(self, enc, pred, reuse_buffers: bool = False):
         """Joint logits [B, T, U, V] for decoding (utils/decoding.py:6-18).  On an MI355X this is the ENGINE at every vocabulary
         size (compute_rnnt_joint_net_logits / compute_rnnt_joint_logits: the fused loss's own forward kernels, first Dense layer
         included); CPU tensors -- the host-logic tests -- and shapes the kernels do not take (joint sizes beyond 704 / 640) use
-        the torch composition."""
+        the torch composition.  The result is a fresh tensor unless `reuse_buffers` is set (see joint_logits: the buffer is then
+        overwritten by the next call of the same shape -- the greedy decoder opts in, a beam search must not)."""
         if enc.is_cuda:
             try:
                 padded_joint_shape(self.W2.shape[0], self.W2.shape[1], "f32" if self.W2.shape[1] <= 32 else "f16")
             except ValueError:
                 return self.logits(enc, pred)
-            return joint_logits(enc, pred, self.W1, self.b1, self.W2, self.b2, reuse_buffers=True)
+            return joint_logits(enc, pred, self.W1, self.b1, self.W2, self.b2, reuse_buffers=reuse_buffers)
         return self.logits(enc, pred)

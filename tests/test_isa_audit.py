@@ -83,7 +83,9 @@ def test_code_objects_are_gfx950_and_have_the_kernels(kernels):
     for needles in (("sweep_ld_kernel", "Li3ELi16E"), ("cell_tile_kernel", "Li32ELb1"), ("cell_tile_kernel", "Li32ELb0"),
                     ("jh_logits_kernel", "Li40ELi0"), ("jh_logits_kernel", "Li40ELi1"), ("jh_logits_kernel", "Li40ELi2"),
                     ("jh_dlogits_kernel",), ("jh_dh_kernel",), ("jh_dw_kernel",),
-                    ("joint_phase1_kernel",), ("joint_phase2_kernel",)):
+                    ("lin_sweep_kernel", "Li3ELi16E"), ("lin_redo_kernel", "Li3ELi16E"), ("joint_redo_kernel", "Li3ELi16E"),
+                    ("joint_fwd_kernel",), ("joint_bwd_kernel",), ("joint_cellrec_kernel",), ("joint_reduce_kernel",),
+                    ("dense_gemm_nt_kernel",), ("dense_gemm_tn_kernel",)):
         _find(meta, *needles)
 
 
@@ -91,8 +93,10 @@ def test_hot_kernels_do_not_spill(kernels):
     meta, _ = kernels
     hot = [("sweep_ld_kernel",), ("cell_tile_kernel", "Li32ELb1ELb1"),
            ("cell_tile_kernel", "Li32ELb0ELb1"), ("jh_logits_kernel", "Li40ELi0"), ("jh_dlogits_kernel",), ("jh_dh_kernel",), ("jh_dw_kernel", "Li512E"),
-           ("joint_phase1_kernel",), ("joint_phase2_kernel",), ("joint_dl_kernel",), ("joint_phase1s_kernel",),
-           ("joint_phase2s_kernel",)]
+           ("joint_dl_kernel",), ("joint_phase1s_kernel",), ("joint_phase2s_kernel",),
+           # round 4 / 5: the linear-domain sweeps, both hand-back kernels, the fused f32-grade joint and its first Dense layer
+           ("lin_sweep_kernel",), ("lin_redo_kernel",), ("joint_redo_kernel",), ("joint_fwd_kernel",), ("joint_bwd_kernel",),
+           ("joint_cellrec_kernel",), ("joint_reduce_kernel",), ("dense_gemm_nt_kernel",), ("dense_gemm_tn_kernel",)]
     for needles in hot:
         for k in _find(meta, *needles):
             m = meta[k]
@@ -137,12 +141,30 @@ def test_instruction_selection(kernels):
     assert ld.count("s_barrier") == 1                 # only the counter-initialisation barrier; the hand-off is two LDS counters
     assert "wave_shr:1" in ld and "wave_shl:1" in ld  # ONE whole-wave DPP shift per diagonal carries the neighbour column
     assert ld.count("v_exp_f32") >= 96 and ld.count("v_log_f32") >= 96  # 2 directions x 16 unrolled diagonals x 3 columns
-    p1 = asm[_find(asm, "joint_phase1_kernel")[0]]
-    assert "v_mfma_f32_32x32x2_f32" in p1
-    # default f32-parity joint: split-precision products (hi + lo binary16 operands) on the f16 MFMA units
-    for name in ("joint_phase1s_kernel", "joint_phase2s_kernel"):
+    # the linear-domain sweeps (the loss op's default and, since round 5, the fused f32-grade joint's): multiply / add only on the
+    # serial chain -- no transcendental anywhere in the kernel --, one whole-wave DPP shift per unrolled diagonal and direction
+    for kk, g in ((1, 16), (2, 16), (3, 16), (4, 16), (6, 8), (8, 8), (12, 4), (16, 4)):
+        ln = asm[_find(asm, "lin_sweep_kernel", f"Li{kk}ELi{g}E")[0]]
+        assert "v_exp_f32" not in ln and "v_log_f32" not in ln and "v_rcp_f32" not in ln, kk
+        assert "global_load_lds_dwordx4" in ln and "v_ldexp_f32" in ln and "v_frexp_exp_i32_f32" in ln
+        assert ln.count("wave_shr:1") >= g and ln.count("wave_shl:1") >= g, kk  # (the renormalisation's look-back shifts come on top)
+    l3 = asm[_find(asm, "lin_sweep_kernel", "Li3ELi16E")[0]]
+    assert "global_store_dwordx3" in l3 and l3.count("s_barrier") == 1
+    for name in ("lin_redo_kernel", "joint_redo_kernel"):  # the log-domain redo: float64 recurrence, LDS-DMA loader, agent-scope phase counter
+        rd = asm[_find(asm, name, "Li3ELi16E")[0]]
+        assert "v_add_f64" in rd and "global_load_lds_dwordx4" in rd and "global_atomic_add" in rd
+    # f32-parity joint: split-precision products (hi + lo binary16 operands) on the f16 MFMA units, in every kernel of it
+    for name, n_mfma in (("joint_fwd_kernel", 6), ("joint_bwd_kernel", 12), ("joint_phase1s_kernel", 12), ("joint_phase2s_kernel", 12),
+                         ("dense_gemm_nt_kernel", 12), ("dense_gemm_tn_kernel", 12)):
         ks = asm[_find(asm, name)[0]]
-        assert ks.count("v_mfma_f32_32x32x16_f16") >= 12 and "v_cvt_pk" in ks and "v_mfma_f32_32x32x2_f32" not in ks
+        assert ks.count("v_mfma_f32_32x32x16_f16") >= n_mfma and "v_mfma_f32_32x32x2_f32" not in ks, name
+    for name in ("joint_fwd_kernel", "joint_bwd_kernel", "joint_phase1s_kernel", "joint_phase2s_kernel"):
+        assert "v_cvt_pk_f16_f32" in asm[_find(asm, name)[0]] and "v_fma_mix_f32" in asm[_find(asm, name)[0]], name
+    fw = asm[_find(asm, "joint_fwd_kernel")[0]]
+    assert "v_permlane32_swap" in fw and "row_newbcast" in fw and "global_load_lds_dwordx4" in fw and "s_barrier" in fw
+    assert "ds_read_b64_tr_b16" in asm[_find(asm, "dense_gemm_tn_kernel")[0]]
+    for name, text in asm.items():
+        assert "v_mfma_f32_32x32x2_f32" not in text, name  # round 5: no plain-f32 MFMA fallback left (W2 is scaled into binary16's range)
     for name, text in asm.items():
         assert "v_mfma_f32_32x32x8" not in text  # no CDNA3-shaped f16 MFMAs: gfx950 forms only
 

@@ -81,28 +81,30 @@ class Call:
         return self.costs.cpu().numpy().astype(np.float64), self.grads.cpu().numpy().reshape(self.shape)
 
     def _tail(self):
-        """Byte sizes of the last three regions of the workspace (csrc/rnnt_common.h make_layout): hand-back words [B][4] int,
-        decay statistics [B][patches x 4 waves] float2, chosen block lengths [B] int -- each rounded up to 256 bytes."""
+        """Byte sizes of the last four regions of the workspace (csrc/rnnt_common.h make_layout): hand-back words [B][4] int,
+        decay statistics [B][patches x 4 waves] float2, chosen block lengths [B] int, hand-back team counters [B] int -- each
+        rounded up to 256 bytes."""
         B, T, U, _ = self.shape
         nu = (U + 31) // 32
         UU = (U + nu - 1) // nu
         TT = min(256 // UU, T)
         n_pstat = ((T + TT - 1) // TT) * ((U + UU - 1) // UU) * 4
         up = lambda n: (n + 255) // 256 * 256
-        return up(B * 16), up(B * n_pstat * 8), up(B * 4)
+        return up(B * 16), up(B * n_pstat * 8), up(B * 4), up(B * 4)
 
     def flags(self):
         """The per-utterance hand-back words [B][4] = (alpha flag, beta flag, certificate flag, state)."""
         B = self.shape[0]
-        f, ps, ls = self._tail()
-        n = self.ws.numel()
+        f, ps, ls, bar = self._tail()
+        n = self.ws.numel() - bar
         return self.ws[n - ls - ps - f: n - ls - ps].view(torch.int32)[: 4 * B].cpu().numpy().reshape(B, 4)
 
     def block_shifts(self):
         """log2 of the diagonals per frame block the sweeps chose, per utterance."""
         B = self.shape[0]
-        _, _, ls = self._tail()
-        return self.ws[self.ws.numel() - ls:].view(torch.int32)[:B].cpu().numpy()
+        _, _, ls, bar = self._tail()
+        n = self.ws.numel() - bar
+        return self.ws[n - ls: n].view(torch.int32)[:B].cpu().numpy()
 
 
 def _check(c, g, acts, labels, il, ll, gtol=1e-4, ctol=1e-4):
@@ -199,6 +201,38 @@ def test_split_calls_and_repeated_backward():
     c, g = k.full()
     _check(c, g, acts, labels, il, ll, gtol=1e-5)
     assert not k.flags().any()
+
+
+def test_certificate_only_hand_back_through_the_autograd_split():
+    """4 x N(0,1) logits at the configs[1] lattice size: both sweeps finish with agreeing, finite likelihoods -- nothing is flagged
+    when compute_rnnt_loss_fwd returns its costs -- and the GRADIENT pass's range certificate then raises the utterance's flag,
+    inside compute_rnnt_loss_bwd: the route rnnt_loss(...).backward() takes (loss.py:31-80).  The costs the forward returned, the
+    flag that fired and the gradients of the redone utterances are all checked."""
+    rng = np.random.default_rng(77)
+    B, T, U, V = 2, 600, 150, 28
+    acts = (rng.normal(size=(B, T, U, V)) * 4.0).astype(np.float32)
+    labels = rng.integers(1, V, size=(B, U - 1)).astype(np.int32)
+    il, ll = np.array([T, T - 37], np.int32), np.array([U - 1, U - 12], np.int32)
+    c_ref, g_ref = orc.rnnt_loss_and_grad(acts, labels, il, ll)
+    # (1) the C entry points the autograd function calls, with the workspace in hand
+    k = Call(acts, labels, il, ll, poison=True)
+    c = k.fwd()
+    f0 = k.flags().copy()
+    assert not f0.any(), f0  # nothing flagged by the forward: the costs below are the linear lattice's
+    np.testing.assert_array_less(np.abs(c - c_ref), 1e-4 * np.maximum(1.0, np.abs(c_ref)))
+    g = k.bwd()
+    f1 = k.flags()
+    assert (f1[:, 2] != 0).all() and not f1[:, :2].any() and (f1[:, 3] == 2).all(), f1  # certificate only; redone: log-domain state
+    assert np.isfinite(g).all() and np.abs(g - g_ref).max() <= 1e-4
+    np.testing.assert_array_equal(g, k.bwd())  # a repeated backward finds the log-domain lattice
+    # (2) the same through autograd: forward, then backward with an upstream gradient
+    x = torch.tensor(acts, device=DEV, requires_grad=True)
+    costs = pkg.rnnt_loss(x, torch.tensor(labels, device=DEV), torch.tensor(il, device=DEV), torch.tensor(ll, device=DEV))
+    up = torch.tensor([0.5, -1.5], device=DEV)
+    (costs * up).sum().backward()
+    torch.cuda.synchronize()
+    np.testing.assert_array_less(np.abs(costs.detach().cpu().numpy() - c_ref), 1e-4 * np.maximum(1.0, np.abs(c_ref)))
+    assert np.abs(x.grad.cpu().numpy() - g_ref * up.cpu().numpy()[:, None, None, None]).max() <= 1.5e-4  # 1e-4 x the largest |upstream|
 
 
 def test_cost_scale_on_both_routes():
