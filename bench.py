@@ -192,7 +192,7 @@ def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
     except RuntimeError as e:
         return {"error": str(e)}
     opts = _lib.make_options(stream.cuda_stream, 0, T, U)
-    f16 = V > 32  # large vocabularies run the J x V products on the f16 MFMA units (joint_dtype = 1)
+    f16 = V > 64  # large vocabularies run the J x V products on the f16 MFMA units (joint_dtype = 1); up to 64 symbols: f32-grade
 
     def step():
         _lib.check(lib.compute_rnnt_joint_loss(ep.data_ptr(), pp.data_ptr(), W2.data_ptr(), b2.data_ptr(),
@@ -230,7 +230,7 @@ def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
     # hi + lo parts (three MFMAs per product, f32-grade result; csrc/joint_kernels.hip joint_phase1s / phase2s), so the
     # matrix-pipe ceiling for "f32-grade" flops is the dense f16 peak / 3.  Issued work: forward GEMM + dh + dW2 on V padded to
     # 32 (no backward recompute: the logits tile is parked).
-    executed = 6.0 * J * 32 * cells
+    executed = 6.0 * J * 32 * ((V + 31) // 32) * cells  # (vocabulary tiles of 32 symbols: two passes for 32 < V <= 64)
     split_peak = MFMA_F16_PEAK_TFLOPS / 3.0
     return {"workload": f"joint+loss+grads from enc_proj/pred_proj, B={B} T={T} U={U} V={V} J={J}, "
                         "f32-grade products on split-precision f16 MFMAs",
@@ -747,7 +747,7 @@ def main():
                   "lengths": "T_b ~ U{T/2..T}, L_b ~ U{(U-1)/2..U-1}, one full-length utterance (SURVEY.md 8d)"}
 
     # ---- fused joint + loss (SURVEY.md 8d "P2"): reported beside the headline, not as `value` ----
-    fused = fused_full = fused_c5 = fused_mid = op_c5 = fused_dp = None
+    fused = fused_full = fused_c5 = fused_mid = fused_ref = fused_v64 = op_c5 = fused_dp = None
     headline_shape = (B, T, U, V) == (32, 600, 150, 28)
     if not a.no_fused:
         nf = max(3, min(a.steps, 10))
@@ -787,6 +787,14 @@ def main():
             # at the headline lattice, native since round 4 (before: padded to 512 columns)
             fused_mid = bench_fused_joint(lib, _lib, dev, B, T, U, 128, 640, stream, 5)
             torch.cuda.empty_cache()
+            # 64 symbols, f32-grade (round 5: two vocabulary tiles of the split-precision joint; before: binary16 products on 128 columns)
+            fused_v64 = bench_fused_joint(lib, _lib, dev, B, T, U, 64, 640, stream, 5)
+            torch.cuda.empty_cache()
+            # the reference's own default hyper-parameters (hparams.py:4 vocab_size 4096, :18,23 joint / hidden size 640) on a
+            # realistic lattice: 600 frames after x2 time reduction, up to 99 word pieces (tests/test_baseline_sizes_gpu.py checks
+            # this shape against the streamed float64 joint)
+            fused_ref = bench_fused_joint(lib, _lib, dev, 16, 300, 100, 4096, 640, stream, 3)
+            torch.cuda.empty_cache()
             try:
                 op_c5 = bench_op_shape(lib, _lib, dev, 16, 1500, 300, 1024, stream, 3)
             except Exception as e:
@@ -819,7 +827,8 @@ def main():
             "warm_value": world * cells * a.steps / dt_warm,
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "roofline": roof, "cpu_baseline": cpu, "ragged_batch": ragged, "fused_joint": fused,
-            "fused_joint_full": fused_full, "fused_joint_config5": fused_c5, "fused_joint_v128": fused_mid, "op_config5": op_c5,
+            "fused_joint_full": fused_full, "fused_joint_config5": fused_c5, "fused_joint_v128": fused_mid, "fused_joint_v64": fused_v64, "fused_joint_refdefault": fused_ref,
+            "op_config5": op_c5,
             "fused_dp_step": fused_dp, "e2e_train_step": e2e,
         }
         if world > 1:

@@ -89,19 +89,25 @@ RNNT_API rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool
  * frame is flushed; whether that mattered is decided per lattice cell by the gradient pass (what a flush can have cost, times
  * the other side's mass, over the likelihood, must stay below 2^-40) and per utterance by the sweeps (likelihood zero /
  * non-finite, alpha-side vs beta-side likelihood, an edge probability below 2^-100).  An utterance that fails is redone by the
- * LOG-domain kernels -- one workgroup per utterance, ~2 ms at T=600 U=150 (a whole batch of such inputs: 1.9 - 2.3 ms per step against
- * 0.23 ms), exact for any range -- so results never depend on the shortcut.
+ * LOG-domain kernels, exact for any range, so results never depend on the shortcut: a TEAM of workgroups per utterance (round 5:
+ * cell phases split over up to 16 CUs, alpha and beta side by side; one flagged utterance in a B=32 T=600 U=150 batch costs
+ * +0.3 ms on a 0.23 ms step -- one workgroup per utterance took +2 ms -- and a batch in which EVERY utterance is handed back
+ * 1.2 ms instead of 2.3).
  * N(0,1) logits and trained-like posteriors (one dominant symbol per cell along any monotone alignment) stay on the linear
- * lattice, and so do unstructured logits up to about 4 x N(0,1) (the sweeps shorten their frame blocks from 8 to 4 diagonals where
- * the lsm pass saw the mass decay fast); beyond that utterances are handed back.  Everything else (larger vocabularies, unaligned
- * tensors, more than 1024 columns, the fused joints) runs on the log-domain kernels throughout.
+ * lattice.  Unstructured logits of 4 x N(0,1) sit on the edge at that size (the sweeps shorten their frame blocks from 8 to 4
+ * diagonals where the lsm pass saw the mass decay fast; some draws pass the certificate, others -- about a third of the
+ * utterances of a batch -- are handed back); from about 5 x N(0,1) on every utterance is.  Larger vocabularies, unaligned
+ * tensors, more than 1024 columns, the wide (640 < joint_size <= 704) and the f16 fused joints run on the log-domain kernels
+ * throughout; the f32-grade fused joint (joint_dtype 0, joint_size <= 640) runs on the linear lattice since round 5, with the
+ * same certificate and the same hand-back (from its parked logits).
  * The log-domain kernels keep alpha / beta as log2 values.  Wherever THIS op uses them (the hand-back, vocabularies above 60
  * symbols, unaligned tensors, more than 1024 columns) the recurrence is carried in float64 registers -- the log2(1 + 2^-|d|) term
  * of a log-add, in (0, 1], on the float32 units -- and only the stored lattice is float32 (residues against an integer offset per
  * block of 8 diagonals and sweep lane / group of 64 columns): a float32 recurrence rounds every log-add at the magnitude of its
  * residue, a random walk that reached 1e-4 ... 5e-4 of gradient error over the ~1,000-step paths of peaked or wide lattices
- * (rounds 1-3; tests/tools/emulate_sweep.py).  The f32-grade fused joint (joint_dtype 0) uses the float64 recurrence as well; the f16
- * joint (joint_dtype 1: binary16 roundings set its error) keeps the float32 one up to 6 columns per lane (maxU <= 384).
+ * (rounds 1-3; tests/tools/emulate_sweep.py).  The wide f32-grade fused joint (joint_dtype 0, 640 < joint_size <= 704) and the
+ * hand-back of the ordinary one use the float64 recurrence as well; the f16 joint (joint_dtype 1: binary16 roundings set its error)
+ * keeps the float32 one up to 6 columns per lane (maxU <= 384).
  * Bars, against a float64 evaluation of the same logits, all tested with FIXED bars (tests/test_lin_gpu.py,
  * tests/test_peaky_gpu.py, tests/test_peaky_wide_gpu.py, tests/test_loss_gpu.py; measured values in profiles/r04_accuracy*.json):
  *   costs      within 1e-4 max(1, |cost|) everywhere (measured <= 6e-6);
@@ -180,9 +186,12 @@ RNNT_API rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, cons
  *                                Fully overwritten.  May all be NULL for score-only.
  *   joint_dtype                  arithmetic of the J x V products.
  *                                0 = f32-grade products (operands split into binary16 hi + lo parts, three f16 MFMAs per product, f32
- *                                    accumulation; when some |W2| leaves the binary16 range the library switches, on the device, to
- *                                    plain f32 MFMA kernels with no such limit), small vocabularies: alphabet_size <= 32 (the
- *                                    reference's character set), joint_size a multiple of 64 (<= 704).
+ *                                    accumulation).  W2 enters the products scaled by the power of two that puts max |W2| into
+ *                                    [2^13, 2^14): any finite magnitude is taken (round 5; before, weights beyond binary16's
+ *                                    65504 switched the call to plain f32 MFMA kernels), weights within 2^-13 of the largest
+ *                                    keep 22 significand bits, smaller ones an absolute error of 2^-38 max |W2|.  Small
+ *                                    vocabularies: alphabet_size <= 32 (the reference's character set), joint_size a multiple
+ *                                    of 64 (<= 704).
  *                                1 = f16 MFMA, larger vocabularies: alphabet_size a multiple of 128 (128 ... 8192),
  *                                    joint_size a multiple of 128 (128 ... 640).  h = tanh(.) and W2 are rounded to binary16
  *                                    (round-to-nearest-even) before the products, accumulation is f32; the loss gradient
@@ -198,7 +207,8 @@ RNNT_API rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, cons
  *                                    logits instead (one rounding less; results differ by binary16 rounding noise).
  *                                    Counterpart of the reference's `mixed_float16` policy (run_rnnt.py:96-99); oracle:
  *                                    oracle/rnnt_oracle.py joint_loss_and_grads_f16 (parked=True / False).
- *                                Any other (joint_dtype, shape) combination returns RNNT_STATUS_INVALID_VALUE.
+ *                                Any other (joint_dtype, shape) combination returns RNNT_STATUS_INVALID_VALUE -- checked before
+ *                                anything is enqueued, in every entry point that takes joint_dtype.
  *                                get_joint_workspace_size needs no dtype: the two shape domains are disjoint.
  * Both: maxU <= 1024; enc_proj, pred_proj (and b2 for joint_dtype 1) 16-byte aligned.
  * compute_rnnt_joint_loss      = costs and all four gradients in one call
@@ -280,7 +290,7 @@ RNNT_API rnntStatus_t compute_rnnt_joint_net_loss_bwd(const float *enc, const fl
  * with enc_proj / pred_proj as for compute_rnnt_joint_loss (the first Dense layer factored, bias folded into enc_proj).
  * It runs the forward kernels of compute_rnnt_joint_loss with the same joint_dtype on a lattice whose every cell is live, so a
  * decoder sees the logits the loss was trained on:
- *   joint_dtype 0  f32-grade split-precision products (and the same device-side switch to plain f32 MFMAs): alphabet_size <= 32,
+ *   joint_dtype 0  f32-grade split-precision products (the same power-of-two scale of W2): alphabet_size <= 32,
  *                  joint_size a multiple of 64 (<= 704);
  *   joint_dtype 1  operands rounded to binary16, f32 accumulation (the reference's default vocabulary of 4096 word pieces,
  *                  hparams.py:4): alphabet_size a multiple of 128 (128 ... 8192), joint_size a multiple of 128 (128 ... 640); logits 16-byte aligned.

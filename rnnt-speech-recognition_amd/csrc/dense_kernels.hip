@@ -126,12 +126,13 @@ __device__ __forceinline__ void dense_split4(const float4 v, const float S, dh4 
 
 // x [rows][cols] f32 (row-major, contiguous) -> hi / lo images at rows [row_off, row_off + rows) of [*][cols] binary16 arrays,
 // scaled by the tensor's power of two; scal[slot] receives S.  Flat, 16-byte loads / 8-byte stores.
-__global__ __launch_bounds__(256) void dense_split_kernel(const float *__restrict__ x, df16 *__restrict__ hi, df16 *__restrict__ lo,
-                                                          size_t n, size_t elem_off, const unsigned *maxarr, int maxcount, float *scal, int slot) {
+__device__ __forceinline__ void dense_split_body(const float *__restrict__ x, df16 *__restrict__ hi, df16 *__restrict__ lo, size_t n,
+                                                 size_t elem_off, const unsigned *maxarr, int maxcount, float *scal, int slot,
+                                                 const unsigned blk, const unsigned nblk) {
     const float S = dense_scale_from_bits(dense_max_of(maxarr, maxcount));
-    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(scal + slot, S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blk == 0 && threadIdx.x == 0) __hip_atomic_store(scal + slot, S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const size_t n4 = n >> 2;  // cols % 8 == 0 (checked by the launcher): n % 4 == 0 and the images are 8-byte aligned
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    for (size_t i = (size_t)blk * 256 + threadIdx.x; i < n4; i += (size_t)nblk * 256) {
         const float4 v = ((const float4 *)x)[i];
         dh4 h, l;
         dense_split4(v, S, h, l);
@@ -143,13 +144,13 @@ __global__ __launch_bounds__(256) void dense_split_kernel(const float *__restric
 // The same for d enc_proj, plus per-block column sums of the UNSCALED input (db1 = sum over the enc rows), written to
 // colpart[block][cols] and summed in a fixed order afterwards.  A block owns kDbRows rows; a thread owns 4 columns.
 constexpr int kDbRows = 16;
-__global__ __launch_bounds__(256) void dense_split_colsum_kernel(const float *__restrict__ x, df16 *__restrict__ hi, df16 *__restrict__ lo,
-                                                                 int rows, int cols, const unsigned *maxarr, int maxcount, float *scal, int slot,
-                                                                 float *__restrict__ colpart) {
+__device__ __forceinline__ void dense_split_colsum_body(const float *__restrict__ x, df16 *__restrict__ hi, df16 *__restrict__ lo, int rows,
+                                                        int cols, const unsigned *maxarr, int maxcount, float *scal, int slot,
+                                                        float *__restrict__ colpart, const unsigned blk) {
     const float S = dense_scale_from_bits(dense_max_of(maxarr, maxcount));
-    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(scal + slot, S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blk == 0 && threadIdx.x == 0) __hip_atomic_store(scal + slot, S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int c4 = cols >> 2;
-    const int r0 = blockIdx.x * kDbRows, nr = min(kDbRows, rows - r0);
+    const int r0 = (int)blk * kDbRows, nr = min(kDbRows, rows - r0);
     for (int cq = threadIdx.x; cq < c4; cq += 256) {
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int rb = 0; rb < nr; rb += 4) {
@@ -168,29 +169,77 @@ __global__ __launch_bounds__(256) void dense_split_colsum_kernel(const float *__
                 *(dh4 *)(lo + o) = l;
             }
         }
-        *(float4 *)(colpart + (size_t)blockIdx.x * cols + cq * 4) = sum;
+        *(float4 *)(colpart + (size_t)blk * cols + cq * 4) = sum;
     }
 }
 
 // zero rows [r0, r1) of a hi / lo image pair (the padding rows of the TN product's K range)
-__global__ __launch_bounds__(256) void dense_zero_rows_kernel(df16 *hi, df16 *lo, int r0, int r1, int cols) {
+__device__ __forceinline__ void dense_zero_rows_body(df16 *hi, df16 *lo, int r0, int r1, int cols, const unsigned blk, const unsigned nblk) {
     const size_t n = (size_t)(r1 - r0) * cols, base = (size_t)r0 * cols;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) hi[base + i] = (df16)0.f, lo[base + i] = (df16)0.f;
+    for (size_t i = (size_t)blk * 256 + threadIdx.x; i < n; i += (size_t)nblk * 256) hi[base + i] = (df16)0.f, lo[base + i] = (df16)0.f;
 }
 
 // W [H][J] f32 -> split images of W ([H][J], for dX = dproj . W^T) and of W^T ([J][H], for proj = X . W); tiny (H J <= 0.5 M)
-__global__ __launch_bounds__(256) void dense_split_w_kernel(const float *W, df16 *whi, df16 *wlo, df16 *thi, df16 *tlo, int H, int J,
-                                                            const unsigned *maxarr, int maxcount, float *scal, int slot) {
+__device__ __forceinline__ void dense_split_w_body(const float *W, df16 *whi, df16 *wlo, df16 *thi, df16 *tlo, int H, int J,
+                                                   const unsigned *maxarr, int maxcount, float *scal, int slot, const unsigned blk,
+                                                   const unsigned nblk) {
     const float S = dense_scale_from_bits(dense_max_of(maxarr, maxcount));
-    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(scal + slot, S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blk == 0 && threadIdx.x == 0) __hip_atomic_store(scal + slot, S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const size_t n = (size_t)H * J;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    for (size_t i = (size_t)blk * 256 + threadIdx.x; i < n; i += (size_t)nblk * 256) {
         const int h = (int)(i / (size_t)J), j = (int)(i - (size_t)h * J);
         const float x = W[i] * S;
         const df16 a = (df16)x, b = (df16)(x - (float)a);
         whi[i] = a, wlo[i] = b;
         thi[(size_t)j * H + h] = a, tlo[(size_t)j * H + h] = b;
     }
+}
+
+// Everything a GEMM pass needs of its operands, in ONE launch (round 5; up to six launches before): the split images of the two
+// row segments (enc / pred rows of X, or of d proj -- the latter with the column partials of db1), the zero padding rows of the
+// image, and (forward) the two images of W1.  Blocks are dealt to the jobs by index ranges; every block redoes its tensor's
+// 512-entry abs-max reduction, as before.
+struct PrepJob {
+    const float *x[2];            // the two row segments
+    df16 *hi, *lo;                // their image pair
+    size_t n[2], elem_off[2];
+    const unsigned *maxarr[2];
+    int maxcount, slot[2];
+    float *scal;
+    int rows0, cols;              // segment 0 as rows x cols ...
+    float *colpart;               // ... with per-block column sums when non-null (then g[0] = ceil(rows0 / kDbRows))
+    int pad[4];                   // zero rows [pad[0], pad[1]) and [pad[2], pad[3]) of the image
+    const float *W;               // nullable
+    df16 *whi, *wlo, *thi, *tlo;
+    int H, J, wslot;
+    const unsigned *wmaxarr;
+    unsigned g[4];                // blocks of: segment 0, segment 1, the padding rows, W
+};
+__global__ __launch_bounds__(256) void dense_prepare_kernel(const PrepJob job) {
+    unsigned blk = blockIdx.x;
+    if (blk < job.g[0]) {
+        if (job.colpart)
+            dense_split_colsum_body(job.x[0], job.hi, job.lo, job.rows0, job.cols, job.maxarr[0], job.maxcount, job.scal, job.slot[0], job.colpart, blk);
+        else
+            dense_split_body(job.x[0], job.hi, job.lo, job.n[0], job.elem_off[0], job.maxarr[0], job.maxcount, job.scal, job.slot[0], blk, job.g[0]);
+        return;
+    }
+    blk -= job.g[0];
+    if (blk < job.g[1]) {
+        dense_split_body(job.x[1], job.hi, job.lo, job.n[1], job.elem_off[1], job.maxarr[1], job.maxcount, job.scal, job.slot[1], blk, job.g[1]);
+        return;
+    }
+    blk -= job.g[1];
+    if (blk < job.g[2]) {
+        const unsigned half = job.g[2] / 2;
+        if (blk < half)
+            dense_zero_rows_body(job.hi, job.lo, job.pad[0], job.pad[1], job.cols, blk, half);
+        else
+            dense_zero_rows_body(job.hi, job.lo, job.pad[2], job.pad[3], job.cols, blk - half, half);
+        return;
+    }
+    blk -= job.g[2];
+    dense_split_w_body(job.W, job.whi, job.wlo, job.thi, job.tlo, job.H, job.J, job.wmaxarr, kAbsBlocks, job.scal, job.wslot, blk, job.g[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -555,9 +604,9 @@ __global__ __launch_bounds__(256) void dense_gemm_tn_kernel(const DenseTN g) {
 // out[i] = sum_q P[q][i] in a FIXED association (deterministic): G lanes share an output float4, lane g sums partials g, g + G,
 // g + 2G, ... in order (four loads in flight), then a binary tree over the G lanes.  n % 4 == 0.
 template <int G>
-__global__ __launch_bounds__(256) void dense_reduce_kernel(float *out, const float *P, int nparts, size_t n) {
+__device__ __forceinline__ void dense_reduce_body(float *out, const float *P, int nparts, size_t n, const unsigned blk) {
     const size_t n4 = n >> 2;
-    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) / G;
+    const size_t i = ((size_t)blk * 256 + threadIdx.x) / G;
     const int grp = threadIdx.x & (G - 1);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n4) {
@@ -581,11 +630,19 @@ __global__ __launch_bounds__(256) void dense_reduce_kernel(float *out, const flo
     if (i < n4 && grp == 0) ((float4 *)out)[i] = s;
 }
 
-template <int G>
-static hipError_t dense_reduce(float *out, const float *P, int nparts, size_t n, hipStream_t s) {
-    if ((n & 3) != 0 || ((uintptr_t)out & 15) != 0) return hipErrorInvalidValue;
-    const size_t threads = (n >> 2) * G;
-    hipLaunchKernelGGL((dense_reduce_kernel<G>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, out, P, nparts, n);
+// dW1 (G = 4) and db1 (G = 64) in one launch
+__global__ __launch_bounds__(256) void dense_reduce2_kernel(float *out0, const float *P0, int nparts0, size_t n0, unsigned g0, float *out1,
+                                                            const float *P1, int nparts1, size_t n1) {
+    if (blockIdx.x < g0)
+        dense_reduce_body<4>(out0, P0, nparts0, n0, blockIdx.x);
+    else
+        dense_reduce_body<64>(out1, P1, nparts1, n1, blockIdx.x - g0);
+}
+static hipError_t dense_reduce2(float *out0, const float *P0, int nparts0, size_t n0, float *out1, const float *P1, int nparts1, size_t n1,
+                                hipStream_t s) {
+    if (((n0 | n1) & 3) != 0 || ((((uintptr_t)out0) | ((uintptr_t)out1)) & 15) != 0) return hipErrorInvalidValue;
+    const unsigned g0 = (unsigned)(((n0 >> 2) * 4 + 255) / 256), g1 = (unsigned)(((n1 >> 2) * 64 + 255) / 256);
+    hipLaunchKernelGGL(dense_reduce2_kernel, dim3(g0 + g1), dim3(256), 0, s, out0, P0, nparts0, n0, g0, out1, P1, nparts1, n1);
     return hipGetLastError();
 }
 
@@ -674,11 +731,6 @@ static void dense_absmax(const AbsmaxJob &job, hipStream_t s) {
     hipLaunchKernelGGL(dense_absmax_kernel, dim3(kAbsBlocks), dim3(256), 0, s, job);
 }
 
-static void dense_zero_pad(df16 *hi, df16 *lo, const DenseLayout &L, int cols, hipStream_t s) {
-    if (L.R0p > L.R0) hipLaunchKernelGGL(dense_zero_rows_kernel, dim3(16), dim3(256), 0, s, hi, lo, L.R0, L.R0p, cols);
-    if (L.Rp > L.R0p + L.R1) hipLaunchKernelGGL(dense_zero_rows_kernel, dim3(16), dim3(256), 0, s, hi, lo, L.R0p + L.R1, L.Rp, cols);
-}
-
 static hipError_t dense_nt_launch(DenseNT &g, hipStream_t s) {
     const size_t shm = (size_t)kNtStages * kNtStage;
     hipError_t e = hipFuncSetAttribute((const void *)dense_gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -707,14 +759,19 @@ hipError_t launch_dense_fwd(const float *enc, const float *pred, const float *W1
         job.count = 3;
         dense_absmax(job, s);
     }
-    hipLaunchKernelGGL(dense_split_kernel, dim3(dense_flat_grid(ne / 4)), dim3(256), 0, s, enc, Xhi, Xlo, ne, (size_t)0,
-                       (const unsigned *)dense_maxarr(scal, kSlotXe), (int)kAbsBlocks, scal, (int)kSlotXe);
-    hipLaunchKernelGGL(dense_split_kernel, dim3(dense_flat_grid(np / 4)), dim3(256), 0, s, pred, Xhi, Xlo, np, (size_t)L.R0p * H,
-                       (const unsigned *)dense_maxarr(scal, kSlotXp), (int)kAbsBlocks, scal, (int)kSlotXp);
-    dense_zero_pad(Xhi, Xlo, L, H, s);
-    hipLaunchKernelGGL(dense_split_w_kernel, dim3(512), dim3(256), 0, s, W1, (df16 *)(ws + L.Whi), (df16 *)(ws + L.Wlo),
-                       (df16 *)(ws + L.WThi), (df16 *)(ws + L.WTlo), H, J, (const unsigned *)dense_maxarr(scal, kSlotW), (int)kAbsBlocks,
-                       scal, (int)kSlotW);
+    {
+        PrepJob pj;
+        pj.x[0] = enc, pj.x[1] = pred, pj.hi = Xhi, pj.lo = Xlo;
+        pj.n[0] = ne, pj.n[1] = np, pj.elem_off[0] = 0, pj.elem_off[1] = (size_t)L.R0p * H;
+        pj.maxarr[0] = dense_maxarr(scal, kSlotXe), pj.maxarr[1] = dense_maxarr(scal, kSlotXp), pj.maxcount = kAbsBlocks;
+        pj.slot[0] = kSlotXe, pj.slot[1] = kSlotXp, pj.scal = scal;
+        pj.rows0 = L.R0, pj.cols = H, pj.colpart = nullptr;
+        pj.pad[0] = L.R0, pj.pad[1] = L.R0p, pj.pad[2] = L.R0p + L.R1, pj.pad[3] = L.Rp;
+        pj.W = W1, pj.whi = (df16 *)(ws + L.Whi), pj.wlo = (df16 *)(ws + L.Wlo), pj.thi = (df16 *)(ws + L.WThi), pj.tlo = (df16 *)(ws + L.WTlo);
+        pj.H = H, pj.J = J, pj.wslot = kSlotW, pj.wmaxarr = dense_maxarr(scal, kSlotW);
+        pj.g[0] = dense_flat_grid(ne / 4), pj.g[1] = dense_flat_grid(np / 4), pj.g[2] = 32, pj.g[3] = 512;
+        hipLaunchKernelGGL(dense_prepare_kernel, dim3(pj.g[0] + pj.g[1] + pj.g[2] + pj.g[3]), dim3(256), 0, s, pj);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     DenseNT g;
@@ -741,11 +798,18 @@ hipError_t launch_dense_bwd(int B, int T, int U, int H, int J, float *d_enc, flo
     const float *de = (const float *)(ws + L.dproj_e), *dp = (const float *)(ws + L.dproj_p);
     const size_t ne = (size_t)L.R0 * J, np = (size_t)L.R1 * J;
     // (the abs-max entries of d enc_proj / d pred_proj were left by the fused joint's reductions: JointHooks)
-    hipLaunchKernelGGL(dense_split_colsum_kernel, dim3(L.db_blocks), dim3(256), 0, s, de, Dhi, Dlo, L.R0, J,
-                       (const unsigned *)dense_maxarr(scal, kSlotDe), (int)kHookBlocks, scal, (int)kSlotDe, (float *)(ws + L.dbpart));
-    hipLaunchKernelGGL(dense_split_kernel, dim3(dense_flat_grid(np / 4)), dim3(256), 0, s, dp, Dhi, Dlo, np, (size_t)L.R0p * J,
-                       (const unsigned *)dense_maxarr(scal, kSlotDp), (int)kHookBlocks, scal, (int)kSlotDp);
-    dense_zero_pad(Dhi, Dlo, L, J, s);
+    {
+        PrepJob pj;
+        pj.x[0] = de, pj.x[1] = dp, pj.hi = Dhi, pj.lo = Dlo;
+        pj.n[0] = ne, pj.n[1] = np, pj.elem_off[0] = 0, pj.elem_off[1] = (size_t)L.R0p * J;
+        pj.maxarr[0] = dense_maxarr(scal, kSlotDe), pj.maxarr[1] = dense_maxarr(scal, kSlotDp), pj.maxcount = kHookBlocks;
+        pj.slot[0] = kSlotDe, pj.slot[1] = kSlotDp, pj.scal = scal;
+        pj.rows0 = L.R0, pj.cols = J, pj.colpart = (float *)(ws + L.dbpart);  // (db1's column partials ride on the enc rows)
+        pj.pad[0] = L.R0, pj.pad[1] = L.R0p, pj.pad[2] = L.R0p + L.R1, pj.pad[3] = L.Rp;
+        pj.W = nullptr, pj.whi = pj.wlo = pj.thi = pj.tlo = nullptr, pj.H = H, pj.J = J, pj.wslot = kSlotW, pj.wmaxarr = nullptr;
+        pj.g[0] = (unsigned)L.db_blocks, pj.g[1] = dense_flat_grid(np / 4), pj.g[2] = 32, pj.g[3] = 0;
+        hipLaunchKernelGGL(dense_prepare_kernel, dim3(pj.g[0] + pj.g[1] + pj.g[2]), dim3(256), 0, s, pj);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // dX = dproj . W1^T  (NT: A = dproj rows, B = W1 rows [H][J], K = J)
     {
@@ -767,9 +831,8 @@ hipError_t launch_dense_bwd(int B, int T, int U, int H, int J, float *d_enc, flo
         g.tiles_m = (H + kTnT - 1) / kTnT, g.tiles_n = (J + kTnT - 1) / kTnT, g.nsplit = L.nsplit, g.ns0 = L.ns0;
         hipLaunchKernelGGL(dense_gemm_tn_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n * g.nsplit)), dim3(256), shm, s, g);
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        if ((e = dense_reduce<4>(dW1, g.P, L.nsplit, (size_t)H * J, s)) != hipSuccess) return e;
+        return dense_reduce2(dW1, g.P, L.nsplit, (size_t)H * J, db1, (const float *)(ws + L.dbpart), L.db_blocks, (size_t)J, s);
     }
-    return dense_reduce<64>(db1, (const float *)(ws + L.dbpart), L.db_blocks, (size_t)J, s);
 }
 
 }  // namespace rnnt

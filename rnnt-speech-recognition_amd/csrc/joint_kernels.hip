@@ -42,6 +42,7 @@ namespace rnnt {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 jf16;
 typedef _Float16 jh8 __attribute__((ext_vector_type(8)));
+typedef float jf2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void jglb_cvoid;
 
@@ -93,12 +94,14 @@ struct JointParams {
                          // [2] = 1 / s2: W2 enters every product as s2 W2, s2 the power of two that puts max |W2| into
                          //       [2^13, 2^14) (binary16 hi + lo parts then carry 22 significand bits whatever W2's magnitude)
                          // [3] == 1: the workspace holds the state of a whole-network forward call (JointHooks::prep_mode)
-    jf16 *W2s;           // [J/16][2 (hi, lo)][64 lanes][8]: s2 W2 as binary16 hi + lo parts in MFMA fragment order
-    float *b2s;          // [2][32]: b2[v] + sum_j W2[j][v] as an f32 hi + lo pair (-1e30 / 0 beyond V), for joint_fwd_kernel
+    jf16 *W2s;           // [VT][J/16][2 (hi, lo)][64 lanes][8]: s2 W2 as binary16 hi + lo parts in MFMA fragment order, per vocabulary tile
+    float *b2s;          // [VT][2][32]: b2[v] + sum_j W2[j][v] as an f32 hi + lo pair (-1e30 / 0 beyond V), for joint_fwd_kernel
 #ifdef JH_TRACE
     long long *trace;    // dev builds only: s_memtime stamps of one workgroup of phase 1 and one of phase 2
 #endif
     int J, n_ut, TR, n_tr, TS, n_ts;
+    int VT, vt;       // vocabulary tiles of 32 symbols (1, or 2 for 32 < V <= 64: round 5) and the tile THIS launch works on; the
+                      // parked logits are [cells][32 VT], W2s / b2s / dWpart / dbpart hold VT consecutive tile images
     int tables_ready; // the e^{2x} tables and tflag[0] were written by the caller (the dense layer's epilogue): prep does W2 only
     int logits_only;  // compute_rnnt_joint_logits: full lengths written by the prep kernel, only the parked logits are kept
     int nblk;         // workgroups per J group of joint_bwd_kernel (sizes what the reduction reads of the partial buffers)
@@ -147,64 +150,82 @@ __global__ __launch_bounds__(256) void joint_prep_kernel(const JointParams jp) {
     // s2 W2[16 ks + 8 (l >> 5) + 0..7][l & 31] (zero beyond V).  s2 = the power of two that puts max |W2| into [2^13, 2^14):
     // hi and lo are then both normal binary16 numbers for every weight within 2^-13 of the largest (22 significand bits
     // together; without the scale the lo part of a weight below 2^-3 sat in binary16's subnormals), and weights beyond
-    // binary16's range (65504) need no other kernels.  Every block that builds fragments finds max |W2| itself (J V <= 22,528
-    // floats out of L2); block 0 publishes 1 / s2.  A non-finite weight gives s2 = 1 and NaN results, as it should.
-    const int nfrag = (jp.J / 16) * 64;
-    if ((int)blockIdx.x * 256 < nfrag) {
-        __shared__ float wred[4];
-        const int nW = jp.J * p.V;
-        float wmax = 0.f;
-        for (int i0 = 0; i0 < nW; i0 += 256 * 16) {
-            float w[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int i = i0 + 256 * k + (int)threadIdx.x;
-                w[k] = (i < nW) ? fabsf(jp.W2[i]) : 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) wmax = fmaxf(wmax, w[k]);  // (a NaN operand is ignored: handled below)
-        }
+    // binary16's range (65504) need no other kernels.  A non-finite weight gives s2 = 1 and NaN results, as it should.
+    // Block 0 reads W2 once, column by column, for the bias table AND max |W2| (it publishes 1 / s2 and the r / h choice);
+    // blocks 1 .. build the fragment image and find max |W2| themselves first (J V <= 22,528 floats out of L2, all loads of a
+    // thread in flight at once): the two run side by side, under the table pass of the other blocks.
+    __shared__ float wred[4];
+    auto scale_of = [&](float wmax, float &s2, float &inv2) {  // wave maxima -> the block's -> the scale
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
         if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = wmax;
         __syncthreads();
         wmax = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
-        float s2 = 1.0f, inv2 = 1.0f;
+        s2 = 1.0f, inv2 = 1.0f;
         if (wmax > 0.f && wmax < 3.0e38f) {
             const int e = ilogbf(wmax);  // wmax in [2^e, 2^(e+1))
             s2 = ldexpf(1.0f, 13 - e), inv2 = ldexpf(1.0f, e - 13);
         }
-        // r form or h form?  The r form forms every logit as (b2 + sum_j W2[j]) - 2 sum_j W2[j] r_j: fine while those sums are of the
-        // order of the logits, a cancellation of two numbers of the magnitude of the LARGEST weight otherwise (a unit with h = 0
-        // and a weight of 1e5 then costs 4e-3 of absolute logit error in f32 accumulators).  Beyond kRFormLimit: accumulate h.
-        const bool hform = !(wmax <= kRFormLimit);
-        if (blockIdx.x == 0 && threadIdx.x == 0) jp.tflag[2] = inv2, jp.tflag[1] = hform ? 1.0f : 0.f;
-        if (blockIdx.x == 0) {  // joint_fwd_kernel accumulates r = (1 - h) / 2: logits = (b2 + sum_j W2) - 2 W2^T r (h form: b2 alone)
-            __shared__ double part[8][32];
-            const int v = threadIdx.x & 31, q = threadIdx.x >> 5;
-            double sum = 0.0;
-            if (v < p.V && !hform) {  // 32 loads in flight per thread: the block is alone on its CU and waits out a full memory latency per
-                            // round (with 8 per round, ten rounds at J = 640, this block alone made the kernel 28 us long)
+        return wmax;
+    };
+    if (blockIdx.x == 0) {
+        // joint_fwd_kernel accumulates r = (1 - h) / 2: logits = (b2 + sum_j W2) - 2 W2^T r.  That forms every logit as the
+        // difference of two sums of the magnitude of the LARGEST weight: fine while those are of the order of the logits, a
+        // cancellation otherwise (a unit with h = 0 and a weight of 1e5 costs 4e-3 of absolute logit error in f32 accumulators).
+        // Beyond kRFormLimit the kernel accumulates h itself and the table holds b2 alone.
+        __shared__ double part[2][8][32];
+        const int v = threadIdx.x & 31, q = threadIdx.x >> 5;
+        double sum[2] = {0.0, 0.0};
+        float wmax = 0.f;
+        for (int tile = 0; tile < jp.VT; ++tile) {
+            const int vv = 32 * tile + v;
+            if (vv < p.V) {  // 32 loads in flight per thread: the block is alone on its CU and waits out a full memory latency per
+                             // round (with 8 per round, ten rounds at J = 640, this block alone made the kernel 28 us long)
                 constexpr int kRound = 32;
                 float w[kRound];
                 for (int j0 = q; j0 < jp.J; j0 += 8 * kRound) {
 #pragma unroll
-                    for (int k = 0; k < kRound; ++k) w[k] = (j0 + 8 * k < jp.J) ? jp.W2[(size_t)(j0 + 8 * k) * p.V + v] : 0.f;
+                    for (int k = 0; k < kRound; ++k) w[k] = (j0 + 8 * k < jp.J) ? jp.W2[(size_t)(j0 + 8 * k) * p.V + vv] : 0.f;
 #pragma unroll
-                    for (int k = 0; k < kRound; ++k) sum += (double)w[k];
+                    for (int k = 0; k < kRound; ++k) sum[tile] += (double)w[k], wmax = fmaxf(wmax, fabsf(w[k]));  // (a NaN operand is ignored by v_max)
                 }
             }
-            part[q][v] = sum;
-            __syncthreads();
-            if (threadIdx.x < 32) {
-                sum = (v < p.V) ? (double)jp.b2[v] : -1.0e30;
-                for (int k = 0; k < 8; ++k) sum += part[k][v];
-                const float hi = (float)sum;
-                jp.b2s[v] = hi, jp.b2s[32 + v] = (v < p.V) ? (float)(sum - (double)hi) : 0.f;
-            }
         }
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < nfrag; i += gridDim.x * 256) {
-            const int ks = i >> 6, l = i & 63, v = l & 31;
+        float s2, inv2;
+        wmax = scale_of(wmax, s2, inv2);
+        const bool hform = !(wmax <= kRFormLimit);
+        if (threadIdx.x == 0) jp.tflag[2] = inv2, jp.tflag[1] = hform ? 1.0f : 0.f;
+        part[0][q][v] = hform ? 0.0 : sum[0], part[1][q][v] = hform ? 0.0 : sum[1];
+        __syncthreads();
+        if (threadIdx.x < 32 * jp.VT) {
+            const int tile = threadIdx.x >> 5, vv = threadIdx.x;  // (v = threadIdx.x & 31)
+            double t = (vv < p.V) ? (double)jp.b2[vv] : -1.0e30;
+            for (int k = 0; k < 8; ++k) t += part[tile][k][v];
+            const float hi = (float)t;
+            jp.b2s[64 * tile + v] = hi, jp.b2s[64 * tile + 32 + v] = (vv < p.V) ? (float)(t - (double)hi) : 0.f;
+        }
+        return;
+    }
+    const int nfrag1 = (jp.J / 16) * 64, nfrag = nfrag1 * jp.VT, fblk = (int)blockIdx.x - 1;
+    if (fblk * 256 < nfrag) {
+        const int nW = jp.J * p.V;
+        float wmax = 0.f;
+        {
+            constexpr int kMaxW = 704 * 32 > 640 * 64 ? 704 * 32 : 640 * 64;  // joint_supported()
+            float w[kMaxW / 256];
+#pragma unroll
+            for (int k = 0; k < kMaxW / 256; ++k) {
+                const int i = 256 * k + (int)threadIdx.x;
+                w[k] = (i < nW) ? fabsf(jp.W2[i]) : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < kMaxW / 256; ++k) wmax = fmaxf(wmax, w[k]);
+        }
+        float s2, inv2;
+        scale_of(wmax, s2, inv2);
+        for (int i = fblk * 256 + threadIdx.x; i < nfrag; i += ((int)gridDim.x - 1) * 256) {
+            const int tile = i / nfrag1, i1 = i - tile * nfrag1;
+            const int ks = i1 >> 6, l = i1 & 63, v = 32 * tile + (l & 31);
             jh8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -213,8 +234,9 @@ __global__ __launch_bounds__(256) void joint_prep_kernel(const JointParams jp) {
                 hi[e] = (jf16)w;
                 lo[e] = (jf16)(w - (float)hi[e]);
             }
-            *(jh8 *)(jp.W2s + ((size_t)(ks * 2 + 0) * 64 + l) * 8) = hi;
-            *(jh8 *)(jp.W2s + ((size_t)(ks * 2 + 1) * 64 + l) * 8) = lo;
+            jf16 *img = jp.W2s + (size_t)tile * jp.J * 64;  // a tile image: J / 16 k-steps x (hi, lo) x 64 lanes x 8 halves
+            *(jh8 *)(img + ((size_t)(ks * 2 + 0) * 64 + l) * 8) = hi;
+            *(jh8 *)(img + ((size_t)(ks * 2 + 1) * 64 + l) * 8) = lo;
         }
     }
 }
@@ -424,15 +446,32 @@ template <int E>
 __device__ __forceinline__ float row_bcast(const float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + E /*row_newbcast:E*/, 0xf, 0xf, true));
 }
+// The two rows of a wave share every pred-side factor: their enc-side addends travel as a PAIR -- one 64-bit DPP broadcast
+// (v_mov_b64_dpp takes row_newbcast) and one v_pk_fma_f32 per joint unit instead of two of each.
+#ifndef RNNT_FWD_DPP64
+#define RNNT_FWD_DPP64 1  // 0: two 32-bit broadcasts per unit (A/B timing)
+#endif
+template <int E>
+__device__ __forceinline__ jf2 row_bcast2(const jf2 x) {
+#if RNNT_FWD_DPP64
+    const long long v = __builtin_amdgcn_update_dpp((long long)0, __builtin_bit_cast(long long, x), 0x150 + E /*row_newbcast:E*/, 0xf, 0xf, true);
+    return __builtin_bit_cast(jf2, v);
+#else
+    return (jf2){row_bcast<E>(x[0]), row_bcast<E>(x[1])};
+#endif
+}
 template <int E, bool SLOW, bool HFORM>
-__device__ __forceinline__ void fwd_h_pair(const float ea0, const float ea1, const float ec, float &h0, float &h1) {
-    const float a0 = row_bcast<E>(ea0), a1 = row_bcast<E>(ea1);
+__device__ __forceinline__ void fwd_h_pair(const jf2 ea01, const float ec, float &h0, float &h1) {
+    const jf2 a = row_bcast2<E>(ea01), c2 = {ec, ec};
+    jf2 r;
     if (!SLOW) {  // r = (1 - h) / 2, see fwd_row_epilogue
-        h0 = r_from_exp(a0, ec), h1 = r_from_exp(a1, ec);
+        const jf2 x = a * c2 + (jf2){1.0f, 1.0f};
+        r = (jf2){__builtin_amdgcn_rcpf(x[0]), __builtin_amdgcn_rcpf(x[1])};
     } else {
-        h0 = fast_r(a0 + ec), h1 = fast_r(a1 + ec);
+        r = (jf2){fast_r(a[0] + ec), fast_r(a[1] + ec)};
     }
-    if (HFORM) h0 = fmaf(h0, -2.0f, 1.0f), h1 = fmaf(h1, -2.0f, 1.0f);  // h itself (huge weights: see joint_prep_kernel)
+    if (HFORM) r = r * (jf2){-2.0f, -2.0f} + (jf2){1.0f, 1.0f};  // h itself (huge weights: see joint_prep_kernel)
+    h0 = r[0], h1 = r[1];
 }
 // The J-long product of one row pair: acc += W2^T . r^T, A = W2 fragments (row = symbol), B = r (column = cell), with
 // r = (1 - h) / 2 = 1 / (1 + e^{2(a + c)}) (see fwd_row_epilogue).  Measured alternatives (profiles/r02_notes.md): building
@@ -473,6 +512,7 @@ __device__ __forceinline__ void fwd_row_pair(const int J, const float *e0, const
                                              const char *wlane, const int half, const int lane, f32x16 &acc0, f32x16 &acc1) {
     const int n = J / 16;
     auto kstep = [&](const int ks, const float a0, const float a1) __attribute__((always_inline)) {
+        const jf2 a01 = {a0, a1};
         const uint32_t c0 = (uint32_t)(4 * ks + 2 * half);
         const float4 c4a = *(const float4 *)(ct_row + (size_t)(c0 ^ ct_swz) * 16);
         const float4 c4b = *(const float4 *)(ct_row + (size_t)((c0 + 1u) ^ ct_swz) * 16);
@@ -480,17 +520,17 @@ __device__ __forceinline__ void fwd_row_pair(const int J, const float *e0, const
         const jh8 wl = *(const jh8 *)(wlane + (size_t)(ks * 2 + 1) * 1024);
         FwdFrags f;
         float x0[2], x1[2];
-        fwd_h_pair<0, SLOW, HFORM>(a0, a1, c4a.x, x0[0], x1[0]);
-        fwd_h_pair<1, SLOW, HFORM>(a0, a1, c4a.y, x0[1], x1[1]);
+        fwd_h_pair<0, SLOW, HFORM>(a01, c4a.x, x0[0], x1[0]);
+        fwd_h_pair<1, SLOW, HFORM>(a01, c4a.y, x0[1], x1[1]);
         fwd_split_quad<0>(x0, x1, f);
-        fwd_h_pair<2, SLOW, HFORM>(a0, a1, c4a.z, x0[0], x1[0]);
-        fwd_h_pair<3, SLOW, HFORM>(a0, a1, c4a.w, x0[1], x1[1]);
+        fwd_h_pair<2, SLOW, HFORM>(a01, c4a.z, x0[0], x1[0]);
+        fwd_h_pair<3, SLOW, HFORM>(a01, c4a.w, x0[1], x1[1]);
         fwd_split_quad<2>(x0, x1, f);
-        fwd_h_pair<4, SLOW, HFORM>(a0, a1, c4b.x, x0[0], x1[0]);
-        fwd_h_pair<5, SLOW, HFORM>(a0, a1, c4b.y, x0[1], x1[1]);
+        fwd_h_pair<4, SLOW, HFORM>(a01, c4b.x, x0[0], x1[0]);
+        fwd_h_pair<5, SLOW, HFORM>(a01, c4b.y, x0[1], x1[1]);
         fwd_split_quad<4>(x0, x1, f);
-        fwd_h_pair<6, SLOW, HFORM>(a0, a1, c4b.z, x0[0], x1[0]);
-        fwd_h_pair<7, SLOW, HFORM>(a0, a1, c4b.w, x0[1], x1[1]);
+        fwd_h_pair<6, SLOW, HFORM>(a01, c4b.z, x0[0], x1[0]);
+        fwd_h_pair<7, SLOW, HFORM>(a01, c4b.w, x0[1], x1[1]);
         fwd_split_quad<6>(x0, x1, f);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, f.hi0, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, f.hi1, acc1, 0, 0, 0);
@@ -534,39 +574,75 @@ __device__ __forceinline__ float half_swap_sum(const float v) {
 // zero where an edge leaves the lattice, NaN -- the utterance is handed back -- where an edge the lattice owns is below 2^-100);
 // lse is still stored (the backward's per-cell set-up needs the denominator and does not re-read the tile).
 // Returns the cell's decay statistic -log2 max(p_blank, p_label) (rnnt_lin.h; 0 for lanes that own no cell, half 1 included).
+// MODE 0: the whole vocabulary is this tile (V <= 32).  Two vocabulary tiles (32 < V <= 64, round 5): MODE 1 = tile 0, launched
+// first: parks its 32 logits and nothing else; MODE 2 = tile 1: re-reads what tile 0 parked for the cell (16 floats per half-lane,
+// the same symbols-per-register layout) and runs the softmax over all 64.  rsel_*: registers of THIS tile, rselo_*: of the other.
+template <int MODE>
 __device__ __forceinline__ float fwd_row_epilogue(const JointParams &jp, const f32x16 &acc, const float m2inv,
-                                                  const int rsel_b, const int rsel_l, const int b, const int t,
-                                                  const int u, const int Tb, const int Ub, const int half) {
+                                                  const int rsel_b, const int rsel_l, const int rselo_b, const int rselo_l,
+                                                  const int b, const int t, const int u, const int Tb, const int Ub, const int half) {
     const LossParams &p = jp.lp;
+    const float *b2t = jp.b2s + 64 * jp.vt;
+    const int Vp = 32 * jp.VT;
     float x[16];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {  // registers 4g .. 4g+3 are the four consecutive symbols 8g + 4 half + 0..3
-        const float4 bh = *(const float4 *)(jp.b2s + 8 * g + 4 * half), bl = *(const float4 *)(jp.b2s + 32 + 8 * g + 4 * half);
+    for (int g = 0; g < 4; ++g) {  // registers 4g .. 4g+3 are the four consecutive symbols 8g + 4 half + 0..3 of the tile
+        const float4 bh = *(const float4 *)(b2t + 8 * g + 4 * half), bl = *(const float4 *)(b2t + 32 + 8 * g + 4 * half);
         x[4 * g + 0] = fmaf(acc[4 * g + 0], m2inv, bh.x) + bl.x;
         x[4 * g + 1] = fmaf(acc[4 * g + 1], m2inv, bh.y) + bl.y;
         x[4 * g + 2] = fmaf(acc[4 * g + 2], m2inv, bh.z) + bl.z;
         x[4 * g + 3] = fmaf(acc[4 * g + 3], m2inv, bh.w) + bl.w;
     }
+    const size_t c = ((size_t)(b * p.T + t)) * p.U + min(u, p.U - 1);
+    if (MODE == 1) {
+        if (u < Ub) {
+            float *dst = jp.dl + c * Vp + 4 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(float4 *)(dst + 8 * g) = make_float4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
+        }
+        return 0.f;
+    }
+    float xo[16];
+    if (MODE == 2) {  // (unconditional loads: clamped cell index, values of padded cells are never used)
+        const float *src = jp.dl + c * Vp + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 q = *(const float4 *)(src + 8 * g);
+            xo[4 * g] = q.x, xo[4 * g + 1] = q.y, xo[4 * g + 2] = q.z, xo[4 * g + 3] = q.w;
+        }
+    }
     float m = x[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fmaxf(m, x[r]);
+    if (MODE == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, xo[r]);
+    }
     m = half_swap_max(m);
     const float nml = -m * kLog2e;
     float ssum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) ssum += jex2(fmaf(x[r], kLog2e, nml));
+    if (MODE == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ssum += jex2(fmaf(xo[r], kLog2e, nml));
+    }
     ssum = half_swap_sum(ssum);
     float xb = -INFINITY, xl = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         xb = (rsel_b == r) ? x[r] : xb;
         xl = (rsel_l == r) ? x[r] : xl;
+        if (MODE == 2) {
+            xb = (rselo_b == r) ? xo[r] : xb;
+            xl = (rselo_l == r) ? xo[r] : xl;
+        }
     }
     xb = half_swap_max(xb);
     xl = half_swap_max(xl);
     float stat = 0.f;
     if (u < Ub) {
-        const size_t c = ((size_t)(b * p.T + t)) * p.U + u;
         if (half == 0) {
             const float inv = __builtin_amdgcn_rcpf(ssum);
             const bool blank_stays = (t < Tb - 1) || (u == Ub - 1);
@@ -586,7 +662,7 @@ __device__ __forceinline__ float fwd_row_epilogue(const JointParams &jp, const f
             stat = (pb != pb || pl != pl) ? 200.f : -jlg2(fmaxf(fmaxf(pb, pl), 1.0e-37f));
         }
         // park the logits (bias included): registers 4g .. 4g+3 are the four consecutive symbols 8g + 4 half + 0..3
-        float *dst = jp.dl + c * 32 + 4 * half;
+        float *dst = jp.dl + c * Vp + 32 * jp.vt + 4 * half;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *(float4 *)(dst + 8 * g) = make_float4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
@@ -595,14 +671,20 @@ __device__ __forceinline__ float fwd_row_epilogue(const JointParams &jp, const f
 }
 
 // {sum of the decay statistic, cells} of one wave's row pair -> its slot of the utterance's statistic table (what the linear
-// sweeps choose their frame-block length from: rnnt_lin.h; slot = u-tile * ceil(T / 2) + row pair, LossParams::pstatStride 1)
-__device__ __forceinline__ void fwd_put_stat(const JointParams &jp, const int b, const int ut, const int t0, float stat, float cnt,
+// sweeps choose their frame-block length from: rnnt_lin.h; slot = u-tile * ceil(T / 2) + row pair, LossParams::pstatStride 1).
+// The sum over the 32 cell lanes runs on DPP row operations + two v_readlane (six __shfl_xor steps -- ds_bpermute round trips
+// in a dependent chain -- cost the kernel 5 %); the cell count is known without looking at the lanes.
+__device__ __forceinline__ void fwd_put_stat(const JointParams &jp, const int b, const int ut, const int t0, float stat, const float cnt,
                                              const int lane) {
     const LossParams &p = jp.lp;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) stat += __shfl_xor(stat, off), cnt += __shfl_xor(cnt, off);
+    stat += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(stat), 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true));
+    stat += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(stat), 0x4E /*quad_perm:[2,3,0,1]*/, 0xf, 0xf, true));
+    stat += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(stat), 0x141 /*row_half_mirror*/, 0xf, 0xf, true));
+    stat += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(stat), 0x140 /*row_mirror*/, 0xf, 0xf, true));
+    // every lane of a 16-lane row now holds its row's sum; the cells sit in lanes 0..31 (half 1 contributes zeros)
+    const float sum = __builtin_amdgcn_readlane(stat, 0) + __builtin_amdgcn_readlane(stat, 16);
     if (lane == 0 && t0 < p.T)
-        p.pstat[(size_t)b * p.nPstat + (size_t)ut * ((p.T + 1) >> 1) + (t0 >> 1)] = make_float2(stat, cnt);
+        p.pstat[(size_t)b * p.nPstat + (size_t)ut * ((p.T + 1) >> 1) + (t0 >> 1)] = make_float2(sum, cnt);
 }
 
 __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointParams jp) {
@@ -620,9 +702,16 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
     char *Wimg = Ct + (size_t)J * 128;      // [J/16][hi, lo][64 lanes][16 B]
     const int cpr = J / 4;                  // 16-byte chunks per Ct row
 
+    const char *w2img = (const char *)(jp.W2s + (size_t)jp.vt * J * 64);  // this launch's vocabulary tile
     for (int pc = wave; pc < J / 8; pc += kFwdWaves)  // W2 fragment image: J/8 pieces of 1 KB, once per workgroup
-        lds_dma16((const char *)jp.W2s + (size_t)pc * 1024 + lane * 16, Wimg + pc * 1024);
-    const int rsel_b = (((p.blank >> 2) & 1) == half) ? (p.blank & 3) + 4 * (p.blank >> 3) : -1;
+        lds_dma16(w2img + (size_t)pc * 1024 + lane * 16, Wimg + pc * 1024);
+    // register that holds symbol v of a 32-symbol tile in this lane's half (or -1: the other half's, or not in this tile)
+    auto reg_of = [&](const int v, const int tile) {
+        const int w = v - 32 * tile;
+        return (w >= 0 && w < 32 && ((w >> 2) & 1) == half) ? (w & 3) + 4 * (w >> 3) : -1;
+    };
+    const int mode = jp.VT == 1 ? 0 : (jp.vt == 0 ? 1 : 2);  // fwd_row_epilogue's MODE (kernel-uniform)
+    const int rsel_b = reg_of(p.blank, jp.vt), rselo_b = reg_of(p.blank, jp.vt ^ 1);
     const uint32_t ct_lane = (uint32_t)(l31 * cpr);          // this lane's Ct row, in chunks
     const uint32_t ct_swz = (uint32_t)(l31 & 15);
     // enc-side addends of a k-step (16 joint units), one per lane: positions 0..7 of every 16-lane row hold the 8 units of
@@ -635,7 +724,7 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
     const int it_lo = (int)((long long)n_items * blockIdx.x / gridDim.x);
     const int it_hi = (int)((long long)n_items * (blockIdx.x + 1) / gridDim.x);
     int ct_owner = -1;
-    int rsel_l = -1;
+    int rsel_l = -1, rselo_l = -1;
     for (int item = it_lo; item < it_hi; ++item) {
         const int bu = item / n_tr, tr = item - bu * n_tr;
         const int b = bu / jp.n_ut, ut = bu - b * jp.n_ut;
@@ -644,7 +733,7 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
         const int t_begin = tr * kFwdRows, t_end = min(min(t_begin + kFwdRows, p.T), Tb);
         const int t0 = t_begin + 2 * wave;
         if (t_begin >= t_end || u0 >= Ub) {  // workgroup-uniform: no lattice cell here -- the statistic slots still get their zeros
-            fwd_put_stat(jp, b, ut, t0, 0.f, 0.f, lane);
+            if (mode != 1) fwd_put_stat(jp, b, ut, t0, 0.f, 0.f, lane);
             continue;
         }
         const int u = u0 + l31;
@@ -658,16 +747,16 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
                 const float *src = Ptab + ((size_t)b * p.U + min(u0 + (int)ur, p.U - 1)) * J + c * 4u;
                 lds_dma16(src, Ct + (size_t)pc * 1024);
             }
-            rsel_l = -1;
+            rsel_l = rselo_l = -1;
             if (u < Ub - 1) {
                 const int lab = min(max(p.labels[(size_t)b * (p.U - 1) + u], 0), V - 1);
-                rsel_l = (((lab >> 2) & 1) == half) ? (lab & 3) + 4 * (lab >> 3) : -1;
+                rsel_l = reg_of(lab, jp.vt), rselo_l = reg_of(lab, jp.vt ^ 1);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
         if (t0 >= t_end) {  // wave-uniform (no barrier below)
-            fwd_put_stat(jp, b, ut, t0, 0.f, 0.f, lane);
+            if (mode != 1) fwd_put_stat(jp, b, ut, t0, 0.f, 0.f, lane);
             continue;
         }
         const bool two = t0 + 1 < t_end;  // wave-uniform
@@ -687,13 +776,18 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
         } else {
             fwd_row_pair<true, false>(J, e0, e1, ct_row, ct_swz, wlane, half, lane, acc0, acc1);
         }
-        float stat = fwd_row_epilogue(jp, acc0, m2inv, rsel_b, rsel_l, b, t0, u, Tb, Ub, half);
-        float cnt = (half == 0 && u < Ub) ? 1.f : 0.f;
-        if (two) {
-            stat += fwd_row_epilogue(jp, acc1, m2inv, rsel_b, rsel_l, b, t0 + 1, u, Tb, Ub, half);
-            cnt += cnt;
+        if (mode == 0) {
+            float stat = fwd_row_epilogue<0>(jp, acc0, m2inv, rsel_b, rsel_l, -1, -1, b, t0, u, Tb, Ub, half);
+            if (two) stat += fwd_row_epilogue<0>(jp, acc1, m2inv, rsel_b, rsel_l, -1, -1, b, t0 + 1, u, Tb, Ub, half);
+            fwd_put_stat(jp, b, ut, t0, stat, (float)(min(32, Ub - u0) * (two ? 2 : 1)), lane);
+        } else if (mode == 1) {
+            fwd_row_epilogue<1>(jp, acc0, m2inv, -1, -1, -1, -1, b, t0, u, Tb, Ub, half);
+            if (two) fwd_row_epilogue<1>(jp, acc1, m2inv, -1, -1, -1, -1, b, t0 + 1, u, Tb, Ub, half);
+        } else {
+            float stat = fwd_row_epilogue<2>(jp, acc0, m2inv, rsel_b, rsel_l, rselo_b, rselo_l, b, t0, u, Tb, Ub, half);
+            if (two) stat += fwd_row_epilogue<2>(jp, acc1, m2inv, rsel_b, rsel_l, rselo_b, rselo_l, b, t0 + 1, u, Tb, Ub, half);
+            fwd_put_stat(jp, b, ut, t0, stat, (float)(min(32, Ub - u0) * (two ? 2 : 1)), lane);
         }
-        fwd_put_stat(jp, b, ut, t0, stat, cnt, lane);
     }
 }
 
@@ -1070,7 +1164,7 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
         float w[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int v = 16 * ks + 8 * half + e;
+            const int v = 32 * jp.vt + 16 * ks + 8 * half + e;  // (this launch's vocabulary tile)
             w[e] = (v < V) ? jp.W2[(size_t)(j0 + l31) * V + v] * s2 : 0.f;
         }
         split_h8(w, wf[ks][0], wf[ks][1]);
@@ -1099,8 +1193,11 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int u = cur_u0 + cd_row(r, half);
-            if (u < p.U)
-                jp.dCpart[(((size_t)cur_slot * p.B + cur_b) * p.U + u) * J + j0 + l31] = poisoned ? NAN : accC[r] * (invS * w2inv);
+            if (u < p.U) {
+                float *dst = jp.dCpart + (((size_t)cur_slot * p.B + cur_b) * p.U + u) * J + j0 + l31;
+                const float val = accC[r] * (invS * w2inv) + (jp.vt > 0 ? *dst : 0.f);  // (a later vocabulary tile adds to the first's)
+                *dst = poisoned ? NAN : val;
+            }
             accC[r] = 0.f;
         }
     };
@@ -1162,9 +1259,32 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
             jh8 fb[2][2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) fb[ks][0] = frag[(4 + ks * 2 + 0) * 64 + lane], fb[ks][1] = frag[(4 + ks * 2 + 1) * 64 + lane];
+#ifndef RNNT_BWD_PK
+#define RNNT_BWD_PK 1  // 0: the scalar form of rounds 2-4 (A/B timing)
+#endif
+#if RNNT_BWD_PK
+            // h tile in the C/D layout, built PAIRWISE (v_pk_fma_f32: two lattice columns per instruction for the multiply-adds in
+            // front of and behind the reciprocals -- 16 instructions less per row than the scalar form the compiler chose)
+            float h[16];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const jf2 e2 = {ec[2 * q], ec[2 * q + 1]}, a2 = {aj, aj};
+                jf2 r2;
+                if (!SLOW) {
+                    const jf2 x = e2 * a2 + (jf2){1.0f, 1.0f};
+                    r2 = (jf2){__builtin_amdgcn_rcpf(x[0]), __builtin_amdgcn_rcpf(x[1])};
+                } else {
+                    const jf2 x = (e2 + a2) * (jf2){2.8853900817779268f, 2.8853900817779268f};
+                    r2 = (jf2){__builtin_amdgcn_rcpf(1.0f + jex2(x[0])), __builtin_amdgcn_rcpf(1.0f + jex2(x[1]))};
+                }
+                const jf2 h2 = r2 * (jf2){-2.0f, -2.0f} + (jf2){1.0f, 1.0f};
+                h[2 * q] = h2[0], h[2 * q + 1] = h2[1];
+            }
+#else
             float h[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) h[r] = SLOW ? fast_tanh(aj + ec[r]) : tanh_from_exp(aj, ec[r]);
+#endif
             BT(1);
             // S dh[u][j] = sum_v (S dl[u][v]) W2[j][v]
             f32x16 dh;
@@ -1195,6 +1315,19 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
             BT(4);
             // every read of this row's slot has returned (fb above, fa one row earlier): hand it back to the loader
             if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(use_a + 4u * slot), "v"(1) : "memory");
+#if RNNT_BWD_PK
+            // dz = dh (1 - h^2), pairwise and stage by stage (a dependent pair of packed instructions back to back costs a wait
+            // state each); the row sum as a tree of packed adds instead of a chain of sixteen
+            jf2 dz2[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dz2[q] = (jf2){dh[2 * q], dh[2 * q + 1]} * (jf2){h[2 * q], h[2 * q + 1]};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dz2[q] = (jf2){dh[2 * q], dh[2 * q + 1]} - dz2[q] * (jf2){h[2 * q], h[2 * q + 1]};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) accC[2 * q] += dz2[q][0], accC[2 * q + 1] += dz2[q][1];
+            const jf2 cs2 = ((dz2[0] + dz2[1]) + (dz2[2] + dz2[3])) + ((dz2[4] + dz2[5]) + (dz2[6] + dz2[7]));
+            float colsum = half_swap_sum(cs2[0] + cs2[1]);
+#else
             float colsum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1203,16 +1336,20 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
                 colsum += dz;
             }
             colsum = half_swap_sum(colsum);
+#endif
             BT(5);
-            if (lane < 32)
-                jp.dApart[(((size_t)it.ut * p.B + it.b) * p.T + t) * J + j0 + lane] = poisoned ? NAN : colsum * (invS * w2inv);
+            if (lane < 32) {
+                float *dst = jp.dApart + (((size_t)it.ut * p.B + it.b) * p.T + t) * J + j0 + lane;
+                const float val = colsum * (invS * w2inv) + (jp.vt > 0 ? *dst : 0.f);
+                *dst = poisoned ? NAN : val;
+            }
         }
     }
     flush_C();
     // this workgroup's dW2 partial: accW is [j rows][v cols]
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-        jp.dWpart[((size_t)blk * J + j0 + cd_row(r, half)) * 32 + l31] = poisoned ? NAN : accW[r] * invS;
+        jp.dWpart[((size_t)(jp.vt * kBwdMaxBlocks + blk) * J + j0 + cd_row(r, half)) * 32 + l31] = poisoned ? NAN : accW[r] * invS;
 }
 
 // Per-cell gradient set-up, once per lattice cell, by the whole chip in parallel (a chain of dependent gathers from the
@@ -1427,7 +1564,8 @@ __device__ __forceinline__ void bwd_row_loads(const JointParams &jp, const BwdIt
     L.b = it.b, L.t = t, L.u0 = it.u0, L.Ub = it.Ub;
     L.rc = jp.rec[c];
     L.lab = jp.reclab[c];
-    const float *xrow = jp.dl + (size_t)c * 32;
+    const int Vp = 32 * jp.VT, vo = 32 * jp.vt;  // row stride of the parked logits, this launch's vocabulary tile
+    const float *xrow = jp.dl + (size_t)c * Vp + vo;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
         L.xa[ks][0] = *(const float4 *)(xrow + 16 * ks + 8 * half), L.xa[ks][1] = *(const float4 *)(xrow + 16 * ks + 8 * half + 4);
@@ -1438,7 +1576,7 @@ __device__ __forceinline__ void bwd_row_loads(const JointParams &jp, const BwdIt
             // every load of a row is unconditional (addresses clamped into the tensor, values masked at use): the number of
             // loads in flight is then a compile-time constant and the wait for THIS row's data need not drain the next row's
             const int uu = min(cd_row(8 * ks + e, half), p.U - 1 - it.u0);
-            L.xb[ks][e] = jp.dl[((size_t)cbase + uu) * 32 + l31];
+            L.xb[ks][e] = jp.dl[((size_t)cbase + uu) * Vp + vo + l31];
         }
     const float *asrc = Etab + ((size_t)it.b * p.T + t) * jp.J + group * n_cons * 32;
 #pragma unroll
@@ -1449,7 +1587,7 @@ __device__ void bwd_producer(const JointParams &jp, char *ring, float *scratch, 
                              const int pw, const int n_cons, const int group, const int blk, const bool want_db, const int lane,
                              const int it_lo, const int it_hi, const int n_tr) {
     const LossParams &p = jp.lp;
-    const int V = p.V;
+    const int V = p.V, vo = 32 * jp.vt;
     const int half = lane >> 5, l31 = lane & 31;
     const float *Etab = (jp.tflag[0] != 0.f) ? jp.enc_proj : jp.expE;
     float dbacc = 0.f;  // db2[v = l31] over the cells this lane has seen (its half's k-slots)
@@ -1495,7 +1633,7 @@ __device__ void bwd_producer(const JointParams &jp, char *ring, float *scratch, 
             float d[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                d[e] = valid ? bwd_dl(xs[e], 16 * ks + 8 * half + e, V, p.blank, L.rc.x, L.rc.y, L.rc.z, L.rc.w, L.lab) : 0.f;
+                d[e] = valid ? bwd_dl(xs[e], vo + 16 * ks + 8 * half + e, V, p.blank, L.rc.x, L.rc.y, L.rc.z, L.rc.w, L.lab) : 0.f;
             if (poisoned) d[0] = NAN;
             jh8 hi, lo;
             split_h8(d, hi, lo);
@@ -1515,7 +1653,7 @@ __device__ void bwd_producer(const JointParams &jp, char *ring, float *scratch, 
                 const int uu = cd_row(8 * ks + e, half);
                 const float4 q = *(const float4 *)(scratch + uu * 8);
                 const int labu = __float_as_int(scratch[uu * 8 + 4]);
-                d[e] = (L.u0 + uu < L.Ub) ? bwd_dl(L.xb[ks][e], l31, V, p.blank, q.x, q.y, q.z, q.w, labu) : 0.f;
+                d[e] = (L.u0 + uu < L.Ub) ? bwd_dl(L.xb[ks][e], vo + l31, V, p.blank, q.x, q.y, q.z, q.w, labu) : 0.f;
                 dbacc = fmaf(d[e], invS, dbacc);
             }
             jh8 hi, lo;
@@ -1529,7 +1667,7 @@ __device__ void bwd_producer(const JointParams &jp, char *ring, float *scratch, 
         row += 2;
     }
     dbacc = half_swap_sum(dbacc);
-    if (want_db && lane < 32) jp.dbpart[((size_t)blk * 2 + pw) * 32 + lane] = poisoned ? NAN : dbacc;
+    if (want_db && lane < 32) jp.dbpart[((size_t)(jp.vt * kBwdMaxBlocks + blk) * 2 + pw) * 32 + lane] = poisoned ? NAN : dbacc;
 }
 
 // Consumers own 32 joint units each; a workgroup holds at most kBwdMaxCons of them (register budget: 12 waves per CU), so
@@ -1730,20 +1868,20 @@ __device__ __forceinline__ void reduce_pred_body(float *out, const float *in, co
 // Deterministic tree: out[i] = poison + sum_p in[p*stride_p + map(i)], 256 threads = 32 outputs x 8 partial lanes.
 // Each partial lane sums its strided share in a fixed order, then the 8 lanes are combined in order.
 template <bool W2MAP>
-__device__ __forceinline__ void reduce_small_body(float *out, const float *in, const int nparts, const int n, const int J, const int V,
-                                                  const unsigned blk, const float poison) {
+__device__ __forceinline__ void reduce_small_body(float *out, const float *in, const int nparts, const int tparts, const int n, const int J,
+                                                  const int V, const unsigned blk, const float poison) {  // tparts: partials ALLOCATED per vocabulary tile
     __shared__ float sm[8][33];
     const int o = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int i = (int)blk * 32 + o;
     float s = 0.f;
     if (i < n) {
         size_t base, stride;
-        if (W2MAP) {  // in is [nparts][J][32], out is [J][V]
+        if (W2MAP) {  // in is [tile][tparts][J][32], out is [J][V]
             const int j = i / V, v = i - j * V;
-            base = (size_t)j * 32 + v;
+            base = ((size_t)(v >> 5) * tparts * J + j) * 32 + (v & 31);
             stride = (size_t)J * 32;
-        } else {  // in is [nparts][32], out is [V]
-            base = (size_t)i;
+        } else {  // in is [tile][tparts][32], out is [V]
+            base = (size_t)(i >> 5) * tparts * 32 + (i & 31);
             stride = 32;
         }
         for (int q = pl; q < nparts; q += 8) s += in[(size_t)q * stride + base];
@@ -1778,9 +1916,11 @@ __global__ __launch_bounds__(256) void joint_reduce_kernel(const JointParams jp,
             reduce_partials_body(jp.d_pred_proj, jp.dCpart, nC, (size_t)p.B * p.U * jp.J, k, kHookBlocks,
                                  dmax_pred ? dmax_pred + k : nullptr, poison);
     } else if (blk < 2u * kHookBlocks + nWblk) {
-        reduce_small_body<true>(jp.dW2, jp.dWpart, single ? jp.nblk : nW, jp.J * p.V, jp.J, p.V, blk - 2u * kHookBlocks, poison);
-    } else {
-        reduce_small_body<false>(jp.db2, jp.dbpart, single ? 2 * jp.nblk : nDb, p.V, jp.J, p.V, 0u, poison);
+        reduce_small_body<true>(jp.dW2, jp.dWpart, single ? jp.nblk : nW, single ? kBwdMaxBlocks : nW, jp.J * p.V, jp.J, p.V,
+                                blk - 2u * kHookBlocks, poison);
+    } else {  // (one or two blocks of 32 symbols)
+        reduce_small_body<false>(jp.db2, jp.dbpart, single ? 2 * jp.nblk : nDb, single ? 2 * kBwdMaxBlocks : nDb, p.V, jp.J, p.V,
+                                 blk - 2u * kHookBlocks - nWblk, poison);
     }
 }
 
@@ -1790,13 +1930,14 @@ __global__ __launch_bounds__(256) void joint_reduce_kernel(const JointParams jp,
 struct JointLayout {
     WsLayout w;
     size_t dl, dlg, rec, reclab, xbl, dApart, dCpart, dWpart, dbpart, expE, expP, tflag, W2s, pstat, total;
-    int n_ut, TR, n_tr, TS, n_ts, nC, nW, nDb, nPstat;
+    int n_ut, TR, n_tr, TS, n_ts, nC, nW, nDb, nPstat, VT;
     bool wide;  // 640 < J <= 704: W2 streams through the LDS (joint_phase1s_kernel), two-kernel backward, log-domain sweeps
 };
 
-static JointLayout make_joint_layout(int T, int U, int B, int J) {
+static JointLayout make_joint_layout(int T, int U, int B, int J, int V) {
     JointLayout L;
     L.w = make_layout(T, U, B);
+    L.VT = (V + 31) / 32;  // vocabulary tiles of 32 symbols: 2 for 32 < V <= 64 (every [.][32] array below then holds two)
     L.wide = (size_t)J * 256 > 160 * 1024;  // the forward's two resident tables no longer fit the LDS together
     L.n_ut = (U + 31) / 32;
     L.TR = 40;  // rows per phase-1 block (amortises the 128*J-byte C^T tile)
@@ -1810,7 +1951,7 @@ static JointLayout make_joint_layout(int T, int U, int B, int J) {
         off = align_up(off + bytes, 256);
         return o;
     };
-    L.dl = take((size_t)B * T * U * 32 * sizeof(float));
+    L.dl = take((size_t)B * T * U * 32 * L.VT * sizeof(float));
     L.dlg = take(L.wide ? (size_t)B * T * U * 32 * sizeof(float) : 0);  // dlogits of the wide joint's two-kernel backward
     L.rec = take((size_t)B * T * U * sizeof(float4));
     L.reclab = take((size_t)B * T * U * sizeof(int));
@@ -1823,12 +1964,12 @@ static JointLayout make_joint_layout(int T, int U, int B, int J) {
     L.nW = L.wide ? B * L.n_ut * L.n_ts : kBwdMaxBlocks;
     L.nDb = L.wide ? (int)gdl : 2 * kBwdMaxBlocks;
     L.dCpart = take((size_t)L.nC * B * U * J * sizeof(float));
-    L.dWpart = take((size_t)L.nW * J * 32 * sizeof(float));
-    L.dbpart = take((size_t)L.nDb * 32 * sizeof(float));
+    L.dWpart = take((size_t)L.VT * L.nW * J * 32 * sizeof(float));
+    L.dbpart = take((size_t)L.VT * L.nDb * 32 * sizeof(float));
     L.expE = take((size_t)B * T * J * sizeof(float));
     L.expP = take((size_t)B * U * J * sizeof(float));
-    L.tflag = take(512);  // flags (zeroed per call) + the b2s table
-    L.W2s = take((size_t)J * 32 * 2 * sizeof(jf16));
+    L.tflag = take(1024);  // flags (64 words, zeroed per call) + the b2s tables (64 words per vocabulary tile)
+    L.W2s = take((size_t)L.VT * J * 32 * 2 * sizeof(jf16));
     L.nPstat = L.n_ut * ((T + 1) / 2);  // decay statistic of the forward kernel: one slot per (u-tile, row pair) (fwd_put_stat)
     L.pstat = take((size_t)B * L.nPstat * sizeof(float2));
     L.total = off;
@@ -1837,8 +1978,10 @@ static JointLayout make_joint_layout(int T, int U, int B, int J) {
 
 static bool joint_supported(int J, int V) {
     // J <= 704: the streaming forward (640 < J) keeps the whole C^T tile (128 J bytes), a row of enc_proj per wave (32 J) and
-    // 50 KB of staging in LDS: 162,816 of the 163,840 bytes at J = 704
-    return V >= 1 && V <= 32 && J >= 64 && (J % 64) == 0 && J <= 704;
+    // 50 KB of staging in LDS: 162,816 of the 163,840 bytes at J = 704.
+    // V <= 64 (round 5; 32 before): a second vocabulary tile of 32 symbols, each tile one pass of the forward / backward kernels
+    // (J <= 640: the wide joint's kernels keep one tile).
+    return V >= 1 && V <= (J <= 640 ? 64 : 32) && J >= 64 && (J % 64) == 0 && J <= 704;
 }
 
 // joint_f16_kernels.hip (large vocabularies on the f16 MFMA units)
@@ -1867,7 +2010,7 @@ hipError_t launch_reduce_partials(float *out, const float *in, int nparts, size_
 // where the fused joint (joint_dtype 0) keeps the e^{2x} tables and its flags: for a caller that fills them itself (JointHooks)
 hipError_t joint_aux_pointers(void *workspace, int T, int U, int B, int J, int V, float **expE, float **expP, float **tflag) {
     if (!joint_supported(J, V) || sweep_K(U) == 0) return hipErrorInvalidValue;
-    const JointLayout L = make_joint_layout(T, U, B, J);
+    const JointLayout L = make_joint_layout(T, U, B, J, V);
     char *ws = (char *)workspace;
     *expE = (float *)(ws + L.expE), *expP = (float *)(ws + L.expP), *tflag = (float *)(ws + L.tflag);
     return hipSuccess;
@@ -1879,7 +2022,7 @@ hipError_t joint_aux_pointers(void *workspace, int T, int U, int B, int J, int V
 // in front of its own launches and says so (JointHooks::prefilled).
 hipError_t launch_joint_prefill(void *workspace, int T, int U, int B, int J, int V, hipStream_t s) {
     if (!joint_supported(J, V) || sweep_K(U) == 0) return hipErrorInvalidValue;
-    const JointLayout L = make_joint_layout(T, U, B, J);
+    const JointLayout L = make_joint_layout(T, U, B, J, V);
     char *ws = (char *)workspace;
     return launch_fill2(ws + L.w.W, L.wide ? kFillByte : 0, L.w.A - L.w.W, ws + L.tflag, 0, 256, s);
 }
@@ -1888,16 +2031,16 @@ hipError_t launch_joint_prefill(void *workspace, int T, int U, int B, int J, int
 // chosen by the vocabulary -- the two domains are disjoint -- and must be the one the requested kernels expect)
 bool joint_dtype_supported(int joint_dtype, int J, int V) {
     if (joint_dtype == 0) return joint_supported(J, V);
-    if (joint_dtype == 1) return V > 32 && joint_f16_supported(J, V);
+    if (joint_dtype == 1) return V > 64 && joint_f16_supported(J, V);
     return false;
 }
 
 hipError_t joint_workspace_bytes(int T, int U, int B, int J, int V, size_t *bytes) {
     // the two joint paths have disjoint shape domains (V <= 32: f32-grade; V % 128 == 0: f16 MFMA), so the
     // workspace query needs no dtype argument; it returns the size for whichever path accepts (J, V)
-    if (V > 32) return joint_f16_workspace_bytes(T, U, B, J, V, bytes);
+    if (V > 64) return joint_f16_workspace_bytes(T, U, B, J, V, bytes);
     if (!joint_supported(J, V) || sweep_K(U) == 0) return hipErrorInvalidValue;
-    *bytes = make_joint_layout(T, U, B, J).total;
+    *bytes = make_joint_layout(T, U, B, J, V).total;
     return hipSuccess;
 }
 
@@ -1920,12 +2063,12 @@ static hipError_t set_lds(K kernel, size_t bytes) {
     return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-// logits[c][0..V) <- the parked tile dl[c][0..32) (bias included)
-__global__ __launch_bounds__(256) void joint_logits_copy_kernel(float *out, const float *dl, const uint32_t cells, const int V) {
+// logits[c][0..V) <- the parked tiles dl[c][0..Vp) (bias included; Vp = 32 or 64)
+__global__ __launch_bounds__(256) void joint_logits_copy_kernel(float *out, const float *dl, const uint32_t cells, const int V, const int Vp) {
     const size_t n = (size_t)cells * (size_t)V;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const size_t c = i / (size_t)V;
-        out[i] = dl[c * 32 + (i - c * (size_t)V)];
+        out[i] = dl[c * Vp + (i - c * (size_t)V)];
     }
 }
 
@@ -1944,21 +2087,25 @@ static void joint_bind(JointParams &jp, const JointLayout &L, char *ws) {
     jp.b2s = jp.tflag + 64;
     jp.W2s = (jf16 *)(ws + L.W2s);
     jp.n_ut = L.n_ut, jp.TR = L.TR, jp.n_tr = L.n_tr, jp.TS = L.TS, jp.n_ts = L.n_ts;
+    jp.VT = L.VT, jp.vt = 0;
     jp.nblk = 0, jp.need_state = 0;
     // the forward kernel's decay statistic (instead of the lsm launch's per-patch slots)
     jp.lp.pstat = (float2 *)(ws + L.pstat), jp.lp.nPstat = L.nPstat, jp.lp.pstatStride = 1;
 }
 
-static hipError_t launch_joint_fwd(const JointParams &jp, const JointLayout &L, int B, int T, hipStream_t s) {
-    const int J = jp.J;
+static hipError_t launch_joint_fwd(const JointParams &jp0, const JointLayout &L, int B, int T, hipStream_t s) {
+    const int J = jp0.J;
     hipError_t e;
     if (!L.wide) {
         const size_t shm_fwd = (size_t)J * 256;  // Ct tile + W2 fragment image, both resident
         if ((e = set_lds(joint_fwd_kernel, shm_fwd)) != hipSuccess) return e;
         const int n_items = ((T + kFwdRows - 1) / kFwdRows) * B * L.n_ut;
         const int ncu = device_cu_count();
-        hipLaunchKernelGGL(joint_fwd_kernel, dim3(n_items < ncu ? n_items : ncu), dim3(kFwdWaves * 64), shm_fwd, s, jp);
-    } else {  // J > 640: the two tables do not fit the LDS together; W2 streams through it in chunks instead
+        JointParams jp = jp0;
+        for (jp.vt = 0; jp.vt < L.VT; ++jp.vt)  // one pass per vocabulary tile; the last one sees every logit of a cell (epilogue MODE 2)
+            hipLaunchKernelGGL(joint_fwd_kernel, dim3(n_items < ncu ? n_items : ncu), dim3(kFwdWaves * 64), shm_fwd, s, jp);
+    } else {
+        const JointParams &jp = jp0;  // J > 640: the two tables do not fit the LDS together; W2 streams through it in chunks instead
         const size_t shm1s = (size_t)J * 32 * sizeof(float) + 2 * 8192 + (kP1Waves * (size_t)J + kP1Waves * 32 * kStagePad) * sizeof(float);
         if ((e = set_lds(joint_phase1s_kernel, shm1s)) != hipSuccess) return e;
         hipLaunchKernelGGL(joint_phase1s_kernel, dim3((unsigned)B * L.n_ut * L.n_tr), dim3(kP1Waves * 64), shm1s, s, jp);
@@ -1973,7 +2120,7 @@ hipError_t launch_joint_logits(const float *enc_proj, const float *pred_proj, co
     if (!joint_supported(J, V) || sweep_K(U) == 0) return hipErrorInvalidValue;
     if (((uintptr_t)enc_proj & 15) || ((uintptr_t)pred_proj & 15)) return hipErrorInvalidValue;
     if ((unsigned long long)B * T * J >= (1ull << 32) || (unsigned long long)B * U * J >= (1ull << 32)) return hipErrorInvalidValue;
-    const JointLayout L = make_joint_layout(T, U, B, J);
+    const JointLayout L = make_joint_layout(T, U, B, J, V);
     char *ws = (char *)workspace;
     // lengths and labels of the "everything is live" lattice sit in workspace regions the forward kernels do not touch
     int *il = (int *)(ws + L.rec), *ll = il + B, *labels = (int *)(ws + L.reclab);
@@ -1995,7 +2142,7 @@ hipError_t launch_joint_logits(const float *enc_proj, const float *pred_proj, co
     if ((e = launch_joint_fwd(jp, L, B, T, s)) != hipSuccess) return e;
     const size_t n = (size_t)jp.lp.cells * V;
     const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(joint_logits_copy_kernel, dim3(grid), dim3(256), 0, s, logits, jp.dl, jp.lp.cells, V);
+    hipLaunchKernelGGL(joint_logits_copy_kernel, dim3(grid), dim3(256), 0, s, logits, jp.dl, jp.lp.cells, V, 32 * L.VT);
     return hipGetLastError();
 }
 
@@ -2013,8 +2160,8 @@ static hipError_t launch_joint_redo_k(const JointParams &jp, const LossParams &q
 static hipError_t launch_joint_redo(const JointParams &jp, const bool want_rec, hipStream_t s) {
     // the loss parameters of the redo: the parked tile [cells][32] as the logits (pad symbols hold -1e30: probability zero)
     LossParams q = jp.lp;
-    q.acts = jp.dl, q.grads = nullptr, q.V = 32;
-    q.divV = make_fastdiv(32u);
+    q.acts = jp.dl, q.grads = nullptr, q.V = 32 * jp.VT;
+    q.divV = make_fastdiv((uint32_t)q.V);
     switch (sweep_K(jp.lp.U)) {
         case 1: return launch_joint_redo_k<1, 16>(jp, q, want_rec, s);
         case 2: return launch_joint_redo_k<2, 16>(jp, q, want_rec, s);
@@ -2042,7 +2189,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     if (((uintptr_t)enc_proj & 15) || ((uintptr_t)pred_proj & 15)) return hipErrorInvalidValue;
     // the reductions over the [B][T][J] / [B][U][J] arrays index with 32 bits (B*T*U < 2^31 alone does not bound B*T*J)
     if ((unsigned long long)B * T * J >= (1ull << 32) || (unsigned long long)B * U * J >= (1ull << 32)) return hipErrorInvalidValue;
-    const JointLayout L = make_joint_layout(T, U, B, J);
+    const JointLayout L = make_joint_layout(T, U, B, J, V);
     JointParams jp;
     if (!fill_loss_params(jp.lp, nullptr, nullptr, labels, label_lengths, input_lengths, cost_scale, V, B, costs,
                           workspace, T, U, blank))
@@ -2110,7 +2257,9 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
         if ((e = launch_joint_redo(jp, true, s)) != hipSuccess) return e;
         const size_t shm_bwd = (size_t)kBwdRing * kBwdSlotBytes + 2 * 32 * 8 * sizeof(float) + 2 * kBwdRing * sizeof(int);
         if ((e = set_lds(joint_bwd_kernel, shm_bwd)) != hipSuccess) return e;
-        hipLaunchKernelGGL(joint_bwd_kernel, dim3(nblk * n_groups), dim3((n_cons + 2) * 64), shm_bwd, s, jp);
+        for (jp.vt = 0; jp.vt < L.VT; ++jp.vt)  // one pass per vocabulary tile (a later one adds its d enc_proj / d pred_proj partials to the first's)
+            hipLaunchKernelGGL(joint_bwd_kernel, dim3(nblk * n_groups), dim3((n_cons + 2) * 64), shm_bwd, s, jp);
+        jp.vt = 0;
     } else {
         // the wide joint: dlogits by their own kernel, then the block-per-tile products; partial buffers zero-filled (rows /
         // workgroups that path does not write must read as zero; the d enc_proj partials need none)
@@ -2125,7 +2274,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const unsigned nWblk = (unsigned)(J * V + 31) / 32u;
-    hipLaunchKernelGGL(joint_reduce_kernel, dim3(2u * kHookBlocks + nWblk + 1u), dim3(256), 0, s, jp, L.wide ? 0 : 1, nC, nW, nDb,
+    hipLaunchKernelGGL(joint_reduce_kernel, dim3(2u * kHookBlocks + nWblk + (unsigned)L.VT), dim3(256), 0, s, jp, L.wide ? 0 : 1, nC, nW, nDb,
                        hooks ? hooks->dmax_enc : (unsigned *)nullptr, hooks ? hooks->dmax_pred : (unsigned *)nullptr);
 #ifdef JH_TRACE
     {

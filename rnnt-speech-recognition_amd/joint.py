@@ -174,7 +174,7 @@ def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_leng
     W2 [J,V], b2 [V]  (Keras Dense kernels are stored [in, out], model.py:162-166).
 
     joint_dtype: arithmetic of the J x V product.  "f32": f32-grade products (binary16 hi + lo operands on the f16 MFMA units, f32 accumulation), small vocabularies (V <= 32, the reference's
-    character set).  "f16": operands rounded to binary16, f32 accumulation, for large vocabularies -- the counterpart
+    character set; up to 64 symbols at joint sizes up to 640, as two vocabulary tiles).  "f16": operands rounded to binary16, f32 accumulation, for large vocabularies -- the counterpart
     of the reference's `mixed_float16` policy (run_rnnt.py:96-99); the lattice stays f32 either way.  "auto" picks by V.
     Shapes the kernels do not take natively (f16: V a multiple of 128, J a multiple of 128 up to 640; f32: J a multiple of
     64) are padded up exactly (zero units / zero-probability symbols).
@@ -183,7 +183,7 @@ def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_leng
     libwarprnnt.so (compute_rnnt_joint_net_loss_*: split-precision MFMA GEMMs, csrc/dense_kernels.hip; hidden size a multiple
     of 32).  "torch": torch.matmul + autograd around compute_rnnt_joint_loss_*.  "auto": the engine whenever it takes the shape."""
     if joint_dtype == "auto":
-        joint_dtype = "f32" if W2.shape[1] <= 32 else "f16"
+        joint_dtype = _auto_joint_dtype(W2.shape[0], W2.shape[1])
     if joint_dtype not in JOINT_DTYPES:
         raise ValueError(f"rnnt_joint_loss: joint_dtype must be one of {sorted(JOINT_DTYPES)} or 'auto'")
     # The kernels take a fixed set of (J, V) shapes; anything else is padded up here, exactly:
@@ -239,7 +239,7 @@ def joint_logits(enc, pred, W1, b1, W2, b2, joint_dtype: str = "auto", reuse_buf
     U = pred.shape[1]
     J, V = W2.shape
     if joint_dtype == "auto":
-        joint_dtype = "f32" if V <= 32 else "f16"
+        joint_dtype = _auto_joint_dtype(J, V)
     Jp, Vp = padded_joint_shape(J, V, joint_dtype)
     if Jp != J:
         W1 = torch.nn.functional.pad(W1, (0, Jp - J))
@@ -285,14 +285,22 @@ _PAD_BIAS = -1.0e4
 _F16_J = (128, 256, 384, 512, 640)
 
 
+def _auto_joint_dtype(J: int, V: int) -> str:
+    """f32-grade products wherever the library has them: up to 32 symbols at any joint size it takes (<= 704), up to 64 symbols
+    -- two vocabulary tiles, round 5 -- at joint sizes up to 640; the f16 MFMA joint beyond."""
+    return "f32" if (V <= 32 or (V <= 64 and J <= 640)) else "f16"
+
+
+
 def padded_joint_shape(J: int, V: int, joint_dtype: str):
     """(J, V) -> the nearest shape the chosen kernels accept (include/rnnt.h), or raises if there is none."""
     if joint_dtype == "f32":
-        if V > 32:
-            raise ValueError("rnnt_joint_loss: the f32 joint takes vocabularies of at most 32 symbols; use joint_dtype='f16'")
         Jp = (J + 63) // 64 * 64
         if Jp > 704:
             raise ValueError("rnnt_joint_loss: the f32 joint takes joint sizes of at most 704")
+        if V > (64 if Jp <= 640 else 32):
+            raise ValueError("rnnt_joint_loss: the f32 joint takes vocabularies of at most 64 symbols (32 at joint sizes above 640); "
+                             "use joint_dtype='f16'")
         return Jp, V
     Jp = next((j for j in _F16_J if j >= J), None)
     if Jp is None:
@@ -335,7 +343,7 @@ class JointLoss(torch.nn.Module):
         overwritten by the next call of the same shape -- the greedy decoder opts in, a beam search must not)."""
         if enc.is_cuda:
             try:
-                padded_joint_shape(self.W2.shape[0], self.W2.shape[1], "f32" if self.W2.shape[1] <= 32 else "f16")
+                padded_joint_shape(self.W2.shape[0], self.W2.shape[1], _auto_joint_dtype(*self.W2.shape))
             except ValueError:
                 return self.logits(enc, pred)
             return joint_logits(enc, pred, self.W1, self.b1, self.W2, self.b2, reuse_buffers=reuse_buffers)

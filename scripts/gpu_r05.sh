@@ -37,9 +37,18 @@ if has lintests; then
   timeout 900 python -m pytest tests/test_lin_gpu.py tests/test_joint_edges_gpu.py tests/test_joint_gpu.py -m gpu -q --maxfail=40 > $OUT/pytest_lin.log 2>&1; echo "lintests rc=$?"; tail -30 $OUT/pytest_lin.log
 fi
 if has fused; then
-  for v in $VARS; do echo "== fused-only $v"; RNNT_LIBWARPRNNT=$(lib $v) timeout 300 python bench.py --fused-only 32,600,150,28 --steps 20 2>$OUT/fused_$v.err | tee $OUT/fused_$v.json | python -c "
+  for rep in 1 2; do for v in $VARS; do RNNT_LIBWARPRNNT=$(lib $v) timeout 300 python bench.py --fused-only 32,600,150,28 --steps 20 2>$OUT/fused_$v.err > $OUT/fused_$v.$rep.json; python - $OUT/fused_$v.$rep.json $v <<'PY'
 import json,sys
-d=json.loads(sys.stdin.readline()); print({k:d[k] for k in d if k in ('ms_per_step','full_ms_per_step','ms_per_step_full','workload')})"; done
+d=json.loads(open(sys.argv[1]).readline()); f=d.get('fused_joint') or d
+print('fused-only %-10s %.4f ms' % (sys.argv[2], f.get('ms_per_step', float('nan'))))
+PY
+  done; done
+fi
+if has profjv; then
+  for v in $VARS; do
+    (cd /tmp && RNNT_LIBWARPRNNT=$(lib $v) timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/profj_$v -o j -- python $R/bench.py --fused-only 32,600,150,28 --steps 10 > $R/$OUT/rocprofj_$v.log 2>&1)
+    python scripts/summarize_trace.py stats $OUT/profj_$v $OUT/joint_kernel_stats_$v.json $OUT/joint_kernel_stats_$v.csv > /dev/null; echo "== kernels $v"; sed -n 2,5p $OUT/joint_kernel_stats_$v.csv | cut -c1-90
+  done
 fi
 if has ab; then
   bash scripts/gpu_bench_variants.sh $TAG $VARS

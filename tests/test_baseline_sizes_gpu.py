@@ -4,6 +4,8 @@ times -- through the C ABI (compute_rnnt_joint_loss_fwd / _bwd behind joint._Joi
   C2 fused   B=32 T=600  U=150 J=640 V=28    f32-grade products (split-precision f16 MFMAs)   model.py:158-166, hparams.py:18,23
   C5         B=16 T=1500 U=300 J=640 V=1024  f16 MFMA joint / f32 lattice                      BASELINE.json configs[4]
   C3 shape   B=64 T'=300 U=100 H=J=320 V=28  the end-to-end model's joint (configs[2])
+  defaults   B=16 T'=300 U=100 J=640 V=4096  the reference's own default hyper-parameters (hparams.py:4,18,23: 4096 word
+                                             pieces, joint size 640), f16 MFMA joint -- the `fused_joint_refdefault` bench leg
 
 The float64 oracle cannot hold a whole batch at these sizes, so each test checks
   * C2: EVERY utterance of the batch against oracle.joint_utterance_streamed (evaluated side by side on the host's cores):
@@ -199,6 +201,26 @@ def test_c5_fused_f16_joint_at_full_size():
     scale = torch.linspace(1.5, 0.5, B) / B
     costs, grads = run_fused(case, scale, "f16")
     picks = list(range(8))  # half the batch: one FULL-length utterance (450,000 cells x 1024 symbols, streamed in float64), one short, six ragged
+    mask = torch.zeros(B)
+    mask[picks] = 1.0
+    _, grads_masked = run_fused(case, scale * mask, "f16")
+    check_against_oracle(case, "f16", picks, scale, costs, grads, grads_masked, gtol=1e-3, also_exact=True)
+    check_properties(case, costs, grads, lambda: run_fused(case, scale, "f16"))
+    np.testing.assert_allclose(costs[:1].cpu().numpy(), unfused_costs(case, 1, True), rtol=5e-5)
+
+
+def test_reference_default_hparams_f16_joint_at_size():
+    """The reference's default hyper-parameters (hparams.py:4 vocab_size 4096, :23 joint_net_size 640) on a realistic lattice --
+    600 frames after x2 time reduction, 99 word pieces: the shape bench.py's `fused_joint_refdefault` leg times.  Three
+    utterances (one full-length, two ragged) against the streamed float64 joint with the f16 path's roundings restated, costs
+    also against the unrounded joint; properties on the whole batch."""
+    B, T, U, J, V = 16, 300, 100, 640, 4096
+    case = make_proj_case(B, T, U, J, V, seed=4096, w2_gain=3.0)
+    case[5][1], case[6][1] = 171, 60
+    case[5][2], case[6][2] = 290, 31
+    scale = torch.linspace(1.5, 0.5, B) / B  # (utterance 0 carries the largest upstream gradient: see the C5 test)
+    costs, grads = run_fused(case, scale, "f16")
+    picks = [0, 1, 2]
     mask = torch.zeros(B)
     mask[picks] = 1.0
     _, grads_masked = run_fused(case, scale * mask, "f16")

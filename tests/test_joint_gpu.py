@@ -52,6 +52,9 @@ SHAPES = [
     (2, 300, 20, 16, 64, 5),    # row splits (T >= 256)
     (2, 40, 37, 16, 704, 28),   # 640 < J <= 704: W2 streams through the LDS (joint_phase1s_kernel), two-kernel backward
     (1, 33, 70, 8, 704, 31),    # widest joint of the f32 path, three u-tiles, V = 31
+    (2, 23, 37, 16, 128, 40),   # round 5: TWO vocabulary tiles (32 < V <= 64), f32-grade; labels and blank in either tile
+    (3, 40, 20, 24, 640, 64),   # both tiles full, the widest single-kernel joint (two J groups)
+    (2, 70, 66, 16, 64, 33),    # one symbol in the second tile, three u-tiles
 ]
 
 
