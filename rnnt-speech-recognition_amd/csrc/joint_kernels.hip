@@ -108,6 +108,7 @@ struct JointParams {
     int need_state;   // backward-only whole-network call: the reductions return NaN unless tflag[3] says the state is there
 };
 
+constexpr int kMaxVT = 4;  // vocabulary tiles of 32 symbols the f32-grade joint takes (V <= 128)
 constexpr float kRFormLimit = 4096.0f;  // largest |W2| the forward kernel's r = (1 - h) / 2 accumulation is used for (joint_prep_kernel)
 
 // tables for tanh_from_exp + the overflow flag (zeroed before the launch)
@@ -173,11 +174,12 @@ __global__ __launch_bounds__(256) void joint_prep_kernel(const JointParams jp) {
         // difference of two sums of the magnitude of the LARGEST weight: fine while those are of the order of the logits, a
         // cancellation otherwise (a unit with h = 0 and a weight of 1e5 costs 4e-3 of absolute logit error in f32 accumulators).
         // Beyond kRFormLimit the kernel accumulates h itself and the table holds b2 alone.
-        __shared__ double part[2][8][32];
+        __shared__ double part[kMaxVT][8][32];
         const int v = threadIdx.x & 31, q = threadIdx.x >> 5;
-        double sum[2] = {0.0, 0.0};
+        double sum[kMaxVT] = {0.0, 0.0, 0.0, 0.0};
         float wmax = 0.f;
-        for (int tile = 0; tile < jp.VT; ++tile) {
+#pragma unroll
+        for (int tile = 0; tile < kMaxVT; ++tile) {
             const int vv = 32 * tile + v;
             if (vv < p.V) {  // 32 loads in flight per thread: the block is alone on its CU and waits out a full memory latency per
                              // round (with 8 per round, ten rounds at J = 640, this block alone made the kernel 28 us long)
@@ -195,7 +197,8 @@ __global__ __launch_bounds__(256) void joint_prep_kernel(const JointParams jp) {
         wmax = scale_of(wmax, s2, inv2);
         const bool hform = !(wmax <= kRFormLimit);
         if (threadIdx.x == 0) jp.tflag[2] = inv2, jp.tflag[1] = hform ? 1.0f : 0.f;
-        part[0][q][v] = hform ? 0.0 : sum[0], part[1][q][v] = hform ? 0.0 : sum[1];
+#pragma unroll
+        for (int tile = 0; tile < kMaxVT; ++tile) part[tile][q][v] = hform ? 0.0 : sum[tile];
         __syncthreads();
         if (threadIdx.x < 32 * jp.VT) {
             const int tile = threadIdx.x >> 5, vv = threadIdx.x;  // (v = threadIdx.x & 31)
@@ -210,16 +213,15 @@ __global__ __launch_bounds__(256) void joint_prep_kernel(const JointParams jp) {
     if (fblk * 256 < nfrag) {
         const int nW = jp.J * p.V;
         float wmax = 0.f;
-        {
-            constexpr int kMaxW = 704 * 32 > 640 * 64 ? 704 * 32 : 640 * 64;  // joint_supported()
-            float w[kMaxW / 256];
+        for (int i0 = 0; i0 < nW; i0 += 256 * 64) {  // 64 loads in flight per thread and round (J V <= 81,920 floats: five rounds at most)
+            float w[64];
 #pragma unroll
-            for (int k = 0; k < kMaxW / 256; ++k) {
-                const int i = 256 * k + (int)threadIdx.x;
+            for (int k = 0; k < 64; ++k) {
+                const int i = i0 + 256 * k + (int)threadIdx.x;
                 w[k] = (i < nW) ? fabsf(jp.W2[i]) : 0.f;
             }
 #pragma unroll
-            for (int k = 0; k < kMaxW / 256; ++k) wmax = fmaxf(wmax, w[k]);
+            for (int k = 0; k < 64; ++k) wmax = fmaxf(wmax, w[k]);
         }
         float s2, inv2;
         scale_of(wmax, s2, inv2);
@@ -451,6 +453,9 @@ __device__ __forceinline__ float row_bcast(const float x) {
 #ifndef RNNT_FWD_DPP64
 #define RNNT_FWD_DPP64 1  // 0: two 32-bit broadcasts per unit (A/B timing)
 #endif
+#ifndef RNNT_FWD_PKFMA
+#define RNNT_FWD_PKFMA 1  // 0: two v_fma_f32 per unit instead of one v_pk_fma_f32 (A/B timing: packed f32 beside MFMAs)
+#endif
 template <int E>
 __device__ __forceinline__ jf2 row_bcast2(const jf2 x) {
 #if RNNT_FWD_DPP64
@@ -465,8 +470,13 @@ __device__ __forceinline__ void fwd_h_pair(const jf2 ea01, const float ec, float
     const jf2 a = row_bcast2<E>(ea01), c2 = {ec, ec};
     jf2 r;
     if (!SLOW) {  // r = (1 - h) / 2, see fwd_row_epilogue
+#if RNNT_FWD_PKFMA
         const jf2 x = a * c2 + (jf2){1.0f, 1.0f};
         r = (jf2){__builtin_amdgcn_rcpf(x[0]), __builtin_amdgcn_rcpf(x[1])};
+#else
+        (void)c2;
+        r = (jf2){r_from_exp(a[0], ec), r_from_exp(a[1], ec)};
+#endif
     } else {
         r = (jf2){fast_r(a[0] + ec), fast_r(a[1] + ec)};
     }
@@ -574,12 +584,13 @@ __device__ __forceinline__ float half_swap_sum(const float v) {
 // zero where an edge leaves the lattice, NaN -- the utterance is handed back -- where an edge the lattice owns is below 2^-100);
 // lse is still stored (the backward's per-cell set-up needs the denominator and does not re-read the tile).
 // Returns the cell's decay statistic -log2 max(p_blank, p_label) (rnnt_lin.h; 0 for lanes that own no cell, half 1 included).
-// MODE 0: the whole vocabulary is this tile (V <= 32).  Two vocabulary tiles (32 < V <= 64, round 5): MODE 1 = tile 0, launched
-// first: parks its 32 logits and nothing else; MODE 2 = tile 1: re-reads what tile 0 parked for the cell (16 floats per half-lane,
-// the same symbols-per-register layout) and runs the softmax over all 64.  rsel_*: registers of THIS tile, rselo_*: of the other.
+// MODE 0: the whole vocabulary is this tile (V <= 32).  Several vocabulary tiles (32 < V <= 128, round 5): MODE 1 = every tile but
+// the last, launched first: park the tile's 32 logits and nothing else; MODE 2 = the last tile: re-reads what the others parked
+// for the cell (16 floats per half-lane and tile, the same symbols-per-register layout; once for the maximum and the blank /
+// label picks, once more -- out of L2 -- for the sum) and runs the softmax over all of them.  rsel_*: registers of THIS tile.
 template <int MODE>
 __device__ __forceinline__ float fwd_row_epilogue(const JointParams &jp, const f32x16 &acc, const float m2inv,
-                                                  const int rsel_b, const int rsel_l, const int rselo_b, const int rselo_l,
+                                                  const int rsel_b, const int rsel_l, const int lab,
                                                   const int b, const int t, const int u, const int Tb, const int Ub, const int half) {
     const LossParams &p = jp.lp;
     const float *b2t = jp.b2s + 64 * jp.vt;
@@ -593,31 +604,45 @@ __device__ __forceinline__ float fwd_row_epilogue(const JointParams &jp, const f
         x[4 * g + 2] = fmaf(acc[4 * g + 2], m2inv, bh.z) + bl.z;
         x[4 * g + 3] = fmaf(acc[4 * g + 3], m2inv, bh.w) + bl.w;
     }
-    const size_t c = ((size_t)(b * p.T + t)) * p.U + min(u, p.U - 1);
+    const size_t c = ((size_t)(b * p.T + t)) * p.U + min(u, p.U - 1);  // (clamped: MODE 2's loads are unconditional)
     if (MODE == 1) {
         if (u < Ub) {
-            float *dst = jp.dl + c * Vp + 4 * half;
+            float *dst = jp.dl + c * Vp + 32 * jp.vt + 4 * half;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *(float4 *)(dst + 8 * g) = make_float4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
         }
         return 0.f;
     }
-    float xo[16];
-    if (MODE == 2) {  // (unconditional loads: clamped cell index, values of padded cells are never used)
-        const float *src = jp.dl + c * Vp + 4 * half;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 q = *(const float4 *)(src + 8 * g);
-            xo[4 * g] = q.x, xo[4 * g + 1] = q.y, xo[4 * g + 2] = q.z, xo[4 * g + 3] = q.w;
-        }
-    }
     float m = x[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fmaxf(m, x[r]);
-    if (MODE == 2) {
+    float xb = -INFINITY, xl = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, xo[r]);
+    for (int r = 0; r < 16; ++r) {
+        xb = (rsel_b == r) ? x[r] : xb;
+        xl = (rsel_l == r) ? x[r] : xl;
+    }
+    auto reg_in = [&](const int v, const int tile) {  // register of symbol v in tile `tile` for this half-lane, or -1
+        const int w = v - 32 * tile;
+        return (w >= 0 && w < 32 && ((w >> 2) & 1) == half) ? (w & 3) + 4 * (w >> 3) : -1;
+    };
+    if (MODE == 2) {
+        for (int ot = 0; ot < jp.VT - 1; ++ot) {
+            const float *src = jp.dl + c * Vp + 32 * ot + 4 * half;
+            const int rb = reg_in(p.blank, ot), rl = reg_in(lab, ot);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 q = *(const float4 *)(src + 8 * g);
+                const float xo[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    m = fmaxf(m, xo[k]);
+                    xb = (rb == 4 * g + k) ? xo[k] : xb;
+                    xl = (rl == 4 * g + k) ? xo[k] : xl;
+                }
+            }
+        }
     }
     m = half_swap_max(m);
     const float nml = -m * kLog2e;
@@ -625,20 +650,16 @@ __device__ __forceinline__ float fwd_row_epilogue(const JointParams &jp, const f
 #pragma unroll
     for (int r = 0; r < 16; ++r) ssum += jex2(fmaf(x[r], kLog2e, nml));
     if (MODE == 2) {
+        for (int ot = 0; ot < jp.VT - 1; ++ot) {
+            const float *src = jp.dl + c * Vp + 32 * ot + 4 * half;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ssum += jex2(fmaf(xo[r], kLog2e, nml));
-    }
-    ssum = half_swap_sum(ssum);
-    float xb = -INFINITY, xl = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        xb = (rsel_b == r) ? x[r] : xb;
-        xl = (rsel_l == r) ? x[r] : xl;
-        if (MODE == 2) {
-            xb = (rselo_b == r) ? xo[r] : xb;
-            xl = (rselo_l == r) ? xo[r] : xl;
+            for (int g = 0; g < 4; ++g) {
+                const float4 q = *(const float4 *)(src + 8 * g);
+                ssum += (jex2(fmaf(q.x, kLog2e, nml)) + jex2(fmaf(q.y, kLog2e, nml))) + (jex2(fmaf(q.z, kLog2e, nml)) + jex2(fmaf(q.w, kLog2e, nml)));
+            }
         }
     }
+    ssum = half_swap_sum(ssum);
     xb = half_swap_max(xb);
     xl = half_swap_max(xl);
     float stat = 0.f;
@@ -710,8 +731,8 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
         const int w = v - 32 * tile;
         return (w >= 0 && w < 32 && ((w >> 2) & 1) == half) ? (w & 3) + 4 * (w >> 3) : -1;
     };
-    const int mode = jp.VT == 1 ? 0 : (jp.vt == 0 ? 1 : 2);  // fwd_row_epilogue's MODE (kernel-uniform)
-    const int rsel_b = reg_of(p.blank, jp.vt), rselo_b = reg_of(p.blank, jp.vt ^ 1);
+    const int mode = jp.VT == 1 ? 0 : (jp.vt < jp.VT - 1 ? 1 : 2);  // fwd_row_epilogue's MODE (kernel-uniform)
+    const int rsel_b = reg_of(p.blank, jp.vt);
     const uint32_t ct_lane = (uint32_t)(l31 * cpr);          // this lane's Ct row, in chunks
     const uint32_t ct_swz = (uint32_t)(l31 & 15);
     // enc-side addends of a k-step (16 joint units), one per lane: positions 0..7 of every 16-lane row hold the 8 units of
@@ -724,7 +745,7 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
     const int it_lo = (int)((long long)n_items * blockIdx.x / gridDim.x);
     const int it_hi = (int)((long long)n_items * (blockIdx.x + 1) / gridDim.x);
     int ct_owner = -1;
-    int rsel_l = -1, rselo_l = -1;
+    int rsel_l = -1, lab_l = -1;  // this lane's label: its register in this tile (or -1), the symbol itself (or -1)
     for (int item = it_lo; item < it_hi; ++item) {
         const int bu = item / n_tr, tr = item - bu * n_tr;
         const int b = bu / jp.n_ut, ut = bu - b * jp.n_ut;
@@ -747,10 +768,10 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
                 const float *src = Ptab + ((size_t)b * p.U + min(u0 + (int)ur, p.U - 1)) * J + c * 4u;
                 lds_dma16(src, Ct + (size_t)pc * 1024);
             }
-            rsel_l = rselo_l = -1;
+            rsel_l = lab_l = -1;
             if (u < Ub - 1) {
-                const int lab = min(max(p.labels[(size_t)b * (p.U - 1) + u], 0), V - 1);
-                rsel_l = reg_of(lab, jp.vt), rselo_l = reg_of(lab, jp.vt ^ 1);
+                lab_l = min(max(p.labels[(size_t)b * (p.U - 1) + u], 0), V - 1);
+                rsel_l = reg_of(lab_l, jp.vt);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -777,15 +798,15 @@ __global__ __launch_bounds__(kFwdWaves * 64) void joint_fwd_kernel(const JointPa
             fwd_row_pair<true, false>(J, e0, e1, ct_row, ct_swz, wlane, half, lane, acc0, acc1);
         }
         if (mode == 0) {
-            float stat = fwd_row_epilogue<0>(jp, acc0, m2inv, rsel_b, rsel_l, -1, -1, b, t0, u, Tb, Ub, half);
-            if (two) stat += fwd_row_epilogue<0>(jp, acc1, m2inv, rsel_b, rsel_l, -1, -1, b, t0 + 1, u, Tb, Ub, half);
+            float stat = fwd_row_epilogue<0>(jp, acc0, m2inv, rsel_b, rsel_l, lab_l, b, t0, u, Tb, Ub, half);
+            if (two) stat += fwd_row_epilogue<0>(jp, acc1, m2inv, rsel_b, rsel_l, lab_l, b, t0 + 1, u, Tb, Ub, half);
             fwd_put_stat(jp, b, ut, t0, stat, (float)(min(32, Ub - u0) * (two ? 2 : 1)), lane);
         } else if (mode == 1) {
-            fwd_row_epilogue<1>(jp, acc0, m2inv, -1, -1, -1, -1, b, t0, u, Tb, Ub, half);
-            if (two) fwd_row_epilogue<1>(jp, acc1, m2inv, -1, -1, -1, -1, b, t0 + 1, u, Tb, Ub, half);
+            fwd_row_epilogue<1>(jp, acc0, m2inv, -1, -1, -1, b, t0, u, Tb, Ub, half);
+            if (two) fwd_row_epilogue<1>(jp, acc1, m2inv, -1, -1, -1, b, t0 + 1, u, Tb, Ub, half);
         } else {
-            float stat = fwd_row_epilogue<2>(jp, acc0, m2inv, rsel_b, rsel_l, rselo_b, rselo_l, b, t0, u, Tb, Ub, half);
-            if (two) stat += fwd_row_epilogue<2>(jp, acc1, m2inv, rsel_b, rsel_l, rselo_b, rselo_l, b, t0 + 1, u, Tb, Ub, half);
+            float stat = fwd_row_epilogue<2>(jp, acc0, m2inv, rsel_b, rsel_l, lab_l, b, t0, u, Tb, Ub, half);
+            if (two) stat += fwd_row_epilogue<2>(jp, acc1, m2inv, rsel_b, rsel_l, lab_l, b, t0 + 1, u, Tb, Ub, half);
             fwd_put_stat(jp, b, ut, t0, stat, (float)(min(32, Ub - u0) * (two ? 2 : 1)), lane);
         }
     }
@@ -1968,7 +1989,7 @@ static JointLayout make_joint_layout(int T, int U, int B, int J, int V) {
     L.dbpart = take((size_t)L.VT * L.nDb * 32 * sizeof(float));
     L.expE = take((size_t)B * T * J * sizeof(float));
     L.expP = take((size_t)B * U * J * sizeof(float));
-    L.tflag = take(1024);  // flags (64 words, zeroed per call) + the b2s tables (64 words per vocabulary tile)
+    L.tflag = take(256 + (size_t)kMaxVT * 256);  // flags (64 words, zeroed per call) + the b2s tables (64 words per vocabulary tile)
     L.W2s = take((size_t)L.VT * J * 32 * 2 * sizeof(jf16));
     L.nPstat = L.n_ut * ((T + 1) / 2);  // decay statistic of the forward kernel: one slot per (u-tile, row pair) (fwd_put_stat)
     L.pstat = take((size_t)B * L.nPstat * sizeof(float2));
@@ -1979,9 +2000,9 @@ static JointLayout make_joint_layout(int T, int U, int B, int J, int V) {
 static bool joint_supported(int J, int V) {
     // J <= 704: the streaming forward (640 < J) keeps the whole C^T tile (128 J bytes), a row of enc_proj per wave (32 J) and
     // 50 KB of staging in LDS: 162,816 of the 163,840 bytes at J = 704.
-    // V <= 64 (round 5; 32 before): a second vocabulary tile of 32 symbols, each tile one pass of the forward / backward kernels
-    // (J <= 640: the wide joint's kernels keep one tile).
-    return V >= 1 && V <= (J <= 640 ? 64 : 32) && J >= 64 && (J % 64) == 0 && J <= 704;
+    // V <= 128 (round 5; 32 before): up to four vocabulary tiles of 32 symbols, each tile one pass of the forward / backward
+    // kernels (J <= 640: the wide joint's kernels keep one tile).
+    return V >= 1 && V <= (J <= 640 ? 32 * kMaxVT : 32) && J >= 64 && (J % 64) == 0 && J <= 704;
 }
 
 // joint_f16_kernels.hip (large vocabularies on the f16 MFMA units)
@@ -2031,16 +2052,20 @@ hipError_t launch_joint_prefill(void *workspace, int T, int U, int B, int J, int
 // chosen by the vocabulary -- the two domains are disjoint -- and must be the one the requested kernels expect)
 bool joint_dtype_supported(int joint_dtype, int J, int V) {
     if (joint_dtype == 0) return joint_supported(J, V);
-    if (joint_dtype == 1) return V > 64 && joint_f16_supported(J, V);
+    if (joint_dtype == 1) return joint_f16_supported(J, V);
     return false;
 }
 
-hipError_t joint_workspace_bytes(int T, int U, int B, int J, int V, size_t *bytes) {
-    // the two joint paths have disjoint shape domains (V <= 32: f32-grade; V % 128 == 0: f16 MFMA), so the
-    // workspace query needs no dtype argument; it returns the size for whichever path accepts (J, V)
-    if (V > 64) return joint_f16_workspace_bytes(T, U, B, J, V, bytes);
-    if (!joint_supported(J, V) || sweep_K(U) == 0) return hipErrorInvalidValue;
-    *bytes = make_joint_layout(T, U, B, J, V).total;
+// Workspace of the fused joint.  joint_dtype 0 / 1: that path's layout (invalid when it does not take the shape); -1: the larger of
+// the two for shapes both take (V = 128 with J <= 640, round 5) -- what a caller that has not chosen yet must allocate, and the
+// offset behind which the whole-network entry points keep their own arrays whatever the arithmetic.
+hipError_t joint_workspace_bytes(int T, int U, int B, int J, int V, int joint_dtype, size_t *bytes) {
+    size_t n32 = 0, n16 = 0;
+    const bool ok32 = joint_dtype != 1 && joint_supported(J, V) && sweep_K(U) != 0;
+    const bool ok16 = joint_dtype != 0 && joint_f16_supported(J, V) && joint_f16_workspace_bytes(T, U, B, J, V, &n16) == hipSuccess;
+    if (ok32) n32 = make_joint_layout(T, U, B, J, V).total;
+    if (!ok32 && !ok16) return hipErrorInvalidValue;
+    *bytes = n32 > n16 ? n32 : n16;
     return hipSuccess;
 }
 

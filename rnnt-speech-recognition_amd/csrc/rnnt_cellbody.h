@@ -79,9 +79,14 @@ __device__ __forceinline__ float cell_body(const LossParams &p, const Cell &cl, 
                 const int lab = clamp_label(p.labels[(size_t)cl.b * (p.U - 1) + cl.u], V);
                 ol = fmaf(xs[lab] - m, kLog2e, -lg2s);
             }
-            p.lse[c] = lse;
             const size_t wi = ((size_t)cl.b * p.Nr + (cl.t + cl.u)) * p.Up + cl.u;
-            ((float2 *)p.W)[wi] = make_float2(ob, ol);
+            if (SC1) {  // the hand-back team (rnnt_redo.h): other workgroups read these within the same launch -- write-through
+                st_f32_wt(p.lse + c, lse);
+                st_f32_wt(p.W + 2 * wi, ob), st_f32_wt(p.W + 2 * wi + 1, ol);
+            } else {
+                p.lse[c] = lse;
+                ((float2 *)p.W)[wi] = make_float2(ob, ol);
+            }
         } else {
             const CellGrad g = cell_grad_setup<SC1>(p, cl, c);
             const float xb = xs[p.blank];

@@ -12,7 +12,7 @@ using namespace rnnt;
 
 namespace rnnt {
 // joint_kernels.hip
-hipError_t joint_workspace_bytes(int T, int U, int B, int J, int V, size_t *bytes);
+hipError_t joint_workspace_bytes(int T, int U, int B, int J, int V, int joint_dtype, size_t *bytes);
 hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2,
                              const int *labels, const int *label_lengths, const int *input_lengths,
                              const float *cost_scale, int J, int V, int B, int T, int U, int blank, float *costs,
@@ -235,7 +235,7 @@ rnntStatus_t get_joint_workspace_size(int maxT, int maxU, int minibatch, int joi
                                       size_t *size_bytes) {
     if (!size_bytes || maxT <= 0 || maxU <= 0 || minibatch <= 0 || joint_size <= 0 || alphabet_size <= 0)
         return RNNT_STATUS_INVALID_VALUE;
-    return from_hip(joint_workspace_bytes(maxT, maxU, minibatch, joint_size, alphabet_size, size_bytes));
+    return from_hip(joint_workspace_bytes(maxT, maxU, minibatch, joint_size, alphabet_size, -1, size_bytes));
 }
 
 static rnntStatus_t joint_call(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2,
@@ -299,7 +299,7 @@ rnntStatus_t get_joint_net_workspace_size(int maxT, int maxU, int minibatch, int
     if (!size_bytes || maxT <= 0 || maxU <= 0 || minibatch <= 0 || hidden_size <= 0 || joint_size <= 0 || alphabet_size <= 0)
         return RNNT_STATUS_INVALID_VALUE;
     size_t base = 0;
-    hipError_t e = joint_workspace_bytes(maxT, maxU, minibatch, joint_size, alphabet_size, &base);
+    hipError_t e = joint_workspace_bytes(maxT, maxU, minibatch, joint_size, alphabet_size, -1, &base);
     if (e != hipSuccess) return from_hip(e);
     return from_hip(dense_workspace_bytes(minibatch, maxT, maxU, hidden_size, joint_size, base, size_bytes));
 }
@@ -326,7 +326,7 @@ static rnntStatus_t joint_net_call(const float *enc, const float *pred, const fl
     const int B = minibatch, T = options.maxT, U = options.maxU;
     hipStream_t s = (hipStream_t)options.stream;
     size_t base = 0;
-    hipError_t e = joint_workspace_bytes(T, U, B, joint_size, alphabet_size, &base);
+    hipError_t e = joint_workspace_bytes(T, U, B, joint_size, alphabet_size, -1, &base);
     if (e != hipSuccess) return from_hip(e);
     // What the dense layer does on the way for the fused joint (JointHooks): with the f32-grade joint, the forward GEMM's
     // epilogue writes the e^{2x} tables and the table-range flag (the prep kernel then only builds the W2 images), the
@@ -424,7 +424,7 @@ rnntStatus_t compute_rnnt_joint_net_logits(const float *enc, const float *pred, 
     const int B = minibatch, T = options.maxT, U = options.maxU;
     hipStream_t s = (hipStream_t)options.stream;
     size_t base = 0;
-    hipError_t e = joint_workspace_bytes(T, U, B, joint_size, alphabet_size, &base);
+    hipError_t e = joint_workspace_bytes(T, U, B, joint_size, alphabet_size, -1, &base);
     if (e != hipSuccess) return from_hip(e);
     // (the joint's own prep kernel builds the tanh tables here: one cell per call is the common case, nothing to save)
     if ((e = launch_dense_fwd(enc, pred, W1, b1, B, T, U, hidden_size, joint_size, workspace, base, nullptr, nullptr, nullptr, s)) != hipSuccess)

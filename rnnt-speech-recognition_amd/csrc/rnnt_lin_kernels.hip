@@ -490,6 +490,13 @@ __global__ __launch_bounds__(kRedoThreads) void lin_redo_kernel(const LossParams
     uint32_t lo, hi;
     redo_cell_range(p, b, tm, lo, hi);
     if (p.grads) redo_cells<true>(p, lo, hi, tid, lds, NB * chunkf);
+#ifdef RNNT_REDO_TRACE
+    REDO_STAMP(tm, 7);
+    if (redo && tid == 0 && blockIdx.x < 8)
+        printf("redo trace wg %d t0 %lld (clocks): fill %lld | sync %lld | lsm %lld | sync %lld | sweep %lld | sync %lld | grad %lld\n", (int)blockIdx.x, tm.ts[0] % 100000000ll,
+               tm.ts[1] - tm.ts[0], tm.ts[2] - tm.ts[1], tm.ts[3] - tm.ts[2], tm.ts[4] - tm.ts[3], tm.ts[5] - tm.ts[4], tm.ts[6] - tm.ts[5],
+               tm.ts[7] - tm.ts[6]);
+#endif
     if (!tm.ok) {  // a team member never arrived (bounded spin): the utterance's results must not look valid
         if (p.costs && tm.k == 0 && tid == 0) st_f32_wt(p.costs + b, NAN);
         if (p.grads)

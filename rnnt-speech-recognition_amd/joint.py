@@ -174,7 +174,7 @@ def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_leng
     W2 [J,V], b2 [V]  (Keras Dense kernels are stored [in, out], model.py:162-166).
 
     joint_dtype: arithmetic of the J x V product.  "f32": f32-grade products (binary16 hi + lo operands on the f16 MFMA units, f32 accumulation), small vocabularies (V <= 32, the reference's
-    character set; up to 64 symbols at joint sizes up to 640, as two vocabulary tiles).  "f16": operands rounded to binary16, f32 accumulation, for large vocabularies -- the counterpart
+    character set; up to 128 symbols at joint sizes up to 640, as up to four vocabulary tiles -- "auto" uses it up to 64).  "f16": operands rounded to binary16, f32 accumulation, for large vocabularies -- the counterpart
     of the reference's `mixed_float16` policy (run_rnnt.py:96-99); the lattice stays f32 either way.  "auto" picks by V.
     Shapes the kernels do not take natively (f16: V a multiple of 128, J a multiple of 128 up to 640; f32: J a multiple of
     64) are padded up exactly (zero units / zero-probability symbols).
@@ -286,8 +286,9 @@ _F16_J = (128, 256, 384, 512, 640)
 
 
 def _auto_joint_dtype(J: int, V: int) -> str:
-    """f32-grade products wherever the library has them: up to 32 symbols at any joint size it takes (<= 704), up to 64 symbols
-    -- two vocabulary tiles, round 5 -- at joint sizes up to 640; the f16 MFMA joint beyond."""
+    """f32-grade products up to 64 symbols (32 at joint sizes above 640): one or two vocabulary tiles of the split-precision joint,
+    as fast as the f16 joint on its smallest (128-column) shape and f32-grade; the f16 MFMA joint beyond.  (joint_dtype="f32"
+    takes up to 128 symbols -- four tiles, four passes -- when f32-grade gradients matter more than time.)"""
     return "f32" if (V <= 32 or (V <= 64 and J <= 640)) else "f16"
 
 
@@ -298,8 +299,8 @@ def padded_joint_shape(J: int, V: int, joint_dtype: str):
         Jp = (J + 63) // 64 * 64
         if Jp > 704:
             raise ValueError("rnnt_joint_loss: the f32 joint takes joint sizes of at most 704")
-        if V > (64 if Jp <= 640 else 32):
-            raise ValueError("rnnt_joint_loss: the f32 joint takes vocabularies of at most 64 symbols (32 at joint sizes above 640); "
+        if V > (128 if Jp <= 640 else 32):
+            raise ValueError("rnnt_joint_loss: the f32 joint takes vocabularies of at most 128 symbols (32 at joint sizes above 640); "
                              "use joint_dtype='f16'")
         return Jp, V
     Jp = next((j for j in _F16_J if j >= J), None)

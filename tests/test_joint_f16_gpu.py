@@ -189,10 +189,12 @@ def test_joint_f16_limits_are_reported():
     with pytest.raises(ValueError, match="at most 8192"):
         pkg.rnnt_joint_loss(enc, pred, W1, b1, W2, b2, torch.ones(1, 2, dtype=torch.int32, device=dev),
                             torch.tensor([4], device=dev), torch.tensor([2], device=dev))
-    # the raw C ABI still rejects shapes it does not implement (here V = 100 handed straight to the f16 entry point)
+    # the raw C ABI still rejects shapes no path implements (V = 200: beyond the f32-grade joint's 128 symbols, not a multiple of
+    # 128 for the f16 one); V = 100 is the f32-grade joint's since round 5 (four vocabulary tiles)
     from rnnt_speech_recognition_amd import _lib
     with pytest.raises(RuntimeError, match="invalid value"):
-        _lib.joint_workspace_bytes(4, 3, 1, 128, 100)
+        _lib.joint_workspace_bytes(4, 3, 1, 128, 200)
+    assert _lib.joint_workspace_bytes(4, 3, 1, 128, 100) > 0
 
 
 def test_joint_f16_second_backward_recomputes_the_logits():

@@ -32,12 +32,12 @@ def make(B, T, U, H, J, V, ragged, seed):
     return enc, pred, W1, b1, W2, b2, labels, il.astype(np.int32), ll.astype(np.int32)
 
 
-def run(case, scale):
+def run(case, scale, joint_dtype="auto"):
     enc, pred, W1, b1, W2, b2, labels, il, ll = case
     dev = torch.device("cuda:0")
     t = lambda x: torch.tensor(x, device=dev)
     params = [t(x).requires_grad_(True) for x in (enc, pred, W1, b1, W2, b2)]
-    costs = pkg.rnnt_joint_loss(*params, t(labels), t(il), t(ll))
+    costs = pkg.rnnt_joint_loss(*params, t(labels), t(il), t(ll), joint_dtype=joint_dtype)
     (costs * t(scale.astype(np.float32))).sum().backward()
     torch.cuda.synchronize()
     return costs.detach().cpu().numpy(), [p.grad.cpu().numpy() for p in params]
@@ -56,6 +56,7 @@ SHAPES = [
     (3, 40, 20, 24, 640, 64),   # both tiles full, the widest single-kernel joint (two J groups)
     (2, 70, 66, 16, 64, 33),    # one symbol in the second tile, three u-tiles
 ]
+SHAPES_F32_WIDE_VOCAB = [(2, 30, 21, 16, 192, 100), (1, 45, 40, 24, 640, 128)]  # three / four tiles: joint_dtype="f32" on request
 
 
 @pytest.mark.parametrize("B,T,U,H,J,V", SHAPES)
@@ -74,6 +75,21 @@ def test_joint_matches_oracle(B, T, U, H, J, V, ragged):
     il, ll = case[7], case[8]
     for b in range(B):
         assert not enc_g[b, il[b]:].any() and not pred_g[b, ll[b] + 1:].any()
+
+
+@pytest.mark.parametrize("B,T,U,H,J,V", SHAPES_F32_WIDE_VOCAB)
+def test_f32_grade_joint_up_to_128_symbols(B, T, U, H, J, V):
+    """joint_dtype="f32" beyond 64 symbols: three / four vocabulary tiles of the split-precision joint (the f16 joint is "auto"'s
+    choice there); f32-grade bars, peaked logits included (the hand-back works from the parked 128-column tile)."""
+    for gain in (1.0, 12.0):
+        case = list(make(B, T, U, H, J, V, True, seed=V + J))
+        case[4] = case[4] * np.float32(gain)
+        scale = np.linspace(0.5, 1.5, B)
+        costs, grads = run(tuple(case), scale, joint_dtype="f32")
+        ref = orc.joint_loss_and_grads(*case, cost_scale=scale)
+        np.testing.assert_allclose(costs, ref["costs"], rtol=1e-4)
+        for g, key in zip(grads, ("d_enc", "d_pred", "dW1", "db1", "dW2", "db2")):
+            assert np.abs(g - ref[key]).max() <= 1e-4 * max(1.0, np.abs(ref[key]).max()), (key, gain)
 
 
 def test_joint_equals_unfused_composition():
