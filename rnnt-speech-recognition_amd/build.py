@@ -16,8 +16,12 @@ LIB_PATH = os.path.join(LIB_DIR, "libwarprnnt.so")
 SOURCES = ["rnnt_kernels.hip", "rnnt_lin_kernels.hip", "joint_kernels.hip", "joint_f16_kernels.hip", "dense_kernels.hip", "rnnt_entrypoint.hip"]
 # -fvisibility=hidden: the library exports exactly the entry points include/rnnt.h marks RNNT_API (tests/test_abi.py)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-inline-asm"]
-# per-source extras: the linear sweeps are written for instruction count (rnnt_lin_kernels.hip lin_alpha_step)
-EXTRA_FLAGS = {"rnnt_lin_kernels.hip": ["-fno-slp-vectorize"]}
+# per-source extras.  -fno-slp-vectorize: no packed-f32 instructions (v_pk_fma_f32 ...) from the compiler -- in the linear sweeps
+# they cost more register moves than they save (rnnt_lin_kernels.hip lin_alpha_step); in the MFMA kernels a packed-f32
+# instruction does not overlap with the matrix pipe (scripts/probes/probe_pk.hip; fused step -0.6 %, config 5 -1.2 %).  The
+# HBM-bound cell kernels of rnnt_kernels.hip keep the vectoriser (the op at config 5's shape: 16.4 against 17.0 ms).
+_NO_SLP = ["-fno-slp-vectorize"]
+EXTRA_FLAGS = {"rnnt_lin_kernels.hip": _NO_SLP, "joint_kernels.hip": _NO_SLP, "joint_f16_kernels.hip": _NO_SLP, "dense_kernels.hip": _NO_SLP}
 
 
 def _deps():

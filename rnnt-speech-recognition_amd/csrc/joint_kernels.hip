@@ -448,40 +448,23 @@ template <int E>
 __device__ __forceinline__ float row_bcast(const float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + E /*row_newbcast:E*/, 0xf, 0xf, true));
 }
-// The two rows of a wave share every pred-side factor: their enc-side addends travel as a PAIR -- one 64-bit DPP broadcast
-// (v_mov_b64_dpp takes row_newbcast) and one v_pk_fma_f32 per joint unit instead of two of each.
-#ifndef RNNT_FWD_DPP64
-#define RNNT_FWD_DPP64 1  // 0: two 32-bit broadcasts per unit (A/B timing)
-#endif
-#ifndef RNNT_FWD_PKFMA
-#define RNNT_FWD_PKFMA 1  // 0: two v_fma_f32 per unit instead of one v_pk_fma_f32 (A/B timing: packed f32 beside MFMAs)
-#endif
+// The two rows of a wave share every pred-side factor: their enc-side addends travel as a PAIR -- ONE 64-bit DPP broadcast per
+// joint unit (v_mov_b64_dpp takes row_newbcast and overlaps with the matrix pipe like any VALU move: probe_pk.hip) instead of two
+// 32-bit ones: -30 us of the kernel's 630 at B32 T600 U150 J640.  The multiply-adds stay scalar (see bwd_consumer on packed f32).
 template <int E>
 __device__ __forceinline__ jf2 row_bcast2(const jf2 x) {
-#if RNNT_FWD_DPP64
     const long long v = __builtin_amdgcn_update_dpp((long long)0, __builtin_bit_cast(long long, x), 0x150 + E /*row_newbcast:E*/, 0xf, 0xf, true);
     return __builtin_bit_cast(jf2, v);
-#else
-    return (jf2){row_bcast<E>(x[0]), row_bcast<E>(x[1])};
-#endif
 }
 template <int E, bool SLOW, bool HFORM>
 __device__ __forceinline__ void fwd_h_pair(const jf2 ea01, const float ec, float &h0, float &h1) {
-    const jf2 a = row_bcast2<E>(ea01), c2 = {ec, ec};
-    jf2 r;
+    const jf2 a = row_bcast2<E>(ea01);
     if (!SLOW) {  // r = (1 - h) / 2, see fwd_row_epilogue
-#if RNNT_FWD_PKFMA
-        const jf2 x = a * c2 + (jf2){1.0f, 1.0f};
-        r = (jf2){__builtin_amdgcn_rcpf(x[0]), __builtin_amdgcn_rcpf(x[1])};
-#else
-        (void)c2;
-        r = (jf2){r_from_exp(a[0], ec), r_from_exp(a[1], ec)};
-#endif
+        h0 = r_from_exp(a[0], ec), h1 = r_from_exp(a[1], ec);
     } else {
-        r = (jf2){fast_r(a[0] + ec), fast_r(a[1] + ec)};
+        h0 = fast_r(a[0] + ec), h1 = fast_r(a[1] + ec);
     }
-    if (HFORM) r = r * (jf2){-2.0f, -2.0f} + (jf2){1.0f, 1.0f};  // h itself (huge weights: see joint_prep_kernel)
-    h0 = r[0], h1 = r[1];
+    if (HFORM) h0 = fmaf(h0, -2.0f, 1.0f), h1 = fmaf(h1, -2.0f, 1.0f);  // h itself (huge weights: see joint_prep_kernel)
 }
 // The J-long product of one row pair: acc += W2^T . r^T, A = W2 fragments (row = symbol), B = r (column = cell), with
 // r = (1 - h) / 2 = 1 / (1 + e^{2(a + c)}) (see fwd_row_epilogue).  Measured alternatives (profiles/r02_notes.md): building
@@ -1280,32 +1263,13 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
             jh8 fb[2][2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) fb[ks][0] = frag[(4 + ks * 2 + 0) * 64 + lane], fb[ks][1] = frag[(4 + ks * 2 + 1) * 64 + lane];
-#ifndef RNNT_BWD_PK
-#define RNNT_BWD_PK 1  // 0: the scalar form of rounds 2-4 (A/B timing)
-#endif
-#if RNNT_BWD_PK
-            // h tile in the C/D layout, built PAIRWISE (v_pk_fma_f32: two lattice columns per instruction for the multiply-adds in
-            // front of and behind the reciprocals -- 16 instructions less per row than the scalar form the compiler chose)
-            float h[16];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const jf2 e2 = {ec[2 * q], ec[2 * q + 1]}, a2 = {aj, aj};
-                jf2 r2;
-                if (!SLOW) {
-                    const jf2 x = e2 * a2 + (jf2){1.0f, 1.0f};
-                    r2 = (jf2){__builtin_amdgcn_rcpf(x[0]), __builtin_amdgcn_rcpf(x[1])};
-                } else {
-                    const jf2 x = (e2 + a2) * (jf2){2.8853900817779268f, 2.8853900817779268f};
-                    r2 = (jf2){__builtin_amdgcn_rcpf(1.0f + jex2(x[0])), __builtin_amdgcn_rcpf(1.0f + jex2(x[1]))};
-                }
-                const jf2 h2 = r2 * (jf2){-2.0f, -2.0f} + (jf2){1.0f, 1.0f};
-                h[2 * q] = h2[0], h[2 * q + 1] = h2[1];
-            }
-#else
+            // (Packed f32 -- v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 -- halves the instruction count of this arithmetic and was
+            // measured NEUTRAL here: a packed-f32 instruction does not overlap with the matrix pipe the way a plain VALU instruction
+            // does (scripts/probes/probe_pk.hip: six of them + one MFMA take 68.8 cycles, six PAIRS of v_fma_f32 + one MFMA 55.5).
+            // This file is compiled with -fno-slp-vectorize, build.py, so that the compiler does not pack them either.)
             float h[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) h[r] = SLOW ? fast_tanh(aj + ec[r]) : tanh_from_exp(aj, ec[r]);
-#endif
             BT(1);
             // S dh[u][j] = sum_v (S dl[u][v]) W2[j][v]
             f32x16 dh;
@@ -1336,19 +1300,6 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
             BT(4);
             // every read of this row's slot has returned (fb above, fa one row earlier): hand it back to the loader
             if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(use_a + 4u * slot), "v"(1) : "memory");
-#if RNNT_BWD_PK
-            // dz = dh (1 - h^2), pairwise and stage by stage (a dependent pair of packed instructions back to back costs a wait
-            // state each); the row sum as a tree of packed adds instead of a chain of sixteen
-            jf2 dz2[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) dz2[q] = (jf2){dh[2 * q], dh[2 * q + 1]} * (jf2){h[2 * q], h[2 * q + 1]};
-#pragma unroll
-            for (int q = 0; q < 8; ++q) dz2[q] = (jf2){dh[2 * q], dh[2 * q + 1]} - dz2[q] * (jf2){h[2 * q], h[2 * q + 1]};
-#pragma unroll
-            for (int q = 0; q < 8; ++q) accC[2 * q] += dz2[q][0], accC[2 * q + 1] += dz2[q][1];
-            const jf2 cs2 = ((dz2[0] + dz2[1]) + (dz2[2] + dz2[3])) + ((dz2[4] + dz2[5]) + (dz2[6] + dz2[7]));
-            float colsum = half_swap_sum(cs2[0] + cs2[1]);
-#else
             float colsum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1357,7 +1308,6 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
                 colsum += dz;
             }
             colsum = half_swap_sum(colsum);
-#endif
             BT(5);
             if (lane < 32) {
                 float *dst = jp.dApart + (((size_t)it.ut * p.B + it.b) * p.T + t) * J + j0 + lane;

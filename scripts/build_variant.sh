@@ -9,7 +9,7 @@ D=$(cd "$(dirname "$0")/.." && pwd)/rnnt-speech-recognition_amd
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-inline-asm"
 T=$(mktemp -d)
 for s in rnnt_kernels rnnt_lin_kernels joint_kernels joint_f16_kernels dense_kernels rnnt_entrypoint; do
-  X=""; [[ $s == rnnt_lin_kernels ]] && X="-fno-slp-vectorize"
+  X="-fno-slp-vectorize"; [[ $s == rnnt_kernels || $s == rnnt_entrypoint ]] && X=""
   /opt/rocm/bin/hipcc $F $X "$@" -c $D/csrc/$s.hip -o $T/$s.o &
 done
 wait
