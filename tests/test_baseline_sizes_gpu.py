@@ -93,7 +93,7 @@ def check_against_oracle(case, dtype, picks, scale, costs, grads, grads_masked, 
         assert np.abs(got - ref).max() <= gtol * max(1.0, np.abs(ref).max()), (name, np.abs(got - ref).max())
 
 
-_abs_report = {}  # max |d| of d enc_proj / d pred_proj over the f32-grade cases of this file -> gpurun_out/r04_accuracy_fused.json
+_abs_report = {}  # max |d| of d enc_proj / d pred_proj over the f32-grade cases of this file -> gpurun_out/r05_accuracy_fused.json
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -104,7 +104,7 @@ def _write_abs_report():
 
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r04_accuracy_fused.json"), "w") as f:
+    with open(os.path.join(out, "r05_accuracy_fused.json"), "w") as f:
         json.dump({"fused_f32_max_abs_d_activation_gradients": _abs_report, "bar": 1e-4}, f, indent=1)
 
 

@@ -16,7 +16,7 @@ f32-grade fused joint carry their recurrence in float64 since round 4 (a float32
 residue: ~1e-5 bits per step, a random walk over the ~750 steps of a path): P1 4 sigma 8.5e-5 -> 4.3e-6, 8 sigma 1.6e-4 -> 1.1e-5 (round 3's
 bar there was 2.5e-4, attributed to the float32 representation of the log-probabilities; it was the recurrence); fused W2 x 5
 2.9e-5 -> 1.0e-6, W2 x 10 1.2e-4 -> 1.4e-6.
-The measured maxima are written to gpurun_out/r04_accuracy.json (copied to profiles/ by hand)."""
+The measured maxima are written to gpurun_out/r05_accuracy.json (copied to profiles/ by hand)."""
 import json
 import math
 import os
@@ -44,7 +44,7 @@ def _setup():
     yield
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r04_accuracy.json"), "w") as f:
+    with open(os.path.join(out, "r05_accuracy.json"), "w") as f:
         json.dump(_report, f, indent=1, sort_keys=True)
 
 

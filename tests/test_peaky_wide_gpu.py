@@ -13,7 +13,7 @@ rounding errors over ~1,000-step paths -- and moved that recurrence to float64 w
 measured 2e-7 ... 4.4e-5 here).
 configs[4]'s shape (T = 1500, U = 300, V = 1024, the wave-per-cell kernels): one full-length utterance and three ragged
 ones against a float64 evaluation streamed over row chunks (450,000 cells x 1,024 symbols do not fit a dense float64 oracle).
-The measured maxima go to gpurun_out/r04_accuracy_wide.json (copied to profiles/ by hand)."""
+The measured maxima go to gpurun_out/r05_accuracy_wide.json (copied to profiles/ by hand)."""
 import json
 import os
 from concurrent.futures import ThreadPoolExecutor
@@ -38,7 +38,7 @@ def _setup():
     yield
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r04_accuracy_wide.json"), "w") as f:
+    with open(os.path.join(out, "r05_accuracy_wide.json"), "w") as f:
         json.dump(_report, f, indent=1, sort_keys=True)
 
 
