@@ -227,7 +227,7 @@ def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
                                      "into dlogits in place)"},
                 "workspace_GB": ws.numel() / 1e9}
     # The f32-parity joint runs its J x V products on v_mfma_f32_32x32x16_f16 with both operands split into binary16
-    # hi + lo parts (three MFMAs per product, f32-grade result; csrc/joint_kernels.hip joint_phase1s / phase2s), so the
+    # hi + lo parts (three MFMAs per product, f32-grade result; csrc/joint_kernels.hip joint_fwd_kernel / joint_bwd_kernel), so the
     # matrix-pipe ceiling for "f32-grade" flops is the dense f16 peak / 3.  Issued work: forward GEMM + dh + dW2 on V padded to
     # 32 (no backward recompute: the logits tile is parked).
     executed = 6.0 * J * 32 * ((V + 31) // 32) * cells  # (vocabulary tiles of 32 symbols: two passes for 32 < V <= 64)
@@ -242,7 +242,7 @@ def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
                          "executed_mfma_tflops": executed / dt / 1e12,
                          "f32_mfma_peak_for_reference": MFMA_F32_PEAK_TFLOPS,
                          "note": "peak = dense f16 MFMA peak / 3 (hi.hi + lo.hi + hi.lo per f32-grade product); achieved "
-                                 "uses the 8*J*V convention (its backward recompute is not executed: the V<=32 logits tile "
+                                 "uses the 8*J*V convention (its backward recompute is not executed: the logits tile, 32 floats per cell and vocabulary tile, "
                                  "is parked); executed_mfma_tflops counts the products actually issued (V padded to 32)",
                          "issue_bound": fused_issue_bound(B, T, U, V, J, dt)},
             "workspace_GB": ws.numel() / 1e9}

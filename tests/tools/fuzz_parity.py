@@ -65,12 +65,14 @@ for case in range(n_cases):
             if f16:
                 J, V = int(rng.choice([128, 200, 256, 320, 384, 500])), int(rng.choice([40, 128, 200, 384, 512, 600, 640, 1024, 1100]))
             else:
-                J, V = int(rng.choice([64, 100, 128, 192, 250])), int(rng.integers(2, 33))
+                # (round 5: up to 128 symbols -- one to four vocabulary tiles --, the widest single-kernel joint, peaked W2 gains that
+                # send utterances through the certificate and the log-domain hand-back)
+                J, V = int(rng.choice([64, 100, 128, 192, 250, 320, 640])), int(rng.integers(2, 33) if rng.random() < 0.5 else rng.integers(33, 129))
             enc = rng.normal(size=(B, T, H)).astype(np.float32)
             pred = rng.normal(size=(B, U, H)).astype(np.float32)
             W1 = (rng.normal(size=(H, J)) * 0.3).astype(np.float32)
             b1 = (0.1 * rng.normal(size=J)).astype(np.float32)
-            W2 = (rng.normal(size=(J, V)) * rng.choice([0.05, 0.2])).astype(np.float32)
+            W2 = (rng.normal(size=(J, V)) * rng.choice([0.05, 0.2] if f16 else [0.05, 0.2, 0.2, 1.0, 3.0])).astype(np.float32)
             b2 = (0.1 * rng.normal(size=V)).astype(np.float32)
             labels = rng.integers(1, V, size=(B, max(U - 1, 1))).astype(np.int32)[:, : max(U - 1, 0)]
             il, ll = lengths(B, T, U)
