@@ -1263,10 +1263,11 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
             jh8 fb[2][2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) fb[ks][0] = frag[(4 + ks * 2 + 0) * 64 + lane], fb[ks][1] = frag[(4 + ks * 2 + 1) * 64 + lane];
-            // (Packed f32 -- v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 -- halves the instruction count of this arithmetic and was
-            // measured NEUTRAL here: a packed-f32 instruction does not overlap with the matrix pipe the way a plain VALU instruction
-            // does (scripts/probes/probe_pk.hip: six of them + one MFMA take 68.8 cycles, six PAIRS of v_fma_f32 + one MFMA 55.5).
-            // This file is compiled with -fno-slp-vectorize, build.py, so that the compiler does not pack them either.)
+            // (Packed f32 -- v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 -- takes 30 instructions per row out of this arithmetic.  Measured
+            // twice: neutral while the kernel was producer-bound, -3.5 % of the step once it was consumer-bound -- the same as the
+            // interleaved order below, and NOT additive with it (profiles/r05_notes.md).  A packed-f32 instruction does not overlap
+            // with the matrix pipe the way a plain VALU instruction does (scripts/probes/probe_pk.hip), so the scalar form + the
+            // interleave is what stays; this file is compiled with -fno-slp-vectorize, build.py.)
             float h[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) h[r] = SLOW ? fast_tanh(aj + ec[r]) : tanh_from_exp(aj, ec[r]);
@@ -1277,6 +1278,18 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
             for (int r = 0; r < 16; ++r) dh[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) dh = mfma3(fa[ks][0], fa[ks][1], wf[ks][0], wf[ks][1], dh);
+            // Order within the row (scripts/probes/probe_mfma_cluster.hip: three waves per SIMD running this row's mix -- 144 VALU
+            // + 12 MFMAs -- take 735 clocks per row and wave with the MFMAs in two clusters, 688 with one MFMA after every twelve
+            // VALU; a SIMD gives a wave's MFMA little cover from the OTHER waves' VALU, the wave has to bring its own): the six
+            // MFMAs of the dh chain go out between the h tile's multiply-adds and reciprocals, which are therefore pinned in front
+            // of the poll (the compiler would sink them behind it, next to their first use).  -3.5 % of the fused step.
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(h[r]));
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x402, 8, 0);  // VALU | transcendental
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);    // MFMA
+            }
             BT(2);
             // next row's A fragments (its sequence word first)
             if (row + 1 < rows_total) {
@@ -1298,8 +1311,6 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
                 accW = mfma3(hhi, hlo, fb[ks][0], fb[ks][1], accW);
             }
             BT(4);
-            // every read of this row's slot has returned (fb above, fa one row earlier): hand it back to the loader
-            if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(use_a + 4u * slot), "v"(1) : "memory");
             float colsum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1308,6 +1319,22 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
                 colsum += dz;
             }
             colsum = half_swap_sum(colsum);
+            // the dW2 chain likewise: split of the first eight columns | three MFMAs with the second split between them | three MFMAs
+            // with the dz arithmetic between them (which is why the slot is handed back below and not in front of dz: the
+            // lane-0 branch would end the scheduling region)
+            __builtin_amdgcn_sched_group_barrier(0x402, 16, 0);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x402, 22, 0);
+            }
+            // every read of this row's slot has returned (fb above, fa one row earlier): hand it back to the loader
+            if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(use_a + 4u * slot), "v"(1) : "memory");
             BT(5);
             if (lane < 32) {
                 float *dst = jp.dApart + (((size_t)it.ut * p.B + it.b) * p.T + t) * J + j0 + lane;
@@ -1521,8 +1548,7 @@ struct BwdRowIter {
 struct BwdRowLoads {
     float4 rc;        // per-cell set-up of this lane's cell
     int lab;
-    float4 xa[2][2];  // this cell's logits for the A fragments
-    float xb[2][8];   // symbol l31 of the 16 lattice columns this lane's k-slots cover, for the B fragments
+    float4 xa[2][2];  // this cell's logits: symbols 16 ks + 8 half + 0..7 of this launch's vocabulary tile
     float av[5];      // enc-side addends of the group's joint units
     int b, t, u0, Ub;
 };
@@ -1531,6 +1557,8 @@ __device__ __forceinline__ void bwd_row_loads(const JointParams &jp, const BwdIt
     const LossParams &p = jp.lp;
     const int half = lane >> 5, l31 = lane & 31;
     const uint32_t cbase = ((uint32_t)(it.b * p.T + t)) * (uint32_t)p.U + (uint32_t)it.u0;
+    // every load of a row is unconditional (addresses clamped into the tensor, values masked at use): the number of loads in
+    // flight is then a compile-time constant and the wait for THIS row's data need not drain the next row's
     const uint32_t c = cbase + (uint32_t)min(l31, p.U - 1 - it.u0);
     L.b = it.b, L.t = t, L.u0 = it.u0, L.Ub = it.Ub;
     L.rc = jp.rec[c];
@@ -1540,31 +1568,48 @@ __device__ __forceinline__ void bwd_row_loads(const JointParams &jp, const BwdIt
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
         L.xa[ks][0] = *(const float4 *)(xrow + 16 * ks + 8 * half), L.xa[ks][1] = *(const float4 *)(xrow + 16 * ks + 8 * half + 4);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            // every load of a row is unconditional (addresses clamped into the tensor, values masked at use): the number of
-            // loads in flight is then a compile-time constant and the wait for THIS row's data need not drain the next row's
-            const int uu = min(cd_row(8 * ks + e, half), p.U - 1 - it.u0);
-            L.xb[ks][e] = jp.dl[((size_t)cbase + uu) * Vp + vo + l31];
-        }
     const float *asrc = Etab + ((size_t)it.b * p.T + t) * jp.J + group * n_cons * 32;
 #pragma unroll
     for (int k = 0; k < 5; ++k) L.av[k] = asrc[min(lane + 64 * k, n_cons * 32 - 1)];
 }
 
-__device__ void bwd_producer(const JointParams &jp, char *ring, float *scratch, const uint32_t seq_a, const uint32_t use_a,
+// One 16-bit element of the row's A image (already in the ring slot), zero-extended.  (Not ds_read_u16_d16 / _d16_hi into the two
+// halves of one register: with SRAM ECC on -- every MI300 / MI355 -- a d16 load clears the other half instead of keeping it.)
+__device__ __forceinline__ uint32_t lds_ld_u16(const uint32_t addr, const int imm) {
+    uint32_t v;
+    asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(imm) : "memory");
+    return v;
+}
+
+// The two producers of a workgroup turn rows of parked logits + per-cell records into the dlogits operand images of the two
+// products, alternating rows.  Round 5 (late): a s_memtime trace (-DJH_TRACE, scripts/probes/bwd_trace.py) showed the kernel
+// PRODUCER-bound -- 7,470 clocks per own row against 3,736 per row for the consumers, which sat in their sequence-word poll for
+// 600 ... 1,500 of them: a producer evaluated every dlogits value TWICE (once per operand layout: 16 more scattered loads of the
+// logits, the per-cell records through an LDS scratch, 16 more exponentials) in ~1,100 instructions per row.  Now it evaluates
+// them once, in the layout of the dh operand (lane = lattice column, 16 symbols), splits and stores that image, and GATHERS the
+// dW2 operand (lane = symbol, 16 lattice columns: the transpose) from the image it has just written, 16-bit element by element
+// (ds_read_u16: 32 reads per lane, immediate offsets, + 16 v_lshl_or_b32; LDS returns a wave's own writes in order).  The db2 sums
+// moved to the first layout (16 per-lane accumulators, reduced over the lattice-column lanes once per workgroup).
+__device__ void bwd_producer(const JointParams &jp, char *ring, const uint32_t seq_a, const uint32_t use_a,
                              const int pw, const int n_cons, const int group, const int blk, const bool want_db, const int lane,
                              const int it_lo, const int it_hi, const int n_tr) {
     const LossParams &p = jp.lp;
-    const int V = p.V, vo = 32 * jp.vt;
+    const int vo = 32 * jp.vt;
     const int half = lane >> 5, l31 = lane & 31;
     const float *Etab = (jp.tflag[0] != 0.f) ? jp.enc_proj : jp.expE;
-    float dbacc = 0.f;  // db2[v = l31] over the cells this lane has seen (its half's k-slots)
+    float dbacc[2][8];  // db2[vo + 16 ks + 8 half + e] over the lattice columns this lane has seen
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dbacc[ks][e] = 0.f;
     float invS = 1.0f;
     int cur_b = -1;
     bool poisoned = false;
+    // element (lattice column u, symbol w of the tile) of the A image sits at byte
+    //   (w >> 4) * 2048 + hl * 1024 + (u + 32 * ((w >> 3) & 1)) * 16 + 2 * (w & 7)      (hl: 0 = hi parts, 1 = lo parts)
+    // this lane gathers symbol l31 of the columns cd_row(8 ks + e, half) = (e & 3) + 8 (e >> 2) + 16 ks + 4 half
+    const uint32_t gather_lane = (uint32_t)((l31 >> 4) * 2048 + ((l31 >> 3) & 1) * 512 + 2 * (l31 & 7) + 64 * half);
+    const uint32_t ring_a = (uint32_t)(uintptr_t)((lds_void *)ring);
     // the producers are the head of the pipeline and by far the lighter role: they win issue arbitration on their SIMD
     __builtin_amdgcn_s_setprio(3);
     // the two producers alternate rows: this one takes rows pw, pw + 2, ...
@@ -1572,14 +1617,27 @@ __device__ void bwd_producer(const JointParams &jp, char *ring, float *scratch, 
     iter.init(jp, it_lo, it_hi, n_tr);
     if (pw == 1 && iter.valid) iter.next(jp);
     int row = pw;
+#ifdef JH_TRACE
+    // producer stamps of workgroup 20, its rows 40..71: 0 = top of the iteration, 1 = next row's loads issued, 2 = slot free,
+    // 3 = row published
+    long long *ptrc = (blk == 10 && group == 0) ? jp.trace + 768 + pw * 64 : nullptr;
+#define PT(k)                                                                                                      \
+    do {                                                                                                           \
+        if (ptrc && lane == 0 && row >= 40 && row < 72) ptrc[((row - 40) >> 1) * 4 + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PT(k) do { } while (0)
+#endif
     BwdRowLoads L;
     if (iter.valid) bwd_row_loads(jp, iter.it, iter.t, Etab, n_cons, group, lane, L);
     while (iter.valid) {
         // ---- my next row's loads go out before this row's arithmetic: a producer never sits behind a memory round trip
+        PT(0);
         iter.next(jp);
         if (iter.valid) iter.next(jp);
         BwdRowLoads Ln = L;
         if (iter.valid) bwd_row_loads(jp, iter.it, iter.t, Etab, n_cons, group, lane, Ln);
+        PT(1);
         if (L.b != cur_b) {
             float S;
             bwd_scale(p, L.b, S, invS);
@@ -1587,24 +1645,27 @@ __device__ void bwd_producer(const JointParams &jp, char *ring, float *scratch, 
         }
         const int slot = row % kBwdRing;
         const bool valid = L.u0 + l31 < L.Ub;
-        // the other layout needs the per-cell set-up per lattice column: through this producer's scratch (lanes 0..31)
-        if (half == 0) {
-            *(float4 *)(scratch + l31 * 8) = L.rc;
-            scratch[l31 * 8 + 4] = __int_as_float(valid ? L.lab : -1);
-        }
         // ---- the slot must be free: every consumer has finished the row that used it kBwdRing rows ago
         if (row >= kBwdRing && !lds_poll_ge(use_a + 4u * slot, n_cons * (row / kBwdRing))) poisoned = true;
+        PT(2);
         char *slotp = ring + (size_t)slot * kBwdSlotBytes;
         jh8 *frag = (jh8 *)slotp;
-        // ---- A fragments of dh (row = this lane's cell, k = symbol 16 ks + 8 half + e)
+        // ---- A fragments of dh (row = this lane's lattice column, k = symbol 16 ks + 8 half + e of the tile): the dlogits values
+        // themselves.  Symbols beyond V need no test: their parked logit is -1e30 (the bias table of joint_prep_kernel), e^x = 0.
+        const int lab_rel = (valid ? L.lab : -1) - vo - 8 * half, blank_rel = p.blank - vo - 8 * half;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const float xs[8] = {L.xa[ks][0].x, L.xa[ks][0].y, L.xa[ks][0].z, L.xa[ks][0].w,
                                  L.xa[ks][1].x, L.xa[ks][1].y, L.xa[ks][1].z, L.xa[ks][1].w};
             float d[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                d[e] = valid ? bwd_dl(xs[e], vo + 16 * ks + 8 * half + e, V, p.blank, L.rc.x, L.rc.y, L.rc.z, L.rc.w, L.lab) : 0.f;
+            for (int e = 0; e < 8; ++e) {
+                float v = L.rc.y * jex2(fmaf(xs[e], kLog2e, L.rc.x));
+                v -= (blank_rel == 16 * ks + e) ? L.rc.z : 0.f;
+                v -= (lab_rel == 16 * ks + e) ? L.rc.w : 0.f;
+                d[e] = valid ? v : 0.f;
+                dbacc[ks][e] = fmaf(d[e], invS, dbacc[ks][e]);
+            }
             if (poisoned) d[0] = NAN;
             jh8 hi, lo;
             split_h8(d, hi, lo);
@@ -1614,31 +1675,46 @@ __device__ void bwd_producer(const JointParams &jp, char *ring, float *scratch, 
 #pragma unroll
         for (int k = 0; k < 5; ++k)
             if (lane + 64 * k < n_cons * 32) *(float *)(slotp + 8192 + (lane + 64 * k) * 4) = L.av[k];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scratch written (a wave only reads its own scratch)
-        // ---- B fragments of dW2 (column = symbol l31, k-slot (ks, half, e) = lattice column cd_row(8 ks + e, half))
+        // ---- B fragments of dW2 (column = symbol l31, k-slot (ks, half, e) = lattice column cd_row(8 ks + e, half)): gathered
+        const uint32_t ga = ring_a + (uint32_t)slot * (uint32_t)kBwdSlotBytes + gather_lane;
+        uint32_t w0[2][2][4], w1[2][2][4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            float d[8];
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int uu = cd_row(8 * ks + e, half);
-                const float4 q = *(const float4 *)(scratch + uu * 8);
-                const int labu = __float_as_int(scratch[uu * 8 + 4]);
-                d[e] = (L.u0 + uu < L.Ub) ? bwd_dl(L.xb[ks][e], vo + l31, V, p.blank, q.x, q.y, q.z, q.w, labu) : 0.f;
-                dbacc = fmaf(d[e], invS, dbacc);
+            for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {  // elements e = 2 q, 2 q + 1
+                    w0[ks][hl][q] = lds_ld_u16(ga, hl * 1024 + (((2 * q) & 3) + 8 * ((2 * q) >> 2) + 16 * ks) * 16);
+                    w1[ks][hl][q] = lds_ld_u16(ga, hl * 1024 + (((2 * q + 1) & 3) + 8 * ((2 * q + 1) >> 2) + 16 * ks) * 16);
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) {
+                const uint4 packed = {w0[ks][hl][0] | (w1[ks][hl][0] << 16), w0[ks][hl][1] | (w1[ks][hl][1] << 16),
+                                      w0[ks][hl][2] | (w1[ks][hl][2] << 16), w0[ks][hl][3] | (w1[ks][hl][3] << 16)};
+                frag[(4 + ks * 2 + hl) * 64 + lane] = __builtin_bit_cast(jh8, packed);
             }
-            jh8 hi, lo;
-            split_h8(d, hi, lo);
-            frag[(4 + ks * 2 + 0) * 64 + lane] = hi;
-            frag[(4 + ks * 2 + 1) * 64 + lane] = lo;
-        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the row's fragments and addends are in LDS
         if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(seq_a + 4u * slot), "v"(row + 1) : "memory");
+        PT(3);
         L = Ln;
         row += 2;
     }
-    dbacc = half_swap_sum(dbacc);
-    if (want_db && lane < 32) jp.dbpart[((size_t)(jp.vt * kBwdMaxBlocks + blk) * 2 + pw) * 32 + lane] = poisoned ? NAN : dbacc;
+    if (want_db) {
+        // sum over the lattice-column lanes of each half; lanes 0 and 32 write their half's 16 symbols
+        float *dst = jp.dbpart + ((size_t)(jp.vt * kBwdMaxBlocks + blk) * 2 + pw) * 32;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = dbacc[ks][e];
+#pragma unroll
+                for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+                if (l31 == 0) dst[16 * ks + 8 * half + e] = poisoned ? NAN : v;
+            }
+    }
 }
 
 // Consumers own 32 joint units each; a workgroup holds at most kBwdMaxCons of them (register budget: 12 waves per CU), so
@@ -1655,8 +1731,7 @@ __global__ __launch_bounds__(768) void joint_bwd_kernel(const JointParams jp) {
     const int n_cons = jp.J / 32 / n_groups;
     const bool slow = jp.tflag[0] != 0.f;  // kernel-uniform
     char *ring = (char *)lds;                                    // [kBwdRing][10 KB] dlogits fragments + enc addends of a row
-    float *scratch = (float *)(ring + kBwdRing * kBwdSlotBytes); // [2 producers][32 cells][8]
-    int *ctr = (int *)(scratch + 2 * 32 * 8);                    // seq[kBwdRing], use[kBwdRing]
+    int *ctr = (int *)(ring + kBwdRing * kBwdSlotBytes);         // seq[kBwdRing], use[kBwdRing]
     if (tid < 2 * kBwdRing) ctr[tid] = 0;
     __syncthreads();
     const uint32_t seq_a = (uint32_t)(uintptr_t)((lds_void *)ctr), use_a = seq_a + 4u * kBwdRing;
@@ -1675,7 +1750,7 @@ __global__ __launch_bounds__(768) void joint_bwd_kernel(const JointParams jp) {
         else
             bwd_consumer<true>(jp, ring, seq_a, use_a, wave, j0, blk, nblk, lane, it_lo, it_hi, n_tr);
     } else {
-        bwd_producer(jp, ring, scratch + (wave - n_cons) * 32 * 8, seq_a, use_a, wave - n_cons, n_cons, group, blk, group == 0, lane,
+        bwd_producer(jp, ring, seq_a, use_a, wave - n_cons, n_cons, group, blk, group == 0, lane,
                      it_lo, it_hi, n_tr);
     }
 }
@@ -2230,7 +2305,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
         hipLaunchKernelGGL(joint_cellrec_kernel, dim3((unsigned)B * L.n_ut * ((T + kRecRows - 1) / kRecRows)), dim3(256), 0, s, jp);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = launch_joint_redo(jp, true, s)) != hipSuccess) return e;
-        const size_t shm_bwd = (size_t)kBwdRing * kBwdSlotBytes + 2 * 32 * 8 * sizeof(float) + 2 * kBwdRing * sizeof(int);
+        const size_t shm_bwd = (size_t)kBwdRing * kBwdSlotBytes + 2 * kBwdRing * sizeof(int);
         if ((e = set_lds(joint_bwd_kernel, shm_bwd)) != hipSuccess) return e;
         for (jp.vt = 0; jp.vt < L.VT; ++jp.vt)  // one pass per vocabulary tile (a later one adds its d enc_proj / d pred_proj partials to the first's)
             hipLaunchKernelGGL(joint_bwd_kernel, dim3(nblk * n_groups), dim3((n_cons + 2) * 64), shm_bwd, s, jp);
