@@ -1284,12 +1284,12 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
             // MFMAs of the dh chain go out between the h tile's multiply-adds and reciprocals, which are therefore pinned in front
             // of the poll (the compiler would sink them behind it, next to their first use).  -3.5 % of the fused step.
 #pragma unroll
-            for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(h[r]));
-#pragma unroll
             for (int g = 0; g < 6; ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x402, 8, 0);  // VALU | transcendental
                 __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);    // MFMA
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(h[r]));
             BT(2);
             // next row's A fragments (its sequence word first)
             if (row + 1 < rows_total) {

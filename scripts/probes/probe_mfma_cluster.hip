@@ -9,6 +9,7 @@
 //   mode 6  48 VALU | 6 chained MFMAs | 6 x (7 VALU + MFMA) | 54 VALU      (what the compiler emits today)
 //   mode 7  12 x (12 VALU + 1 MFMA)                                        (everything interleaved)
 //   mode 8  144 VALU only         mode 9  12 MFMAs only (two chains of six)
+//   mode 10 128 v_fma_f32 + 16 v_rcp_f32 only      mode 11 = mode 7 with 16 of its VALU being v_rcp_f32
 // W waves per SIMD (workgroup = 4 W waves, one per CU).  Prints shader clocks per group and SIMD-resident wave.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -71,6 +72,24 @@ __global__ __launch_bounds__(1024) void k(int iters, long long *out, float *sink
             for (int v = 0; v < 144; ++v) VALU(v);
         }
         if (MODE == 9) { MF0; MF0; MF0; MF0; MF0; MF0; MF1; MF1; MF1; MF1; MF1; MF1; }
+        if (MODE == 10) {  // 128 fma + 16 rcp
+#pragma unroll
+            for (int v = 0; v < 144; ++v) {
+                if (v % 9 == 4) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[v & 7]));
+                else VALU(v);
+            }
+        }
+        if (MODE == 11) {  // the row with its 16 reciprocals, interleaved
+#pragma unroll
+            for (int g = 0; g < 12; ++g) {
+#pragma unroll
+                for (int v = 0; v < 12; ++v) {
+                    if ((g * 12 + v) % 9 == 4) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[v & 7]));
+                    else VALU(g * 12 + v);
+                }
+                if (g < 6) MF0; else MF1;
+            }
+        }
     }
     const long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0.f;
@@ -100,12 +119,12 @@ static double run(int waves_per_simd) {
 int main() {
     (void)hipMalloc(&g_out, 256 * 16 * sizeof(long long));
     (void)hipMalloc(&g_sink, 256 * 1024 * sizeof(float));
-    const char *names[10] = {"36 VALU + 6 chained MFMA (1 acc)", "36 VALU + 6 MFMA (2 accs)", "6 x (6 VALU + MFMA), 1 acc",
+    const char *names[12] = {"36 VALU + 6 chained MFMA (1 acc)", "36 VALU + 6 MFMA (2 accs)", "6 x (6 VALU + MFMA), 1 acc",
                             "6 x (6 VALU + MFMA), 2 accs", "36 VALU only", "6 chained MFMA only",
-                            "row: 48 V | 6 M | 6 x (7 V + M) | 54 V", "row: 12 x (12 V + M)", "row: 144 VALU only", "row: 12 MFMA only"};
+                            "row: 48 V | 6 M | 6 x (7 V + M) | 54 V", "row: 12 x (12 V + M)", "row: 144 VALU only", "row: 12 MFMA only", "row: 128 fma + 16 rcp only", "row: 12 x (12 V + M), 16 of the V are v_rcp_f32"};
     for (int w = 1; w <= 4; ++w) {
-        const double r[10] = {run<0>(w), run<1>(w), run<2>(w), run<3>(w), run<4>(w), run<5>(w), run<6>(w), run<7>(w), run<8>(w), run<9>(w)};
-        for (int m = 0; m < 10; ++m) printf("%d wave(s)/SIMD  %-36s %7.1f clocks per group and wave\n", w, names[m], r[m]);
+        const double r[12] = {run<0>(w), run<1>(w), run<2>(w), run<3>(w), run<4>(w), run<5>(w), run<6>(w), run<7>(w), run<8>(w), run<9>(w), run<10>(w), run<11>(w)};
+        for (int m = 0; m < 12; ++m) printf("%d wave(s)/SIMD  %-36s %7.1f clocks per group and wave\n", w, names[m], r[m]);
     }
     return 0;
 }

@@ -181,6 +181,12 @@ def test_instruction_selection(kernels):
         for k in _find(asm, name):
             assert not re.search(r"v_pk_(fma|mul|add)_f32", asm[k]), k
     assert "v_mov_b64_dpp" in fw
+    # round 5 (late): a producer of joint_bwd_kernel evaluates a row's dlogits ONCE (16 exponentials per lane; the slow-tanh consumer
+    # instance has 16 more) and gathers the dW2 operand from the LDS image it has just written: 32 zero-extending 16-bit reads per
+    # lane -- not d16 loads into register halves, which clear the other half with SRAM ECC on (every MI300 / MI355)
+    bw = asm[_find(asm, "joint_bwd_kernel")[0]]
+    assert len(re.findall(r"\bv_exp_f32", bw)) == 32, len(re.findall(r"\bv_exp_f32", bw))
+    assert len(re.findall(r"\bds_read_u16 ", bw)) == 32 and "ds_read_u16_d16" not in bw
     for name, text in asm.items():
         assert "v_mfma_f32_32x32x8" not in text  # no CDNA3-shaped f16 MFMAs: gfx950 forms only
 
