@@ -922,7 +922,7 @@ __global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
 #endif
 template <bool PARTIAL, int VT>
 __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(const JhParams jp) {
-    // VT = columns of a workgroup's V tile: 512 (one workgroup per CU, 126 KB of LDS) or 256 (TWO per CU at 80 KB each: while one
+    // VT = columns of a workgroup's V tile: 512 (one workgroup per CU, 126 KB of LDS), 256 or -- V = 128 only -- 128 (TWO per CU at 80 / 57 KB each: while one
     // sits in its barrier / fragment-read phase the other has the matrix pipe)
     constexpr int VB = VT / 128;       // 32-column accumulator blocks per wave
     constexpr int WCOL = VT / 4;       // columns per wave
@@ -1159,10 +1159,12 @@ struct JhLayout {
     int n_ut, n_tt, n_ts, TS, n_tq, n_units, n_ranges;
 };
 
-// Columns of K4's V tile: 512 = one workgroup per CU, 256 = two (see jh_dw_kernel).  Measured (profiles/r04_notes.md): 256-column
+// Columns of K4's V tile: 512 = one workgroup per CU, 256 / 128 = two (see jh_dw_kernel).  Measured (profiles/r04_notes.md): 256-column
 // tiles win while they are the only tile (V = 128: 4.97 -> 4.31 ms, V = 256: 4.40 -> 3.83 ms at B32 T600 U150) and lose beyond
-// (V = 384: 7.89 -> 8.77 ms; config 5, V = 1024: K4 11.3 -> 15.5 ms -- every tile rebuilds the h^T image).
-static int k4_vt(int V) { return V <= 256 ? 256 : 512; }
+// (V = 384: 7.89 -> 8.77 ms; config 5, V = 1024: K4 11.3 -> 15.5 ms -- every tile rebuilds the h^T image).  Round 5: V = 128 has its own
+// 128-column instantiation -- all eight waves multiply (32 columns each) instead of four of a half-empty 256-column tile, 97 registers
+// instead of 128 + 71 spilled: 4.32 -> 3.97 ms per step at the headline lattice (two 128-column tiles at V = 256: 5.32 -> 6.31 ms, not used).
+static int k4_vt(int V) { return V <= 128 ? 128 : V <= 256 ? 256 : 512; }
 
 bool joint_f16_supported(int J, int V) {
     // J: whole 128-unit tiles of K3 / K4 (K1 is instantiated per J); V: whole 128-column groups (four 32-column chunks share one
@@ -1414,7 +1416,8 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), shm, s, jp);
             return hipGetLastError();
         };
-        if (vt == 256) e = (V % 256 == 0) ? go(jh_dw_kernel<false, 256>) : go(jh_dw_kernel<true, 256>);
+        if (vt == 128) e = go(jh_dw_kernel<false, 128>);
+        else if (vt == 256) e = go(jh_dw_kernel<false, 256>);  // (V = 256: the tile is full)
         else e = (V % 512 == 0) ? go(jh_dw_kernel<false, 512>) : go(jh_dw_kernel<true, 512>);
         if (e != hipSuccess) return e;
         if ((e = hipGetLastError()) != hipSuccess) return e;
