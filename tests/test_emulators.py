@@ -43,3 +43,34 @@ def test_f16_joint_shapes_are_padded_to_the_native_grid():
     from rnnt_speech_recognition_amd.joint import _auto_joint_dtype
     assert [_auto_joint_dtype(640, v) for v in (28, 32, 33, 64, 65, 128, 4096)] == ["f32", "f32", "f32", "f32", "f16", "f16", "f16"]
     assert _auto_joint_dtype(704, 40) == "f16"
+
+
+def test_backward_producer_gathers_the_transposed_operand_from_its_own_image():
+    """Address arithmetic of joint_bwd_kernel's producers (csrc/joint_kernels.hip bwd_producer, round 5): the dh operand image of a
+    lattice row -- lane (column u, half) holds symbols 16 ks + 8 half + e, as binary16 hi / lo fragments of 1 KB each -- is written
+    to the ring slot, and the dW2 operand (lane (symbol v, half), k-slot (ks, e) <-> lattice column cd_row(8 ks + e, half)) is
+    gathered from it 16-bit element by element.  Restated in NumPy on a slot of distinct 16-bit words."""
+    import numpy as np
+
+    def cd_row(reg, half):  # C/D layout of v_mfma_f32_32x32x16_f16 (joint_kernels.hip cd_row)
+        return (reg & 3) + 8 * (reg >> 2) + 4 * half
+
+    rng = np.random.default_rng(5)
+    dl = rng.integers(0, 1 << 16, size=(2, 32, 32), dtype=np.uint16)  # [hi/lo][column u][symbol w]
+    slot = np.zeros(8192, dtype=np.uint8).view(np.uint16)             # 4096 halfwords
+    for hl in range(2):
+        for ks in range(2):
+            for lane in range(64):
+                u, half = lane & 31, lane >> 5
+                for e in range(8):
+                    byte = ((ks * 2 + hl) * 64 + lane) * 16 + 2 * e  # frag[(ks * 2 + hl) * 64 + lane], element e
+                    slot[byte // 2] = dl[hl, u, 16 * ks + 8 * half + e]
+    for lane in range(64):
+        v, half = lane & 31, lane >> 5
+        gather_lane = (v >> 4) * 2048 + ((v >> 3) & 1) * 512 + 2 * (v & 7) + 64 * half
+        for ks in range(2):
+            for hl in range(2):
+                for e in range(8):
+                    imm = hl * 1024 + ((e & 3) + 8 * (e >> 2) + 16 * ks) * 16
+                    got = slot[(gather_lane + imm) // 2]
+                    assert got == dl[hl, cd_row(8 * ks + e, half), v], (lane, ks, hl, e)
