@@ -1687,13 +1687,27 @@ __device__ void bwd_producer(const JointParams &jp, char *ring, const uint32_t s
                     w0[ks][hl][q] = lds_ld_u16(ga, hl * 1024 + (((2 * q) & 3) + 8 * ((2 * q) >> 2) + 16 * ks) * 16);
                     w1[ks][hl][q] = lds_ld_u16(ga, hl * 1024 + (((2 * q + 1) & 3) + 8 * ((2 * q + 1) >> 2) + 16 * ks) * 16);
                 }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // The compiler does not know that the asm reads above are loads: the wait must DEFINE the gathered registers, or their first
+        // use is scheduled in front of it (it was: four v_lshl_or_b32 ahead of the s_waitcnt -- right by luck, the reads they used were
+        // ~130 cycles old -- until the registers were tied to the wait; tests/test_isa_audit.py checks the order).
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 g0[2][2], g1[2][2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int hl = 0; hl < 2; ++hl) {
-                const uint4 packed = {w0[ks][hl][0] | (w1[ks][hl][0] << 16), w0[ks][hl][1] | (w1[ks][hl][1] << 16),
-                                      w0[ks][hl][2] | (w1[ks][hl][2] << 16), w0[ks][hl][3] | (w1[ks][hl][3] << 16)};
+                g0[ks][hl] = (u32x4){w0[ks][hl][0], w0[ks][hl][1], w0[ks][hl][2], w0[ks][hl][3]};
+                g1[ks][hl] = (u32x4){w1[ks][hl][0], w1[ks][hl][1], w1[ks][hl][2], w1[ks][hl][3]};
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(g0[0][0]), "+v"(g0[0][1]), "+v"(g0[1][0]), "+v"(g0[1][1]), "+v"(g1[0][0]), "+v"(g1[0][1]), "+v"(g1[1][0]), "+v"(g1[1][1])
+                     :
+                     : "memory");
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) {
+                const u32x4 packed = g0[ks][hl] | (g1[ks][hl] << 16);
                 frag[(4 + ks * 2 + hl) * 64 + lane] = __builtin_bit_cast(jh8, packed);
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the row's fragments and addends are in LDS

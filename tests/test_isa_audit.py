@@ -221,3 +221,65 @@ def test_no_transcendental_result_is_read_by_the_next_instruction(kernels):
             if dst in regs:
                 bad.append((name[:60], cur.strip(), nxt.strip()))
     assert not bad, bad[:5]
+
+
+def _vregs(tok):
+    tok = tok.strip().split(" ")[0]
+    m = re.match(r"^v(\d+)$", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.match(r"^v\[(\d+):(\d+)\]$", tok)
+    return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+
+
+def _lds_results_read_before_their_wait(text):
+    """Straight-line scan of one kernel's disassembly: every ds_read / ds_bpermute ... destination register stays "pending" until an
+    s_waitcnt lgkmcnt(N) retires it (LDS returns in order: all but the newest N operations; with a scalar load in flight only
+    lgkmcnt(0) counts), a later instruction overwrites it, or a branch ends the block.  Returns the instructions that read one."""
+    bad, pending, issued, smem = [], [], 0, False
+    for line in text.splitlines():
+        ins = line.split("//")[0].strip()
+        if not ins or not re.match(r"^[a-z]", ins):
+            continue
+        parts = ins.split(None, 1)
+        op, ops = parts[0], [o.strip() for o in (parts[1].split(",") if len(parts) > 1 else [])]
+        if op.startswith(("s_cbranch", "s_branch", "s_setpc", "s_endpgm")):
+            pending = []
+            continue
+        if op == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", ins)
+            if m:
+                n = int(m.group(1))
+                if n == 0:
+                    pending, smem = [], False
+                elif not smem:
+                    pending = [p for p in pending if p[0] > issued - n]
+            continue
+        lds_read = op.startswith(("ds_read", "ds_bpermute", "ds_permute", "ds_swizzle")) or (op.startswith("ds_") and "rtn" in op)
+        has_dst = lds_read or op.startswith(("v_", "global_load", "buffer_load"))
+        used = set()
+        for o in (ops[1:] if has_dst else ops):
+            used |= _vregs(o)
+        if any(used & rs for _, rs in pending):
+            bad.append(ins)
+        if has_dst and ops:
+            w = _vregs(ops[1]) if (op.startswith("v_") and ops[0].startswith(("s", "vcc")) and len(ops) > 1) else _vregs(ops[0])
+            pending = [(q, rs - w) for q, rs in pending if rs - w]
+        if op.startswith("ds_"):
+            issued += 1
+            if lds_read:
+                pending.append((issued, _vregs(ops[0])))
+        elif op.startswith(("s_load", "s_buffer_load", "s_memtime", "s_memrealtime")):
+            issued, smem = issued + 1, True
+    return bad
+
+
+def test_no_lds_read_result_is_used_before_its_wait(kernels):
+    """The compiler counts waits for the loads IT emits; an LDS read written in inline asm is invisible to it, and a consumer of
+    the asm's output may be scheduled in front of a separate `s_waitcnt` asm (round 5: four v_lshl_or_b32 of joint_bwd_kernel's
+    producer sat in front of theirs -- right by luck, the reads were ~130 cycles old).  Every kernel of the library is scanned."""
+    _, asm = kernels
+    probe = "ds_read_u16 v5, v4\nv_lshl_or_b32 v6, v5, 16, v7\ns_waitcnt lgkmcnt(0)\nv_mov_b32_e32 v8, v5\n"
+    assert _lds_results_read_before_their_wait(probe) == ["v_lshl_or_b32 v6, v5, 16, v7"]  # (the checker sees what it is for)
+    bad = {name: found[:3] for name, text in asm.items() if (found := _lds_results_read_before_their_wait(text))}
+    assert not bad, bad
