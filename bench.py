@@ -22,6 +22,7 @@ ranks; under a launcher (WORLD_SIZE set) --gpus must equal WORLD_SIZE.
 Prints ONE JSON line (rank 0).  Extra objects: `roofline`, `cpu_baseline` (rank 0, N=1 only).
 """
 import argparse
+import ctypes
 import json
 import os
 import socket
@@ -230,7 +231,12 @@ def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
     # hi + lo parts (three MFMAs per product, f32-grade result; csrc/joint_kernels.hip joint_fwd_kernel / joint_bwd_kernel), so the
     # matrix-pipe ceiling for "f32-grade" flops is the dense f16 peak / 3.  Issued work: forward GEMM + dh + dW2 on V padded to
     # 32 (no backward recompute: the logits tile is parked).
-    executed = 6.0 * J * 32 * ((V + 31) // 32) * cells  # (vocabulary tiles of 32 symbols: two passes for 32 < V <= 64)
+    # The backward visits the lattice rows (x 32-column tiles) that carry mass (include/rnnt.h get_rnnt_joint_backward_rows: a row whose
+    # cells all have an occupancy below 2^-50 adds nothing an f32 sum can hold); how many that is depends on the data -- measured here.
+    rows = (ctypes.c_int * 2)(-1, -1)
+    _lib.check(lib.get_rnnt_joint_backward_rows(ws.data_ptr(), J, V, B, opts, rows))
+    visited = rows[0] / rows[1] if rows[1] > 0 else 1.0
+    executed = (2.0 + 4.0 * visited) * J * 32 * ((V + 31) // 32) * cells  # (vocabulary tiles of 32 symbols: one pass each)
     split_peak = MFMA_F16_PEAK_TFLOPS / 3.0
     return {"workload": f"joint+loss+grads from enc_proj/pred_proj, B={B} T={T} U={U} V={V} J={J}, "
                         "f32-grade products on split-precision f16 MFMAs",
@@ -240,10 +246,13 @@ def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
                          "unit": "TFLOP/s", "frac": flops / dt / 1e12 / split_peak,
                          "algorithmic_flops_per_step": flops,
                          "executed_mfma_tflops": executed / dt / 1e12,
+                         "backward_rows_visited": visited,
                          "f32_mfma_peak_for_reference": MFMA_F32_PEAK_TFLOPS,
                          "note": "peak = dense f16 MFMA peak / 3 (hi.hi + lo.hi + hi.lo per f32-grade product); achieved "
                                  "uses the 8*J*V convention (its backward recompute is not executed: the logits tile, 32 floats per cell and vocabulary tile, "
-                                 "is parked); executed_mfma_tflops counts the products actually issued (V padded to 32)",
+                                 "is parked); executed_mfma_tflops counts the products actually issued (V padded to 32; the backward's on the "
+                                 "backward_rows_visited fraction of the lattice rows: it skips the rows none of whose cells has an occupancy above 2^-50, "
+                                 "which depends on the data -- synthetic N(0,1) projections here)",
                          "issue_bound": fused_issue_bound(B, T, U, V, J, dt)},
             "workspace_GB": ws.numel() / 1e9}
 

@@ -301,6 +301,16 @@ RNNT_API rnntStatus_t compute_rnnt_joint_logits(const float *enc_proj, const flo
                                                 int alphabet_size, int minibatch, float *logits,
                                                 int joint_dtype, void *workspace, rnntOptions options);
 
+/* Diagnostics of the f32-grade fused joint's backward (joint_dtype 0, joint_size <= 640): how many lattice rows x 32-column tiles the
+ * LAST backward on this workspace visited (rows[0]) out of those inside the utterances (rows[1]).  The backward skips a row of a
+ * tile when none of its 32 cells has an occupancy alpha.beta/L above 2^-50: every dlogits value of a cell is bounded by
+ * 2 |cost_scale| x that occupancy, so such a row adds less than 2^-44 |cost_scale| to anything -- its cells get exactly zero where
+ * the reference leaves 1e-15's.  How many rows that is depends on the data (unstructured N(0,1) logits on a 600 x 150 lattice: about
+ * half; a trained model: most).  Synchronises options.stream.  rows = {-1, -1} where nothing is skipped (the wide joint, 640 < joint_size).
+ * The work of a backward call is divided among the workgroups by these counts, deterministically. */
+RNNT_API rnntStatus_t get_rnnt_joint_backward_rows(void *workspace, int joint_size, int alphabet_size, int minibatch,
+                                                   rnntOptions options, int rows[2]);
+
 /* The same from the encoder / prediction-network outputs: the first Dense layer (model.py:162-163, utils/decoding.py:8,15) runs
  * in the library too (the split-precision GEMMs of compute_rnnt_joint_net_loss), then the joint as above.
  *   enc [minibatch, maxT, hidden_size], pred [minibatch, maxU, hidden_size], W1 [hidden_size, joint_size], b1 [joint_size]

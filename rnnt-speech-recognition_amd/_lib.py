@@ -29,6 +29,7 @@ SYMBOLS = [
     "compute_rnnt_joint_loss_bwd",
     "compute_rnnt_joint_logits",
     "compute_rnnt_joint_net_logits",
+    "get_rnnt_joint_backward_rows",
     "get_joint_net_workspace_size",
     "compute_rnnt_joint_net_loss",
     "compute_rnnt_joint_net_loss_fwd",
@@ -98,6 +99,9 @@ def load():
     if LIB_PATH == _DEFAULT_LIB_PATH or hasattr(lib, "compute_rnnt_joint_logits"):  # (an older dev variant may lack it)
         lib.compute_rnnt_joint_logits.restype = ci
         lib.compute_rnnt_joint_logits.argtypes = [vp] * 4 + [ci, ci, ci, vp, ci, vp, rnntOptions]
+    if LIB_PATH == _DEFAULT_LIB_PATH or hasattr(lib, "get_rnnt_joint_backward_rows"):
+        lib.get_rnnt_joint_backward_rows.restype = ci
+        lib.get_rnnt_joint_backward_rows.argtypes = [vp, ci, ci, ci, rnntOptions, ctypes.POINTER(ctypes.c_int)]
     if LIB_PATH == _DEFAULT_LIB_PATH or hasattr(lib, "compute_rnnt_joint_net_logits"):
         lib.compute_rnnt_joint_net_logits.restype = ci
         lib.compute_rnnt_joint_net_logits.argtypes = [vp] * 6 + [ci] * 4 + [vp, ci, vp, rnntOptions]

@@ -83,6 +83,10 @@ struct JointParams {
     float4 *rec;    // [cells] per-cell gradient set-up of the single-kernel backward (joint_cellrec_kernel)
     int *reclab;    // [cells] label of the cell, or -1
     float2 *xbl;    // [cells] blank / label logits of the cell, written by joint_fwd_kernel for joint_cellrec_kernel
+    int *plan;       // joint_rowplan_kernel: [0] = target weight per workgroup, [1 + k] = first item of workgroup k (k = 0 .. nblk),
+                     // [2 + kBwdMaxBlocks + i] = weight of the items before item i (i = 0 .. n_items), then {rows visited, rows inside the utterances}
+    uint8_t *live8;  // [B][n_ut][4 n_tr32] one BIT per (lattice row, u-tile): some cell of the tile has occupancy above 2^-kOccFloor
+                     // (joint_cellrec_kernel; joint_bwd_kernel skips the other rows -- see kOccFloor); n_tr32 = ceil(T / 32)
     float *dApart;  // [n_ut][B][T][J]
     float *dCpart;  // [n_ts][B][U][J]
     float *dWpart;  // [B*n_ut*n_ts][J][32]
@@ -1100,24 +1104,75 @@ __global__ __launch_bounds__(256, P2S_WG_PER_CU) void joint_phase2s_kernel(const
 constexpr int kBwdRing = 8;
 constexpr int kBwdSlotBytes = 8192 + 2048;  // fragment image + the row's enc-side addends for the group's joint units
 constexpr int kBwdRows = 32;
-constexpr int kBwdSlots = 3;  // d pred_proj partial slabs: an (utterance, u-tile) spans at most this many workgroups
+// Lattice rows the backward does not visit.  Every dlogits value of a cell is bounded by 2 |cost_scale| x the cell's occupancy
+// alpha beta / L (the softmax term is occupancy x probability, the blank / label corrections are occupancy x an edge probability x
+// beta' / beta <= occupancy).  A (row, u-tile) none of whose 32 cells has an occupancy above 2^-kOccFloor contributes less than
+// 2^-(kOccFloor - 6) |cost_scale| per logit row to anything -- below the resolution of an f32 sum that holds one O(1) term -- and is
+// skipped: its cells get exactly zero where the reference leaves 1e-15's.  On a 600 x 150 lattice that is 40 ... 52 % of the rows for
+// unstructured logits (the mass sits in a band around the diagonal; hypergeometric tails), more for a trained model.  NaN counts as
+// occupied.  An utterance the hand-back redoes is visited whole.
+#ifndef RNNT_OCC_FLOOR
+#define RNNT_OCC_FLOOR 50  // (dev builds: 100000 = visit every row, for same-box timing of the pruning)
+#endif
+constexpr int kOccFloor = RNNT_OCC_FLOOR;
+__device__ __forceinline__ uint32_t bwd_live_mask(const JointParams &jp, const int b, const int ut, const int tr, const int t_begin, const int t_end) {
+    const int n_tr32 = (jp.lp.T + 31) >> 5;
+    uint32_t m = ((const uint32_t *)jp.live8)[((size_t)b * jp.n_ut + ut) * n_tr32 + tr];
+    const int n = t_end - t_begin;  // rows of this tile inside the utterance (1 .. 32); the tile starts at a multiple of 32
+    return n >= 32 ? m : (m & ((1u << n) - 1u));
+}
+// Work distribution with the row pruning (round 5): the rows the pruning leaves form a band whose shape and width depend on the data
+// (bench.py's input: an utterance keeps 36 ... 84 % of its rows, a (utterance, u-tile) column of it anything from 0 to 100 %), so equal
+// numbers of ITEMS per workgroup meant 150 ... 690 rows per workgroup and the slowest one set the kernel's time; so did every static
+// interleave of the items that was tried (by row-tile class, by utterance).  joint_rowplan_kernel therefore cuts the item list
+// (utterance, u-tile, row tile -- columns stay contiguous) into ranges of equal WEIGHT, weight = rows visited + kBwdItemCost per
+// item inside its utterance: prefix[i] = weight of the items before i, item i belongs to workgroup min(prefix[i] / target, nblk - 1).
+// The target is at least a (kBwdSlots - 2)-th of a full column, so that a column spans fewer than kBwdSlots workgroups (its d pred_proj
+// partial slabs); with little to do, fewer workgroups than the grid holds get any.  Deterministic: the cuts depend on the data, not on timing.
+constexpr int kBwdSlots = 8;     // d pred_proj partial slabs per (utterance, u-tile)
+constexpr int kBwdItemCost = 3;  // rows' worth of time an item costs before its first row (decode, run change)
 constexpr int kBwdMaxBlocks = 256;  // workgroups per group at most (sizes the dW2 / db2 partial buffers)
 
+// workgroup (of a J group) that owns an item under joint_rowplan_kernel's cut
+__device__ __forceinline__ int bwd_blk_of(const int *plan, const int item, const int nblk) { return min(plan[2 + kBwdMaxBlocks + item] / plan[0], nblk - 1); }
 struct BwdItem {
-    int b, ut, u0, Tb, Ub, t_begin, t_end, bu;
+    int b, ut, u0, Tb, Ub, t_begin, t_end;
+    int col_first;     // first item of this item's column (utterance, u-tile)
+    uint32_t mask;     // bit r: row t_begin + r is visited (bwd_live_mask)
     bool live;
 };
+// What an item needs from memory -- the utterance's two lengths and the row bits of its tile: three dependent round trips when
+// fetched item by item, and with the pruning a workgroup walks over items it has nothing to do in (first version: ~3 us per dead
+// item, a 14 us hole in the ring at every run change).  joint_bwd_kernel fetches them for its whole range at once, a thread per
+// item, into this table (static LDS, in front of the kernel's dynamic ring); ranges beyond kBwdItemCache items fall back to memory.
+constexpr int kBwdItemCache = 2048;
+struct BwdItemMem {
+    uint32_t mask;
+    int Tb, Ub;
+};
+__shared__ BwdItemMem bwd_item_cache[kBwdItemCache];
+__shared__ int bwd_item_cache_lo, bwd_item_cache_n;
+
+template <bool CACHED = true>
 __device__ __forceinline__ BwdItem bwd_item(const JointParams &jp, const int item, const int n_tr) {
     const LossParams &p = jp.lp;
     BwdItem it;
-    it.bu = item / n_tr;
-    const int tr = item - it.bu * n_tr;
-    it.b = it.bu / jp.n_ut, it.ut = it.bu - it.b * jp.n_ut;
+    const int col = item / n_tr, tr = item - col * n_tr;
+    it.b = col / jp.n_ut, it.ut = col - it.b * jp.n_ut;
+    it.col_first = col * n_tr;
     it.u0 = it.ut * 32;
-    it.Tb = length_T(p, it.b), it.Ub = length_U(p, it.b);
     it.t_begin = tr * kBwdRows;
+    const int ci = item - bwd_item_cache_lo;
+    const bool hit = CACHED && (unsigned)ci < (unsigned)bwd_item_cache_n;
+    if (hit) {
+        const BwdItemMem m = bwd_item_cache[ci];
+        it.Tb = m.Tb, it.Ub = m.Ub, it.mask = m.mask;
+    } else {
+        it.Tb = length_T(p, it.b), it.Ub = length_U(p, it.b);
+    }
     it.t_end = min(min(it.t_begin + kBwdRows, p.T), it.Tb);
     it.live = (it.t_begin < it.t_end) && (it.u0 < it.Ub);
+    if (!hit) it.mask = it.live ? bwd_live_mask(jp, it.b, it.ut, tr, it.t_begin, it.t_end) : 0u;
     return it;
 }
 // power-of-two dlogits scale of an utterance: |S dl| <= 2^14 (|dl| <= 2 |cost_scale|)
@@ -1177,10 +1232,12 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
     // stagger of about a third of a row keeps them from queueing for the same pipe at the same moment.
     for (int i = 0; i < (cw >> 2); ++i) __builtin_amdgcn_s_sleep(4);
 
-    int rows_total = 0;  // rows this workgroup will process (all waves count alike)
-    for (int item = it_lo; item < it_hi; ++item) {
-        const BwdItem it = bwd_item(jp, item, n_tr);
-        if (it.live) rows_total += it.t_end - it.t_begin;
+    int rows_total = 0;  // rows this workgroup will visit (all waves count alike): an item per lane, one round trip for the masks
+    for (int base = it_lo; base < it_hi; base += 64) {
+        int c = (base + lane < it_hi) ? __popc(bwd_item(jp, base + lane, n_tr).mask) : 0;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+        rows_total += __builtin_amdgcn_readfirstlane(c);
     }
 
     f32x16 accC, accW;
@@ -1188,7 +1245,7 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
     for (int r = 0; r < 16; ++r) accC[r] = 0.f, accW[r] = 0.f;
     float ec[16];
     float S = 1.0f, invS = 1.0f;
-    int cur_bu = -1, cur_b = -1, cur_u0 = 0, cur_slot = 0;
+    int cur_bu = -1, cur_b = -1, cur_u0 = 0, cur_slot = 0;  // (cur_bu: the current column's first item)
     int row = 0;
     bool poisoned = false;
 
@@ -1211,6 +1268,8 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
 #ifdef JH_TRACE
     // dev builds: s_memtime stamps of consumers 0, 4, 8 (one SIMD) of workgroup 20, rows 40..71, 6 stamps per row
     long long *trc = (blockIdx.x == 20 && (cw & 3) == 0 && cw < 12) ? jp.trace + (cw >> 2) * 256 : nullptr;
+    int rc_count = 0;
+    const long long wg_t0 = (long long)__builtin_amdgcn_s_memtime();
 #define BT(k)                                                                                          \
     do {                                                                                               \
         if (trc && lane == 0 && row >= 40 && row < 72) trc[(row - 40) * 6 + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
@@ -1231,15 +1290,19 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
     for (int item = it_lo; item < it_hi; ++item) {
         const BwdItem it = bwd_item(jp, item, n_tr);
         if (!it.live) continue;
-        if (it.bu != cur_bu) {
+        if (it.col_first != cur_bu) {
+#ifdef JH_TRACE
+            int rc_slot = -1;
+            if (trc && lane == 0 && rc_count < 12) rc_slot = 192 + 5 * rc_count, trc[rc_slot] = (long long)__builtin_amdgcn_s_memtime(), trc[rc_slot + 4] = row;
+            ++rc_count;
+#endif
             flush_C();
-            cur_bu = it.bu, cur_u0 = it.u0;
-            {   // which of the (at most kBwdSlots) workgroups of my group that share this (utterance, u-tile) am I?
-                const long long first = (long long)it.bu * n_tr;  // first item of this (utterance, u-tile)
-                const int n_items = n_tr * p.B * jp.n_ut;
-                const int blk_first = (int)(((first + 1) * nblk - 1) / n_items);  // workgroup (of the group) that owns item `first`
-                cur_slot = blk - blk_first;
-            }
+#ifdef JH_TRACE
+            if (rc_slot >= 0) trc[rc_slot + 1] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+            cur_bu = it.col_first, cur_u0 = it.u0;
+            // which of the workgroups of my group that share this column am I?  (its d pred_proj slab)
+            cur_slot = blk - bwd_blk_of(jp.plan, it.col_first, nblk);
             if (it.b != cur_b) {  // S changes: re-scale the dW2 accumulator (exact, powers of two)
                 float Sn, invSn;
                 bwd_scale(p, it.b, Sn, invSn);
@@ -1253,8 +1316,16 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
                 const int u = min(it.u0 + cd_row(r, half), p.U - 1);
                 ec[r] = Ptab[((size_t)it.b * p.U + u) * J + j0 + l31];
             }
+#ifdef JH_TRACE
+            if (rc_slot >= 0) {
+                trc[rc_slot + 2] = (long long)__builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                trc[rc_slot + 3] = (long long)__builtin_amdgcn_s_memtime();
+            }
+#endif
         }
-        for (int t = it.t_begin; t < it.t_end; ++t, ++row) {
+        for (int t = it.t_begin; t < it.t_end; ++t) {
+            if (!((it.mask >> (t - it.t_begin)) & 1u)) continue;  // (no cell of this row's tile carries mass: kOccFloor)
             const float aj = aj_next;
             const int slot = row % kBwdRing;
             const jh8 *frag = (const jh8 *)(ring + (size_t)slot * kBwdSlotBytes);
@@ -1341,9 +1412,16 @@ __device__ void bwd_consumer(const JointParams &jp, char *ring, const uint32_t s
                 const float val = colsum * (invS * w2inv) + (jp.vt > 0 ? *dst : 0.f);
                 *dst = poisoned ? NAN : val;
             }
+            ++row;
         }
     }
     flush_C();
+#ifdef JH_TRACE
+    if (cw == 0 && lane == 0) {  // every workgroup: {clocks from the first poll to here, rows visited}
+        jp.trace[1024 + 2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memtime() - wg_t0;
+        jp.trace[1024 + 2 * blockIdx.x + 1] = rows_total;
+    }
+#endif
     // this workgroup's dW2 partial: accW is [j rows][v cols]
 #pragma unroll
     for (int r = 0; r < 16; ++r)
@@ -1435,14 +1513,17 @@ __global__ __launch_bounds__(256) void joint_cellrec_kernel(const JointParams jp
             (arr ? Bs : As)[n][k] = (arr ? p.Bt : p.A)[idx];
         }
     }
+    __shared__ int rowbits;  // bit r: row t0 + r of this patch has a cell with occupancy above 2^-kOccFloor
+    if (tid == 0) rowbits = 0;
     __syncthreads();
     const int r = tid >> 5, cu = tid & 31;
     const int t = t0 + r, u = u0 + cu;
-    if (t >= p.T || u >= p.U) return;
-    const uint32_t c = ((uint32_t)(b * p.T + t)) * (uint32_t)p.U + (uint32_t)u;
+    const bool inside = t < p.T && u < p.U;
+    const uint32_t c = ((uint32_t)(b * p.T + min(t, p.T - 1))) * (uint32_t)p.U + (uint32_t)min(u, p.U - 1);
     float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
     int lab = -1;
-    if (live && t < Tb && u < Ub) {
+    bool occupied = false;
+    if (inside && live && t < Tb && u < Ub) {
         Cell cl;
         cl.b = b, cl.t = t, cl.u = u, cl.Tb = Tb, cl.Ub = Ub, cl.valid = true;
         const int n = r + cu, n1 = n + 1;
@@ -1459,9 +1540,20 @@ __global__ __launch_bounds__(256) void joint_cellrec_kernel(const JointParams jp
             const CellGrad g = cell_grad_from(p, cl, c, As[n][cu - w0], Bs[n][cu - w0], Bs[n1][cu - w1], Bs[n1][cu + 1 - w1]);
             rec_from_log(jp, g, xx, S, rec, lab);
         }
+        // rec.x = log2(occupancy) - lse log2 e: the occupancy alone decides whether the backward visits the cell's row (NaN: yes)
+        occupied = !(fmaf(p.lse[c], kLog2e, rec.x) <= (float)-kOccFloor);
     }
-    jp.rec[c] = rec;
-    jp.reclab[c] = lab;
+    const unsigned long long occ = __ballot(occupied);
+    if ((tid & 63) == 0) {
+        const int bits = ((uint32_t)occ ? 1 : 0) | ((uint32_t)(occ >> 32) ? 2 : 0);
+        if (bits) atomicOr(&rowbits, bits << (2 * (tid >> 6)));
+    }
+    if (inside) {
+        jp.rec[c] = rec;
+        jp.reclab[c] = lab;
+    }
+    __syncthreads();
+    if (tid == 0) jp.live8[((size_t)b * jp.n_ut + ut) * (size_t)(4 * ((p.T + 31) >> 5)) + tt] = (uint8_t)rowbits;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1507,6 +1599,64 @@ __global__ __launch_bounds__(kRedoThreads) void joint_redo_kernel(const JointPar
         jp.rec[c] = rec;
         jp.reclab[c] = lab;
     }
+    if (tm.k == 0) {  // the row bits joint_cellrec_kernel formed from the abandoned lattice: the backward visits this utterance whole
+        const int nbytes = jp.n_ut * 4 * ((p.T + 31) >> 5);
+        for (int i = tid; i < nbytes; i += kRedoThreads) jp.live8[(size_t)b * nbytes + i] = 0xff;
+    }
+}
+
+// The cut of joint_bwd_kernel's item list into ranges of equal weight (see kBwdSlots).  One workgroup: a chunk of items per thread,
+// a scan over the threads' sums, then each thread writes its items' prefix weights and the cuts that fall into its chunk.
+constexpr int kPlanThreads = 1024;
+__global__ __launch_bounds__(kPlanThreads) void joint_rowplan_kernel(const JointParams jp) {
+    __shared__ int part[kPlanThreads];
+    const LossParams &p = jp.lp;
+    const int tid = threadIdx.x, nblk = jp.nblk;
+    const int n_tr = (p.T + kBwdRows - 1) / kBwdRows, n_items = n_tr * p.B * jp.n_ut;
+    const int chunk = (n_items + kPlanThreads - 1) / kPlanThreads, lo = min(tid * chunk, n_items), hi = min(lo + chunk, n_items);
+    auto weight = [&](const int item) -> int {
+        const BwdItem it = bwd_item<false>(jp, item, n_tr);
+        return it.live ? __popc(it.mask) + kBwdItemCost : 0;
+    };
+    __shared__ int rows_visited, rows_inside;  // (for get_rnnt_joint_backward_rows: what the pruning left of the lattice rows)
+    if (tid == 0) rows_visited = 0, rows_inside = 0;
+    __syncthreads();
+    int sum = 0, vis = 0, ins = 0;
+    for (int i = lo; i < hi; ++i) {
+        const BwdItem it = bwd_item<false>(jp, i, n_tr);
+        if (it.live) sum += __popc(it.mask) + kBwdItemCost, vis += __popc(it.mask), ins += it.t_end - it.t_begin;
+    }
+    if (vis) atomicAdd(&rows_visited, vis);
+    if (ins) atomicAdd(&rows_inside, ins);
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) jp.plan[3 + kBwdMaxBlocks + n_items] = rows_visited, jp.plan[4 + kBwdMaxBlocks + n_items] = rows_inside;
+    for (int d = 1; d < kPlanThreads; d <<= 1) {  // inclusive scan
+        const int v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const int total = part[kPlanThreads - 1], before = part[tid] - sum;
+    const int col_w = n_tr * (kBwdRows + kBwdItemCost);  // the heaviest column there can be
+    // (at least one item's weight: consecutive items then sit in the same or in neighbouring workgroups -- no workgroup inside a
+    // column's span is left without an item of it, which is what the d pred_proj reduction assumes of the slabs)
+    const int target = max(max((total + nblk - 1) / nblk, (col_w + kBwdSlots - 3) / (kBwdSlots - 2)), kBwdRows + kBwdItemCost);
+    int *prefix = jp.plan + 2 + kBwdMaxBlocks, *first = jp.plan + 1;
+    if (tid == 0) jp.plan[0] = target;
+    int w = before;
+    for (int i = lo; i < hi; ++i) {
+        prefix[i] = w;
+        const int k = min(w / target, nblk - 1);
+        const int kp = i == 0 ? -1 : min((w - weight(i - 1)) / target, nblk - 1);  // workgroup of the item before (the chunk's first: re-derived)
+        for (int q = kp + 1; q <= k; ++q) first[q] = i;  // workgroups kp + 1 .. k start here (all but the last of them empty)
+        w += weight(i);
+    }
+    if (hi == n_items && lo < hi) {  // (whoever holds the last item)
+        prefix[n_items] = total;
+        const int klast = min((total - weight(n_items - 1)) / target, nblk - 1);
+        for (int q = klast + 1; q <= nblk; ++q) first[q] = n_items;
+    }
 }
 
 // dlogits fragments of one lattice row tile (32 cells x 32 symbols), 8 KB: pieces 0..3 = A fragments of dh ([ks][hi, lo],
@@ -1521,7 +1671,14 @@ struct BwdRowIter {
     bool valid;
     __device__ __forceinline__ void settle(const JointParams &jp) {  // move to the first live row at or after (item, t)
         while (item < it_hi) {
-            if (it.live && t < it.t_end) { valid = true; return; }
+            if (it.live && t < it.t_end) {
+                const uint32_t rest = it.mask >> (t - it.t_begin);  // rows of this tile still to come, this one at bit 0
+                if (rest) {
+                    t += __builtin_ctz(rest);
+                    valid = true;
+                    return;
+                }
+            }
             ++item;
             if (item < it_hi) {
                 it = bwd_item(jp, item, n_tr);
@@ -1747,16 +1904,25 @@ __global__ __launch_bounds__(768) void joint_bwd_kernel(const JointParams jp) {
     char *ring = (char *)lds;                                    // [kBwdRing][10 KB] dlogits fragments + enc addends of a row
     int *ctr = (int *)(ring + kBwdRing * kBwdSlotBytes);         // seq[kBwdRing], use[kBwdRing]
     if (tid < 2 * kBwdRing) ctr[tid] = 0;
-    __syncthreads();
     const uint32_t seq_a = (uint32_t)(uintptr_t)((lds_void *)ctr), use_a = seq_a + 4u * kBwdRing;
 
     // gridDim.x = n_groups * nblk: workgroup -> (group, index within the group); contiguous item range per workgroup
     const int nblk = gridDim.x / n_groups;
     const int group = blockIdx.x % n_groups, blk = blockIdx.x / n_groups;
     const int n_tr = (p.T + kBwdRows - 1) / kBwdRows;
-    const int n_items = n_tr * p.B * jp.n_ut;
-    const int it_lo = (int)((long long)n_items * blk / nblk);
-    const int it_hi = (int)((long long)n_items * (blk + 1) / nblk);
+    const int it_lo = jp.plan[1 + blk], it_hi = jp.plan[2 + blk];  // joint_rowplan_kernel: ranges of equal weight, not of equal length
+    {   // the items' lengths and row bits, a thread per item (bwd_item_cache)
+        const int n_c = min(it_hi - it_lo, kBwdItemCache);
+        for (int i = tid; i < n_c; i += (int)blockDim.x) {
+            const BwdItem it = bwd_item<false>(jp, it_lo + i, n_tr);
+            bwd_item_cache[i].mask = it.mask, bwd_item_cache[i].Tb = it.Tb, bwd_item_cache[i].Ub = it.Ub;
+#ifdef JH_TRACE
+            if (blockIdx.x < 8 && (blockIdx.x & 1) == 0 && i < 24) jp.trace[1536 + 24 * (blockIdx.x >> 1) + i] = it.mask;
+#endif
+        }
+        if (tid == 0) bwd_item_cache_lo = it_lo, bwd_item_cache_n = n_c;
+    }
+    __syncthreads();
     if (wave < n_cons) {
         const int j0 = (group * n_cons + wave) * 32;
         if (!slow)
@@ -1830,11 +1996,18 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(float *out, const 
 // d enc_proj[b][t][:] = sum over the u-tiles of their partial rows, in u-tile order.  Every backward kernel writes the row
 // (ut, b, t) exactly when the u-tile starts inside the utterance's label range and t < T_b, and never otherwise: the reduction
 // reads only those rows (and writes zeros for t >= T_b), so the 4 n_ut B T J bytes of partials need no zero-fill.
+// `live8` (the fused f32-grade joint; nullptr for the f16 joint): joint_bwd_kernel's row bits -- a partial row it skipped was never
+// written and counts as zero.
 __device__ __forceinline__ void reduce_enc_body(float *out, const float *in, const int n_ut, const LossParams &p, const int J,
-                                                const unsigned blk, const unsigned nblk, unsigned *bmslot, const float poison) {
+                                                const unsigned blk, const unsigned nblk, unsigned *bmslot, const float poison,
+                                                const uint8_t *live8) {
     const uint32_t J4 = (uint32_t)J >> 2, n4 = (uint32_t)p.B * (uint32_t)p.T * J4;
     const float4 *in4 = (const float4 *)in;
     unsigned bm = 0u;
+    const uint32_t lrow = 4u * (((uint32_t)p.T + 31u) >> 5);  // bytes of row bits per (utterance, u-tile)
+    auto visited = [&](const uint32_t b, const uint32_t t, const int q) -> bool {
+        return !live8 || ((live8[((size_t)b * n_ut + q) * lrow + (t >> 3)] >> (t & 7u)) & 1u);
+    };
     if (((uintptr_t)out & 15) != 0) {  // a caller's gradient buffer off the 16-byte grid (the partials are workspace: aligned)
         const uint32_t n = n4 * 4u;
         for (uint32_t i = blk * 256u + threadIdx.x; i < n; i += nblk * 256u) {
@@ -1842,7 +2015,8 @@ __device__ __forceinline__ void reduce_enc_body(float *out, const float *in, con
             float s = 0.f;
             if ((int)t < length_T(p, (int)b)) {
                 const int nv = min(n_ut, (length_U(p, (int)b) + 31) >> 5);
-                for (int q = 0; q < nv; ++q) s += in[(size_t)q * n + i];
+                for (int q = 0; q < nv; ++q)
+                    if (visited(b, t, q)) s += in[(size_t)q * n + i];
             }
             s += poison;
             out[i] = s;
@@ -1857,6 +2031,15 @@ __device__ __forceinline__ void reduce_enc_body(float *out, const float *in, con
         if ((int)t < length_T(p, (int)b)) {
             const int nv = min(n_ut, (length_U(p, (int)b) + 31) >> 5);
             int q = 0;
+            if (live8) {  // (the same left-to-right association as below, minus the rows that do not exist)
+                uint32_t vis = 0u;  // all the row bits first (independent loads), then the rows
+                for (int k = 0; k < min(nv, 32); ++k) vis |= (visited(b, t, k) ? 1u : 0u) << k;
+                for (; q < nv; ++q)
+                    if (q >= 32 ? visited(b, t, q) : ((vis >> q) & 1u)) {
+                        const float4 a = in4[(size_t)q * n4 + i];
+                        s.x += a.x, s.y += a.y, s.z += a.z, s.w += a.w;
+                    }
+            }
             for (; q + 4 <= nv; q += 4) {
                 const float4 a = in4[(size_t)q * n4 + i], bb = in4[(size_t)(q + 1) * n4 + i];
                 const float4 c = in4[(size_t)(q + 2) * n4 + i], d = in4[(size_t)(q + 3) * n4 + i];
@@ -1876,7 +2059,7 @@ __device__ __forceinline__ void reduce_enc_body(float *out, const float *in, con
 }
 __global__ __launch_bounds__(256) void reduce_enc_kernel(float *out, const float *in, int n_ut, const LossParams p, int J,
                                                          unsigned *blockmax) {
-    reduce_enc_body(out, in, n_ut, p, J, blockIdx.x, gridDim.x, blockmax ? blockmax + blockIdx.x : nullptr, 0.f);
+    reduce_enc_body(out, in, n_ut, p, J, blockIdx.x, gridDim.x, blockmax ? blockmax + blockIdx.x : nullptr, 0.f, nullptr);
 }
 
 // d pred_proj[b][u][:] from the partial slabs of joint_bwd_kernel: an (utterance, u-tile) is written by the workgroups of a J
@@ -1891,18 +2074,16 @@ __device__ __forceinline__ void reduce_pred_body(float *out, const float *in, co
     const bool vec = (((uintptr_t)out) & 15) == 0;
     const uint32_t step = vec ? 4u : 1u, nq = n / step, Jq = (uint32_t)J / step;
     const int n_tr = (p.T + kBwdRows - 1) / kBwdRows;
-    const long long n_items = (long long)n_tr * p.B * jp.n_ut;
     unsigned bm = 0u;
     for (uint32_t i = blk * 256u + threadIdx.x; i < nq; i += nblk * 256u) {
         const uint32_t row = i / Jq, b = row / (uint32_t)p.U, u = row - b * (uint32_t)p.U;
         const int ut = (int)(u >> 5);
+        // the slabs that exist for this (utterance, u-tile): one per workgroup whose range (joint_rowplan_kernel) holds items of the
+        // column inside the utterance
         int ns = 0;
         if (ut * 32 < length_U(p, (int)b)) {
-            const long long first = ((long long)b * jp.n_ut + ut) * n_tr;
-            const int n_live = (length_T(p, (int)b) + kBwdRows - 1) / kBwdRows;
-            const int blk_first = (int)(((first + 1) * jp.nblk - 1) / n_items);
-            const int blk_last = (int)(((first + n_live) * jp.nblk - 1) / n_items);
-            ns = min(blk_last - blk_first + 1, kBwdSlots);
+            const int first = ((int)b * jp.n_ut + ut) * n_tr, n_live = (length_T(p, (int)b) + kBwdRows - 1) / kBwdRows;
+            ns = min(bwd_blk_of(jp.plan, first + n_live - 1, jp.nblk) - bwd_blk_of(jp.plan, first, jp.nblk) + 1, kBwdSlots);
         }
         if (vec) {
             const float4 *in4 = (const float4 *)in;
@@ -1967,7 +2148,8 @@ __global__ __launch_bounds__(256) void joint_reduce_kernel(const JointParams jp,
     const unsigned blk = blockIdx.x;
     const unsigned nWblk = (unsigned)(jp.J * p.V + 31) / 32u;
     if (blk < (unsigned)kHookBlocks) {
-        reduce_enc_body(jp.d_enc_proj, jp.dApart, jp.n_ut, p, jp.J, blk, kHookBlocks, dmax_enc ? dmax_enc + blk : nullptr, poison);
+        reduce_enc_body(jp.d_enc_proj, jp.dApart, jp.n_ut, p, jp.J, blk, kHookBlocks, dmax_enc ? dmax_enc + blk : nullptr, poison,
+                        single ? jp.live8 : nullptr);  // (single: the partials are joint_bwd_kernel's)
     } else if (blk < 2u * kHookBlocks) {
         const unsigned k = blk - kHookBlocks;
         if (single)
@@ -1989,7 +2171,7 @@ __global__ __launch_bounds__(256) void joint_reduce_kernel(const JointParams jp,
 // ---------------------------------------------------------------------------------------------
 struct JointLayout {
     WsLayout w;
-    size_t dl, dlg, rec, reclab, xbl, dApart, dCpart, dWpart, dbpart, expE, expP, tflag, W2s, pstat, total;
+    size_t dl, dlg, rec, reclab, xbl, live8, plan, dApart, dCpart, dWpart, dbpart, expE, expP, tflag, W2s, pstat, total;
     int n_ut, TR, n_tr, TS, n_ts, nC, nW, nDb, nPstat, VT;
     bool wide;  // 640 < J <= 704: W2 streams through the LDS (joint_phase1s_kernel), two-kernel backward, log-domain sweeps
 };
@@ -2016,6 +2198,8 @@ static JointLayout make_joint_layout(int T, int U, int B, int J, int V) {
     L.rec = take((size_t)B * T * U * sizeof(float4));
     L.reclab = take((size_t)B * T * U * sizeof(int));
     L.xbl = take((size_t)B * T * U * sizeof(float2));
+    L.live8 = take((size_t)B * L.n_ut * 4 * ((T + 31) / 32));  // one bit per (row, u-tile): joint_cellrec_kernel -> joint_bwd_kernel
+    L.plan = take((size_t)(5 + kBwdMaxBlocks + (size_t)B * L.n_ut * ((T + kBwdRows - 1) / kBwdRows)) * sizeof(int));  // joint_rowplan_kernel
     L.dApart = take((size_t)L.n_ut * B * T * J * sizeof(float));
     // partial buffers: what joint_bwd_kernel writes (kBwdSlots slabs of d pred_proj, one dW2 / two db2 partials per workgroup of a
     // J group; no zero-fill: the reduction knows what exists), or what the wide joint's two-kernel backward writes (zero-filled)
@@ -2065,6 +2249,18 @@ hipError_t launch_reduce_partials(float *out, const float *in, int nparts, size_
     const unsigned grid = blockmax ? (unsigned)kHookBlocks : (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, s, out, in, nparts, n, blockmax);
     return hipGetLastError();
+}
+
+// {lattice rows (x u-tiles) the last backward on this workspace visited, rows inside the utterances}: device -> host, synchronous
+hipError_t joint_backward_rows(void *workspace, int T, int U, int B, int J, int V, int rows[2], hipStream_t s) {
+    rows[0] = rows[1] = -1;
+    if (!joint_supported(J, V)) return hipErrorInvalidValue;
+    const JointLayout L = make_joint_layout(T, U, B, J, V);
+    if (L.wide) return hipSuccess;  // (the wide joint's two-kernel backward visits everything)
+    const size_t n_items = (size_t)B * L.n_ut * ((T + kBwdRows - 1) / kBwdRows);
+    const hipError_t e = hipMemcpyAsync(rows, (char *)workspace + L.plan + (3 + kBwdMaxBlocks + n_items) * sizeof(int), 2 * sizeof(int),
+                                        hipMemcpyDeviceToHost, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
 }
 
 // where the fused joint (joint_dtype 0) keeps the e^{2x} tables and its flags: for a caller that fills them itself (JointHooks)
@@ -2143,6 +2339,8 @@ static void joint_bind(JointParams &jp, const JointLayout &L, char *ws) {
     jp.rec = (float4 *)(ws + L.rec);
     jp.reclab = (int *)(ws + L.reclab);
     jp.xbl = (float2 *)(ws + L.xbl);
+    jp.live8 = (uint8_t *)(ws + L.live8);
+    jp.plan = (int *)(ws + L.plan);
     jp.dApart = (float *)(ws + L.dApart);
     jp.dCpart = (float *)(ws + L.dCpart);
     jp.dWpart = (float *)(ws + L.dWpart);
@@ -2265,7 +2463,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     jp.d_enc_proj = d_enc_proj, jp.d_pred_proj = d_pred_proj, jp.dW2 = dW2, jp.db2 = db2;
 #ifdef JH_TRACE
     static long long *trace_dev = nullptr;
-    const size_t trace_bytes = 1024 * sizeof(long long);
+    const size_t trace_bytes = 2048 * sizeof(long long);
     if (!trace_dev) (void)hipMalloc(&trace_dev, trace_bytes);
     (void)hipMemsetAsync(trace_dev, 0, trace_bytes, s);
     jp.trace = trace_dev;
@@ -2311,7 +2509,6 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
         const int n_cons = J / 32 / n_groups;
         const int n_items = ((T + kBwdRows - 1) / kBwdRows) * B * L.n_ut;
         int nblk = device_cu_count() / n_groups;
-        if (nblk > 2 * B * L.n_ut) nblk = 2 * B * L.n_ut;  // an (utterance, u-tile) then spans at most kBwdSlots workgroups
         if (nblk > n_items) nblk = n_items;
         if (nblk > kBwdMaxBlocks) nblk = kBwdMaxBlocks;
         if (nblk < 1) nblk = 1;
@@ -2319,6 +2516,8 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
         hipLaunchKernelGGL(joint_cellrec_kernel, dim3((unsigned)B * L.n_ut * ((T + kRecRows - 1) / kRecRows)), dim3(256), 0, s, jp);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = launch_joint_redo(jp, true, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(joint_rowplan_kernel, dim3(1), dim3(kPlanThreads), 0, s, jp);  // (after the hand-back: it turns whole utterances on)
+        if ((e = hipGetLastError()) != hipSuccess) return e;
         const size_t shm_bwd = (size_t)kBwdRing * kBwdSlotBytes + 2 * kBwdRing * sizeof(int);
         if ((e = set_lds(joint_bwd_kernel, shm_bwd)) != hipSuccess) return e;
         for (jp.vt = 0; jp.vt < L.VT; ++jp.vt)  // one pass per vocabulary tile (a later one adds its d enc_proj / d pred_proj partials to the first's)
@@ -2343,7 +2542,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
 #ifdef JH_TRACE
     {
         (void)hipStreamSynchronize(s);
-        long long h[1024];
+        static long long h[2048];
         (void)hipMemcpy(h, trace_dev, trace_bytes, hipMemcpyDeviceToHost);
         const char *path = getenv("JH_TRACE_FILE32");
         if (FILE *f = fopen(path ? path : "/tmp/j32_trace.bin", "wb")) {

@@ -13,6 +13,7 @@ using namespace rnnt;
 namespace rnnt {
 // joint_kernels.hip
 hipError_t joint_workspace_bytes(int T, int U, int B, int J, int V, int joint_dtype, size_t *bytes);
+hipError_t joint_backward_rows(void *workspace, int T, int U, int B, int J, int V, int rows[2], hipStream_t s);
 hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2,
                              const int *labels, const int *label_lengths, const int *input_lengths,
                              const float *cost_scale, int J, int V, int B, int T, int U, int blank, float *costs,
@@ -405,6 +406,17 @@ rnntStatus_t compute_rnnt_joint_logits(const float *enc_proj, const float *pred_
                                                 options.maxU, logits, workspace, s));
     return from_hip(launch_joint_logits(enc_proj, pred_proj, W2, b2, joint_size, alphabet_size, minibatch, options.maxT,
                                         options.maxU, logits, workspace, s));
+}
+
+// Rows (x u-tiles) the last f32-grade backward on this workspace visited / rows inside the utterances (include/rnnt.h).
+rnntStatus_t get_rnnt_joint_backward_rows(void *workspace, int joint_size, int alphabet_size, int minibatch, rnntOptions options,
+                                          int rows[2]) {
+    if (!workspace || !rows || joint_size <= 0 || alphabet_size <= 0 || minibatch <= 0) return RNNT_STATUS_INVALID_VALUE;
+    rnntStatus_t st = check_options(options);
+    if (st != RNNT_STATUS_SUCCESS) return st;
+    if (((uintptr_t)workspace & 255) != 0 || !joint_dtype_supported(0, joint_size, alphabet_size)) return RNNT_STATUS_INVALID_VALUE;
+    return from_hip(joint_backward_rows(workspace, options.maxT, options.maxU, minibatch, joint_size, alphabet_size, rows,
+                                        (hipStream_t)options.stream));
 }
 
 // The whole joint network without the loss: first Dense layer (the library's split-precision GEMMs, as in the fused loss) + the
