@@ -234,7 +234,7 @@ def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
     # The backward visits the lattice rows (x 32-column tiles) that carry mass (include/rnnt.h get_rnnt_joint_backward_rows: a row whose
     # cells all have an occupancy below 2^-50 adds nothing an f32 sum can hold); how many that is depends on the data -- measured here.
     rows = (ctypes.c_int * 2)(-1, -1)
-    _lib.check(lib.get_rnnt_joint_backward_rows(ws.data_ptr(), J, V, B, opts, rows))
+    _lib.check(lib.get_rnnt_joint_backward_rows(ws.data_ptr(), J, V, B, opts, rows), "backward rows")
     visited = rows[0] / rows[1] if rows[1] > 0 else 1.0
     executed = (2.0 + 4.0 * visited) * J * 32 * ((V + 31) // 32) * cells  # (vocabulary tiles of 32 symbols: one pass each)
     split_peak = MFMA_F16_PEAK_TFLOPS / 3.0
