@@ -84,7 +84,7 @@ def test_code_objects_are_gfx950_and_have_the_kernels(kernels):
                     ("jh_logits_kernel", "Li40ELi0"), ("jh_logits_kernel", "Li40ELi1"), ("jh_logits_kernel", "Li40ELi2"),
                     ("jh_dlogits_kernel",), ("jh_dh_kernel",), ("jh_dw_kernel",),
                     ("lin_sweep_kernel", "Li3ELi16E"), ("lin_redo_kernel", "Li3ELi16E"), ("joint_redo_kernel", "Li3ELi16E"),
-                    ("joint_fwd_kernel",), ("joint_bwd_kernel",), ("joint_cellrec_kernel",), ("joint_reduce_kernel",),
+                    ("joint_fwd_kernel",), ("joint_bwd_kernel",), ("joint_cellrec_kernel",), ("joint_rowplan_kernel",), ("joint_reduce_kernel",),
                     ("dense_gemm_nt_kernel",), ("dense_gemm_tn_kernel",)):
         _find(meta, *needles)
 
@@ -96,7 +96,7 @@ def test_hot_kernels_do_not_spill(kernels):
            ("joint_dl_kernel",), ("joint_phase1s_kernel",),
            # round 4 / 5: the linear-domain sweeps, both hand-back kernels, the fused f32-grade joint and its first Dense layer
            ("lin_sweep_kernel",), ("joint_redo_kernel",), ("joint_fwd_kernel",), ("joint_bwd_kernel",),
-           ("joint_cellrec_kernel",), ("joint_reduce_kernel",), ("dense_gemm_nt_kernel",), ("dense_gemm_tn_kernel",)]
+           ("joint_cellrec_kernel",), ("joint_rowplan_kernel",), ("joint_reduce_kernel",), ("dense_gemm_nt_kernel",), ("dense_gemm_tn_kernel",)]
     for needles in hot:
         for k in _find(meta, *needles):
             m = meta[k]
