@@ -74,3 +74,43 @@ def test_backward_producer_gathers_the_transposed_operand_from_its_own_image():
                     imm = hl * 1024 + ((e & 3) + 8 * (e >> 2) + 16 * ks) * 16
                     got = slot[(gather_lane + imm) // 2]
                     assert got == dl[hl, cd_row(8 * ks + e, half), v], (lane, ks, hl, e)
+
+
+def test_row_plan_cuts_keep_the_slab_invariants():
+    """The arithmetic of joint_rowplan_kernel (csrc/joint_kernels.hip, round 5) restated in NumPy on random row bits: items
+    (utterance, u-tile, row tile) in column-major order, weight = rows visited + 3 for an item inside its utterance, workgroup of
+    item i = min(prefix[i] / target, nblk - 1) with target >= total / nblk, >= a sixth of the heaviest possible column and >= one
+    item's weight.  What the backward and the d pred_proj reduction rely on: the assignment is monotone, a column's live items
+    fall into fewer than 8 workgroups, and every workgroup inside that span holds at least one of them (its slab exists)."""
+    import numpy as np
+
+    kRows, kCost, kSlots = 32, 3, 8
+    rng = np.random.default_rng(7)
+    for trial in range(300):
+        B, n_ut, n_tr = int(rng.integers(1, 9)), int(rng.integers(1, 7)), int(rng.integers(1, 40))
+        nblk = int(rng.integers(1, 257))
+        n_live = rng.integers(0, n_tr + 1, size=B)              # row tiles inside each utterance
+        ut_live = rng.integers(1, n_ut + 1, size=B)             # u-tiles inside each utterance
+        dens = rng.choice([0.0, 0.05, 0.5, 1.0])                # how much of the lattice carries mass
+        w = np.zeros(B * n_ut * n_tr, dtype=np.int64)
+        for b in range(B):
+            for ut in range(n_ut):
+                for tr in range(n_tr):
+                    if tr < n_live[b] and ut < ut_live[b]:
+                        rows = int(rng.binomial(kRows, dens)) if rng.random() < 0.7 else (kRows if rng.random() < dens else 0)
+                        w[(b * n_ut + ut) * n_tr + tr] = rows + kCost
+        nblk = max(1, min(nblk, w.size))
+        prefix = np.concatenate([[0], np.cumsum(w)])
+        total = int(prefix[-1])
+        col_w = n_tr * (kRows + kCost)
+        target = max(-(-total // nblk), -(-col_w // (kSlots - 2)), kRows + kCost)
+        blk = np.minimum(prefix[:-1] // target, nblk - 1)
+        assert (np.diff(blk) >= 0).all()
+        for b in range(B):
+            for ut in range(n_ut):
+                first = (b * n_ut + ut) * n_tr
+                if ut >= ut_live[b] or n_live[b] == 0:
+                    continue
+                span = blk[first: first + n_live[b]]
+                assert span[-1] - span[0] + 1 < kSlots, (trial, span)
+                assert set(range(int(span[0]), int(span[-1]) + 1)) == set(int(x) for x in span), (trial, span)
