@@ -314,7 +314,9 @@ def bench_fused_full(dev, B, T, U, V, J, reps):
             "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": split_peak, "unit": "TFLOP/s",
                          "frac": flops / dt / 1e12 / split_peak, "algorithmic_flops_per_step": flops,
                          "note": "8*J*V per cell + 6*B*(T+U)*H*J; peak = dense f16 MFMA peak / 3 (three f16 MFMAs per f32-grade "
-                                 "product) for the W1 GEMMs and the J x V products alike"}}
+                                 "product) for the W1 GEMMs and the J x V products alike; the joint's backward visits the lattice rows "
+                                 "that carry mass, as in `fused_joint` (whose roofline.backward_rows_visited gives the fraction on a batch "
+                                 "of the same shape and distribution)"}}
 
 
 def bench_fused_dp_step(dev, world, rank, B, T, U, V, J, reps, sync):
