@@ -1548,7 +1548,9 @@ __global__ __launch_bounds__(256) void joint_cellrec_kernel(const JointParams jp
         const int bits = ((uint32_t)occ ? 1 : 0) | ((uint32_t)(occ >> 32) ? 2 : 0);
         if (bits) atomicOr(&rowbits, bits << (2 * (tid >> 6)));
     }
-    if (inside) {
+    // (a row the backward will not visit needs no records: its 32 cells are this half-wave's)
+    const bool row_visited = ((tid & 32) ? (uint32_t)(occ >> 32) : (uint32_t)occ) != 0u;
+    if (inside && row_visited) {
         jp.rec[c] = rec;
         jp.reclab[c] = lab;
     }
@@ -1621,11 +1623,17 @@ __global__ __launch_bounds__(kPlanThreads) void joint_rowplan_kernel(const Joint
     __shared__ int rows_visited, rows_inside;  // (for get_rnnt_joint_backward_rows: what the pruning left of the lattice rows)
     if (tid == 0) rows_visited = 0, rows_inside = 0;
     __syncthreads();
+    // (the weights are fetched once -- lengths and row bits: two dependent round trips per item -- and kept in LDS for the second pass)
+    constexpr int kPlanCache = 8192;
+    __shared__ int wl[kPlanCache];
     int sum = 0, vis = 0, ins = 0;
     for (int i = lo; i < hi; ++i) {
         const BwdItem it = bwd_item<false>(jp, i, n_tr);
-        if (it.live) sum += __popc(it.mask) + kBwdItemCost, vis += __popc(it.mask), ins += it.t_end - it.t_begin;
+        const int wi = it.live ? __popc(it.mask) + kBwdItemCost : 0;
+        if (it.live) sum += wi, vis += __popc(it.mask), ins += it.t_end - it.t_begin;
+        if (i < kPlanCache) wl[i] = wi;
     }
+    auto weight2 = [&](const int item) -> int { return item < kPlanCache ? wl[item] : weight(item); };
     if (vis) atomicAdd(&rows_visited, vis);
     if (ins) atomicAdd(&rows_inside, ins);
     part[tid] = sum;
@@ -1648,13 +1656,13 @@ __global__ __launch_bounds__(kPlanThreads) void joint_rowplan_kernel(const Joint
     for (int i = lo; i < hi; ++i) {
         prefix[i] = w;
         const int k = min(w / target, nblk - 1);
-        const int kp = i == 0 ? -1 : min((w - weight(i - 1)) / target, nblk - 1);  // workgroup of the item before (the chunk's first: re-derived)
+        const int kp = i == 0 ? -1 : min((w - weight2(i - 1)) / target, nblk - 1);  // workgroup of the item before
         for (int q = kp + 1; q <= k; ++q) first[q] = i;  // workgroups kp + 1 .. k start here (all but the last of them empty)
-        w += weight(i);
+        w += weight2(i);
     }
     if (hi == n_items && lo < hi) {  // (whoever holds the last item)
         prefix[n_items] = total;
-        const int klast = min((total - weight(n_items - 1)) / target, nblk - 1);
+        const int klast = min((total - weight2(n_items - 1)) / target, nblk - 1);
         for (int q = klast + 1; q <= nblk; ++q) first[q] = n_items;
     }
 }
