@@ -190,8 +190,13 @@ RNNT_API rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, cons
  *                                    [2^13, 2^14): any finite magnitude is taken (round 5; before, weights beyond binary16's
  *                                    65504 switched the call to plain f32 MFMA kernels), weights within 2^-13 of the largest
  *                                    keep 22 significand bits, smaller ones an absolute error of 2^-38 max |W2|.  Small
- *                                    vocabularies: alphabet_size <= 32 (the reference's character set), joint_size a multiple
- *                                    of 64 (<= 704).
+ *                                    vocabularies: alphabet_size <= 128 for joint_size a multiple of 64 up to 640 (vocabulary
+ *                                    tiles of 32 symbols, one pass of the kernels per tile; <= 32 is the reference's character
+ *                                    set), alphabet_size <= 32 for joint_size 704.
+ *                                    The backward (joint_size <= 640) does not visit lattice rows, in tiles of 32 columns, whose
+ *                                    cells all have an occupancy alpha.beta/L below 2^-50: those cells get exactly zero where the
+ *                                    reference leaves ~1e-15 (get_rnnt_joint_backward_rows below: the bound, and how many rows a
+ *                                    call visited); its run time follows the width of the alignment band.
  *                                1 = f16 MFMA, larger vocabularies: alphabet_size a multiple of 128 (128 ... 8192),
  *                                    joint_size a multiple of 128 (128 ... 640).  h = tanh(.) and W2 are rounded to binary16
  *                                    (round-to-nearest-even) before the products, accumulation is f32; the loss gradient
