@@ -214,7 +214,8 @@ RNNT_API rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, cons
  *                                    oracle/rnnt_oracle.py joint_loss_and_grads_f16 (parked=True / False).
  *                                Any other (joint_dtype, shape) combination returns RNNT_STATUS_INVALID_VALUE -- checked before
  *                                anything is enqueued, in every entry point that takes joint_dtype.
- *                                get_joint_workspace_size needs no dtype: the two shape domains are disjoint.
+ *                                get_joint_workspace_size needs no dtype: where both arithmetic types take the shape (alphabet_size 128)
+ *                                it returns the larger of the two layouts.
  * Both: maxU <= 1024; enc_proj, pred_proj (and b2 for joint_dtype 1) 16-byte aligned.
  * compute_rnnt_joint_loss      = costs and all four gradients in one call
  * compute_rnnt_joint_loss_fwd  = costs (+ the state a _bwd call needs, kept in `workspace`); for costs ONLY (evaluation) call
