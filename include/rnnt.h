@@ -115,6 +115,9 @@ RNNT_API rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool
  *              of up to 8192 columns, every vocabulary size (measured: linear lattice 1e-7 ... 4e-6; log-domain paths 4e-6 at
  *              4 x N(0,1) and 1.1e-5 at 8 x N(0,1) at B=32 T=600 U=150 V=28, up to 4.4e-5 at 8 x N(0,1) on 1000-column lattices,
  *              5.5e-5 at T=1500 U=300 V=1024; 5,000 random shapes up to 1000 columns, half of them at 4 x N(0,1): 3.0e-5).
+ * Vocabularies of more than 60 symbols (one lattice cell per wavefront): a cell whose occupancy alpha.beta/L is below 2^-50 gets
+ * exactly zero gradients -- every gradient of a cell is bounded by 2 |cost_scale| x its occupancy -- and its logits are not read
+ * (the reference's kernel leaves values around 1e-15 there).  The headline path (alphabet_size <= 60) visits every cell.
  * Out-of-range per-utterance lengths (T_b < 1, T_b > maxT, L_b < 0, L_b > maxU-1) are device data and cannot be
  * checked at enqueue time: the kernels clamp them into the tensor (no out-of-bounds access) and report that
  * utterance with a NaN cost and NaN gradients.  Labels outside [0, alphabet_size) are clamped into range. */

@@ -21,6 +21,7 @@ __host__ __device__ inline int wave_cells(int V) { return V >= 1024 ? 1 : 1024 /
 
 // The cells [c_lo, c_hi) by ONE wave, lanes striding over V.  SC1: read the lattice state with agent-scope loads (the caller
 // wrote it itself earlier in the same kernel: rnnt_lin_kernels.hip's log-domain redo).
+constexpr int kOccFloorWave = 50;  // (the fused joint's backward uses the same floor per row tile: joint_kernels.hip kOccFloor)
 template <bool V4, bool GRAD, bool SC1 = false>
 __device__ __forceinline__ void cell_wave_range(const LossParams &p, const uint32_t c_lo, const uint32_t c_hi, const int lane) {
     const int V = p.V;
@@ -87,6 +88,19 @@ __device__ __forceinline__ void cell_wave_range(const LossParams &p, const uint3
                 continue;
             }
             const CellGrad g = cell_grad_setup<SC1>(p, cl, c);
+            // A cell without mass: every gradient of it is bounded by 2 |cost_scale| x its occupancy alpha beta / L = 2^(c0 - nl); below
+            // 2^-kOccFloorWave that is nothing an f32 sum holds, and the cell's V logits need not be read: zeros are written (the
+            // reference leaves ~1e-15 there).  On an unstructured 1500 x 300 lattice that is most of the cells.  NaN counts as occupied.
+            if (g.c0 - g.nl <= (float)-kOccFloorWave) {
+                if (V4) {
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    const v4f z = {0.f, 0.f, 0.f, 0.f};
+                    for (int i = lane * 4; i < V; i += 256) __builtin_nontemporal_store(z, (v4f *)(gd + i));
+                } else {
+                    for (int i = lane; i < V; i += 64) gd[i] = 0.f;
+                }
+                continue;
+            }
             const float corr_b = g.has_blank_corr ? g.scale * ex2(fmaf(x[p.blank], kLog2e, g.nl) + g.cb) : 0.f;
             const float corr_l = g.has_label ? g.scale * ex2(fmaf(x[g.lab], kLog2e, g.nl) + g.cl) : 0.f;
             const int lab = g.has_label ? g.lab : -1;
