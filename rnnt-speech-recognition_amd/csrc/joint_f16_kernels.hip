@@ -17,11 +17,13 @@
 //             log-softmax is an in-register online reduction.  Out: lse, lattice edge weights W (-> sweeps), the
 //             blank / label logits of every cell, and (MODE 1, when a backward pass follows) the PARKED softmax
 //             numerators 2^(y - R) in binary16, R = the integer at or above the largest y of the cell's 32-symbol chunk.
-//   K2 dlogits (jh_dlogits_kernel)  one streaming pass over the parked values: dl = binary16(S scale 2^(R + c0) parked),
-//             blank / label columns from the f32 edge logits; in place.  (Rounds 1-2 ran the product a second time here;
-//             that kernel -- MODE 2 of jh_logits_kernel -- still serves a second backward call over one forward.)
-//   K3 dh     (jh_dh_kernel)  dh = dl . W2^T as an "NT" GEMM (both operands K-contiguous, XOR-swizzled LDS images
-//             filled by LDS-DMA), epilogue dz = dh (1 - h^2), sum_u -> d enc_proj partials, sum_t -> d pred_proj.
+//   K3 dh     (jh_dhx_kernel<J/128>, round 6)  the pass over the parked values AND dh = dl . W2^T in one kernel: a workgroup owns
+//             128 cells x ALL J units, so every dl row is fetched, multiplied back with its cell's factor (dl = binary16(S scale
+//             2^(R + c0) parked), blank / label columns from the f32 edge logits) and written back for K4 exactly ONCE, in the
+//             loader of the product; epilogue dz = dh (1 - h^2), sum_u -> d enc_proj partials, sum_t -> d pred_proj.
+//             (Rounds 3-5: a separate 29.5 GB streaming pass K2 + a dh kernel whose five J-tile workgroups each fetched dl.
+//             Rounds 1-2 ran the forward product a second time -- that kernel, MODE 2 of jh_logits_kernel, still serves a
+//             second backward call over one forward.)
 //   K4 dW2    (jh_dw_kernel)  dW2 = h^T . dl, split over ranges of cells; h^T is generated in A-fragment layout,
 //             dl rows are DMA'd row-major and read TRANSPOSED with ds_read_b64_tr_b16; db2 rides along (v_dot2).
 //
@@ -72,6 +74,12 @@ __device__ __forceinline__ float dot8(const h8 a, const h8 b, float c) {
     c = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 6, 7), __builtin_shufflevector(b, b, 6, 7), c, false);
     return c;
 }
+// An opaque copy: what is computed from it cannot be hoisted out of the region it is made in (values derived from the thread
+// index that a kernel's epilogue needs must not stay in registers through its main loop).
+__device__ __forceinline__ int launder(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
 __device__ __forceinline__ float lane_f32(float x, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
 }
@@ -80,6 +88,20 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
     const uint32_t xcd = bid & 7u, idx = bid >> 3, q = nwg >> 3, r = nwg & 7u;
     return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
 }
+
+// LDS-DMA with a SCALAR base and a 32-bit lane offset, issued as inline assembly (jh_dhx_kernel): the builtin made the compiler
+// form 64-bit lane addresses, hoist them out of the loop, spill them, and wait vmcnt(0) behind every reload.  `lds`: byte address in
+// LDS (wave-uniform); lane l lands at lds + SIZE l.  The callers order the DMA with s_waitcnt vmcnt / barriers themselves.
+__device__ __forceinline__ void lds_dma16_s(const void *base, uint32_t lane_off, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(base), "s"(lds) : "m0");
+}
+__device__ __forceinline__ void lds_dma16_s_nt(const void *base, uint32_t lane_off, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(lane_off), "s"(base), "s"(lds) : "m0");
+}
+__device__ __forceinline__ void lds_dma4_s(const void *base, uint32_t lane_off, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(lane_off), "s"(base), "s"(lds) : "m0");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void *q) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)q; }
 
 constexpr int kDlScaleLog2 = 14;   // |dlogits * S| <= 2^14 before the binary16 rounding
 constexpr int kStageStride = 36;   // halfs per row of the K1/K2 staging tile: one chunk of 32 columns + 8 bytes.  18 dwords per row:
@@ -96,9 +118,10 @@ struct JhParams {
     const float *enc_proj, *pred_proj, *W2, *b2;
     f16 *W2Tp;    // [V/32][J/16][2 halves][32 v][8 j]  W2^T packed so that lane l of an MFMA A fragment reads
                   // bytes [16 l, 16 l + 16) of a contiguous 1 KB block (conflict-free ds_read_b128)
-    f16 *W2h;     // [J][V]
+    f16 *W2c;     // [V/32][J][32 v]  W2 in K-chunk-major order: the 64 J bytes K3 brings in per 32-symbol step are contiguous
+    float *dCacc; // K3: running sum over a workgroup's lattice rows of its d pred_proj tile, [workgroup][wave][2][NT][64 lanes][4]
     f16 *dl;      // [cells][V]  parked softmax numerators 2^(y - ref) after K1 (park mode), dlogits * S after K2
-    short *pref;  // [cells][V/32]  the integer references of the parked values, one per (cell, 32-symbol chunk)
+    short *pref;  // [B T][V/32][32 n_ut]  the integer references of the parked values, one per (cell, 32-symbol chunk): row, chunk, column
     int *state;   // [0]: 1 = dl holds the parked values of the forward call with these inputs; anything else: it does not
     float *xbl;   // [cells][2]  blank / label logits, log2-scaled (x * log2 e)
     float *scal;  // [0] = S, [1] = 1/S, [2] != 0: some |enc_proj| or |pred_proj| exceeds kExpTabLimit (use htanh)
@@ -111,7 +134,6 @@ struct JhParams {
     float *dbpart;  // [n_ranges][V]
     const f16 *zrow;  // 1 KB of zeros: stands in for dl rows beyond the tensor (u >= U) in K4
     int J, n_ut, n_tt, n_ts, TS, n_tq, n_units, n_ranges;
-    FastDiv div_ppc;  // K2: 16-byte pieces per cell (V / 8)
     int b2_lds_off;  // K1/K2: byte offset of the bias table in LDS, -1 = read it from global memory (does not fit)
     float *logits_out;  // MODE 3 of K1 (compute_rnnt_joint_logits, decoding): f32 logits [cells][V]
     int logits_only;    // every lattice cell is wanted: the prep kernel writes full lengths + zero labels into the workspace
@@ -138,7 +160,7 @@ __global__ __launch_bounds__(256) void jh_prep_kernel(const JhParams jp) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int j = (int)(i / V), v = (int)(i - (size_t)j * V);
         const f16 w = (f16)jp.W2[i];
-        jp.W2h[i] = w;
+        jp.W2c[((size_t)(v >> 5) * J + j) * 32 + (v & 31)] = w;
         jp.W2Tp[((((size_t)(v >> 5) * (J >> 4) + (j >> 4)) * 2 + ((j >> 3) & 1)) * 32 + (v & 31)) * 8 + (j & 7)] = w;
     }
     {
@@ -187,7 +209,7 @@ __global__ __launch_bounds__(256) void jh_prep_kernel(const JhParams jp) {
 // ---------------------------------------------------------------------------------------------
 // MODE 0: forward (lse, edge weights, edge logits).  MODE 1: forward + PARK: the softmax numerators of every chunk are also
 // written to dl as binary16, relative to the chunk's own integer reference, so that the backward pass is a streaming kernel
-// (jh_dlogits_kernel) instead of this product a second time.  MODE 2: the product again with the dlogits epilogue (the
+// (the loader of jh_dhx_kernel) instead of this product a second time.  MODE 2: the product again with the dlogits epilogue (the
 // route a backward call takes when the parked values are not there any more: a second backward over one forward).
 template <int KS, int MODE, bool B2LDS>
 __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
@@ -328,11 +350,9 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
         char *const base = (char *)(jp.dl + cell0 * V + vcf * 32);  // wave-uniform
         if (u0 + 16 * j + (lane >> 2) < p.U) *(h8 *)(base + st_off + (uint32_t)(32 * j * V)) = v;
     };
-    uint32_t ref01 = 0, ref23 = 0;  // PARK: the references of the current group of four chunks, as packed int16
-    auto store_refs = [&](const int vcf) {  // after the fourth chunk of a group: the cell's four references, 8 bytes
-        if (PARK && (vcf & 3) == 3 && lane < 32 && u0 + lane < p.U)
-            *(uint2 *)(jp.pref + (cell0 + lane) * (size_t)(V >> 5) + (vcf - 3)) = make_uint2(ref01, ref23);
-    };
+    // PARK: the chunk references go out one short per cell and chunk, [lattice row][chunk][column (row pitch 32 n_ut)]: K3 brings the
+    // references of a (4 rows x 32 columns) tile and one chunk in as four 64-byte segments (round 6; before: [cell][chunk])
+    short *const pref_row = jp.pref + (size_t)(b * p.T + t) * (size_t)(V >> 5) * (size_t)(jp.n_ut * 32) + u0;
 
     // ---- epilogue of one 32-column chunk: acc[r] = logit (without bias) of this lane's cell at v = 32 vc + cdrow(r, half)
     auto epilogue = [&](const f32x16 &acc, const int vc) {
@@ -404,15 +424,7 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
                     *(h4 *)(row + 8 * q) = d;
                 }
                 ssum = fmaf(sc, hex2(ref - mref), ssum);
-                {
-                    const uint32_t r16 = (uint32_t)(int)ref & 0xffffu;
-                    switch (vc & 3) {  // wave-uniform
-                        case 0: ref01 = r16; break;
-                        case 1: ref01 |= r16 << 16; break;
-                        case 2: ref23 = r16; break;
-                        default: ref23 |= r16 << 16; break;
-                    }
-                }
+                if (lane < 32) pref_row[(uint32_t)vc * (uint32_t)(jp.n_ut * 32) + (uint32_t)lane] = (short)(int)ref;
             }
             if (LOGITS && cell_valid) {  // decoding: the chunk's 16 logits of this half-lane, natural scale, straight to the caller
                 float *o = jp.logits_out + (size_t)c * V + vc * 32 + 4 * half;
@@ -532,7 +544,6 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
                     }
                     if (g4 == kE2) {
                         stage_store(1, vc - 1, sp);
-                        store_refs(vc - 1);
                     }
                 }
 #pragma unroll
@@ -540,7 +551,6 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
             }
             if (STAGE && staged && kE2 >= NG) {
                 stage_store(1, vc - 1, sp);
-                store_refs(vc - 1);
             }
         }
 #pragma unroll
@@ -553,7 +563,6 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
     if (STAGE && wave_live) {  // the last chunk's pieces
         stage_store(0, NC - 1, stage_read(0));
         stage_store(1, NC - 1, stage_read(1));
-        store_refs(NC - 1);
     }
 
     if (!BWD && wave_live) {
@@ -579,331 +588,452 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2 (streaming): dl[cell][v] = binary16( S * scale * 2^(ref + c0) * parked ), edge columns as in the recompute epilogue.
-// In place, one pass over the parked values: 4 B of HBM traffic per logit instead of 2 J flop.  Writes what K1 wrote: the
-// cells of lattice rows t < T_b in column tiles that start below U_b (zeros for the columns u >= U_b inside them).
-// Shape: ONE contiguous 16 KB span per 256-thread workgroup, four 16-byte pieces per thread, no grid stride -- what reaches
-// 6.1 TB/s in place on this part (scripts/probes/probe_hbm.hip: 4.7-5.0 TB/s for grid-stride loops, 4.5 for 32 KB spans; the
-// first version, a wave per lattice row of K1's tiles, ran at 5.2 TB/s).  The span's loads are issued first; the few threads
-// that set the span's cells up (gathers from the lattice state) work under their latency.
+// K3, round 6 (jh_dhx_kernel<NT>, J = 128 NT): the streaming pass K2 and the dh product in ONE kernel, every dl element touched once.
+//   workgroup = (utterance, u-tile of 32 columns, row split); per iteration 4 lattice rows x 32 columns = 128 cells x ALL J units
+//   (the old K3 gave a workgroup 128 units: five workgroups fetched -- and would have had to convert -- every dl row).
+//   A operand: the cell rows of dl.  A thread owns one 16-byte piece of one cell row per 32-symbol step: it loads the PARKED
+//   numerators two steps ahead (registers), multiplies them back with the cell's factor (exactly K2's arithmetic: one f32 factor per
+//   (cell, chunk), the blank / label columns from the f32 edge terms), writes the binary16 result into the LDS stage AND back to
+//   dl for K4 -- in place, once.  B operand: W2, chunk-major (W2c), 64 J bytes per step by LDS-DMA.
+//   8 waves = 2 (column halves of the tile) x 4 (J quarters); a wave multiplies 64 cells x 32 NT units: 2 + NT fragment reads for
+//   2 NT MFMAs per k-step (0.7 reads per MFMA at J = 640; the old 2 x 2 wave tile: 1.0).
+//   An MFMA row tile holds 4 lattice rows x 8 columns (not 1 x 32), so that in the accumulator layout a lane's 16 registers are
+//   4 rows x 4 columns: sum_t collapses to 4 values per tile in registers.  Those running column sums (d pred_proj) do not fit the
+//   register file beside 32 NT accumulators: they live in a workspace slab the SAME wave re-reads and re-writes once per iteration
+//   (16 bytes per lane and tile: L2 traffic of 160 KB per 640 MFMAs).  sum_u (d enc_proj): in registers + one pass through LDS
+//   between the two column halves.
+// LDS: 3 stages x (A 128 rows x 64 B + B J rows x 64 B), 16-byte chunks XOR-swizzled by (row >> 2) & 3 (conflict-free b128 reads),
+//      + [4][J] floats for the d enc_proj hand-over = 157,696 bytes at J = 640.
 // ---------------------------------------------------------------------------------------------
-#ifndef JH_K2_SPAN
-#define JH_K2_SPAN 1024
-#endif
-constexpr int kK2Span = JH_K2_SPAN;  // 16-byte pieces per workgroup (16 KB; 8 KB and 32 KB spans measured slower)
-constexpr int kK2Per = kK2Span / 256;   // ... per thread
-__global__ __launch_bounds__(256) void jh_dlogits_kernel(const JhParams jp) {
-    if (jp.state[0] != 1) return;  // no parked values: the recompute kernel (MODE 2) does this call's work
-    __shared__ float4 sset[64];    // per cell of the span: factor scale * S, c0, blank value, label value
-    __shared__ int slab[64];       // ... the label column to patch (-1: none), -2: the cell is not written at all
-    const LossParams &p = jp.lp;
-    const int V = p.V, tid = threadIdx.x;
-    const int ppc = V >> 3, cw = kK2Span / ppc;  // pieces per cell, cells per workgroup (1 at V = 8192 .. 64 at V = 128)
-    const uint32_t cell_lo = (uint32_t)p.b0 * (uint32_t)(p.T * p.U), cell_hi = cell_lo + (uint32_t)p.nb * (uint32_t)(p.T * p.U);
-    const uint32_t c0w = cell_lo + blockIdx.x * (uint32_t)cw;  // first cell of this workgroup
-    h8 v[kK2Per];
-    short rf[kK2Per];
-    int cl[kK2Per], pj[kK2Per];
-#pragma unroll
-    for (int k = 0; k < kK2Per; ++k) {
-        const int q = tid + 256 * k;
-        cl[k] = (int)fdiv((uint32_t)q, jp.div_ppc), pj[k] = q - cl[k] * ppc;
-        if (cl[k] < cw && c0w + cl[k] < cell_hi) {
-            const size_t c = c0w + cl[k];
-            v[k] = __builtin_nontemporal_load((const h8 *)(jp.dl + c * V) + pj[k]);
-            rf[k] = jp.pref[c * (size_t)(V >> 5) + (pj[k] >> 2)];
-        } else {
-            cl[k] = -1;
-        }
-    }
-    if (tid < cw && c0w + tid < cell_hi) {
-        const uint32_t c = c0w + tid;
-        const Cell cel = decode(p, c);
-        float mulS = 0.f, c0 = kNeg, eb = 0.f, el = 0.f;
-        int labc = -1;
-        if (!(cel.t < cel.Tb && (cel.u & ~31) < cel.Ub)) {
-            labc = -2;  // a row or a column tile K1 did not touch
-        } else if (cel.valid) {
-            const CellGrad g = cell_grad_setup(p, cel, c);
-            mulS = g.scale * jp.scal[0];
-            c0 = g.c0;
-            const float2 x = ((const float2 *)jp.xbl)[c];  // log2-scaled blank / label logits
-            const float cb = g.has_blank_corr ? hex2(x.x + g.nl + g.cb) : 0.f;
-            const float clb = g.has_label ? hex2(x.y + g.nl + g.cl) : 0.f;
-            const bool same = g.has_label && (g.lab == p.blank);
-            eb = mulS * (hex2(x.x + c0) - cb - (same ? clb : 0.f));
-            el = mulS * (hex2(x.y + c0) - clb);
-            labc = (g.has_label && !same) ? g.lab : -1;
-        }
-        sset[tid] = make_float4(mulS, c0, eb, el);
-        slab[tid] = labc;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kK2Per; ++k) {
-        if (cl[k] < 0) continue;
-        const int li = slab[cl[k]];
-        if (li == -2) continue;
-        const float4 st = sset[cl[k]];
-        const int vb = 8 * pj[k];
-        const float mult = st.x * hex2((float)rf[k] + st.y);
-        h8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (f16)(mult * (float)v[k][e]);
-        if (li == -1 && st.x == 0.f) {  // a padded column (u >= U_b) inside a live tile: exact zeros whatever was parked
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (f16)0.f;
-        }
-        const int ib = p.blank - vb, il = li - vb;
-        if ((unsigned)ib < 8u) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (e == ib) ? (f16)st.z : o[e];
-        }
-        if ((unsigned)il < 8u) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (e == il) ? (f16)st.w : o[e];
-        }
-        __builtin_nontemporal_store(o, (h8 *)(jp.dl + (size_t)(c0w + cl[k]) * V) + pj[k]);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K3: dh = dl . W2^T  ->  dz = dh (1 - h^2) / S  ->  sum_u (d enc_proj partial), sum_t (d pred_proj partial)
-// workgroup = (utterance, u-tile of 32, 128-wide J tile, row split); 8 waves as 4 (row pairs) x 2 (64 joint units);
-// per iteration 8 lattice rows x 32 columns = 256 cells; K = V in chunks of 64.
-// LDS per stage: A = dl tile [256 cells][64 v] + B = W2 tile [128 j][64 v], 128-byte rows, 16-byte chunks XOR-swizzled
-// by (row >> 1) & 7 (conflict-free b128 fragment reads); three stages (two chunks in flight under the MFMAs).
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void jh_dh_kernel(const JhParams jp) {
+template <int NT>
+__global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LossParams &p = jp.lp;
-    const int J = jp.J, V = p.V;
+    constexpr int J = 128 * NT, JW = 32 * NT;
+    constexpr uint32_t kBS = J * 64;                    // bytes of a W2 stage
+    constexpr uint32_t kAoff = 3 * kBS;                 // four A stages of 8 KB behind the three W2 stages
+    constexpr uint32_t kRoff = kAoff + 4 * 8192;        // four reference tiles [4 rows][32 columns] of shorts
+    constexpr uint32_t kCoff = kRoff + 4 * 256;         // 2 x [4 rows][128 units] floats: row sums of column half 1 on their way to half 0
+    constexpr uint32_t kLoff = kCoff + 4096;            // [32] ints: the tile's labels
+    const int V = p.V, NK = V >> 5;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, n = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 3, wn = wave >> 2;
-    constexpr int kStage = (256 + 128) * 128;  // three stages
+    const int wm = wave & 1, wn = wave >> 1;
+    float *const comb = (float *)(smem + kCoff);
+    const uint32_t smem0 = lds_addr(smem);
 
-    uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int n_jt = J >> 7;
-    const int jt = (int)(bid % (uint32_t)n_jt);
-    bid /= (uint32_t)n_jt;
+    const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
+    uint32_t bid = wg;
     const int ts = (int)(bid % (uint32_t)jp.n_ts);
     bid /= (uint32_t)jp.n_ts;
     const int ut = (int)(bid % (uint32_t)jp.n_ut);
-    const int b = p.b0 + (int)(bid / (uint32_t)jp.n_ut);  // the launch covers utterances [b0, b0 + nb)
-    const int u0 = ut * 32, j0 = jt * 128;
+    const int b = p.b0 + (int)(bid / (uint32_t)jp.n_ut);
+    const int u0 = ut * 32;
     const int Tb = length_T(p, b), Ub = length_U(p, b);
     const int t_begin = ts * jp.TS, t_end = min(min(t_begin + jp.TS, p.T), Tb);
     if (t_begin >= t_end || u0 >= Ub) return;
-
-    // pred_proj values of this lane's joint units at its 16 lattice columns; validity of those columns
-    const bool slow = jp.scal[2] != 0.f;  // kernel-uniform: tabulated e^{2x} factors unusable, fall back to tanh(a + c)
+    const bool parked = jp.state[0] == 1;  // kernel-uniform: dl holds parked numerators (else: dlogits from the recompute kernel)
+    const bool slow = jp.scal[2] != 0.f;   // kernel-uniform: tabulated e^{2x} factors unusable, fall back to tanh(a + c)
     const float *Etab = slow ? jp.enc_proj : jp.expE, *Ptab = slow ? jp.pred_proj : jp.expP;
-    float pr[2][16];
-    unsigned vmask = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int uu = u0 + cdrow(r, half);
-        if (uu < Ub) vmask |= 1u << r;
-        const size_t ro = ((size_t)b * p.U + min(uu, p.U - 1)) * J + j0 + wn * 64 + n;
-        pr[0][r] = Ptab[ro];
-        pr[1][r] = Ptab[ro + 32];
-    }
-    float accC[2][16];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accC[q][r] = 0.f;
-    const float c4 = 4.0f * jp.scal[1];  // 4 / S: (1 - h^2) is formed as 4 r (1 - r), S is the dlogits scale
-    const int NK = V >> 6;
+    const float c4 = 4.0f * jp.scal[1];    // 4 / S: (1 - h^2) is formed as 4 r (1 - r), S is the dlogits scale
+    const int Upad = jp.n_ut * 32;
 
-    // DMA descriptors of this wave: wave-instructions i = wave + 8 k (k = 0..5) of the 48 that fill one stage.  i < 32 are
-    // dl rows (row = 8 i + lane/8: lattice row offset i/4, column offset 8 (i&3) + lane/8), i >= 32 are W2 rows.
-    // Everything but the lattice row t and the chunk index is fixed per lane: keep it in registers.
-    uint32_t doff[6];  // element offset inside the row block
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const int i = wave + 8 * k;
-        const int row = (i < 32 ? i : i - 32) * 8 + (lane >> 3);
-        const int ck = (lane & 7) ^ ((row >> 1) & 7);
-        if (i < 32) doff[k] = (uint32_t)min(u0 + (row & 31), p.U - 1) * (uint32_t)V + (uint32_t)(ck * 8);
-        else doff[k] = (uint32_t)(j0 + row) * (uint32_t)V + (uint32_t)(ck * 8);
-    }
-#ifdef JH_TRACE
-    long long *tr = (blockIdx.x == 200) ? jp.trace + (size_t)(kTraceBlocks * 8 + 8 + wave) * kTraceSlots : nullptr;
-    int tstep = 0;
+    // ---- this thread's piece of the A operand: LDS row `slot` (MFMA row tile slot >> 5; row m of a tile = lattice row m >> 3, column
+    // m & 7), 16-byte position tid & 3 of it -- which holds the row's chunk lc (swizzle).  The lane that brings the piece in (LDS-DMA:
+    // lane-linear image) is the lane that converts it.  Everything here is RECOMPUTED from the thread index where it is needed (Geo
+    // of a laundered copy): kept in registers through the main loop, beside 32 NT accumulators, it was spilled, and the compiler
+    // waits vmcnt(0) -- for every LDS-DMA piece in flight -- behind a scratch reload.  The column's label sits in LDS for the same reason.
+    struct Geo {
+        int slot, lc, crow, ccol, cu;
+    };
+    auto geo_of = [&](const int t2) -> Geo {
+        Geo g;
+        g.slot = t2 >> 2, g.lc = (t2 & 3) ^ ((g.slot >> 2) & 3);
+        g.crow = (g.slot & 31) >> 3, g.ccol = 8 * (g.slot >> 5) + (g.slot & 7);
+        g.cu = u0 + g.ccol;
+        return g;
+    };
+    int *const labtab = (int *)(smem + kLoff);  // [32 columns]: the label that leaves the column's cells (clamped), -1 where there is none
+    if (tid < 32) labtab[tid] = (u0 + tid < Ub - 1) ? clamp_label(p.labels[(size_t)b * (p.U - 1) + u0 + tid], V) : -1;
+    __syncthreads();
+    const double ll2 = p.ll[2 * b];
+    const float cscale = (p.cost_scale ? p.cost_scale[b] : 1.0f) * jp.scal[0];
+    // wave-uniform bases (scalar registers); everything per lane is a 32-bit offset from one of them
+    const float *const offA_b = p.offA + (size_t)b * p.NC * p.NG, *const offB_b = p.offB + (size_t)b * p.NC * p.NG;
+    const float *const A_b = p.A + (size_t)b * p.Nr * p.Up, *const Bt_b = p.Bt + (size_t)b * p.Nr * p.Up;
+    auto row_block = [&](const int t) -> size_t { return ((size_t)(b * p.T + t) * p.U + u0); };  // first cell of the tile's row t
+
+    struct CellSt {    // what the conversion of this thread's cell row needs, per iteration
+        uint32_t off;  // byte offset of the thread's piece from the iteration's dl row block (row and column clamped into what K1 wrote)
+        int flags;     // 1: the cell row exists in the tensor (store it); 2: it is a lattice cell of the utterance (else: zeros)
+        float c0, eb, el;
+    };
+    auto cell_place = [&](CellSt &c, const int t_it) {
+        const Geo g = geo_of(launder(tid));
+        const int ct = t_it + g.crow;
+        const bool row_live = ct < t_end;
+        c.flags = ((row_live && g.cu < p.U) ? 1 : 0) | ((row_live && g.cu < Ub) ? 2 : 0);
+        const int ccol_c = min(g.cu, p.U - 1) - u0;  // (the column this thread LOADS: clamped into the tensor)
+        c.off = ((uint32_t)((min(ct, t_end - 1) - t_it) * p.U + ccol_c) * (uint32_t)V + (uint32_t)g.lc * 8u) * 2u;
+        c.c0 = kNeg, c.eb = 0.f, c.el = 0.f;
+    };
+    // cell_grad_from + K2's edge terms (ordinary loads: called where no LDS-DMA needs to stay in flight -- prologue and epilogue)
+    auto cell_factors = [&](CellSt &c, const int t_it) {
+        if (!((c.flags & 2) && parked)) return;
+        const Geo g = geo_of(launder(tid));
+        const int cu = g.cu, lab = labtab[g.ccol];
+        const bool has_label = lab >= 0, same = lab == p.blank;
+        const uint32_t og0 = fdiv((uint32_t)cu, p.divOG), og1 = fdiv((uint32_t)cu + 1u, p.divOG);
+        const int ct = t_it + g.crow, nd = ct + cu;
+        const uint32_t kc_ = (uint32_t)nd / kRebase, kc1 = (uint32_t)(nd + 1) / kRebase;
+        const uint32_t sk = (uint32_t)nd * (uint32_t)p.Up + (uint32_t)cu;
+        const float a = A_b[sk], bt = Bt_b[sk];
+        const float b_t1 = (ct < Tb - 1) ? Bt_b[sk + p.Up] : 0.f;
+        const float b_u1 = has_label ? Bt_b[sk + p.Up + 1] : 0.f;
+        const float oa = offA_b[kc_ * p.NG + og0], obt = offB_b[kc_ * p.NG + og0];
+        const float ob_t1 = offB_b[kc1 * p.NG + og0], ob_u1 = offB_b[kc1 * p.NG + og1];
+        const size_t c0w = row_block(t_it);  // uniform
+        const uint32_t co = (uint32_t)(g.crow * p.U + g.ccol);
+        const float lse = (p.lse + c0w)[co];
+        const float2 x = ((const float2 *)jp.xbl + c0w)[co];
+        const double da = (double)a + ((double)oa - ll2);
+        const float nl = -lse * kLog2e;
+        const float c0 = (float)(da + ((double)bt + (double)obt)) + nl;
+        float cb = 0.f;
+        bool has_bc = true;
+        if (ct < Tb - 1) cb = (float)(da + ((double)b_t1 + (double)ob_t1));
+        else if (cu == Ub - 1) cb = (float)da;
+        else has_bc = false;
+        const float cl = has_label ? (float)(da + ((double)b_u1 + (double)ob_u1)) : 0.f;
+        const float cbv = has_bc ? hex2(x.x + nl + cb) : 0.f;
+        const float clb = has_label ? hex2(x.y + nl + cl) : 0.f;
+        c.c0 = c0;
+        c.eb = cscale * (hex2(x.x + c0) - cbv - (same ? clb : 0.f));
+        c.el = cscale * (hex2(x.y + c0) - clb);
+    };
+    // LDS-DMA of one step, per wave: its 1 KB of the A stage (16 cell rows x 64 B of parked values), the step's reference tile (every
+    // wave brings the same 256 bytes: the waves' counts of outstanding pieces stay equal), NT pieces (16 W2 rows each) of the W2 stage
+    auto dma_a = [&](const CellSt &c, const int t, const int kc, const int sa) {  // t = first row of the chunk's iteration: uniform
+#ifdef DHX_A_HOT
+        const char *base = (const char *)(jp.dl + row_block(t_begin) * V + (kc & 1) * 32);
+#else
+        const char *base = (const char *)(jp.dl + row_block(t) * V + kc * 32);
 #endif
-    // The LDS stages form ONE pipeline over all (iteration, chunk) pairs of the workgroup: two chunks are always in
-    // flight, also across the epilogue of an iteration.  Prefetch cursor: iteration row tp, chunk kp, stage sp.
-    int tp = t_begin, kp = 0, sp = 0;
-    const f16 *arowP[4];  // wave-uniform dl row blocks of the prefetch iteration's four lattice rows of this wave
-    auto set_arow = [&]() {
+#ifdef DHX_A_NT
+        lds_dma16_s_nt(base, c.off, smem0 + kAoff + sa * 8192 + wave * 1024);
+#else
+        lds_dma16_s(base, c.off, smem0 + kAoff + sa * 8192 + wave * 1024);
+#endif
+        const int rmax = t_end - 1 - t;  // rows of the tile beyond the strip read the last one's references (unused)
+        const char *rb = (const char *)(jp.pref + ((size_t)(b * p.T + t) * NK + kc) * Upad + u0);
+        const int ln = launder(tid) & 63;
+        const uint32_t ro = (uint32_t)min(ln >> 4, rmax) * (uint32_t)(NK * Upad * 2) + (uint32_t)(ln & 15) * 4u;
+        lds_dma4_s(rb, ro, smem0 + kRoff + sa * 256);
+    };
+    const uint32_t boff = (uint32_t)(16 * wave + (lane >> 2)) * 64u + (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);  // bytes; piece k: + 8192 k
+    auto dma_b = [&](const int kc, const int sb, const int k) {
+#ifdef DHX_NO_B
+        return;
+#endif
+        const char *src = (const char *)(jp.W2c + (size_t)kc * (J * 32)) + k * 8192;  // uniform
+        lds_dma16_s(src, boff, smem0 + sb * kBS + (wave + 8 * k) * 1024);
+    };
+    // the A piece in stage sa: parked values -> dlogits (K2's arithmetic), in place in LDS and, for K4, in dl
+    auto a_convert = [&](const CellSt &c, const int kc, const int sa) -> h8 {
+        const int t2 = launder(tid);
+        const Geo g = geo_of(t2);
+        h8 *const pa = (h8 *)(smem + kAoff + sa * 8192 + t2 * 16);
+        const h8 v = *pa;
+        h8 o = v;
+        if (parked) {
+            const float rf = (float)*(const short *)(smem + kRoff + sa * 256 + (g.crow * 32 + g.ccol) * 2);
+            const int lab = labtab[g.ccol];
+            const float mult = ((c.flags & 2) ? cscale : 0.f) * hex2(rf + c.c0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int trw = min(tp + ((wave + 8 * k) >> 2), t_end - 1);
-            arowP[k] = jp.dl + (size_t)(b * p.T + trw) * p.U * V;
+            for (int e = 0; e < 8; ++e) o[e] = (f16)(mult * (float)v[e]);
+            const int vb = 32 * kc + 8 * g.lc, ib = p.blank - vb, il = ((lab >= 0 && lab != p.blank) ? lab : -1) - vb;
+            if ((unsigned)ib < 8u) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (e == ib) ? (f16)c.eb : o[e];
+            }
+            if ((unsigned)il < 8u) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (e == il) ? (f16)c.el : o[e];
+            }
         }
-    };
-    set_arow();
-    auto dma_piece = [&](const int k) {  // piece k (0..5) of the chunk under the prefetch cursor
-        const f16 *src = (k < 4 ? arowP[k] : jp.W2h) + doff[k] + kp * 64;
-        lds_dma16(src, smem + sp * kStage + (wave + 8 * k) * 1024);
-    };
-    auto advance = [&]() {  // move the prefetch cursor to the next chunk
-        sp = (sp == 2) ? 0 : sp + 1;
-        if (++kp == NK) {
-            kp = 0;
-            tp += 8;
-            if (tp < t_end) set_arow();
+        if (!(c.flags & 2)) {  // a padded column inside a live tile / a row beyond the strip: exact zeros whatever the memory holds
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (f16)0.f;
         }
+        *pa = o;
+        return o;
     };
-    bool pf_live = true;  // the cursor points at a chunk that exists
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int k = 0; k < 6; ++k) dma_piece(k);
-    advance();
-    pf_live = tp < t_end;
-    if (pf_live) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) dma_piece(k);
-            advance();
-        pf_live = tp < t_end;
-    }
-    int sc = 0;  // stage of the chunk being multiplied
+    // ... and its way back to dl.  Issued at the START of the next step, in front of that step's LDS-DMA: the wait at the top of a
+    // step allows the NT + 2 youngest operations to be outstanding, and those must be exactly the last step's DMA pieces.
+    auto a_store = [&](const h8 o, const CellSt &c, const int t, const int kc) {
+#ifndef DHX_NOSTORE
+        if ((c.flags & 1) && parked) {
+            char *base = (char *)(jp.dl + row_block(t) * V + kc * 32);
+#ifdef DHX_PLAINSTORE
+            *(h8 *)(base + (uint32_t)launder((int)c.off)) = o;
+#else
+            __builtin_nontemporal_store(o, (h8 *)(base + (uint32_t)launder((int)c.off)));
+#endif
+        }
+#endif
+    };
 
-    for (int t_it = t_begin; t_it < t_end; t_it += 8) {
-        f32x16 acc[2][2];
+    // fragment read offsets of this lane (row n of a 32-row tile, k-step ks)
+    const int sw = (n >> 2) & 3;
+    const uint32_t foff0 = (uint32_t)(n * 64 + ((half ^ sw) * 16)), foff1 = (uint32_t)(n * 64 + (((2 + half) ^ sw) * 16));
+    const uint32_t a_rd = kAoff + (uint32_t)((2 * wm) * 2048);  // + stage * 8192 + mi * 2048
+    const uint32_t b_rd = (uint32_t)((wn * JW) * 64);           // + stage * kBS + ni * 2048
+
+    // ---- prologue: factors of the first two iterations; chunks 0..2 of A, 0..1 of W2 under way; chunk 0 converted
+    CellSt cur, nxt;
+    cell_place(cur, t_begin);
+    cell_factors(cur, t_begin);
+    nxt = cur;
+    if (t_begin + 4 < t_end) {
+        cell_place(nxt, t_begin + 4);
+        cell_factors(nxt, t_begin + 4);
+    }
+    dma_a(cur, t_begin, 0, 0);
+#pragma unroll
+    for (int k = 0; k < NT; ++k) dma_b(0, 0, k);
+    dma_a(cur, t_begin, 1, 1);
+#pragma unroll
+    for (int k = 0; k < NT; ++k) dma_b(1, 1, k);
+    dma_a(cur, t_begin, 2, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    h8 o_pend = a_convert(cur, 0, 0);  // the converted piece whose store is pending (chunk pk of the iteration at row pt, state pst)
+    a_store(o_pend, cur, t_begin, 0);
+    bool pend = false;
+    bool pend_next = false;
+    int pk = 0;
+    int sb = 0;  // W2 stage of the chunk being multiplied (the A stage is kc & 3)
+    bool first = true;
+#ifdef JH_TRACE
+    long long *tr = (wg == 200) ? jp.trace + (size_t)(kTraceBlocks * 8 + 8 + wave) * kTraceSlots : nullptr;
+    int tstep = 0;
+#define DT(k)                                                                                          \
+    do {                                                                                               \
+        if (tr && tstep < 22 && lane == 0) tr[7 * tstep + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define DT(k) do { } while (0)
+#endif
+
+    for (int t_it = t_begin; t_it < t_end; t_it += 4) {
+        const bool has_next = t_it + 4 < t_end;
+        f32x16 acc[2][NT];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-        // enc_proj factors of the epilogue, fetched now (their latency hides under the K loop)
-        float ejv[2][2];
+        for (int kg = 0; kg < NK; kg += 4) {
+            const bool last_group = kg + 4 >= NK;  // uniform
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+            for (int q = 0; q < 4; ++q) {
+                const int kc = kg + q;
+                // Chunk (t_it, kc) must be complete: its W2 pieces and the raw A piece of the chunk converted in THIS step were issued
+                // two steps ago; the last step issued NT + 2 pieces behind them (its store, if counted at all, in front of them), so
+                // "at most NT + 2 outstanding" means everything up to two steps ago has landed.  The converted A pieces of the chunk:
+                // LDS writes of the last step.  The first step of an iteration follows an epilogue with ordinary loads and stores, the
+                // last steps of a workgroup issue less: drain there.
+                DT(0);
+                if (kc == 0 || (!has_next && last_group)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT + 2) : "memory");
+                wait_lgkm();
+                DT(1);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                DT(2);
+                const int sb1 = (sb == 2) ? 0 : sb + 1, sb2 = (sb1 == 2) ? 0 : sb1 + 1;
+                // what this step prepares: the converted A piece of chunk +1, W2 chunk +2, the raw A piece of chunk +3
+                const bool x1 = last_group && q + 1 >= 4, x2 = last_group && q + 2 >= 4, x3 = last_group && q + 3 >= 4;  // ... lies in the next iteration
+                const bool e1 = !x1 || has_next, e2 = !x2 || has_next, e3 = !x3 || has_next;                            // ... exists
+                const int k1 = x1 ? kc + 1 - NK : kc + 1, k2 = x2 ? kc + 2 - NK : kc + 2, k3 = x3 ? kc + 3 - NK : kc + 3;
+                // fragment reads: k-step 0 and the A side of k-step 1 first; the W2 fragments of k-step 1 follow their k-step-0
+                // counterparts into the registers those leave (56 registers of fragments would not fit beside 32 NT accumulators)
+                h8 a[2][2], bf[NT];
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-                ejv[mi][ni] = Etab[((size_t)b * p.T + min(t_it + 2 * wm + mi, t_end - 1)) * J + j0 + wn * 64 + ni * 32 + n];
-        for (int kc = 0; kc < NK; ++kc) {
-#ifdef JH_TRACE
-            const bool tron = tr && tstep < 52;
-            if (tron && lane == 0) tr[3 * tstep] = (long long)__builtin_amdgcn_s_memtime();
-#endif
-            // chunk (t_it, kc) must have landed.  The first chunk of an iteration follows an epilogue whose stores
-            // share vmcnt with the DMA (and may retire out of order): drain everything there (the two chunks in flight
-            // were issued before the epilogue, long ago); otherwise all but the newest stage.
-            const bool last_chunk = (t_it + 8 >= t_end) && (kc == NK - 1);
-            if (kc == 0 || last_chunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // chunk complete in LDS; the stage under the prefetch cursor is free
-            asm volatile("" ::: "memory");
-#ifdef JH_TRACE
-            if (tron && lane == 0) tr[3 * tstep + 1] = (long long)__builtin_amdgcn_s_memtime();
-            if (tron && lane == 0) tr[3 * tstep + 2] = (long long)__builtin_amdgcn_s_memtime();
-            ++tstep;
-#endif
-            if (kc == 1) asm volatile("" ::"v"(ejv[0][0]), "v"(ejv[0][1]), "v"(ejv[1][0]), "v"(ejv[1][1]));
-            const char *A = smem + sc * kStage, *Bm = A + 256 * 128;
-            h8 a[2][2], bf[2][2];  // fragments of k-step ks in [ks & 1]: read one k-step ahead of their MFMAs
-            auto rd = [&](const int ks, h8 (&aa)[2], h8 (&bb)[2]) {
+                for (int mi = 0; mi < 2; ++mi) a[0][mi] = *(const h8 *)(smem + a_rd + q * 8192 + mi * 2048 + foff0);
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    const int row = (2 * wm + mi) * 32 + n;
-                    aa[mi] = *(const h8 *)(A + row * 128 + (((ks * 2 + half) ^ ((row >> 1) & 7)) * 16));
-                }
+                for (int ni = 0; ni < NT; ++ni) bf[ni] = *(const h8 *)(smem + b_rd + sb * kBS + ni * 2048 + foff0);
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const int row = wn * 64 + ni * 32 + n;
-                    bb[ni] = *(const h8 *)(Bm + row * 128 + (((ks * 2 + half) ^ ((row >> 1) & 7)) * 16));
-                }
-            };
-            rd(0, a[0], bf[0]);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (ks + 1 < 4) rd(ks + 1, a[(ks + 1) & 1], bf[(ks + 1) & 1]);
+                for (int mi = 0; mi < 2; ++mi) a[1][mi] = *(const h8 *)(smem + a_rd + q * 8192 + mi * 2048 + foff1);
                 __builtin_amdgcn_sched_barrier(0);
-                // the six LDS-DMA pieces of the chunk two ahead are issued between the MFMA groups (2 + 2 + 2)
-                if (pf_live && ks < 3) {
-                    dma_piece(2 * ks);
-                    dma_piece(2 * ks + 1);
+                if (pend) {
+                    if (pend_next) a_store(o_pend, nxt, t_it + 4, pk);
+                    else a_store(o_pend, cur, t_it, pk);
                 }
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks & 1][mi], bf[ks & 1][ni], acc[mi][ni], 0, 0, 0);
+#ifdef DHX_A_FIRST
+                if (e3) {
+                    if (x3) dma_a(nxt, t_it + 4, k3, (q + 3) & 3);
+                    else dma_a(cur, t_it, k3, (q + 3) & 3);
+                }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
+                DT(5);
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) {
+                    if (e2) dma_b(k2, sb2, ni);
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mi], bf[ni], acc[mi][ni], 0, 0, 0);
+                    bf[ni] = *(const h8 *)(smem + b_rd + sb * kBS + ni * 2048 + foff1);
+                }
+#ifndef DHX_A_FIRST
+                if (e3) {
+                    if (x3) dma_a(nxt, t_it + 4, k3, (q + 3) & 3);
+                    else dma_a(cur, t_it, k3, (q + 3) & 3);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                DT(6);
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) {
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][mi], bf[ni], acc[mi][ni], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                DT(3);
+                // the conversion of the next chunk's A piece comes LAST: its ~40 temporaries do not fit beside the fragments, and
+                // its VALU work runs under the MFMAs the wave has just queued
+                pend = e1, pend_next = x1, pk = k1;
+#ifdef DHX_NOCONV
+                if (false) {
+#else
+                if (e1) {
+#endif
+                    if (x1) o_pend = a_convert(nxt, k1, (q + 1) & 3);
+                    else o_pend = a_convert(cur, k1, (q + 1) & 3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                DT(4);
+#ifdef JH_TRACE
+                ++tstep;
+#endif
+                sb = sb1;
             }
-            if (pf_live) {
-                            advance();
-                pf_live = tp < t_end;
-            }
-            sc = (sc == 2) ? 0 : sc + 1;
         }
-        // epilogue: acc[mi][ni][r] = S * dh[row t_it + 2 wm + mi][column u0 + cdrow(r, half)][unit j0 + 64 wn + 32 ni + n]
+#ifdef DHX_NOEPI
+        {
+            float z = 0.f;
+            for (int mi = 0; mi < 2; ++mi)
+                for (int ni = 0; ni < NT; ++ni)
+                    for (int r = 0; r < 16; ++r) z += acc[mi][ni][r];
+            if (z == 1.2345f) jp.dApart[0] = z;
+            first = false;
+            cur = nxt;
+            pend_next = false;
+            continue;
+        }
+#endif
+        // ---- epilogue: acc[mi][ni][r] = S dh[row t_it + (r >> 2)][column u0 + 16 wm + 8 mi + 4 half + (r & 3)][unit JW wn + 32 ni + n]
+        const bool last = !has_next;
+        // What a row tile of a 32-unit tile reads -- the enc-side factors of the 4 rows (per unit tile), the pred-side factors of
+        // this lane's 4 columns, the running column sums -- is loaded one tile AHEAD of its arithmetic (loaded where it was used,
+        // every tile paid a full memory latency three times: 6.9 of the kernel's 18.7 ms at config 5); the row sums are handed from
+        // column half 1 to half 0 per unit tile (two 2 KB buffers, one barrier each), so that 4, not 4 NT, of them are alive.
+        struct EpiT {
+            float pr[4];
+            float4 cs;
+        };
+        auto load_ej = [&](float (&ej)[4], const int ni) {
+            const int jw = wn * JW + ni * 32;  // uniform; this lane's unit: jw + n
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int t = t_it + 2 * wm + mi;
-            if (t < t_end) {
+            for (int rw = 0; rw < 4; ++rw) ej[rw] = (Etab + ((size_t)b * p.T + min(t_it + rw, t_end - 1)) * J + jw)[n];
+        };
+        auto load_tile = [&](EpiT &in, const int ni, const int mi) {
+            const int jw = wn * JW + ni * 32, ubw = u0 + 16 * wm + 8 * mi;  // uniform; this lane's columns: ubw + 4 half + 0..3
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const int j = j0 + wn * 64 + ni * 32 + n;
-                    const float ej = ejv[mi][ni];
-                    float colsum = 0.f;
-                    // q = (1 - h^2) / 4 = r (1 - r) with r = 1 / (1 + e^{2(a + c)}): multiply-add, reciprocal, multiply-add;
-                    // the factor 4 / S is applied once per output (column sums here, accC after the row loop)
-                    float q[16];
+            for (int cq = 0; cq < 4; ++cq)
+                in.pr[cq] = (Ptab + (size_t)b * p.U * J + jw)[(uint32_t)min(ubw + 4 * half + cq, p.U - 1) * (uint32_t)J + (uint32_t)n];
+            // (read even in the first iteration, where nothing has been written yet: the value is dropped below)
+            in.cs = ((const float4 *)jp.dCacc + ((((size_t)wg * 8 + wave) * 2 + mi) * NT + ni) * 64)[lane];
+        };
+        float ejp[2][4];
+        EpiT tin[2];
+        load_ej(ejp[0], 0);
+        load_tile(tin[0], 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            const int jw = wn * JW + ni * 32;
+            float rs[4] = {0.f, 0.f, 0.f, 0.f};  // per row of the iteration: sum over this wave's 16 columns of dz, this lane's unit
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int idx = 2 * ni + mi;
+                if (idx + 1 < 2 * NT) {
+                    if (mi == 1) load_ej(ejp[(ni + 1) & 1], ni + 1);
+                    load_tile(tin[(idx + 1) & 1], (idx + 1) >> 1, (idx + 1) & 1);
+                }
+                const EpiT &in = tin[idx & 1];
+                const float(&ej)[4] = ejp[ni & 1];
+                const int ubw = u0 + 16 * wm + 8 * mi;
+                float4 *const cslot = (float4 *)jp.dCacc + ((((size_t)wg * 8 + wave) * 2 + mi) * NT + ni) * 64;  // uniform; + lane
+                float4 cs = first ? make_float4(0.f, 0.f, 0.f, 0.f) : in.cs;
+                float dz[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // q = (1 - h^2) / 4 = r (1 - r) with r = 1 / (1 + e^{2(a + c)}); the factor 4 / S is applied once per output
+                    float qv;
                     if (!slow) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float rr = __builtin_amdgcn_rcpf(fmaf(ej, pr[ni][r], 1.0f));
-                            q[r] = fmaf(-rr, rr, rr);
-                        }
+                        const float rr = __builtin_amdgcn_rcpf(fmaf(ej[r >> 2], in.pr[r & 3], 1.0f));
+                        qv = fmaf(-rr, rr, rr);
                     } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float h = htanh(ej + pr[ni][r]);
-                            q[r] = 0.25f * fmaf(-h, h, 1.0f);
-                        }
+                        const float h = htanh(ej[r >> 2] + in.pr[r & 3]);
+                        qv = 0.25f * fmaf(-h, h, 1.0f);
                     }
-                    if (u0 + 32 <= Ub) {  // workgroup-uniform: every column of the tile is a real cell
+                    dz[r] = acc[mi][ni][r] * qv;
+                }
+                cs.x += (dz[0] + dz[4]) + (dz[8] + dz[12]);
+                cs.y += (dz[1] + dz[5]) + (dz[9] + dz[13]);
+                cs.z += (dz[2] + dz[6]) + (dz[10] + dz[14]);
+                cs.w += (dz[3] + dz[7]) + (dz[11] + dz[15]);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float dz = acc[mi][ni][r] * q[r];
-                            accC[ni][r] += dz;
-                            colsum += dz;
-                        }
-                    } else {
+                for (int rw = 0; rw < 4; ++rw) rs[rw] += (dz[4 * rw] + dz[4 * rw + 1]) + (dz[4 * rw + 2] + dz[4 * rw + 3]);
+                if (!last) {
+                    cslot[lane] = cs;
+                } else {  // the strip is done: the d pred_proj partial of this row split
+                    const float cv[4] = {cs.x, cs.y, cs.z, cs.w};
+                    float *const crow_out = jp.dCpart + (((size_t)ts * p.B + b) * p.U) * J + jw;  // uniform
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            float dz = acc[mi][ni][r] * q[r];
-                            dz = ((vmask >> r) & 1u) ? dz : 0.f;
-                            accC[ni][r] += dz;
-                            colsum += dz;
-                        }
+                    for (int cq = 0; cq < 4; ++cq) {
+                        const int uu = ubw + 4 * half + cq;
+                        if (uu < p.U) crow_out[(uint32_t)uu * (uint32_t)J + (uint32_t)n] = cv[cq] * c4;
                     }
-                    colsum *= c4;
-                    colsum += __shfl_xor(colsum, 32);
-                    if (lane < 32) jp.dApart[(((size_t)ut * p.B + b) * p.T + t) * J + j] = colsum;
                 }
             }
+            // d enc_proj partial rows of the unit tile: the two half-lanes of a unit, then the two column halves
+            float *const cb = comb + (ni & 1) * 512;  // [4 rows][4 wn x 32 units]
+#pragma unroll
+            for (int rw = 0; rw < 4; ++rw) rs[rw] += __shfl_xor(rs[rw], 32);
+            if (wm == 1 && lane < 32) {
+#pragma unroll
+                for (int rw = 0; rw < 4; ++rw) cb[rw * 128 + wn * 32 + n] = rs[rw];
+            }
+            __syncthreads();
+            if (wm == 0 && lane < 32) {
+#pragma unroll
+                for (int rw = 0; rw < 4; ++rw)
+                    if (t_it + rw < t_end)
+                        (jp.dApart + (((size_t)ut * p.B + b) * p.T + t_it + rw) * J + jw)[n] = (rs[rw] + cb[rw * 128 + wn * 32 + n]) * c4;
+            }
         }
-    }
-    // d pred_proj partial: sum the four row-pair waves in a fixed order through LDS
-    __syncthreads();
-    float *red = (float *)smem;  // [wm 4][wn 2][ni 2][32 rows][33]
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[(((wm * 2 + wn) * 2 + ni) * 32 + cdrow(r, half)) * 33 + n] = accC[ni][r] * c4;
-    __syncthreads();
-    for (int e = tid; e < 32 * 128; e += 512) {
-        const int uu = e >> 7, jj = e & 127, wn2 = jj >> 6, ni = (jj >> 5) & 1, nn = jj & 31;
-        float s = 0.f;
-        for (int w = 0; w < 4; ++w) s += red[(((w * 2 + wn2) * 2 + ni) * 32 + uu) * 33 + nn];
-        if (u0 + uu < p.U) jp.dCpart[(((size_t)ts * p.B + b) * p.U + u0 + uu) * J + j0 + jj] = s;
+        // the factors of the iteration after the next (its first chunk is converted in the last step of the next one)
+        CellSt nn = nxt;
+        if (t_it + 8 < t_end) {
+            cell_place(nn, t_it + 8);
+            cell_factors(nn, t_it + 8);
+        }
+        first = false;
+        cur = nxt, nxt = nn;
+        pend_next = false;  // (the piece converted in the last step belongs to what is now the current iteration)
     }
 }
 
@@ -1155,7 +1285,7 @@ __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(
 // ---------------------------------------------------------------------------------------------
 struct JhLayout {
     WsLayout w;
-    size_t W2Tp, W2h, dl, pref, xbl, scal, expE, expP, b2l, dApart, dCpart, zrow, dWpart, dbpart, total;
+    size_t W2Tp, W2c, dCacc, dl, pref, xbl, scal, expE, expP, b2l, dApart, dCpart, zrow, dWpart, dbpart, total;
     int n_ut, n_tt, n_ts, TS, n_tq, n_units, n_ranges;
 };
 
@@ -1196,9 +1326,10 @@ static JhLayout make_jh_layout(int T, int U, int B, int J, int V) {
     };
     const size_t cells = (size_t)B * T * U;
     L.W2Tp = take((size_t)J * V * 2);
-    L.W2h = take((size_t)J * V * 2);
+    L.W2c = take((size_t)J * V * 2);
+    L.dCacc = take((size_t)B * L.n_ut * L.n_ts * 8 * 2 * (J / 128) * 64 * 16);
     L.dl = take(cells * V * 2);
-    L.pref = take(cells * (size_t)(V / 32) * sizeof(short));
+    L.pref = take((size_t)B * T * (size_t)(V / 32) * (size_t)(L.n_ut * 32) * sizeof(short));
     L.xbl = take(cells * 2 * sizeof(float));
     L.scal = take(64);
     L.expE = take((size_t)B * T * J * sizeof(float));
@@ -1289,7 +1420,7 @@ static hipError_t jh_fill_params(JhParams &jp, const JhLayout &L, const float *e
         return hipErrorInvalidValue;
     char *ws = (char *)workspace;
     jp.enc_proj = enc_proj, jp.pred_proj = pred_proj, jp.W2 = W2, jp.b2 = b2;
-    jp.W2Tp = (f16 *)(ws + L.W2Tp), jp.W2h = (f16 *)(ws + L.W2h), jp.dl = (f16 *)(ws + L.dl);
+    jp.W2Tp = (f16 *)(ws + L.W2Tp), jp.W2c = (f16 *)(ws + L.W2c), jp.dCacc = (float *)(ws + L.dCacc), jp.dl = (f16 *)(ws + L.dl);
     jp.pref = (short *)(ws + L.pref);
     jp.xbl = (float *)(ws + L.xbl), jp.scal = (float *)(ws + L.scal);
     jp.state = (int *)(ws + L.scal) + 8;  // behind the words the prep kernel owns (zeroed before it runs, 32 bytes)
@@ -1299,7 +1430,6 @@ static hipError_t jh_fill_params(JhParams &jp, const JhLayout &L, const float *e
     jp.zrow = (const f16 *)(ws + L.zrow);
     jp.J = J, jp.n_ut = L.n_ut, jp.n_tt = L.n_tt, jp.n_ts = L.n_ts, jp.TS = L.TS, jp.n_tq = L.n_tq;
     jp.n_units = L.n_units, jp.n_ranges = L.n_ranges;
-    jp.div_ppc = make_fastdiv((uint32_t)(V >> 3));
     jp.logits_out = nullptr, jp.logits_only = 0;
     jp.b2_lds_off = -1;
 #ifdef JH_TRACE
@@ -1390,20 +1520,26 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     // are enqueued; the one whose precondition does not hold returns at once.
     // (Cutting the batch into utterance ranges and converting range q + 1 on a second stream beside the dh kernel of range q
     // was measured at config 5: the two kernels do overlap, and slow each other down by as much as the overlap hides.)
-    {
-        const unsigned cw = (unsigned)(kK2Span / (V >> 3)), cells = (unsigned)B * T * U;
-        hipLaunchKernelGGL(jh_dlogits_kernel, dim3((cells + cw - 1) / cw), dim3(256), 0, s, jp);
-    }
-    if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = logits(2)) != hipSuccess) return e;
     // dC partials + the zero row (the dA partials need no zero-fill: launch_reduce_enc reads only the rows K3 writes)
     if (launch_fill(jp.dCpart, 0, L.dWpart - L.dCpart, s) != hipSuccess) return hipErrorUnknown;
     {
-        const size_t shm = 3 * (size_t)(256 + 128) * 128;
-        if ((e = set_lds_f16(jh_dh_kernel, shm)) != hipSuccess) return e;
-        const unsigned grid = (unsigned)B * L.n_ut * L.n_ts * (J / 128);
-        hipLaunchKernelGGL(jh_dh_kernel, dim3(grid), dim3(512), shm, s, jp);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
+        const size_t shm = 3 * (size_t)(J * 64) + 4 * 8192 + 4 * 256 + 4096 + 128;  // W2 stages, A stages, reference tiles, hand-over rows, labels
+        const unsigned grid = (unsigned)B * L.n_ut * L.n_ts;
+        auto go = [&](auto kernel) -> hipError_t {
+            hipError_t e2 = set_lds_f16(kernel, shm);
+            if (e2 != hipSuccess) return e2;
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), shm, s, jp);
+            return hipGetLastError();
+        };
+        switch (J / 128) {
+            case 1: e = go(jh_dhx_kernel<1>); break;
+            case 2: e = go(jh_dhx_kernel<2>); break;
+            case 3: e = go(jh_dhx_kernel<3>); break;
+            case 4: e = go(jh_dhx_kernel<4>); break;
+            default: e = go(jh_dhx_kernel<5>); break;
+        }
+        if (e != hipSuccess) return e;
     }
     if ((e = set_state(2)) != hipSuccess) return e;
     {
