@@ -95,9 +95,6 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
 __device__ __forceinline__ void lds_dma16_s(const void *base, uint32_t lane_off, uint32_t lds) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(base), "s"(lds) : "m0");
 }
-__device__ __forceinline__ void lds_dma16_s_nt(const void *base, uint32_t lane_off, uint32_t lds) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(lane_off), "s"(base), "s"(lds) : "m0");
-}
 __device__ __forceinline__ void lds_dma4_s(const void *base, uint32_t lane_off, uint32_t lds) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(lane_off), "s"(base), "s"(lds) : "m0");
 }
@@ -662,6 +659,10 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
     const float *const offA_b = p.offA + (size_t)b * p.NC * p.NG, *const offB_b = p.offB + (size_t)b * p.NC * p.NG;
     const float *const A_b = p.A + (size_t)b * p.Nr * p.Up, *const Bt_b = p.Bt + (size_t)b * p.Nr * p.Up;
     auto row_block = [&](const int t) -> size_t { return ((size_t)(b * p.T + t) * p.U + u0); };  // first cell of the tile's row t
+    // the strip's first dl row block / reference row, and the byte pitch of a lattice row in both
+    const char *const dl_s = (const char *)(jp.dl + row_block(t_begin) * V);
+    const char *const rf_s = (const char *)(jp.pref + ((size_t)(b * p.T + t_begin) * NK) * Upad + u0);
+    const uint32_t dl_pitch = (uint32_t)p.U * (uint32_t)V * 2u, rf_pitch = (uint32_t)NK * (uint32_t)Upad * 2u;
 
     struct CellSt {    // what the conversion of this thread's cell row needs, per iteration
         uint32_t off;  // byte offset of the thread's piece from the iteration's dl row block (row and column clamped into what K1 wrote)
@@ -678,109 +679,128 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
         c.c0 = kNeg, c.eb = 0.f, c.el = 0.f;
     };
     // cell_grad_from + K2's edge terms (ordinary loads: called where no LDS-DMA needs to stay in flight -- prologue and epilogue)
-    auto cell_factors = [&](CellSt &c, const int t_it) {
+    struct CellRaw {  // the lattice values behind the factors: loaded early in the epilogue, used at its end
+        float a, bt, b_t1, b_u1, oa, obt, ob_t1, ob_u1, lse;
+        float2 x;
+    };
+    auto cell_fetch = [&](CellRaw &r, const CellSt &c, const int t_it) {
         if (!((c.flags & 2) && parked)) return;
         const Geo g = geo_of(launder(tid));
         const int cu = g.cu, lab = labtab[g.ccol];
-        const bool has_label = lab >= 0, same = lab == p.blank;
+        const bool has_label = lab >= 0;
         const uint32_t og0 = fdiv((uint32_t)cu, p.divOG), og1 = fdiv((uint32_t)cu + 1u, p.divOG);
         const int ct = t_it + g.crow, nd = ct + cu;
         const uint32_t kc_ = (uint32_t)nd / kRebase, kc1 = (uint32_t)(nd + 1) / kRebase;
         const uint32_t sk = (uint32_t)nd * (uint32_t)p.Up + (uint32_t)cu;
-        const float a = A_b[sk], bt = Bt_b[sk];
-        const float b_t1 = (ct < Tb - 1) ? Bt_b[sk + p.Up] : 0.f;
-        const float b_u1 = has_label ? Bt_b[sk + p.Up + 1] : 0.f;
-        const float oa = offA_b[kc_ * p.NG + og0], obt = offB_b[kc_ * p.NG + og0];
-        const float ob_t1 = offB_b[kc1 * p.NG + og0], ob_u1 = offB_b[kc1 * p.NG + og1];
+        r.a = A_b[sk], r.bt = Bt_b[sk];
+        r.b_t1 = (ct < Tb - 1) ? Bt_b[sk + p.Up] : 0.f;
+        r.b_u1 = has_label ? Bt_b[sk + p.Up + 1] : 0.f;
+        r.oa = offA_b[kc_ * p.NG + og0], r.obt = offB_b[kc_ * p.NG + og0];
+        r.ob_t1 = offB_b[kc1 * p.NG + og0], r.ob_u1 = offB_b[kc1 * p.NG + og1];
         const size_t c0w = row_block(t_it);  // uniform
         const uint32_t co = (uint32_t)(g.crow * p.U + g.ccol);
-        const float lse = (p.lse + c0w)[co];
-        const float2 x = ((const float2 *)jp.xbl + c0w)[co];
-        const double da = (double)a + ((double)oa - ll2);
-        const float nl = -lse * kLog2e;
-        const float c0 = (float)(da + ((double)bt + (double)obt)) + nl;
+        r.lse = (p.lse + c0w)[co];
+        r.x = ((const float2 *)jp.xbl + c0w)[co];
+    };
+    auto cell_finish = [&](CellSt &c, const CellRaw &r, const int t_it) {
+        if (!((c.flags & 2) && parked)) return;
+        const Geo g = geo_of(launder(tid));
+        const int cu = g.cu, lab = labtab[g.ccol];
+        const bool has_label = lab >= 0, same = lab == p.blank;
+        const int ct = t_it + g.crow;
+        const double da = (double)r.a + ((double)r.oa - ll2);
+        const float nl = -r.lse * kLog2e;
+        const float c0 = (float)(da + ((double)r.bt + (double)r.obt)) + nl;
         float cb = 0.f;
         bool has_bc = true;
-        if (ct < Tb - 1) cb = (float)(da + ((double)b_t1 + (double)ob_t1));
+        if (ct < Tb - 1) cb = (float)(da + ((double)r.b_t1 + (double)r.ob_t1));
         else if (cu == Ub - 1) cb = (float)da;
         else has_bc = false;
-        const float cl = has_label ? (float)(da + ((double)b_u1 + (double)ob_u1)) : 0.f;
-        const float cbv = has_bc ? hex2(x.x + nl + cb) : 0.f;
-        const float clb = has_label ? hex2(x.y + nl + cl) : 0.f;
+        const float cl = has_label ? (float)(da + ((double)r.b_u1 + (double)r.ob_u1)) : 0.f;
+        const float cbv = has_bc ? hex2(r.x.x + nl + cb) : 0.f;
+        const float clb = has_label ? hex2(r.x.y + nl + cl) : 0.f;
         c.c0 = c0;
-        c.eb = cscale * (hex2(x.x + c0) - cbv - (same ? clb : 0.f));
-        c.el = cscale * (hex2(x.y + c0) - clb);
+        c.eb = cscale * (hex2(r.x.x + c0) - cbv - (same ? clb : 0.f));
+        c.el = cscale * (hex2(r.x.y + c0) - clb);
+    };
+    auto cell_factors = [&](CellSt &c, const int t_it) {
+        CellRaw r;
+        cell_fetch(r, c, t_it);
+        cell_finish(c, r, t_it);
     };
     // LDS-DMA of one step, per wave: its 1 KB of the A stage (16 cell rows x 64 B of parked values), the step's reference tile (every
     // wave brings the same 256 bytes: the waves' counts of outstanding pieces stay equal), NT pieces (16 W2 rows each) of the W2 stage
     auto dma_a = [&](const CellSt &c, const int t, const int kc, const int sa) {  // t = first row of the chunk's iteration: uniform
-#ifdef DHX_A_HOT
-        const char *base = (const char *)(jp.dl + row_block(t_begin) * V + (kc & 1) * 32);
-#else
-        const char *base = (const char *)(jp.dl + row_block(t) * V + kc * 32);
-#endif
-#ifdef DHX_A_NT
-        lds_dma16_s_nt(base, c.off, smem0 + kAoff + sa * 8192 + wave * 1024);
-#else
+        const char *base = dl_s + (size_t)(uint32_t)(t - t_begin) * dl_pitch + (uint32_t)kc * 64u;
         lds_dma16_s(base, c.off, smem0 + kAoff + sa * 8192 + wave * 1024);
-#endif
         const int rmax = t_end - 1 - t;  // rows of the tile beyond the strip read the last one's references (unused)
-        const char *rb = (const char *)(jp.pref + ((size_t)(b * p.T + t) * NK + kc) * Upad + u0);
+        const char *rb = rf_s + (size_t)(uint32_t)(t - t_begin) * rf_pitch + (uint32_t)kc * (uint32_t)(Upad * 2);
         const int ln = launder(tid) & 63;
-        const uint32_t ro = (uint32_t)min(ln >> 4, rmax) * (uint32_t)(NK * Upad * 2) + (uint32_t)(ln & 15) * 4u;
+        const uint32_t ro = (uint32_t)min(ln >> 4, rmax) * rf_pitch + (uint32_t)(ln & 15) * 4u;
         lds_dma4_s(rb, ro, smem0 + kRoff + sa * 256);
     };
     const uint32_t boff = (uint32_t)(16 * wave + (lane >> 2)) * 64u + (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);  // bytes; piece k: + 8192 k
     auto dma_b = [&](const int kc, const int sb, const int k) {
-#ifdef DHX_NO_B
-        return;
-#endif
         const char *src = (const char *)(jp.W2c + (size_t)kc * (J * 32)) + k * 8192;  // uniform
         lds_dma16_s(src, boff, smem0 + sb * kBS + (wave + 8 * k) * 1024);
     };
     // the A piece in stage sa: parked values -> dlogits (K2's arithmetic), in place in LDS and, for K4, in dl
-    auto a_convert = [&](const CellSt &c, const int kc, const int sa) -> h8 {
+    // the A piece in stage sa: parked values -> dlogits (K2's arithmetic), in place in LDS and, for K4, in dl.  In two halves: what it
+    // reads from LDS (the raw piece, the cell's chunk reference, the column's label) is fetched with the step's fragment reads; the
+    // arithmetic and the LDS writes sit among the MFMAs of the step's second k-step.
+    struct ARaw {
+        h8 v;
+        short rf;
+        int lab;
+    };
+    auto a_fetch = [&](ARaw &r, const int sa) {
+        const int t2 = launder(tid);
+        const Geo g = geo_of(t2);
+        r.v = *(const h8 *)(smem + kAoff + sa * 8192 + t2 * 16);
+        r.rf = *(const short *)(smem + kRoff + sa * 256 + (g.crow * 32 + g.ccol) * 2);
+        r.lab = labtab[g.ccol];
+    };
+    auto a_finish = [&](const ARaw &r, const CellSt &c, const int kc, const int sa) -> h8 {
         const int t2 = launder(tid);
         const Geo g = geo_of(t2);
         h8 *const pa = (h8 *)(smem + kAoff + sa * 8192 + t2 * 16);
-        const h8 v = *pa;
-        h8 o = v;
-        if (parked) {
-            const float rf = (float)*(const short *)(smem + kRoff + sa * 256 + (g.crow * 32 + g.ccol) * 2);
-            const int lab = labtab[g.ccol];
-            const float mult = ((c.flags & 2) ? cscale : 0.f) * hex2(rf + c.c0);
+        // Straight-line (it is scheduled among the MFMAs): one factor per piece.  A cell outside the utterance -- a padded column of a
+        // live tile, a row beyond the strip -- has c0 = "log zero", i.e. the factor 0, and what it multiplies is a value K1 wrote (rows
+        // and columns are clamped where they are loaded): exact zeros without a select.  Where dl already holds dlogits (the
+        // recompute kernel ran) the factor is 1 -- the round trip through f32 is exact -- or 0.
+        const float mult = parked ? cscale * hex2((float)r.rf + c.c0) : ((c.flags & 2) ? 1.0f : 0.f);
+        h8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (f16)(mult * (float)v[e]);
-            const int vb = 32 * kc + 8 * g.lc, ib = p.blank - vb, il = ((lab >= 0 && lab != p.blank) ? lab : -1) - vb;
-            if ((unsigned)ib < 8u) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (e == ib) ? (f16)c.eb : o[e];
-            }
-            if ((unsigned)il < 8u) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (e == il) ? (f16)c.el : o[e];
-            }
-        }
-        if (!(c.flags & 2)) {  // a padded column inside a live tile / a row beyond the strip: exact zeros whatever the memory holds
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (f16)0.f;
-        }
+        for (int e = 0; e < 8; ++e) o[e] = (f16)(mult * (float)r.v[e]);
         *pa = o;
+        // the blank / label column, where this piece holds it: one 2-byte LDS write over the piece (the same wave's LDS operations
+        // land in program order); a_store does the same to dl
+        const int vb = 32 * kc + 8 * g.lc, ib = p.blank - vb, il = ((r.lab >= 0 && r.lab != p.blank) ? r.lab : -1) - vb;
+        const bool live = (c.flags & 2) && parked;
+        if (live && (unsigned)ib < 8u) ((f16 *)pa)[ib] = (f16)c.eb;
+        if (live && (unsigned)il < 8u) ((f16 *)pa)[il] = (f16)c.el;
         return o;
+    };
+    auto a_convert = [&](const CellSt &c, const int kc, const int sa) -> h8 {
+        ARaw r;
+        a_fetch(r, sa);
+        return a_finish(r, c, kc, sa);
     };
     // ... and its way back to dl.  Issued at the START of the next step, in front of that step's LDS-DMA: the wait at the top of a
     // step allows the NT + 2 youngest operations to be outstanding, and those must be exactly the last step's DMA pieces.
     auto a_store = [&](const h8 o, const CellSt &c, const int t, const int kc) {
-#ifndef DHX_NOSTORE
         if ((c.flags & 1) && parked) {
-            char *base = (char *)(jp.dl + row_block(t) * V + kc * 32);
-#ifdef DHX_PLAINSTORE
-            *(h8 *)(base + (uint32_t)launder((int)c.off)) = o;
-#else
-            __builtin_nontemporal_store(o, (h8 *)(base + (uint32_t)launder((int)c.off)));
-#endif
+            char *base = (char *)const_cast<char *>(dl_s) + (size_t)(uint32_t)(t - t_begin) * dl_pitch + (uint32_t)kc * 64u;
+            const uint32_t off = (uint32_t)launder((int)c.off);
+            __builtin_nontemporal_store(o, (h8 *)(base + off));
+            if (c.flags & 2) {  // the blank / label column over it (the same lane's stores to one address stay in order)
+                const Geo g = geo_of(launder(tid));
+                const int lab = labtab[g.ccol];
+                const int vb = 32 * kc + 8 * g.lc, ib = p.blank - vb, il = ((lab >= 0 && lab != p.blank) ? lab : -1) - vb;
+                if ((unsigned)ib < 8u) ((f16 *)(base + off))[ib] = (f16)c.eb;
+                if ((unsigned)il < 8u) ((f16 *)(base + off))[il] = (f16)c.el;
+            }
         }
-#endif
     };
 
     // fragment read offsets of this lane (row n of a 32-row tile, k-step ks)
@@ -856,6 +876,9 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
                 const bool x1 = last_group && q + 1 >= 4, x2 = last_group && q + 2 >= 4, x3 = last_group && q + 3 >= 4;  // ... lies in the next iteration
                 const bool e1 = !x1 || has_next, e2 = !x2 || has_next, e3 = !x3 || has_next;                            // ... exists
                 const int k1 = x1 ? kc + 1 - NK : kc + 1, k2 = x2 ? kc + 2 - NK : kc + 2, k3 = x3 ? kc + 3 - NK : kc + 3;
+                // (Measured and dropped, config 5: waves 0..3 converting FIRST and their SIMD partners 4..7 last 14.8 against 14.2 ms;
+                // `s_setprio 1` for waves 4..7, the reference tile brought in by one wave instead of all eight, the A pieces issued
+                // in front of the W2 pieces (+1.1 ms), non-temporal A loads (+0.7 ms): profiles/r06_notes.md.)
                 // fragment reads: k-step 0 and the A side of k-step 1 first; the W2 fragments of k-step 1 follow their k-step-0
                 // counterparts into the registers those leave (56 registers of fragments would not fit beside 32 NT accumulators)
                 h8 a[2][2], bf[NT];
@@ -865,17 +888,13 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
                 for (int ni = 0; ni < NT; ++ni) bf[ni] = *(const h8 *)(smem + b_rd + sb * kBS + ni * 2048 + foff0);
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) a[1][mi] = *(const h8 *)(smem + a_rd + q * 8192 + mi * 2048 + foff1);
+                ARaw araw;
+                a_fetch(araw, (q + 1) & 3);  // (also in the workgroup's last step, where nothing reads the result)
                 __builtin_amdgcn_sched_barrier(0);
                 if (pend) {
                     if (pend_next) a_store(o_pend, nxt, t_it + 4, pk);
                     else a_store(o_pend, cur, t_it, pk);
                 }
-#ifdef DHX_A_FIRST
-                if (e3) {
-                    if (x3) dma_a(nxt, t_it + 4, k3, (q + 3) & 3);
-                    else dma_a(cur, t_it, k3, (q + 3) & 3);
-                }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 DT(5);
 #pragma unroll
@@ -886,12 +905,10 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mi], bf[ni], acc[mi][ni], 0, 0, 0);
                     bf[ni] = *(const h8 *)(smem + b_rd + sb * kBS + ni * 2048 + foff1);
                 }
-#ifndef DHX_A_FIRST
                 if (e3) {
                     if (x3) dma_a(nxt, t_it + 4, k3, (q + 3) & 3);
                     else dma_a(cur, t_it, k3, (q + 3) & 3);
                 }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 DT(6);
 #pragma unroll
@@ -900,18 +917,15 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
                     for (int mi = 0; mi < 2; ++mi)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][mi], bf[ni], acc[mi][ni], 0, 0, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
                 DT(3);
-                // the conversion of the next chunk's A piece comes LAST: its ~40 temporaries do not fit beside the fragments, and
-                // its VALU work runs under the MFMAs the wave has just queued
+                // the conversion of the next chunk's A piece shares its scheduling region with the MFMAs of the second k-step (its
+                // LDS reads were issued with the fragment reads)
                 pend = e1, pend_next = x1, pk = k1;
-#ifdef DHX_NOCONV
-                if (false) {
-#else
-                if (e1) {
-#endif
-                    if (x1) o_pend = a_convert(nxt, k1, (q + 1) & 3);
-                    else o_pend = a_convert(cur, k1, (q + 1) & 3);
+                {
+                    CellSt cc = cur;  // (a select, not a branch: the block stays one scheduling region)
+                    cc.off = x1 ? nxt.off : cur.off, cc.flags = x1 ? nxt.flags : cur.flags;
+                    cc.c0 = x1 ? nxt.c0 : cur.c0, cc.eb = x1 ? nxt.eb : cur.eb, cc.el = x1 ? nxt.el : cur.el;
+                    o_pend = a_finish(araw, cc, k1, (q + 1) & 3);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 DT(4);
@@ -921,19 +935,6 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
                 sb = sb1;
             }
         }
-#ifdef DHX_NOEPI
-        {
-            float z = 0.f;
-            for (int mi = 0; mi < 2; ++mi)
-                for (int ni = 0; ni < NT; ++ni)
-                    for (int r = 0; r < 16; ++r) z += acc[mi][ni][r];
-            if (z == 1.2345f) jp.dApart[0] = z;
-            first = false;
-            cur = nxt;
-            pend_next = false;
-            continue;
-        }
-#endif
         // ---- epilogue: acc[mi][ni][r] = S dh[row t_it + (r >> 2)][column u0 + 16 wm + 8 mi + 4 half + (r & 3)][unit JW wn + 32 ni + n]
         const bool last = !has_next;
         // What a row tile of a 32-unit tile reads -- the enc-side factors of the 4 rows (per unit tile), the pred-side factors of
@@ -944,23 +945,39 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
             float pr[4];
             float4 cs;
         };
+        // (lane offsets from a laundered copy of the thread index, beside scalar bases: hoisted out of the row loop as 64-bit lane
+        // addresses they were spilled, and every reload -- a wait for vmcnt(0) -- drained the tile loads prefetched just before)
+        const int ln3 = launder(tid) & 63, n3 = ln3 & 31, half3 = ln3 >> 5;
         auto load_ej = [&](float (&ej)[4], const int ni) {
             const int jw = wn * JW + ni * 32;  // uniform; this lane's unit: jw + n
 #pragma unroll
-            for (int rw = 0; rw < 4; ++rw) ej[rw] = (Etab + ((size_t)b * p.T + min(t_it + rw, t_end - 1)) * J + jw)[n];
+            for (int rw = 0; rw < 4; ++rw) ej[rw] = (Etab + ((size_t)b * p.T + min(t_it + rw, t_end - 1)) * J + jw)[(uint32_t)n3];
         };
         auto load_tile = [&](EpiT &in, const int ni, const int mi) {
             const int jw = wn * JW + ni * 32, ubw = u0 + 16 * wm + 8 * mi;  // uniform; this lane's columns: ubw + 4 half + 0..3
 #pragma unroll
             for (int cq = 0; cq < 4; ++cq)
-                in.pr[cq] = (Ptab + (size_t)b * p.U * J + jw)[(uint32_t)min(ubw + 4 * half + cq, p.U - 1) * (uint32_t)J + (uint32_t)n];
+                in.pr[cq] = (Ptab + (size_t)b * p.U * J + jw)[(uint32_t)min(ubw + 4 * half3 + cq, p.U - 1) * (uint32_t)J + (uint32_t)n3];
             // (read even in the first iteration, where nothing has been written yet: the value is dropped below)
-            in.cs = ((const float4 *)jp.dCacc + ((((size_t)wg * 8 + wave) * 2 + mi) * NT + ni) * 64)[lane];
+            in.cs = ((const float4 *)jp.dCacc + ((((size_t)wg * 8 + wave) * 2 + mi) * NT + ni) * 64)[(uint32_t)ln3];
         };
+#ifdef JH_TRACE
+#define ET(k)                                                                                                   \
+    do {                                                                                                        \
+        if (tr && t_it == t_begin + 4 && lane == 0) tr[154 + (k)] = (long long)__builtin_amdgcn_s_memtime();    \
+    } while (0)
+#else
+#define ET(k) do { } while (0)
+#endif
+        ET(0);
         float ejp[2][4];
-        EpiT tin[2];
-        load_ej(ejp[0], 0);
-        load_tile(tin[0], 0, 0);
+        EpiT tin[3];
+        auto load_idx = [&](const int idx) {  // the loads of row tile idx & 1 of unit tile idx >> 1 (idx: compile-time constant)
+            if ((idx & 1) == 0) load_ej(ejp[(idx >> 1) & 1], idx >> 1);
+            load_tile(tin[idx % 3], idx >> 1, idx & 1);
+        };
+        load_idx(0);
+        load_idx(1);
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
             const int jw = wn * JW + ni * 32;
@@ -968,28 +985,28 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 const int idx = 2 * ni + mi;
-                if (idx + 1 < 2 * NT) {
-                    if (mi == 1) load_ej(ejp[(ni + 1) & 1], ni + 1);
-                    load_tile(tin[(idx + 1) & 1], (idx + 1) >> 1, (idx + 1) & 1);
-                }
-                const EpiT &in = tin[idx & 1];
+                if (idx + 2 < 2 * NT) load_idx(idx + 2);  // two tiles ahead (one ahead left ~1,000 clocks of latency exposed per tile)
+                const EpiT &in = tin[idx % 3];
                 const float(&ej)[4] = ejp[ni & 1];
                 const int ubw = u0 + 16 * wm + 8 * mi;
                 float4 *const cslot = (float4 *)jp.dCacc + ((((size_t)wg * 8 + wave) * 2 + mi) * NT + ni) * 64;  // uniform; + lane
                 float4 cs = first ? make_float4(0.f, 0.f, 0.f, 0.f) : in.cs;
                 float dz[16];
+                // q = (1 - h^2) / 4 = r (1 - r) with r = 1 / (1 + e^{2(a + c)}); the factor 4 / S is applied once per output.  (The
+                // branch AROUND the loops: inside, the compiler kept it per element -- 66 branches per unit tile, 52,000 clocks per
+                // epilogue instead of ~15,000.)
+                if (!slow) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    // q = (1 - h^2) / 4 = r (1 - r) with r = 1 / (1 + e^{2(a + c)}); the factor 4 / S is applied once per output
-                    float qv;
-                    if (!slow) {
+                    for (int r = 0; r < 16; ++r) {
                         const float rr = __builtin_amdgcn_rcpf(fmaf(ej[r >> 2], in.pr[r & 3], 1.0f));
-                        qv = fmaf(-rr, rr, rr);
-                    } else {
-                        const float h = htanh(ej[r >> 2] + in.pr[r & 3]);
-                        qv = 0.25f * fmaf(-h, h, 1.0f);
+                        dz[r] = acc[mi][ni][r] * fmaf(-rr, rr, rr);
                     }
-                    dz[r] = acc[mi][ni][r] * qv;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float h = htanh(ej[r >> 2] + in.pr[r & 3]);
+                        dz[r] = acc[mi][ni][r] * (0.25f * fmaf(-h, h, 1.0f));
+                    }
                 }
                 cs.x += (dz[0] + dz[4]) + (dz[8] + dz[12]);
                 cs.y += (dz[1] + dz[5]) + (dz[9] + dz[13]);
@@ -998,14 +1015,14 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
 #pragma unroll
                 for (int rw = 0; rw < 4; ++rw) rs[rw] += (dz[4 * rw] + dz[4 * rw + 1]) + (dz[4 * rw + 2] + dz[4 * rw + 3]);
                 if (!last) {
-                    cslot[lane] = cs;
+                    cslot[(uint32_t)ln3] = cs;
                 } else {  // the strip is done: the d pred_proj partial of this row split
                     const float cv[4] = {cs.x, cs.y, cs.z, cs.w};
                     float *const crow_out = jp.dCpart + (((size_t)ts * p.B + b) * p.U) * J + jw;  // uniform
 #pragma unroll
                     for (int cq = 0; cq < 4; ++cq) {
-                        const int uu = ubw + 4 * half + cq;
-                        if (uu < p.U) crow_out[(uint32_t)uu * (uint32_t)J + (uint32_t)n] = cv[cq] * c4;
+                        const int uu = ubw + 4 * half3 + cq;
+                        if (uu < p.U) crow_out[(uint32_t)uu * (uint32_t)J + (uint32_t)n3] = cv[cq] * c4;
                     }
                 }
             }
@@ -1013,24 +1030,29 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
             float *const cb = comb + (ni & 1) * 512;  // [4 rows][4 wn x 32 units]
 #pragma unroll
             for (int rw = 0; rw < 4; ++rw) rs[rw] += __shfl_xor(rs[rw], 32);
-            if (wm == 1 && lane < 32) {
+            if (wm == 1 && ln3 < 32) {
 #pragma unroll
-                for (int rw = 0; rw < 4; ++rw) cb[rw * 128 + wn * 32 + n] = rs[rw];
+                for (int rw = 0; rw < 4; ++rw) cb[rw * 128 + wn * 32 + n3] = rs[rw];
             }
             __syncthreads();
-            if (wm == 0 && lane < 32) {
+            if (wm == 0 && ln3 < 32) {
 #pragma unroll
                 for (int rw = 0; rw < 4; ++rw)
                     if (t_it + rw < t_end)
-                        (jp.dApart + (((size_t)ut * p.B + b) * p.T + t_it + rw) * J + jw)[n] = (rs[rw] + cb[rw * 128 + wn * 32 + n]) * c4;
+                        (jp.dApart + (((size_t)ut * p.B + b) * p.T + t_it + rw) * J + jw)[(uint32_t)n3] = (rs[rw] + cb[rw * 128 + wn * 32 + n3]) * c4;
             }
+            if (ni == 0) ET(1);
+            if (ni == 1) ET(2);
+            if (ni == NT - 1) ET(3);
         }
-        // the factors of the iteration after the next (its first chunk is converted in the last step of the next one)
+        // the factors of the iteration after the next (its first chunk is converted in the last step of the next one).  (Their loads
+        // issued two unit tiles earlier, the arithmetic here: 11 more live registers, spilled -- 13.7 against 13.1 ms at config 5.)
         CellSt nn = nxt;
         if (t_it + 8 < t_end) {
             cell_place(nn, t_it + 8);
             cell_factors(nn, t_it + 8);
         }
+        ET(4);
         first = false;
         cur = nxt, nxt = nn;
         pend_next = false;  // (the piece converted in the last step belongs to what is now the current iteration)
@@ -1307,8 +1329,12 @@ static JhLayout make_jh_layout(int T, int U, int B, int J, int V) {
     L.w = make_layout(T, U, B);
     L.n_ut = (U + 31) / 32;
     L.n_tt = (T + 7) / 8;
-    L.n_ts = (T >= 1024) ? 8 : (T >= 512) ? 4 : (T >= 128 ? 2 : 1);  // row splits of K3 (measured at config 5: 8 beats 4 by 3 %)
-    L.TS = ((T + L.n_ts - 1) / L.n_ts + 7) / 8 * 8;
+    // row splits of K3: its workgroups own (utterance, 32 columns, TS rows) x ALL joint units (round 6) -- as many splits as give about
+    // 1280 workgroups (five rounds of one per CU; config 5: 8), strips of at least 16 rows (four iterations of four)
+    L.n_ts = (1280 + B * L.n_ut - 1) / (B * L.n_ut);
+    if (L.n_ts > (T + 15) / 16) L.n_ts = (T + 15) / 16;
+    if (L.n_ts < 1) L.n_ts = 1;
+    L.TS = ((T + L.n_ts - 1) / L.n_ts + 3) / 4 * 4;
     L.n_ts = (T + L.TS - 1) / L.TS;
     L.n_tq = (T + kTQ - 1) / kTQ;
     L.n_units = B * L.n_ut * L.n_tq;

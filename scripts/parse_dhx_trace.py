@@ -15,3 +15,5 @@ for w in (0, 4, 1, 7):
         print("   step %2d: %6d %6d %6d %6d %6d %6d %6d" % (i, t[i, 1] - t[i, 0], t[i, 2] - t[i, 1], t[i, 5] - t[i, 2], t[i, 6] - t[i, 5], t[i, 3] - t[i, 6],
                                                         t[i, 4] - t[i, 3], t[i + 1, 0] - t[i, 4]))
     print("   step period avg (steps 2..20)", float(np.mean(np.diff(t[2:21, 0]))))
+    e = k3[w, 154:159]
+    print("   epilogue of the second iteration: first unit tile %d, second %d, tiles 2..%d, next factors %d" % (e[1] - e[0], e[2] - e[1], e[3] - e[2], e[4] - e[3]))
