@@ -170,6 +170,23 @@ RNNT_API rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, cons
                                   const float *cost_scale, int alphabet_size, int minibatch,
                                   float *costs, void *workspace, rnntOptions options);
 
+/* Build-only flag (no upstream counterpart): RNNT_VISIT_ALL switches the occupancy floor OFF -- the gradient kernels then visit
+ * every lattice cell / row, as the reference's op and TensorFlow's autodiff do (run_rnnt.py:284), whatever the data.  Where the
+ * floor applies (vocabularies above 60 symbols here; the backward of the fused joints below) a cell, or a lattice row of a
+ * 32-column tile, whose occupancy alpha.beta/L is at most 2^-50 gets exact zeros without its logits being read: results differ
+ * from the all-visited ones by less than 2^-44 |cost_scale| per element and run times follow the width of the alignment band.
+ * The floor hides no NaN: the forward pass reads every cell, a NaN logit makes the utterance's lattice, cost and occupancies NaN,
+ * and a NaN occupancy counts as occupied (tests/test_loss_gpu.py::test_occupancy_floor_and_its_opt_out).  The flag is there for
+ * parity debugging and for timing that does not depend on the data (bench.py reports both).
+ *   compute_rnnt_loss_flags = compute_rnnt_loss_ex with `flags` (0 or RNNT_VISIT_ALL);  costs == NULL: the gradient pass alone
+ *   (compute_rnnt_loss_bwd), grads == NULL: the forward alone.
+ *   The fused-joint entry points take the same bit OR-ed into joint_dtype (joint_dtype | RNNT_VISIT_ALL). */
+#define RNNT_VISIT_ALL 0x100
+RNNT_API rnntStatus_t compute_rnnt_loss_flags(const float *acts, float *grads, const int *flat_labels,
+                                     const int *label_lengths, const int *input_lengths,
+                                     const float *cost_scale, int alphabet_size, int minibatch,
+                                     float *costs, void *workspace, rnntOptions options, unsigned int flags);
+
 /* ------------------------------------------------------------------------------------------
  * Build-only extension (no upstream counterpart): the joint network fused with the loss, so the
  * [B,T,U,J] and [B,T,U,V] tensors of model.py:158-166 are never materialised.
@@ -215,6 +232,8 @@ RNNT_API rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, cons
  *                                    logits instead (one rounding less; results differ by binary16 rounding noise).
  *                                    Counterpart of the reference's `mixed_float16` policy (run_rnnt.py:96-99); oracle:
  *                                    oracle/rnnt_oracle.py joint_loss_and_grads_f16 (parked=True / False).
+ *                                Either value may carry RNNT_VISIT_ALL (above): joint_dtype = 0 | RNNT_VISIT_ALL makes the backward
+ *                                visit every lattice row.
  *                                Any other (joint_dtype, shape) combination returns RNNT_STATUS_INVALID_VALUE -- checked before
  *                                anything is enqueued, in every entry point that takes joint_dtype.
  *                                get_joint_workspace_size needs no dtype: where both arithmetic types take the shape (alphabet_size 128)
@@ -315,7 +334,8 @@ RNNT_API rnntStatus_t compute_rnnt_joint_logits(const float *enc_proj, const flo
  * tile when none of its 32 cells has an occupancy alpha.beta/L above 2^-50: every dlogits value of a cell is bounded by
  * 2 |cost_scale| x that occupancy, so such a row adds less than 2^-44 |cost_scale| to anything -- its cells get exactly zero where
  * the reference leaves 1e-15's.  How many rows that is depends on the data (unstructured N(0,1) logits on a 600 x 150 lattice: about
- * half; a trained model: most).  Synchronises options.stream.  rows = {-1, -1} where nothing is skipped (the wide joint, 640 < joint_size).
+ * half; a trained model: most).  Synchronises options.stream.  rows = {-1, -1} where nothing is skipped (the wide joint, 640 < joint_size)
+ * and where the workspace does not hold the counts of a backward of THIS shape (fresh, or used by another shape since: the row plan stamps them).
  * The work of a backward call is divided among the workgroups by these counts, deterministically. */
 RNNT_API rnntStatus_t get_rnnt_joint_backward_rows(void *workspace, int joint_size, int alphabet_size, int minibatch,
                                                    rnntOptions options, int rows[2]);

@@ -23,6 +23,7 @@ SYMBOLS = [
     "compute_rnnt_loss_fwd",
     "compute_rnnt_loss_bwd",
     "compute_rnnt_loss_ex",
+    "compute_rnnt_loss_flags",
     "get_joint_workspace_size",
     "compute_rnnt_joint_loss",
     "compute_rnnt_joint_loss_fwd",
@@ -60,6 +61,9 @@ class RNNTLibraryError(RuntimeError):
     pass
 
 
+RNNT_VISIT_ALL = 0x100  # include/rnnt.h: no occupancy floor -- the gradient kernels visit every lattice cell / row
+
+
 def load():
     """Load libwarprnnt.so (once).  Raises RNNTLibraryError loudly when it is absent."""
     global _lib
@@ -88,6 +92,9 @@ def load():
     lib.compute_rnnt_loss_bwd.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, vp, rnntOptions]
     lib.compute_rnnt_loss_ex.restype = ci
     lib.compute_rnnt_loss_ex.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, rnntOptions]
+    if LIB_PATH == _DEFAULT_LIB_PATH or hasattr(lib, "compute_rnnt_loss_flags"):
+        lib.compute_rnnt_loss_flags.restype = ci
+        lib.compute_rnnt_loss_flags.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, rnntOptions, ctypes.c_uint]
     lib.get_joint_workspace_size.restype = ci
     lib.get_joint_workspace_size.argtypes = [ci, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_size_t)]
     lib.compute_rnnt_joint_loss.restype = ci

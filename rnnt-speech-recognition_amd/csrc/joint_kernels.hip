@@ -85,6 +85,7 @@ struct JointParams {
     float2 *xbl;    // [cells] blank / label logits of the cell, written by joint_fwd_kernel for joint_cellrec_kernel
     int *plan;       // joint_rowplan_kernel: [0] = target weight per workgroup, [1 + k] = first item of workgroup k (k = 0 .. nblk),
                      // [2 + kBwdMaxBlocks + i] = weight of the items before item i (i = 0 .. n_items), then {rows visited, rows inside the utterances}
+    int visit_all;   // 1: every lattice row of an utterance counts as occupied (RNNT_VISIT_ALL: no occupancy floor)
     uint8_t *live8;  // [B][n_ut][4 n_tr32] one BIT per (lattice row, u-tile): some cell of the tile has occupancy above 2^-kOccFloor
                      // (joint_cellrec_kernel; joint_bwd_kernel skips the other rows -- see kOccFloor); n_tr32 = ceil(T / 32)
     float *dApart;  // [n_ut][B][T][J]
@@ -1541,7 +1542,7 @@ __global__ __launch_bounds__(256) void joint_cellrec_kernel(const JointParams jp
             rec_from_log(jp, g, xx, S, rec, lab);
         }
         // rec.x = log2(occupancy) - lse log2 e: the occupancy alone decides whether the backward visits the cell's row (NaN: yes)
-        occupied = !(fmaf(p.lse[c], kLog2e, rec.x) <= (float)-kOccFloor);
+        occupied = jp.visit_all || !(fmaf(p.lse[c], kLog2e, rec.x) <= (float)-kOccFloor);
     }
     const unsigned long long occ = __ballot(occupied);
     if ((tid & 63) == 0) {
@@ -1574,7 +1575,7 @@ __global__ __launch_bounds__(kRedoThreads) void joint_redo_kernel(const JointPar
     const int ub = (int)blockIdx.x / team;
     const int b = p.b0 + ub;
     RedoTeam tm;
-    tm.k = (int)blockIdx.x - ub * team, tm.n = team, tm.bar = p.bar + b, tm.ok = true;
+    tm.k = (int)blockIdx.x - ub * team, tm.n = team, tm.bar = p.bar + kRedoCtr * b, tm.ok = true;
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     typedef double f64x2 __attribute__((ext_vector_type(2)));
     const i32x4 fw = __builtin_nontemporal_load((const i32x4 *)(p.flags + 4 * b));
@@ -1610,6 +1611,9 @@ __global__ __launch_bounds__(kRedoThreads) void joint_redo_kernel(const JointPar
 // The cut of joint_bwd_kernel's item list into ranges of equal weight (see kBwdSlots).  One workgroup: a chunk of items per thread,
 // a scan over the threads' sums, then each thread writes its items' prefix weights and the cuts that fall into its chunk.
 constexpr int kPlanThreads = 1024;
+__host__ __device__ inline int plan_stamp(int T, int U, int B, int J, int V) {
+    return (int)(0x5eed0000u ^ ((unsigned)T * 73856093u) ^ ((unsigned)U * 19349663u) ^ ((unsigned)B * 83492791u) ^ ((unsigned)J * 2654435761u) ^ (unsigned)V);
+}
 __global__ __launch_bounds__(kPlanThreads) void joint_rowplan_kernel(const JointParams jp) {
     __shared__ int part[kPlanThreads];
     const LossParams &p = jp.lp;
@@ -1638,7 +1642,10 @@ __global__ __launch_bounds__(kPlanThreads) void joint_rowplan_kernel(const Joint
     if (ins) atomicAdd(&rows_inside, ins);
     part[tid] = sum;
     __syncthreads();
-    if (tid == 0) jp.plan[3 + kBwdMaxBlocks + n_items] = rows_visited, jp.plan[4 + kBwdMaxBlocks + n_items] = rows_inside;
+    if (tid == 0) {
+        jp.plan[3 + kBwdMaxBlocks + n_items] = rows_visited, jp.plan[4 + kBwdMaxBlocks + n_items] = rows_inside;
+        jp.plan[5 + kBwdMaxBlocks + n_items] = plan_stamp(p.T, p.U, p.B, jp.J, p.V);  // (joint_backward_rows: the counts are this shape's)
+    }
     for (int d = 1; d < kPlanThreads; d <<= 1) {  // inclusive scan
         const int v = tid >= d ? part[tid - d] : 0;
         __syncthreads();
@@ -2207,7 +2214,7 @@ static JointLayout make_joint_layout(int T, int U, int B, int J, int V) {
     L.reclab = take((size_t)B * T * U * sizeof(int));
     L.xbl = take((size_t)B * T * U * sizeof(float2));
     L.live8 = take((size_t)B * L.n_ut * 4 * ((T + 31) / 32));  // one bit per (row, u-tile): joint_cellrec_kernel -> joint_bwd_kernel
-    L.plan = take((size_t)(5 + kBwdMaxBlocks + (size_t)B * L.n_ut * ((T + kBwdRows - 1) / kBwdRows)) * sizeof(int));  // joint_rowplan_kernel
+    L.plan = take((size_t)(6 + kBwdMaxBlocks + (size_t)B * L.n_ut * ((T + kBwdRows - 1) / kBwdRows)) * sizeof(int));  // joint_rowplan_kernel
     L.dApart = take((size_t)L.n_ut * B * T * J * sizeof(float));
     // partial buffers: what joint_bwd_kernel writes (kBwdSlots slabs of d pred_proj, one dW2 / two db2 partials per workgroup of a
     // J group; no zero-fill: the reduction knows what exists), or what the wide joint's two-kernel backward writes (zero-filled)
@@ -2266,9 +2273,14 @@ hipError_t joint_backward_rows(void *workspace, int T, int U, int B, int J, int 
     const JointLayout L = make_joint_layout(T, U, B, J, V);
     if (L.wide) return hipSuccess;  // (the wide joint's two-kernel backward visits everything)
     const size_t n_items = (size_t)B * L.n_ut * ((T + kBwdRows - 1) / kBwdRows);
-    const hipError_t e = hipMemcpyAsync(rows, (char *)workspace + L.plan + (3 + kBwdMaxBlocks + n_items) * sizeof(int), 2 * sizeof(int),
-                                        hipMemcpyDeviceToHost, s);
-    return e != hipSuccess ? e : hipStreamSynchronize(s);
+    int h[3] = {-1, -1, 0};
+    hipError_t e = hipMemcpyAsync(h, (char *)workspace + L.plan + (3 + kBwdMaxBlocks + n_items) * sizeof(int), 3 * sizeof(int),
+                                  hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    // the row plan stamps its counters with the shape it ran on: a workspace no f32-grade backward of THIS shape has written
+    // (fresh, or used by another shape / arithmetic type since) answers {-1, -1}, not whatever the words hold
+    if (e == hipSuccess && h[2] == plan_stamp(T, U, B, J, V)) rows[0] = h[0], rows[1] = h[1];
+    return e;
 }
 
 // where the fused joint (joint_dtype 0) keeps the e^{2x} tables and its flags: for a caller that fills them itself (JointHooks)
@@ -2423,7 +2435,7 @@ static hipError_t launch_joint_redo_k(const JointParams &jp, const LossParams &q
     constexpr size_t shm = (size_t)NB * G * 2 * 64 * K * sizeof(float) + 16;
     hipError_t e = set_lds(joint_redo_kernel<K, G, NB>, shm);
     if (e != hipSuccess) return e;
-    const int team = redo_team_size(jp.lp.nb, jp.lp.T, jp.lp.U);
+    const int team = redo_team_size(jp.lp.nb, jp.lp.T, jp.lp.U, device_cu_count());
     hipLaunchKernelGGL((joint_redo_kernel<K, G, NB>), dim3(jp.lp.nb * team), dim3(kRedoThreads), shm, s, jp, q, want_rec ? 1 : 0, team);
     return hipGetLastError();
 }
@@ -2451,7 +2463,8 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
                              float *d_enc_proj, float *d_pred_proj, float *dW2, float *db2, int joint_dtype,
                              int phases, void *workspace, hipStream_t s, const JointHooks *hooks) {
     // phases: bit 0 = forward (costs + lattice state in the workspace), bit 1 = backward (needs that state),
-    // bit 2 = a backward-only call will follow this forward-only one (the f16 joint parks its softmax numerators for it)
+    // bit 2 = a backward-only call will follow this forward-only one (the f16 joint parks its softmax numerators for it),
+    // bit 3 = RNNT_VISIT_ALL: the backward visits every lattice row (no occupancy floor)
     if (joint_dtype == 1)
         return launch_joint_loss_f16(enc_proj, pred_proj, W2, b2, labels, label_lengths, input_lengths, cost_scale, J, V,
                                      B, T, U, blank, costs, d_enc_proj, d_pred_proj, dW2, db2, phases, workspace, s, hooks);
@@ -2477,6 +2490,7 @@ hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, cons
     jp.trace = trace_dev;
 #endif
     jp.logits_only = 0;
+    jp.visit_all = (phases & 8) ? 1 : 0;
     const int prep_mode = hooks ? hooks->prep_mode : 0;
     jp.tables_ready = prep_mode == 1;
     jp.need_state = prep_mode == 2;

@@ -91,7 +91,7 @@ __device__ __forceinline__ void cell_wave_range(const LossParams &p, const uint3
             // A cell without mass: every gradient of it is bounded by 2 |cost_scale| x its occupancy alpha beta / L = 2^(c0 - nl); below
             // 2^-kOccFloorWave that is nothing an f32 sum holds, and the cell's V logits need not be read: zeros are written (the
             // reference leaves ~1e-15 there).  On an unstructured 1500 x 300 lattice that is most of the cells.  NaN counts as occupied.
-            if (g.c0 - g.nl <= (float)-kOccFloorWave) {
+            if (!p.visit_all && g.c0 - g.nl <= (float)-kOccFloorWave) {
                 if (V4) {
                     typedef float v4f __attribute__((ext_vector_type(4)));
                     const v4f z = {0.f, 0.f, 0.f, 0.f};

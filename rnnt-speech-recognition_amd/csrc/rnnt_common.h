@@ -72,11 +72,12 @@ struct LossParams {
     int NCl;     // frame blocks per utterance (tables are [NCl][64])
     float2 *pstat;  // [B][nPstat]: per (patch, wave) of the lsm launch {sum of -log2 max(p_blank, p_label), cells}: how fast mass decays
     int *lshift;    // [B]: log2 of the diagonals per frame block the sweeps chose for the utterance (rnnt_lin.h)
-    int *bar;       // [B]: phase counter of the utterance's hand-back team (rnnt_redo.h), zeroed by the forward sweeps
+    int *bar;       // [B][8]: ticket / completion counters of the utterance's hand-back team (rnnt_redo.h), zeroed by the forward sweeps
     int nPstat;
     int pstatStride;  // the sweeps sample slot pstatStride * i, i < nPstat / pstatStride (4: wave 0 of every patch of the lsm launch)
     int B, T, U, V, blank;
     int b0, nb;  // this launch covers utterances [b0, b0+nb)
+    int visit_all;  // 1: no occupancy floor -- the gradient kernels visit every cell / lattice row (RNNT_VISIT_ALL, include/rnnt.h)
     int precise;  // 1: the log-domain sweeps carry their recurrence in float64 (rnnt_sweep.h alpha_sweep_pr); lattices of 8+ columns per lane always do
     int N, Nr, Up, NC, NG;  // NG = Up/OG offset groups (offset tables are [NC][NG])
     uint32_t cells;  // B*T*U
@@ -137,7 +138,7 @@ inline WsLayout make_layout(int T, int U, int B) {
     }
     w.pstat = take((size_t)B * w.nPstat * 2 * sizeof(float));
     w.lshift = take((size_t)B * sizeof(int));
-    w.bar = take((size_t)B * sizeof(int));
+    w.bar = take((size_t)B * 8 * sizeof(int));  // rnnt_redo.h kRedoCtr words per utterance
     w.total = off;
     return w;
 }

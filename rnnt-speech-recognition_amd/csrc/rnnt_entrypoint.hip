@@ -83,6 +83,7 @@ static bool fill_params(LossParams &p, const float *acts, float *grads, const in
     p.B = B, p.T = o.maxT, p.U = o.maxU, p.V = V, p.blank = o.blank_label;
     p.b0 = 0, p.nb = B;
     p.precise = 0;
+    p.visit_all = 0;
     p.tile = make_tile(o.maxT, o.maxU, V);
     p.N = w.N, p.Nr = w.Nr, p.Up = w.Up, p.NC = w.NC, p.NG = w.NG;
     p.cells = (uint32_t)cells;
@@ -202,15 +203,16 @@ rnntStatus_t compute_rnnt_loss_bwd(const float *acts, float *grads, const int *f
     return run_backward(p, (hipStream_t)options.stream);
 }
 
-// compute_rnnt_loss with the upstream gradient folded in (cost_scale NULL = 1).
-rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, const int *flat_labels,
-                                  const int *label_lengths, const int *input_lengths, const float *cost_scale,
-                                  int alphabet_size, int minibatch, float *costs, void *workspace,
-                                  rnntOptions options) {
+// compute_rnnt_loss with the upstream gradient folded in (cost_scale NULL = 1) and the build-only flags (include/rnnt.h):
+// costs == NULL = the gradient pass alone (compute_rnnt_loss_bwd), grads == NULL = the forward alone.
+rnntStatus_t compute_rnnt_loss_flags(const float *acts, float *grads, const int *flat_labels,
+                                     const int *label_lengths, const int *input_lengths, const float *cost_scale,
+                                     int alphabet_size, int minibatch, float *costs, void *workspace,
+                                     rnntOptions options, unsigned int flags) {
+    if (flags & ~(unsigned)RNNT_VISIT_ALL) return RNNT_STATUS_INVALID_VALUE;
     if (!grads)
         return compute_rnnt_loss_fwd(acts, flat_labels, label_lengths, input_lengths, alphabet_size, minibatch,
                                      costs, workspace, options);
-    if (!costs) return RNNT_STATUS_INVALID_VALUE;
     rnntStatus_t st = validate(acts, flat_labels, label_lengths, input_lengths, workspace, alphabet_size, minibatch,
                                options);
     if (st != RNNT_STATUS_SUCCESS) return st;
@@ -218,11 +220,23 @@ rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, const int *fl
     if (!fill_params(p, acts, grads, flat_labels, label_lengths, input_lengths, cost_scale, alphabet_size,
                      minibatch, costs, workspace, options))
         return RNNT_STATUS_INVALID_VALUE;
+    p.visit_all = (flags & RNNT_VISIT_ALL) ? 1 : 0;
     hipStream_t s = (hipStream_t)options.stream;
-    const WsLayout w = make_layout(options.maxT, options.maxU, minibatch);
-    st = run_forward(p, w, s);
-    if (st != RNNT_STATUS_SUCCESS) return st;
+    if (costs) {
+        const WsLayout w = make_layout(options.maxT, options.maxU, minibatch);
+        st = run_forward(p, w, s);
+        if (st != RNNT_STATUS_SUCCESS) return st;
+    }
     return run_backward(p, s);
+}
+
+rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, const int *flat_labels,
+                                  const int *label_lengths, const int *input_lengths, const float *cost_scale,
+                                  int alphabet_size, int minibatch, float *costs, void *workspace,
+                                  rnntOptions options) {
+    if (grads && !costs) return RNNT_STATUS_INVALID_VALUE;
+    return compute_rnnt_loss_flags(acts, grads, flat_labels, label_lengths, input_lengths, cost_scale, alphabet_size, minibatch,
+                                   costs, workspace, options, 0u);
 }
 
 rnntStatus_t compute_rnnt_loss(const float *acts, float *grads, const int *flat_labels,
@@ -252,6 +266,9 @@ static rnntStatus_t joint_call(const float *enc_proj, const float *pred_proj, co
     if (st != RNNT_STATUS_SUCCESS) return st;
     if (options.blank_label >= alphabet_size) return RNNT_STATUS_INVALID_VALUE;
     if (options.maxU > 1024) return RNNT_STATUS_INVALID_VALUE;  // the fused joint paths are built on the register-resident sweeps
+    if (joint_dtype & ~(0xff | RNNT_VISIT_ALL)) return RNNT_STATUS_INVALID_VALUE;
+    if (joint_dtype & RNNT_VISIT_ALL) phases |= 8;  // (launch_joint_loss: no occupancy floor in the backward)
+    joint_dtype &= 0xff;
     if (!joint_dtype_supported(joint_dtype, joint_size, alphabet_size)) return RNNT_STATUS_INVALID_VALUE;
     const bool any_grad = d_enc_proj || d_pred_proj || dW2 || db2;
     if (any_grad && !(d_enc_proj && d_pred_proj && dW2 && db2)) return RNNT_STATUS_INVALID_VALUE;
@@ -323,6 +340,9 @@ static rnntStatus_t joint_net_call(const float *enc, const float *pred, const fl
     if (any_grad && ((((uintptr_t)dW1 | (uintptr_t)db1 | (uintptr_t)d_enc | (uintptr_t)d_pred) & 15) != 0)) return RNNT_STATUS_INVALID_VALUE;  // 16-byte stores
     if ((((uintptr_t)enc | (uintptr_t)pred | (uintptr_t)W1 | (uintptr_t)b1) & 15) != 0) return RNNT_STATUS_INVALID_VALUE;
     if ((phases & 2) && !(phases & 1) && !any_grad) return RNNT_STATUS_INVALID_VALUE;
+    if (joint_dtype & ~(0xff | RNNT_VISIT_ALL)) return RNNT_STATUS_INVALID_VALUE;
+    if (joint_dtype & RNNT_VISIT_ALL) phases |= 8;  // (launch_joint_loss: no occupancy floor in the backward)
+    joint_dtype &= 0xff;
     if (!joint_dtype_supported(joint_dtype, joint_size, alphabet_size)) return RNNT_STATUS_INVALID_VALUE;  // before anything is enqueued
     const int B = minibatch, T = options.maxT, U = options.maxU;
     hipStream_t s = (hipStream_t)options.stream;

@@ -275,7 +275,8 @@ __device__ void lin_alpha_sweep(const LossParams &p, float *bufs, const LdLink l
         st_i32_wt(p.flags + 4 * b + kFlagG, 0);
         st_i32_wt(p.flags + 4 * b + kFlagState, 0);
         st_i32_wt(p.lshift + b, SH);  // the block length this utterance's frame tables are indexed with
-        st_i32_wt(p.bar + b, 0);      // phase counter of the utterance's hand-back team (rnnt_redo.h)
+        // the ticket / completion counters of the utterance's hand-back team (rnnt_redo.h; read by a LATER launch: plain stores)
+        ((int4 *)p.bar)[2 * b] = make_int4(0, 0, 0, 0), ((int4 *)p.bar)[2 * b + 1] = make_int4(0, 0, 0, 0);
     }
     float a[K];
 #pragma unroll
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(kRedoThreads) void lin_redo_kernel(const LossParams
     const int ub = (int)blockIdx.x / team;
     const int b = p.b0 + ub;
     RedoTeam tm;
-    tm.k = (int)blockIdx.x - ub * team, tm.n = team, tm.bar = p.bar + b, tm.ok = true;
+    tm.k = (int)blockIdx.x - ub * team, tm.n = team, tm.bar = p.bar + kRedoCtr * b, tm.ok = true;
     int *fl = p.flags + 4 * b;
     // one round trip: the four flag words and the two likelihoods (both written write-through by the sweeps / the gradient pass)
     typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -511,6 +512,16 @@ __global__ __launch_bounds__(kRedoThreads) void lin_redo_kernel(const LossParams
 // sweeps cover (up to 1024 columns).  One frame per lane spans up to 16 columns there: lattices on which that is too coarse
 // (more label columns than frames, unstructured logits) fail the certificate and are redone in the log domain.
 // (V >= 2: the lsm pass parks a cell's two edge probabilities in the cell's own LDS slot of V floats)
+static int lin_cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }
+    return n;
+}
+
 bool lin_path_ok(const LossParams &p) { return p.V >= 2 && sweep_K(p.U) >= 1 && tile_path_ok(p, false); }
 
 template <int K, int G>
@@ -533,7 +544,7 @@ static hipError_t launch_lin_redo(const LossParams &p, const bool force, hipStre
         hipError_t e = hipFuncSetAttribute((const void *)lin_redo_kernel<K, G, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
     }
-    const int team = redo_team_size(p.nb, p.T, p.U);
+    const int team = redo_team_size(p.nb, p.T, p.U, lin_cu_count());
     hipLaunchKernelGGL((lin_redo_kernel<K, G, NB>), dim3(p.nb * team), dim3(kRedoThreads), shm, s, p, force ? 1 : 0, team);
     return hipGetLastError();
 }

@@ -78,7 +78,8 @@ class _JointLossFunction(torch.autograd.Function):
                                                  labels.data_ptr(), ll.data_ptr(), il.data_ptr(), scale.data_ptr(),
                                                  J, V, B, d_ep.data_ptr(), d_pp.data_ptr(), d_w2.data_ptr(),
                                                  d_b2.data_ptr(), ctx.joint_dtype, ws.data_ptr(), opts)
-        _lib.check(st, "compute_rnnt_joint_loss_bwd")
+            _lib.check(st, "compute_rnnt_joint_loss_bwd")
+            _note_backward_rows(ws, T, U, B, J, V, ctx.blank)
         return d_ep, d_pp, d_w2, d_b2, None, None, None, None, None
 
 
@@ -148,11 +149,37 @@ class _JointNetLossFunction(torch.autograd.Function):
                                                      bb2.data_ptr(), labels.data_ptr(), ll.data_ptr(), il.data_ptr(),
                                                      scale.data_ptr(), H, J, V, B, *(g.data_ptr() for g in grads),
                                                      ctx.joint_dtype, ws.data_ptr(), opts)
-        _lib.check(st, "compute_rnnt_joint_net_loss_bwd")
+            _lib.check(st, "compute_rnnt_joint_net_loss_bwd")
+            _note_backward_rows(ws, T, U, B, J, V, ctx.blank)
         return (*grads, None, None, None, None, None)
 
 
 JOINT_DTYPES = {"f32": 0, "f16": 1}
+
+# Diagnostics (off by default): with TRACK_BACKWARD_ROWS set, every backward of this module asks the library how many lattice rows
+# (x 32-column tiles) it visited -- the data-dependent part of the f32-grade joint's run time (include/rnnt.h
+# get_rnnt_joint_backward_rows; the query synchronises the stream) -- and last_backward_rows() returns the answer.
+TRACK_BACKWARD_ROWS = False
+_LAST_ROWS = None
+
+
+def _note_backward_rows(ws, T, U, B, J, V, blank):
+    global _LAST_ROWS
+    if not TRACK_BACKWARD_ROWS:
+        return
+    import ctypes
+
+    rows = (ctypes.c_int * 2)(-1, -1)
+    opts = _lib.make_options(torch.cuda.current_stream().cuda_stream, blank, T, U)
+    st = _lib.load().get_rnnt_joint_backward_rows(ws.data_ptr(), J, V, B, opts, rows)
+    _LAST_ROWS = (rows[0], rows[1]) if st == 0 else (-1, -1)
+
+
+def last_backward_rows():
+    """(rows x 32-column tiles the last tracked backward visited, rows inside the utterances); (-1, -1) where nothing is skipped
+    (the f16 joint, the wide joint); None when nothing was tracked (TRACK_BACKWARD_ROWS)."""
+    return _LAST_ROWS
+
 
 # Test hook: when set to a byte value, every workspace this module allocates is filled with it before the forward call
 # (0xFF = a NaN bit pattern in every float: a backward kernel that read a workspace word nobody wrote would show it).
@@ -167,7 +194,7 @@ def _new_workspace(nbytes: int, dev) -> torch.Tensor:
 
 
 def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_lengths, blank_label: int = 0,
-                    joint_dtype: str = "auto", first_layer: str = "auto"):
+                    joint_dtype: str = "auto", first_layer: str = "auto", visit_all: bool = False):
     """costs[b] = transducer NLL of  logits = tanh((enc[:,:,None]+pred[:,None]) @ W1 + b1) @ W2 + b2.
 
     enc [B,T,H] (encoder output), pred [B,U,H] (prediction-network output), W1 [H,J], b1 [J],
@@ -181,7 +208,12 @@ def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_leng
 
     first_layer: where the first Dense layer (enc @ W1 + b1, pred @ W1, and dW1 / db1 / d enc / d pred) runs.  "engine": inside
     libwarprnnt.so (compute_rnnt_joint_net_loss_*: split-precision MFMA GEMMs, csrc/dense_kernels.hip; hidden size a multiple
-    of 32).  "torch": torch.matmul + autograd around compute_rnnt_joint_loss_*.  "auto": the engine whenever it takes the shape."""
+    of 32).  "torch": torch.matmul + autograd around compute_rnnt_joint_loss_*.  "auto": the engine whenever it takes the shape.
+
+    visit_all: RNNT_VISIT_ALL of include/rnnt.h -- the backward visits every lattice row instead of skipping the rows (x 32-column
+    tiles) whose cells all have an occupancy below 2^-50 (results differ by < 2^-44 |cost_scale| per element; timing then does not
+    depend on the data)."""
+    dtype_word = lambda name: JOINT_DTYPES[name] | (_lib.RNNT_VISIT_ALL if visit_all else 0)  # noqa: E731
     if joint_dtype == "auto":
         joint_dtype = _auto_joint_dtype(W2.shape[0], W2.shape[1])
     if joint_dtype not in JOINT_DTYPES:
@@ -205,7 +237,7 @@ def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_leng
     if first_layer == "engine":
         # the whole joint network behind the C ABI: W1 GEMMs, their backward, tanh, W2, the lattice (include/rnnt.h)
         return _JointNetLossFunction.apply(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_lengths, blank_label,
-                                           JOINT_DTYPES[joint_dtype])
+                                           dtype_word(joint_dtype))
     if first_layer != "torch":
         raise ValueError("rnnt_joint_loss: first_layer must be 'auto', 'engine' or 'torch'")
     # hidden sizes the library's dense kernels do not take (not a multiple of 32): the first layer through torch.matmul
@@ -213,7 +245,7 @@ def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_leng
     enc_proj = torch.matmul(enc, W1) + b1
     pred_proj = torch.matmul(pred, W1)
     return _JointLossFunction.apply(enc_proj, pred_proj, W2, b2, labels, input_lengths, label_lengths, blank_label,
-                                    JOINT_DTYPES[joint_dtype])
+                                    dtype_word(joint_dtype))
 
 
 _LOGITS_CACHE = {}  # (device, entry, shape) -> (workspace, output): a greedy decoder asks for one cell per emitted symbol
@@ -316,9 +348,10 @@ class JointLoss(torch.nn.Module):
     """The reference's joint network (model.py:158-166) + loss as one module.  Parameters follow Keras'
     Dense defaults: glorot-uniform kernels, zero biases."""
 
-    def __init__(self, hidden: int, joint_size: int, vocab_size: int, blank_label: int = 0):
+    def __init__(self, hidden: int, joint_size: int, vocab_size: int, blank_label: int = 0, visit_all: bool = False):
         super().__init__()
         self.blank_label = blank_label
+        self.visit_all = visit_all  # RNNT_VISIT_ALL: no occupancy floor in the backward (rnnt_joint_loss)
         self.W1 = torch.nn.Parameter(torch.empty(hidden, joint_size))
         self.b1 = torch.nn.Parameter(torch.zeros(joint_size))
         self.W2 = torch.nn.Parameter(torch.empty(joint_size, vocab_size))
@@ -329,7 +362,7 @@ class JointLoss(torch.nn.Module):
 
     def forward(self, enc, pred, labels, input_lengths, label_lengths):
         return rnnt_joint_loss(enc, pred, self.W1, self.b1, self.W2, self.b2, labels, input_lengths,
-                               label_lengths, self.blank_label)
+                               label_lengths, self.blank_label, visit_all=self.visit_all)
 
     def logits(self, enc, pred):
         """Unfused reference form (materialises [B,T,U,J] and [B,T,U,V] in torch); for tests and host-logic checks on CPU."""

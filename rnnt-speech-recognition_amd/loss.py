@@ -88,10 +88,12 @@ def rnnt_loss(acts, labels, input_lengths, label_lengths, blank_label: int = 0):
     return _RNNTLossFunction.apply(acts, labels, input_lengths, label_lengths, blank_label)
 
 
-def rnnt_loss_and_grad(acts, labels, input_lengths, label_lengths, blank_label: int = 0):
+def rnnt_loss_and_grad(acts, labels, input_lengths, label_lengths, blank_label: int = 0, visit_all: bool = False):
     """The upstream C entry point as one call: compute_rnnt_loss(acts, grads, ...) ->
     (costs [B], grads [B,T,U,V]) with grads = d cost_b / d acts (unscaled), like the two outputs of
-    the reference's WarpRNNT op.  No autograd graph is built."""
+    the reference's WarpRNNT op.  No autograd graph is built.
+    visit_all: compute_rnnt_loss_flags(..., RNNT_VISIT_ALL) -- no occupancy floor (vocabularies above 60 symbols otherwise
+    write zeros for cells whose occupancy is below 2^-50 without reading their logits)."""
     lib = _lib.load()
     if not acts.is_cuda:
         raise RuntimeError("rnnt_loss_and_grad: acts must live on an MI355X (cuda/HIP) device")
@@ -110,9 +112,14 @@ def rnnt_loss_and_grad(acts, labels, input_lengths, label_lengths, blank_label: 
         costs = torch.empty(B, dtype=torch.float32, device=dev)
         grads = torch.empty_like(acts_c)
         opts = _lib.make_options(torch.cuda.current_stream().cuda_stream, int(blank_label), T, U)
-        st = lib.compute_rnnt_loss(
-            acts_c.data_ptr(), grads.data_ptr(), labels.data_ptr(), label_lengths.data_ptr(),
-            input_lengths.data_ptr(), V, B, costs.data_ptr(), ws.data_ptr(), opts)
+        if visit_all:
+            st = lib.compute_rnnt_loss_flags(
+                acts_c.data_ptr(), grads.data_ptr(), labels.data_ptr(), label_lengths.data_ptr(),
+                input_lengths.data_ptr(), None, V, B, costs.data_ptr(), ws.data_ptr(), opts, _lib.RNNT_VISIT_ALL)
+        else:
+            st = lib.compute_rnnt_loss(
+                acts_c.data_ptr(), grads.data_ptr(), labels.data_ptr(), label_lengths.data_ptr(),
+                input_lengths.data_ptr(), V, B, costs.data_ptr(), ws.data_ptr(), opts)
     _lib.check(st, "compute_rnnt_loss")
     return costs, grads
 

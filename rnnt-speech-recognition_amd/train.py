@@ -14,6 +14,8 @@ from __future__ import annotations
 import time
 from typing import Callable, Dict, Iterable, Optional, Sequence, Tuple
 
+import math
+
 import torch
 import torch.distributed as dist
 
@@ -231,3 +233,41 @@ def synthetic_batch(hp, batch: int, frames: int, max_labels: int, device, seed: 
         labels[b, lab_len[b]:] = 0
     pred_inp = torch.cat([torch.zeros(batch, 1, dtype=torch.int32), labels], dim=1)  # [0] ++ labels
     return [t.to(device) for t in (mel, pred_inp, spec_len, lab_len, labels)]
+
+
+def synthetic_trained_like_joint(B: int, T: int, U: int, V: int, J: int, seed: int = 7, gain: float = 10.0, late_every: int = 2,
+                                 input_lengths=None, label_lengths=None):
+    """Projections and output-layer weights of a joint network whose posteriors look like a TRAINED transducer's: one dominant
+    symbol per lattice cell along a monotone alignment -- blank until the cell's label is due, the label afterwards (bonus `gain`
+    nats, as tests/test_peaky_gpu.py builds them on logits) -- under N(0,1)-sized noise from the remaining joint units.  Every
+    `late_every`-th utterance emits all its labels in the last 40 % of its frames (alignments far from the lattice's diagonal).
+    What the headline's N(0,1) inputs do not show: the alignment band is narrow, so the backward's row pruning skips most rows.
+
+    Construction (exact in the reference's joint, model.py:158-166): M = min(V - 1, J // 2) "symbol units"; unit k = v mod M of
+    symbol v carries tanh(a (t - emit_u)) where the cell's label belongs to it (enc_proj = a (t - T/2), pred_proj = -a (emit_u - T/2))
+    and -1 elsewhere (pred_proj = -40), W2[k, v] = gain; the other J - M units are N(0,1) projections with glorot weights.
+    input_lengths / label_lengths (optional, [B]): the utterances' frames T_b / labels L_b -- emission times fall inside T_b.
+    Returns CPU tensors (enc_proj [B,T,J], pred_proj [B,U,J], W2 [J,V], b2 [V], labels i32 [B,U-1])."""
+    g = torch.Generator().manual_seed(seed)
+    M = min(V - 1, J // 2)
+    a = min(0.1, 76.0 / T)  # |a (t - T/2)| stays inside the tanh tables' range (|x| <= 43, csrc/rnnt_common.h)
+    labels = torch.randint(1, V, (B, U - 1), generator=g, dtype=torch.int32)
+    ep = torch.randn(B, T, J, generator=g)
+    pp = torch.randn(B, U, J, generator=g)
+    lim = math.sqrt(6.0 / (J + V))
+    W2 = (torch.rand(J, V, generator=g) * 2 - 1) * lim
+    b2 = torch.zeros(V)
+    W2[:M] = 0.0
+    for v in range(1, V):
+        W2[v % M, v] = gain
+    t = torch.arange(T, dtype=torch.float32)
+    ep[:, :, :M] = (a * (t - T / 2.0))[None, :, None]
+    pp[:, :, :M] = -40.0
+    for b in range(B):
+        Tb = int(input_lengths[b]) if input_lengths is not None else T
+        Lb = int(label_lengths[b]) if label_lengths is not None else U - 1
+        lo = int(0.6 * Tb) if (late_every and b % late_every == late_every - 1) else 0
+        emit = torch.sort(torch.randint(lo, max(Tb, lo + 1), (Lb,), generator=g)).values.to(torch.float32)
+        k = (labels[b, :Lb].to(torch.int64) % M)
+        pp[b, torch.arange(Lb), k] = -a * (emit - T / 2.0)
+    return ep, pp, W2, b2, labels

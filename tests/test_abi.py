@@ -117,6 +117,13 @@ def test_argument_validation_needs_no_device(lib):
     assert lib.compute_rnnt_loss(fake, None, fake, fake, fake, 0, 4, fake, fake, o) == 2
     misaligned = ctypes.c_void_p(260)
     assert lib.compute_rnnt_loss(fake, None, fake, fake, fake, 28, 4, fake, misaligned, o) == 2
+    # the build-only flags: anything but RNNT_VISIT_ALL is refused, for the op and -- OR-ed into joint_dtype -- for the fused joint
+    assert _lib.RNNT_VISIT_ALL == 0x100 and re.search(r"#define\s+RNNT_VISIT_ALL\s+0x100", open(os.path.join(ROOT, "include", "rnnt.h")).read())
+    assert lib.compute_rnnt_loss_flags(fake, fake, fake, fake, fake, None, 28, 4, fake, fake, o, 0x2) == 2
+    assert lib.compute_rnnt_loss_flags(fake, fake, fake, fake, fake, None, 28, 4, fake, fake, o, 0x101) == 2
+    jargs = [fake] * 7 + [None, 640, 28, 4] + [fake] * 5
+    assert lib.compute_rnnt_joint_loss(*jargs, 0x200, fake, o) == 2   # unknown flag bit
+    assert lib.compute_rnnt_joint_loss(*jargs, 0x102, fake, o) == 2   # unknown arithmetic type under the flag
 
 
 def test_python_surface_fails_loudly_on_cpu_tensors(lib):

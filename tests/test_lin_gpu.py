@@ -261,3 +261,30 @@ def test_out_of_range_lengths_come_back_nan():
     il[1] = 20
     c_ref, g_ref = orc.rnnt_loss_and_grad(acts[[0, 2]], labels[[0, 2]], il[[0, 2]], ll[[0, 2]])
     assert np.abs(g[[0, 2]] - g_ref).max() <= 1e-5
+
+
+def test_hand_back_completes_while_another_stream_holds_the_cus():
+    """The hand-back team's phases are dealt by tickets (rnnt_redo.h, round 6): whoever draws a part is running, so a phase completes
+    however few of the team's workgroups are resident.  Here a second stream keeps every CU busy with large GEMMs while a batch in
+    which every utterance is handed back (8 sigma) goes through: results must be the ones of an undisturbed call, bit for bit
+    (the round-5 barrier counted ARRIVALS of all members and gave up -- NaN results -- when some could not become resident)."""
+    B, T, U, V = 32, 600, 150, 28
+    acts, labels, il, ll = _case(B, T, U, V, seed=88, sigma=8.0, ragged=False)
+    ref = Call(acts, labels, il, ll)
+    ref.full()
+    torch.cuda.synchronize()
+    c_ref, g_ref = ref.costs.clone(), ref.grads.clone()
+    assert bool(torch.isfinite(c_ref).all())
+    side = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device=DEV)
+    b = torch.randn(8192, 8192, device=DEV)
+    out = torch.empty_like(a)
+    with torch.cuda.stream(side):
+        for _ in range(30):  # ~1.1 TFLOP each in f32: the side stream stays busy for the whole call below
+            torch.mm(a, b, out=out)
+    c = Call(acts, labels, il, ll)
+    for _ in range(3):
+        c.full()
+    torch.cuda.synchronize()
+    assert torch.equal(c.costs, c_ref)
+    assert torch.equal(c.grads, g_ref)
