@@ -56,6 +56,8 @@ def parse(argv=None):
     ap.add_argument("--fused-only", type=str, default="",
                     help="B,T,U,V: time only the fused joint+loss on this shape (e.g. 16,1500,300,1024 = BASELINE "
                          "config 5) and print its JSON object")
+    ap.add_argument("--fused-leg", choices=["all", "n01", "n01_all_rows", "trained", "trained_all_rows"], default="all",
+                    help="with --fused-only: time just one of the four legs (profiling runs: the kernel trace then holds one kind of launch)")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip BASELINE configs[2] (end-to-end train step, 2x320 LSTM encoder / 1x320 decoder, B=64 per GPU)")
     ap.add_argument("--no-config5", action="store_true",
@@ -170,7 +172,7 @@ def cpu_baseline(B, T, U, V, reps):
 # ----------------------------------------------------------------------------------------------------------------
 # fused joint + loss (SURVEY.md 8d "P2")
 # ----------------------------------------------------------------------------------------------------------------
-def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
+def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps, only="all"):
     """compute_rnnt_joint_loss (costs + d_enc_proj, d_pred_proj, dW2, db2) from enc_proj / pred_proj.  Four timings where the
     backward skips work (the f32-grade joint: lattice rows x 32-column tiles without mass, include/rnnt.h RNNT_VISIT_ALL):
         ms_per_step           N(0,1) projections, glorot W2 -- the pruned default, as a caller gets it
@@ -228,20 +230,15 @@ def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
         rows = (ctypes.c_int * 2)(-1, -1)
-        if not f16:
-            _lib.check(lib.get_rnnt_joint_backward_rows(ws.data_ptr(), J, V, B, opts, rows), "backward rows")
+        _lib.check(lib.get_rnnt_joint_backward_rows(ws.data_ptr(), J, V, B, opts, rows), "backward rows")
         visited = rows[0] / rows[1] if rows[1] > 0 else 1.0
         return dt, visited, bool(torch.isfinite(costs).all()), float(costs.mean())
 
     conv = 8.0 * J * V * cells  # SURVEY.md 8(d) convention (includes a backward recompute of the logits GEMM)
-    if f16:
-        peak, vp = MFMA_F16_PEAK_TFLOPS, V
-        executed_of = lambda visited: 6.0 * J * V * cells  # noqa: E731  three J x V products, every row (no pruning in this engine yet)
-    else:
-        # split-precision products: three f16 MFMAs per f32-grade product -> ceiling = dense f16 peak / 3; issued on V padded to
-        # vocabulary tiles of 32 symbols; forward (2 J V) on every row, dh + dW2 (4 J V) on the visited rows
-        peak, vp = MFMA_F16_PEAK_TFLOPS / 3.0, 32 * ((V + 31) // 32)
-        executed_of = lambda visited: (2.0 + 4.0 * visited) * J * vp * cells  # noqa: E731
+    # forward product (2 J V per cell) on every row, dh + dW2 (4 J V) on the visited rows.  f16: one MFMA per product; f32-grade:
+    # split-precision products, three f16 MFMAs each -> ceiling = dense f16 peak / 3, issued on V padded to vocabulary tiles of 32
+    peak, vp = (MFMA_F16_PEAK_TFLOPS, V) if f16 else (MFMA_F16_PEAK_TFLOPS / 3.0, 32 * ((V + 31) // 32))
+    executed_of = lambda visited: (2.0 + 4.0 * visited) * J * vp * cells  # noqa: E731
 
     def leg(kind, visit_all):
         dt, visited, finite, mean_cost = run(kind, visit_all)
@@ -249,6 +246,12 @@ def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
         return {"ms_per_step": dt * 1e3, "cells_per_s": cells / dt, "backward_rows_visited": visited, "costs_finite": finite,
                 "mean_cost_nats": mean_cost, "executed_tflops": ex / dt / 1e12, "frac": ex / dt / 1e12 / peak}
 
+    if only != "all":  # one leg (profiling)
+        kind, va = {"n01": ("n01", False), "n01_all_rows": ("n01", True), "trained": ("trained_like", False),
+                    "trained_all_rows": ("trained_like", True)}[only]
+        one = leg(kind, va)
+        one["leg"] = only
+        return one
     main = leg("n01", False)
     out = {"workload": f"joint+loss+grads from enc_proj/pred_proj, B={B} T={T} U={U} V={V} J={J}, "
                        + ("f16 MFMA joint / f32 lattice" if f16 else "f32-grade products on split-precision f16 MFMAs"),
@@ -259,23 +262,19 @@ def bench_fused_joint(lib, _lib, dev, B, T, U, V, J, stream, reps):
                         "backward_rows_visited": main["backward_rows_visited"],
                         "convention_flops_per_step": conv, "convention_tflops": conv / (main["ms_per_step"] * 1e-3) / 1e12,
                         "convention_frac": conv / (main["ms_per_step"] * 1e-3) / 1e12 / peak,
-                        "note": "achieved / frac = matrix-core flops actually ISSUED (f16: three J x V products -- forward, dh, dW2; f32-grade: "
-                                "forward on every row + dh and dW2 on the visited fraction of the lattice rows, V padded to 32-symbol tiles, "
-                                "peak = dense f16 peak / 3 because a product is three f16 MFMAs) over time; convention_* = SURVEY.md 8(d)'s "
+                        "note": "achieved / frac = matrix-core flops actually ISSUED (the forward product on every row + dh and dW2 on the visited "
+                                "fraction of the lattice rows; f32-grade: V padded to 32-symbol tiles and peak = dense f16 peak / 3 because a "
+                                "product is three f16 MFMAs) over time; convention_* = SURVEY.md 8(d)'s "
                                 "8*J*V per cell, which counts a backward recompute nobody executes and every row whether visited or not"},
            "workspace_GB": ws.numel() / 1e9}
     if not f16:
         out["roofline"]["f32_mfma_peak_for_reference"] = MFMA_F32_PEAK_TFLOPS
         out["roofline"]["issue_bound"] = fused_issue_bound(B, T, U, V, J, main["ms_per_step"] * 1e-3)
-        out["all_rows"] = leg("n01", True)
-        out["trained_like"] = {"pruned": leg("trained_like", False), "all_rows": leg("trained_like", True),
-                               "input": "pkg.synthetic_trained_like_joint(seed=7): one dominant symbol per cell along a monotone alignment "
-                                        "(bonus 10 nats), every second utterance emitting its labels in the last 40 % of the frames"}
-        out["all_rows"]["note"] = "RNNT_VISIT_ALL (include/rnnt.h): no occupancy floor -- the backward visits every lattice row, as the reference's autodiff does"
-    else:
-        out["trained_like"] = {"all_rows": leg("trained_like", False),
-                               "input": "pkg.synthetic_trained_like_joint(seed=7)"}
-        out["roofline"]["backward_rows_visited"] = 1.0
+    out["all_rows"] = leg("n01", True)
+    out["all_rows"]["note"] = "RNNT_VISIT_ALL (include/rnnt.h): no occupancy floor -- the backward visits every lattice row, as the reference's autodiff does"
+    out["trained_like"] = {"pruned": leg("trained_like", False), "all_rows": leg("trained_like", True),
+                           "input": "pkg.synthetic_trained_like_joint(seed=7): one dominant symbol per cell along a monotone alignment "
+                                    "(bonus 10 nats), every second utterance emitting its labels in the last 40 % of the frames"}
     return out
 
 
@@ -665,7 +664,7 @@ def main():
         fB, fT, fU, fV = (int(v) for v in a.fused_only.split(","))
         st = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(st):
-            out = bench_fused_joint(lib, _lib, dev, fB, fT, fU, fV, a.joint_size, st, max(2, min(a.steps, 5)))
+            out = bench_fused_joint(lib, _lib, dev, fB, fT, fU, fV, a.joint_size, st, max(2, min(a.steps, 5)), only=a.fused_leg)
         if rank == 0:
             real_stdout.write(json.dumps({"fused_joint": out}) + "\n")
             real_stdout.flush()

@@ -221,7 +221,9 @@ RNNT_API rnntStatus_t compute_rnnt_loss_flags(const float *acts, float *grads, c
  *                                    joint_size a multiple of 128 (128 ... 640).  h = tanh(.) and W2 are rounded to binary16
  *                                    (round-to-nearest-even) before the products, accumulation is f32; the loss gradient
  *                                    w.r.t. the logits is scaled by 2^(14 - ceil(log2 max|cost_scale|)) and rounded to
- *                                    binary16 before dh = dl.W2^T and dW2 = h^T.dl.  The lattice (log-softmax, alpha,
+ *                                    binary16 before dh = dl.W2^T and dW2 = h^T.dl (the backward skips lattice rows without mass,
+ *                                    as joint_dtype 0 does -- groups of four rows of a 32-column tile here; RNNT_VISIT_ALL
+ *                                    switches that off).  The lattice (log-softmax, alpha,
  *                                    beta, costs) stays f32.  A forward pass that knows a backward pass follows (the
  *                                    one-call entry with gradients, or _fwd) PARKS the softmax numerators in the workspace:
  *                                    per (cell, 32-symbol chunk) 2^(x log2 e - R) rounded to binary16, R = the integer at or
@@ -329,7 +331,7 @@ RNNT_API rnntStatus_t compute_rnnt_joint_logits(const float *enc_proj, const flo
                                                 int alphabet_size, int minibatch, float *logits,
                                                 int joint_dtype, void *workspace, rnntOptions options);
 
-/* Diagnostics of the f32-grade fused joint's backward (joint_dtype 0, joint_size <= 640): how many lattice rows x 32-column tiles the
+/* Diagnostics of the fused joints' backward (joint_dtype 0 at joint_size <= 640; joint_dtype 1 since round 6): how many lattice rows x 32-column tiles the
  * LAST backward on this workspace visited (rows[0]) out of those inside the utterances (rows[1]).  The backward skips a row of a
  * tile when none of its 32 cells has an occupancy alpha.beta/L above 2^-50: every dlogits value of a cell is bounded by
  * 2 |cost_scale| x that occupancy, so such a row adds less than 2^-44 |cost_scale| to anything -- its cells get exactly zero where

@@ -130,6 +130,11 @@ struct JhParams {
     float *dWpart;  // [n_ranges][J][V]
     float *dbpart;  // [n_ranges][V]
     const f16 *zrow;  // 1 KB of zeros: stands in for dl rows beyond the tensor (u >= U) in K4
+    uint8_t *live8;   // [B][n_ut][4 ceil(T/32)] one BIT per (lattice row, u-tile): the backward visits the row (jh_rowbits_kernel; the
+                      // four rows of an aligned group share their bit: K3 works in iterations of four rows)
+    int *rowcnt;      // [0] = (rows x u-tiles) the backward visits, [1] = those inside the utterances, [2] = shape stamp
+    int *order;       // [B n_ut n_ts] K3's strips, the ones with the most visited rows first (jh_order_kernel)
+    int visit_all;    // RNNT_VISIT_ALL: no occupancy floor
     int J, n_ut, n_tt, n_ts, TS, n_tq, n_units, n_ranges;
     int b2_lds_off;  // K1/K2: byte offset of the bias table in LDS, -1 = read it from global memory (does not fit)
     float *logits_out;  // MODE 3 of K1 (compute_rnnt_joint_logits, decoding): f32 logits [cells][V]
@@ -585,6 +590,110 @@ __global__ __launch_bounds__(512) void jh_logits_kernel(const JhParams jp) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Lattice rows the backward does not visit (round 6; the f32-grade joint has had this since round 5: joint_kernels.hip kOccFloor).
+// Every dlogits value of a cell is bounded by 2 |cost_scale| x the cell's occupancy alpha.beta / L.  One workgroup per (utterance,
+// 8 rows, 32 columns): a row's bit is set when some cell of it has an occupancy above 2^-kOccFloorH (NaN counts as occupied), and
+// the four rows of an aligned group then share the OR of their bits -- K3 works in iterations of four rows, K4 row by row, the
+// d enc_proj reduction reads the rows K3 wrote: all three follow these bits.  RNNT_VISIT_ALL (include/rnnt.h): every row inside
+// the utterance.  How many rows that is depends on the data: counted for get_rnnt_joint_backward_rows.
+// ---------------------------------------------------------------------------------------------
+constexpr int kOccFloorH = 50;
+#ifndef JH_DHX_WGS
+#define JH_DHX_WGS 2560  // (measured at config 5: 1280 / 2560 / 3840 workgroups: pruned N(0,1) 5.5 / 5.3 ms, trained-like 2.5 / 1.9 ms, all rows the same)
+#endif
+__host__ __device__ inline int rowcnt_stamp(int T, int U, int B, int J, int V) {
+    return (int)(0x16f16000u ^ ((unsigned)T * 73856093u) ^ ((unsigned)U * 19349663u) ^ ((unsigned)B * 83492791u) ^ ((unsigned)J * 2654435761u) ^ (unsigned)V);
+}
+constexpr int kRowbitsRows = 64;  // lattice rows per workgroup of jh_rowbits_kernel
+__global__ __launch_bounds__(256) void jh_rowbits_kernel(const JhParams jp) {
+    // One workgroup per (utterance, 64 rows, 32 columns), walked DIAGONAL by diagonal: the lattice state is stored diagonal-major
+    // (a diagonal's 32 columns of the tile are 128 consecutive bytes; a row's would be 32 different cache lines: 0.69 ms at config 5)
+    const LossParams &p = jp.lp;
+    const int tid = threadIdx.x, n_tb = (p.T + kRowbitsRows - 1) / kRowbitsRows;
+    int bid = blockIdx.x;
+    const int ut = bid % jp.n_ut;
+    bid /= jp.n_ut;
+    const int tb = bid % n_tb, b = bid / n_tb;
+    const int t0 = tb * kRowbitsRows, u0 = ut * 32;
+    const int Tb = length_T(p, b), Ub = length_U(p, b);
+    __shared__ unsigned long long rowmask;  // bit r: row t0 + r has a cell with occupancy above the floor
+    if (tid == 0) rowmask = 0ull;
+    __syncthreads();
+    const bool tile_live = t0 < Tb && u0 < Ub;
+    if (tile_live) {
+        const int ul = tid & 31, u = u0 + ul;
+        const double ll2 = p.ll[2 * b];
+        const size_t ob = (size_t)b * p.NC * p.NG + fdiv((uint32_t)u, p.divOG);
+        unsigned long long mine = 0ull;
+        for (int d = tid >> 5; d < kRowbitsRows + 31; d += 8) {  // diagonal n = t0 + u0 + d of the tile
+            const int n = t0 + u0 + d, t = n - u;
+            if (t >= t0 && t < t0 + kRowbitsRows && t < Tb && u < Ub) {
+                const size_t sk = ((size_t)b * p.Nr + n) * p.Up + u, ok = ob + (size_t)(n / kRebase) * p.NG;
+                const double l2occ = ((double)p.A[sk] + (double)p.offA[ok]) + ((double)p.Bt[sk] + (double)p.offB[ok]) - ll2;
+                if (jp.visit_all || !(l2occ <= (double)-kOccFloorH)) mine |= 1ull << (t - t0);
+            }
+        }
+        if (mine) atomicOr(&rowmask, mine);
+    }
+    __syncthreads();
+    if (tid < kRowbitsRows / 8) {  // one byte of bits per 8 rows
+        int m = (int)((rowmask >> (8 * tid)) & 0xffull);
+        m = ((m & 0x0f) ? 0x0f : 0) | ((m & 0xf0) ? 0xf0 : 0);  // the groups of four rows
+        // (rows of a group beyond T_b carry the group's bit: K3 / K4 / the reduction clip rows at T_b themselves)
+        const int tt = tb * (kRowbitsRows / 8) + tid;
+        if (tt < 4 * ((p.T + 31) >> 5)) jp.live8[((size_t)b * jp.n_ut + ut) * (size_t)(4 * ((p.T + 31) >> 5)) + tt] = (uint8_t)m;
+        int vis = 0, ins = 0;
+        for (int q = 0; q < 8; ++q) {
+            const bool in = tile_live && (tt * 8 + q < Tb);
+            ins += in, vis += in && ((m >> q) & 1);
+        }
+        if (vis) atomicAdd(jp.rowcnt, vis);
+        if (ins) atomicAdd(jp.rowcnt + 1, ins);
+    }
+    if (blockIdx.x == 0 && tid == 0) jp.rowcnt[2] = rowcnt_stamp(p.T, p.U, p.B, jp.J, p.V);
+}
+
+// K3's strips (utterance, u-tile, row split) in the order of their work, heaviest first: one workgroup counts each strip's visited
+// rows and sorts by counting (<= 256 buckets).  With the pruning the strips' work follows the alignment band -- about a third of
+// them do everything on unstructured inputs -- and dealt in lattice order some CUs drew three or four full strips while others
+// drew none (config 5: K3 at 35 % of the rows took 71 % of its all-rows time).  The order inside a bucket depends on timing; the
+// results do not depend on the order (every strip writes its own slabs).
+__global__ __launch_bounds__(1024) void jh_order_kernel(const JhParams jp, const int n_strips) {
+    __shared__ int hist[257], cursor[257];
+    const LossParams &p = jp.lp;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 257; i += 1024) hist[i] = 0;
+    __syncthreads();
+    auto weight = [&](const int i) -> int {
+        int q = i;
+        const int ts = q % jp.n_ts;
+        q /= jp.n_ts;
+        const int ut = q % jp.n_ut, b = p.b0 + q / jp.n_ut;
+        const int Tb = length_T(p, b), Ub = length_U(p, b);
+        const int t0 = ts * jp.TS, t1 = min(min(t0 + jp.TS, p.T), Tb);
+        if (t0 >= t1 || ut * 32 >= Ub) return 0;
+        const uint32_t *bits = (const uint32_t *)(jp.live8 + ((size_t)b * jp.n_ut + ut) * (size_t)(4 * ((p.T + 31) >> 5)));
+        int w = 0;
+        for (int t = t0; t < t1;) {  // (t0 is a multiple of 4; whole words where possible)
+            const int e = min(t1, (t | 31) + 1);
+            uint32_t m = bits[t >> 5] >> (t & 31);
+            if (e - t < 32) m &= (1u << (e - t)) - 1u;
+            w += __popc(m);
+            t = e;
+        }
+        return min((w + 3) >> 2, 256);  // groups of four rows
+    };
+    for (int i = tid; i < n_strips; i += 1024) atomicAdd(&hist[weight(i)], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int pos = 0;
+        for (int w = 256; w >= 0; --w) cursor[w] = pos, pos += hist[w];
+    }
+    __syncthreads();
+    for (int i = tid; i < n_strips; i += 1024) jp.order[atomicAdd(&cursor[weight(i)], 1)] = i;
+}
+
+// ---------------------------------------------------------------------------------------------
 // K3, round 6 (jh_dhx_kernel<NT>, J = 128 NT): the streaming pass K2 and the dh product in ONE kernel, every dl element touched once.
 //   workgroup = (utterance, u-tile of 32 columns, row split); per iteration 4 lattice rows x 32 columns = 128 cells x ALL J units
 //   (the old K3 gave a workgroup 128 units: five workgroups fetched -- and would have had to convert -- every dl row).
@@ -619,7 +728,7 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
     float *const comb = (float *)(smem + kCoff);
     const uint32_t smem0 = lds_addr(smem);
 
-    const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t wg = (uint32_t)jp.order[blockIdx.x];  // the strips with the most visited rows first (jh_order_kernel)
     uint32_t bid = wg;
     const int ts = (int)(bid % (uint32_t)jp.n_ts);
     bid /= (uint32_t)jp.n_ts;
@@ -809,25 +918,40 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
     const uint32_t a_rd = kAoff + (uint32_t)((2 * wm) * 2048);  // + stage * 8192 + mi * 2048
     const uint32_t b_rd = (uint32_t)((wn * JW) * 64);           // + stage * kBS + ni * 2048
 
+    // The iterations of this workgroup: the groups of four rows of its strip that the backward visits (jh_rowbits_kernel: some cell of
+    // the group's 4 x 32 tile carries mass, or RNNT_VISIT_ALL).  next_live(t) = first row of the first such group at or after row t
+    // (a multiple of four); anything >= t_end: none.  Scalar code: a 32-row word of bits per look.
+    const uint32_t *const rowbits = (const uint32_t *)(jp.live8 + ((size_t)b * jp.n_ut + ut) * (size_t)(4 * ((p.T + 31) >> 5)));
+    auto next_live = [&](int t) -> int {
+        while (t < t_end) {
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowbits[t >> 5]) >> (t & 31);
+            if (w) return t + __builtin_ctz(w);
+            t = (t | 31) + 1;
+        }
+        return t_end;
+    };
+    const int t_first = next_live(t_begin);
+    if (t_first >= t_end) return;  // nothing of this strip carries mass (its d enc_proj rows read as zero: the reduction follows the same bits)
+    int t_n1 = next_live(t_first + 4);
     // ---- prologue: factors of the first two iterations; chunks 0..2 of A, 0..1 of W2 under way; chunk 0 converted
     CellSt cur, nxt;
-    cell_place(cur, t_begin);
-    cell_factors(cur, t_begin);
+    cell_place(cur, t_first);
+    cell_factors(cur, t_first);
     nxt = cur;
-    if (t_begin + 4 < t_end) {
-        cell_place(nxt, t_begin + 4);
-        cell_factors(nxt, t_begin + 4);
+    if (t_n1 < t_end) {
+        cell_place(nxt, t_n1);
+        cell_factors(nxt, t_n1);
     }
-    dma_a(cur, t_begin, 0, 0);
+    dma_a(cur, t_first, 0, 0);
 #pragma unroll
     for (int k = 0; k < NT; ++k) dma_b(0, 0, k);
-    dma_a(cur, t_begin, 1, 1);
+    dma_a(cur, t_first, 1, 1);
 #pragma unroll
     for (int k = 0; k < NT; ++k) dma_b(1, 1, k);
-    dma_a(cur, t_begin, 2, 2);
+    dma_a(cur, t_first, 2, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     h8 o_pend = a_convert(cur, 0, 0);  // the converted piece whose store is pending (chunk pk of the iteration at row pt, state pst)
-    a_store(o_pend, cur, t_begin, 0);
+    a_store(o_pend, cur, t_first, 0);
     bool pend = false;
     bool pend_next = false;
     int pk = 0;
@@ -844,8 +968,9 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
 #define DT(k) do { } while (0)
 #endif
 
-    for (int t_it = t_begin; t_it < t_end; t_it += 4) {
-        const bool has_next = t_it + 4 < t_end;
+    for (int t_it = t_first; t_it < t_end;) {
+        const bool has_next = t_n1 < t_end;                            // (t_n1: the next visited group, t_n2: the one after)
+        const int t_n2 = has_next ? next_live(t_n1 + 4) : t_end;
         f32x16 acc[2][NT];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -892,7 +1017,7 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
                 a_fetch(araw, (q + 1) & 3);  // (also in the workgroup's last step, where nothing reads the result)
                 __builtin_amdgcn_sched_barrier(0);
                 if (pend) {
-                    if (pend_next) a_store(o_pend, nxt, t_it + 4, pk);
+                    if (pend_next) a_store(o_pend, nxt, t_n1, pk);
                     else a_store(o_pend, cur, t_it, pk);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -906,7 +1031,7 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
                     bf[ni] = *(const h8 *)(smem + b_rd + sb * kBS + ni * 2048 + foff1);
                 }
                 if (e3) {
-                    if (x3) dma_a(nxt, t_it + 4, k3, (q + 3) & 3);
+                    if (x3) dma_a(nxt, t_n1, k3, (q + 3) & 3);
                     else dma_a(cur, t_it, k3, (q + 3) & 3);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -964,7 +1089,7 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
 #ifdef JH_TRACE
 #define ET(k)                                                                                                   \
     do {                                                                                                        \
-        if (tr && t_it == t_begin + 4 && lane == 0) tr[154 + (k)] = (long long)__builtin_amdgcn_s_memtime();    \
+        if (tr && !first && tstep >= 22 && tstep < 70 && lane == 0) tr[154 + (k)] = (long long)__builtin_amdgcn_s_memtime();    \
     } while (0)
 #else
 #define ET(k) do { } while (0)
@@ -1048,14 +1173,15 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
         // the factors of the iteration after the next (its first chunk is converted in the last step of the next one).  (Their loads
         // issued two unit tiles earlier, the arithmetic here: 11 more live registers, spilled -- 13.7 against 13.1 ms at config 5.)
         CellSt nn = nxt;
-        if (t_it + 8 < t_end) {
-            cell_place(nn, t_it + 8);
-            cell_factors(nn, t_it + 8);
+        if (t_n2 < t_end) {
+            cell_place(nn, t_n2);
+            cell_factors(nn, t_n2);
         }
         ET(4);
         first = false;
         cur = nxt, nxt = nn;
         pend_next = false;  // (the piece converted in the last step belongs to what is now the current iteration)
+        t_it = t_n1, t_n1 = t_n2;
     }
 }
 
@@ -1095,8 +1221,8 @@ __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(
     const int vw = PARTIAL ? min(VT, V - v0) : VT;     // columns of this V tile (a multiple of 128)
     const bool wv_live = !PARTIAL || wv * WCOL < vw;   // wave-uniform: this wave's columns exist
     constexpr bool kAllLanes = !PARTIAL && VT == 512;  // a dl row piece fills all 64 lanes of its LDS-DMA instruction
-    const int unit_lo = (int)((long long)jp.n_units * range / jp.n_ranges);
-    const int unit_hi = (int)((long long)jp.n_units * (range + 1) / jp.n_ranges);
+    // (round 6: a range takes every n_ranges-th unit -- with the backward's row pruning the units' work follows the alignment band,
+    // and consecutive units, one utterance's neighbouring tiles, are busy or idle together)
 
     f32x16 acc[2][VB];
 #pragma unroll
@@ -1119,7 +1245,9 @@ __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(
     long long *tr = (blockIdx.x == 100) ? jp.trace + (size_t)(kTraceBlocks * 8 + wave) * kTraceSlots : nullptr;
     int tstep = 0;
 #endif
-    for (int unit = unit_lo; unit < unit_hi; ++unit) {
+    int *const rowlist = (int *)(ebuf + 4 * 512);  // [kTQ] the visited rows of the current unit, as offsets from its first row
+    int *const rowcount = rowlist + kTQ;
+    for (int unit = range; unit < jp.n_units; unit += jp.n_ranges) {
         int q = unit;
         const int tq = q % jp.n_tq;
         q /= jp.n_tq;
@@ -1129,21 +1257,40 @@ __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(
         const int Tb = length_T(p, b), Ub = length_U(p, b);
         const int t_begin = tq * kTQ, t_end = min(min(t_begin + kTQ, p.T), Tb);
         if (t_begin >= t_end || u0 >= Ub) continue;  // workgroup-uniform
-        const int nsteps = t_end - t_begin;
+        // the rows of the unit the backward visits (jh_rowbits_kernel), in order: wave 0 compacts the unit's 128 row bits
+        wait_lgkm();
+        __builtin_amdgcn_s_barrier();  // (the previous unit's last step has read its row list)
+        if (wave == 0) {
+            const uint32_t *bits = (const uint32_t *)(jp.live8 + ((size_t)b * jp.n_ut + ut) * (size_t)(4 * ((p.T + 31) >> 5))) + (t_begin >> 5);
+            static_assert(kTQ == 128, "two ballots cover a unit");
+            const bool a0 = t_begin + lane < t_end && ((bits[lane >> 5] >> (lane & 31)) & 1u);
+            const bool a1 = t_begin + 64 + lane < t_end && ((bits[2 + (lane >> 5)] >> (lane & 31)) & 1u);
+            const unsigned long long m0 = __ballot(a0), m1 = __ballot(a1);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const int n0 = __builtin_popcountll(m0);
+            if (a0) rowlist[__builtin_popcountll(m0 & lt)] = lane;
+            if (a1) rowlist[n0 + __builtin_popcountll(m1 & lt)] = 64 + lane;
+            if (lane == 0) rowcount[0] = n0 + __builtin_popcountll(m1);
+        }
+        wait_lgkm();
+        __builtin_amdgcn_s_barrier();
+        const int nsteps = rowcount[0];
+        if (nsteps == 0) continue;  // workgroup-uniform
+        // lattice row of step st (scalar: one LDS look per step in the main loop, not one per DMA piece)
+        auto row_of = [&](const int st) -> int { return t_begin + __builtin_amdgcn_readfirstlane(rowlist[min(st, nsteps - 1)]); };
         float pv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             pv[e] = Ptab[((size_t)b * p.U + min(u0 + 8 * cg + e, p.U - 1)) * J + j0 + jl];
         // Three stages of (dl rows + h^T fragments), enc_proj rows one step further ahead (four small buffers): at step s
         // the DMA of row s+2's dl and of row s+3's enc_proj slice are issued, row s+2's h^T is built, row s is multiplied.
-        auto dma_e = [&](const int s) {  // wave 0, lanes 0..31: 128 floats
+        auto dma_e = [&](const int s, const int t) {  // wave 0, lanes 0..31: 128 floats of lattice row t (= row_of(s))
             if (wave == 0 && lane < 32) {
-                const float *src = Etab + ((size_t)b * p.T + min(t_begin + s, t_end - 1)) * J + j0 + lane * 4;
+                const float *src = Etab + ((size_t)b * p.T + t) * J + j0 + lane * 4;
                 lds_dma16(src, ebuf + (s & 3) * 512);
             }
         };
-        auto dma_d = [&](const int s, char *st) {
-            const int t = t_begin + s;
+        auto dma_d = [&](const int t, char *st) {  // the dl rows of lattice row t
 #pragma unroll
             for (int k = 0; k < 4; ++k) {  // one dl row (512 columns = 1 KB) per wave-instruction
                 const int i = wave + 8 * k;
@@ -1152,8 +1299,8 @@ __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(
                 if (kAllLanes || lane * 8 < vw) lds_dma16(src, st + i * kRow);
             }
         };
-        auto dma_d_piece = [&](const int s, char *st, const int k) {  // piece k (0..3) of the same
-            const int t = t_begin + s, i = wave + 8 * k;
+        auto dma_d_piece = [&](const int t, char *st, const int k) {  // piece k (0..3) of the same
+            const int i = wave + 8 * k;
             const f16 *src = (u0 + i < p.U) ? jp.dl + ((size_t)(b * p.T + t) * p.U + u0 + i) * V + v0 + lane * 8
                                             : jp.zrow + lane * 8;
             if (kAllLanes || lane * 8 < vw) lds_dma16(src, st + i * kRow);
@@ -1177,14 +1324,14 @@ __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(
         wait_lgkm();
         __builtin_amdgcn_s_barrier();  // the previous unit is done with every stage
         asm volatile("" ::: "memory");
-        dma_e(0), dma_e(1), dma_e(2);
+        dma_e(0, row_of(0)), dma_e(1, row_of(1)), dma_e(2, row_of(2));
         wait_vm();
         __builtin_amdgcn_s_barrier();  // enc_proj rows 0..2 visible
         asm volatile("" ::: "memory");
-        dma_d(0, smem);
+        dma_d(row_of(0), smem);
         build_h(0, smem);
         if (nsteps > 1) {
-            dma_d(1, smem + kStage);
+            dma_d(row_of(1), smem + kStage);
             build_h(1, smem + kStage);
         }
         for (int s = 0; s < nsteps; ++s) {
@@ -1205,6 +1352,7 @@ __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(
             // written to LDS at the end.  (Done up front, as a block, they cost 1100-1500 cycles per 32-cell step with
             // the matrix pipe idle: all eight waves are in the same phase after every barrier.)
             const bool pf = s + 2 < nsteps;
+            const int t_s2 = row_of(s + 2), t_s3 = row_of(s + 3);  // (the rows whose pieces this step issues)
             char *stn = smem + ((s + 2) % 3) * kStage;
             float ejn = 0.f, hh[8];
             if (pf) ejn = ((const float *)(ebuf + ((s + 2) & 3) * 512))[jl];
@@ -1249,9 +1397,9 @@ __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(
                     if (pf) {
                         constexpr int PP = 4 / VB, HP = 8 / VB;  // DMA pieces / h values per MFMA pair
                         if (ks == 0) {
-                            if (vb == 0 && s + 3 < nsteps) dma_e(s + 3);
+                            if (vb == 0 && s + 3 < nsteps) dma_e(s + 3, t_s3);
 #pragma unroll
-                            for (int k = 0; k < PP; ++k) dma_d_piece(s + 2, stn, vb * PP + k);
+                            for (int k = 0; k < PP; ++k) dma_d_piece(t_s2, stn, vb * PP + k);
                         } else {
                             // this thread's eight h values of row s+2, spread over the MFMA pairs of the second k-step
                             if (!slow) {
@@ -1307,7 +1455,7 @@ __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(
 // ---------------------------------------------------------------------------------------------
 struct JhLayout {
     WsLayout w;
-    size_t W2Tp, W2c, dCacc, dl, pref, xbl, scal, expE, expP, b2l, dApart, dCpart, zrow, dWpart, dbpart, total;
+    size_t W2Tp, W2c, dCacc, dl, pref, xbl, scal, expE, expP, b2l, dApart, dCpart, zrow, rowcnt, live8, order, dWpart, dbpart, total;
     int n_ut, n_tt, n_ts, TS, n_tq, n_units, n_ranges;
 };
 
@@ -1330,8 +1478,8 @@ static JhLayout make_jh_layout(int T, int U, int B, int J, int V) {
     L.n_ut = (U + 31) / 32;
     L.n_tt = (T + 7) / 8;
     // row splits of K3: its workgroups own (utterance, 32 columns, TS rows) x ALL joint units (round 6) -- as many splits as give about
-    // 1280 workgroups (five rounds of one per CU; config 5: 8), strips of at least 16 rows (four iterations of four)
-    L.n_ts = (1280 + B * L.n_ut - 1) / (B * L.n_ut);
+    // JH_DHX_WGS workgroups (ten rounds of one per CU; config 5: 16), strips of at least 16 rows (four iterations of four)
+    L.n_ts = (JH_DHX_WGS + B * L.n_ut - 1) / (B * L.n_ut);
     if (L.n_ts > (T + 15) / 16) L.n_ts = (T + 15) / 16;
     if (L.n_ts < 1) L.n_ts = 1;
     L.TS = ((T + L.n_ts - 1) / L.n_ts + 3) / 4 * 4;
@@ -1364,6 +1512,9 @@ static JhLayout make_jh_layout(int T, int U, int B, int J, int V) {
     L.dApart = take((size_t)L.n_ut * B * T * J * sizeof(float));
     L.dCpart = take((size_t)L.n_ts * B * U * J * sizeof(float));
     L.zrow = take(1024);
+    L.rowcnt = take(256);  // (inside the region the backward zero-fills in front of its kernels: dCpart .. dWpart)
+    L.live8 = take((size_t)B * L.n_ut * 4 * ((T + 31) / 32));
+    L.order = take((size_t)B * L.n_ut * L.n_ts * sizeof(int));
     L.dWpart = take((size_t)L.n_ranges * J * V * sizeof(float));
     L.dbpart = take((size_t)L.n_ranges * V * sizeof(float));
     L.total = off;
@@ -1380,7 +1531,8 @@ bool fill_loss_params(LossParams &p, const float *acts, float *grads, const int 
                       const int *input_lengths, const float *cost_scale, int V, int B, float *costs, void *workspace,
                       int maxT, int maxU, int blank);
 hipError_t launch_reduce_partials(float *out, const float *in, int nparts, size_t n, hipStream_t s, unsigned *blockmax);
-hipError_t launch_reduce_enc(float *out, const float *in, int n_ut, const LossParams &lp, int J, hipStream_t s, unsigned *blockmax);
+hipError_t launch_reduce_enc(float *out, const float *in, int n_ut, const LossParams &lp, int J, hipStream_t s, unsigned *blockmax,
+                             const uint8_t *live8);
 
 template <typename K>
 static hipError_t set_lds_f16(K kernel, size_t bytes) {
@@ -1435,6 +1587,19 @@ static hipError_t launch_logits(const JhParams &jp, int mode, unsigned grid, hip
     }
 }
 
+// {rows x 32-column tiles the last backward on this workspace visited, rows inside the utterances} of the f16 joint; {-1, -1} when
+// the workspace does not hold the counts of a backward of this shape
+hipError_t joint_f16_backward_rows(void *workspace, int T, int U, int B, int J, int V, int rows[2], hipStream_t s) {
+    rows[0] = rows[1] = -1;
+    if (!joint_f16_supported(J, V) || sweep_K(U) == 0) return hipErrorInvalidValue;
+    const JhLayout L = make_jh_layout(T, U, B, J, V);
+    int h[3] = {-1, -1, 0};
+    hipError_t e = hipMemcpyAsync(h, (char *)workspace + L.rowcnt, 3 * sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess && h[2] == rowcnt_stamp(T, U, B, J, V)) rows[0] = h[0], rows[1] = h[1];
+    return e;
+}
+
 // one word of workspace state, set on the stream between the kernels that depend on it
 __global__ void jh_set_state_kernel(int *state, int value) { state[0] = value; }
 
@@ -1454,6 +1619,8 @@ static hipError_t jh_fill_params(JhParams &jp, const JhLayout &L, const float *e
     jp.dApart = (float *)(ws + L.dApart), jp.dCpart = (float *)(ws + L.dCpart);
     jp.dWpart = (float *)(ws + L.dWpart), jp.dbpart = (float *)(ws + L.dbpart);
     jp.zrow = (const f16 *)(ws + L.zrow);
+    jp.live8 = (uint8_t *)(ws + L.live8), jp.rowcnt = (int *)(ws + L.rowcnt), jp.visit_all = 0;
+    jp.order = (int *)(ws + L.order);
     jp.J = J, jp.n_ut = L.n_ut, jp.n_tt = L.n_tt, jp.n_ts = L.n_ts, jp.TS = L.TS, jp.n_tq = L.n_tq;
     jp.n_units = L.n_units, jp.n_ranges = L.n_ranges;
     jp.logits_out = nullptr, jp.logits_only = 0;
@@ -1547,8 +1714,14 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     // (Cutting the batch into utterance ranges and converting range q + 1 on a second stream beside the dh kernel of range q
     // was measured at config 5: the two kernels do overlap, and slow each other down by as much as the overlap hides.)
     if ((e = logits(2)) != hipSuccess) return e;
-    // dC partials + the zero row (the dA partials need no zero-fill: launch_reduce_enc reads only the rows K3 writes)
-    if (launch_fill(jp.dCpart, 0, L.dWpart - L.dCpart, s) != hipSuccess) return hipErrorUnknown;
+    // dC partials + the zero row + the row counters (the dA partials need no zero-fill: launch_reduce_enc reads only the rows K3 writes)
+    if (launch_fill(jp.dCpart, 0, L.live8 - L.dCpart, s) != hipSuccess) return hipErrorUnknown;
+    // which lattice rows (x 32-column tiles) the backward visits: K3, K4 and the d enc_proj reduction follow these bits
+    jp.visit_all = (phases & 8) ? 1 : 0;
+    hipLaunchKernelGGL(jh_rowbits_kernel, dim3((unsigned)B * L.n_ut * ((T + kRowbitsRows - 1) / kRowbitsRows)), dim3(256), 0, s, jp);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(jh_order_kernel, dim3(1), dim3(1024), 0, s, jp, B * L.n_ut * L.n_ts);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
     {
         const size_t shm = 3 * (size_t)(J * 64) + 4 * 8192 + 4 * 256 + 4096 + 128;  // W2 stages, A stages, reference tiles, hand-over rows, labels
         const unsigned grid = (unsigned)B * L.n_ut * L.n_ts;
@@ -1570,7 +1743,7 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     if ((e = set_state(2)) != hipSuccess) return e;
     {
         const int vt = k4_vt(V);
-        const size_t shm = 3 * (size_t)(32 * (2 * vt + 64) + 2 * 4 * 32 * 32) + 4 * 512;
+        const size_t shm = 3 * (size_t)(32 * (2 * vt + 64) + 2 * 4 * 32 * 32) + 4 * 512 + 1024;  // stages, enc row slices, the unit's row list
         const unsigned grid = (unsigned)L.n_ranges * (J / 128) * ((V + vt - 1) / vt);
         auto go = [&](auto kernel) -> hipError_t {
             hipError_t e2 = set_lds_f16(kernel, shm);
@@ -1584,7 +1757,7 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
         if (e != hipSuccess) return e;
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if ((e = launch_reduce_enc(d_enc_proj, jp.dApart, L.n_ut, jp.lp, J, s, hooks ? hooks->dmax_enc : nullptr)) != hipSuccess) return e;
+    if ((e = launch_reduce_enc(d_enc_proj, jp.dApart, L.n_ut, jp.lp, J, s, hooks ? hooks->dmax_enc : nullptr, jp.live8)) != hipSuccess) return e;
     if ((e = launch_reduce_partials(d_pred_proj, jp.dCpart, L.n_ts, (size_t)B * U * J, s, hooks ? hooks->dmax_pred : nullptr)) != hipSuccess) return e;
     if ((e = launch_reduce_partials(dW2, jp.dWpart, L.n_ranges, (size_t)J * V, s, nullptr)) != hipSuccess) return e;
     e = launch_reduce_partials(db2, jp.dbpart, L.n_ranges, (size_t)V, s, nullptr);

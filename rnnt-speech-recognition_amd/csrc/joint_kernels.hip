@@ -2073,8 +2073,8 @@ __device__ __forceinline__ void reduce_enc_body(float *out, const float *in, con
     if (bmslot) store_block_max(bm, bmslot);
 }
 __global__ __launch_bounds__(256) void reduce_enc_kernel(float *out, const float *in, int n_ut, const LossParams p, int J,
-                                                         unsigned *blockmax) {
-    reduce_enc_body(out, in, n_ut, p, J, blockIdx.x, gridDim.x, blockmax ? blockmax + blockIdx.x : nullptr, 0.f, nullptr);
+                                                         unsigned *blockmax, const uint8_t *live8) {
+    reduce_enc_body(out, in, n_ut, p, J, blockIdx.x, gridDim.x, blockmax ? blockmax + blockIdx.x : nullptr, 0.f, live8);
 }
 
 // d pred_proj[b][u][:] from the partial slabs of joint_bwd_kernel: an (utterance, u-tile) is written by the workgroups of a J
@@ -2253,9 +2253,10 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
                                  void *workspace, hipStream_t s, const JointHooks *hooks);
 
 // d enc_proj from its [n_ut][B][T][J] partial rows (reduce_enc_kernel); shared with the f16 joint
-hipError_t launch_reduce_enc(float *out, const float *in, int n_ut, const LossParams &lp, int J, hipStream_t s, unsigned *blockmax) {
+hipError_t launch_reduce_enc(float *out, const float *in, int n_ut, const LossParams &lp, int J, hipStream_t s, unsigned *blockmax,
+                             const uint8_t *live8) {
     if ((unsigned long long)lp.B * lp.T * J >= (1ull << 32)) return hipErrorInvalidValue;  // 32-bit element indices in the kernel
-    hipLaunchKernelGGL(reduce_enc_kernel, dim3(kHookBlocks), dim3(256), 0, s, out, in, n_ut, lp, J, blockmax);
+    hipLaunchKernelGGL(reduce_enc_kernel, dim3(kHookBlocks), dim3(256), 0, s, out, in, n_ut, lp, J, blockmax, live8);
     return hipGetLastError();
 }
 

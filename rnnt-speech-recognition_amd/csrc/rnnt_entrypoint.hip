@@ -13,6 +13,7 @@ using namespace rnnt;
 namespace rnnt {
 // joint_kernels.hip
 hipError_t joint_workspace_bytes(int T, int U, int B, int J, int V, int joint_dtype, size_t *bytes);
+hipError_t joint_f16_backward_rows(void *workspace, int T, int U, int B, int J, int V, int rows[2], hipStream_t s);
 hipError_t joint_backward_rows(void *workspace, int T, int U, int B, int J, int V, int rows[2], hipStream_t s);
 hipError_t launch_joint_loss(const float *enc_proj, const float *pred_proj, const float *W2, const float *b2,
                              const int *labels, const int *label_lengths, const int *input_lengths,
@@ -434,9 +435,19 @@ rnntStatus_t get_rnnt_joint_backward_rows(void *workspace, int joint_size, int a
     if (!workspace || !rows || joint_size <= 0 || alphabet_size <= 0 || minibatch <= 0) return RNNT_STATUS_INVALID_VALUE;
     rnntStatus_t st = check_options(options);
     if (st != RNNT_STATUS_SUCCESS) return st;
-    if (((uintptr_t)workspace & 255) != 0 || !joint_dtype_supported(0, joint_size, alphabet_size)) return RNNT_STATUS_INVALID_VALUE;
-    return from_hip(joint_backward_rows(workspace, options.maxT, options.maxU, minibatch, joint_size, alphabet_size, rows,
-                                        (hipStream_t)options.stream));
+    if (((uintptr_t)workspace & 255) != 0) return RNNT_STATUS_INVALID_VALUE;
+    const bool t32 = joint_dtype_supported(0, joint_size, alphabet_size), t16 = joint_dtype_supported(1, joint_size, alphabet_size);
+    if (!t32 && !t16) return RNNT_STATUS_INVALID_VALUE;
+    rows[0] = rows[1] = -1;
+    rnntStatus_t r = RNNT_STATUS_SUCCESS;
+    if (t32)
+        r = from_hip(joint_backward_rows(workspace, options.maxT, options.maxU, minibatch, joint_size, alphabet_size, rows,
+                                         (hipStream_t)options.stream));
+    // (a shape both arithmetic types take, alphabet_size 128: whichever backward stamped the workspace last answers)
+    if (r == RNNT_STATUS_SUCCESS && rows[1] < 0 && t16)
+        r = from_hip(joint_f16_backward_rows(workspace, options.maxT, options.maxU, minibatch, joint_size, alphabet_size, rows,
+                                             (hipStream_t)options.stream));
+    return r;
 }
 
 // The whole joint network without the loss: first Dense layer (the library's split-precision GEMMs, as in the fused loss) + the

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round-6 GPU session driver (runs on the GPU box via gpurun).  usage: scripts/gpu_r06.sh TAG "steps..." [variants...]
 #   f16       tests/test_joint_f16_gpu.py per library variant
-#   c5        per-kernel times (rocprofv3 --stats) of the f16 joint at BASELINE config 5 per variant (gpu_c5_variants.sh)
+#   c5        per-kernel times (rocprofv3 --stats) of the f16 joint at BASELINE config 5 per variant; LEG=n01|n01_all_rows|trained|trained_all_rows
+#             picks the input / RNNT_VISIT_ALL leg (default: N(0,1) projections, every row visited)
 #   mid       the same at B32 T600 U150 V128 / V256 and at the reference-default shape B16 T300 U100 V4096
 #   sizes     tests/test_baseline_sizes_gpu.py (at-size parity)
 #   test      full `pytest -m gpu`
@@ -18,7 +19,7 @@ if has f16; then
 fi
 shape_prof() {  # name shape
   for v in $VARS; do
-    (cd /tmp && RNNT_LIBWARPRNNT=$(lib $v) timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$1_$v -o b -- python $R/bench.py --fused-only $2 --steps 3 > /tmp/log_$1_$v 2>/tmp/err_$1_$v)
+    (cd /tmp && RNNT_LIBWARPRNNT=$(lib $v) timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$1_$v -o b -- python $R/bench.py --fused-only $2 --steps 3 --fused-leg ${LEG:-n01_all_rows} > /tmp/log_$1_$v 2>/tmp/err_$1_$v)
     python - /tmp/prof_$1_$v $v /tmp/log_$1_$v $1 <<'PY' | tee -a $OUT/shapes.txt
 import csv,glob,sys,json
 f=glob.glob(sys.argv[1]+'/**/*kernel_stats.csv',recursive=True)

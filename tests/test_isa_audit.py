@@ -112,8 +112,8 @@ def test_hot_kernels_do_not_spill(kernels):
         assert int(meta[k]["private_segment_fixed_size"]) <= 64, (k, meta[k]["private_segment_fixed_size"])
     # the dW2 kernel's 256-column instantiations (vocabularies of 128 / 256 symbols) are compiled for FOUR waves per SIMD -- two
     # workgroups per CU, measured 10 % faster than one -- and pay for the 128-register budget with a few spilled registers
-    for k in _find(meta, "jh_dw_kernel", "Li256E"):
-        assert int(meta[k]["vgpr_count"]) <= 128 and int(meta[k]["private_segment_fixed_size"]) <= 64, (k, meta[k])
+    for k in _find(meta, "jh_dw_kernel", "Li256E"):  # (round 6: + the unit's row list and the scalar row look-ups: 88 bytes)
+        assert int(meta[k]["vgpr_count"]) <= 128 and int(meta[k]["private_segment_fixed_size"]) <= 96, (k, meta[k])
     # round 5: V = 128 has its own 128-column instantiation (before: the half-empty 256-column one with 71 spilled registers)
     for k in _find(meta, "jh_dw_kernel", "Li128E"):
         assert int(meta[k]["vgpr_count"]) <= 128 and int(meta[k]["private_segment_fixed_size"]) == 0, (k, meta[k])

@@ -13,8 +13,8 @@ oracle.joint_utterance_streamed -- cost, d enc_proj, d pred_proj -- and the batc
 cost_scale is zero for every other utterance (tests/test_baseline_sizes_gpu.py).  Bars: f32-grade 1e-4 (costs relative, gradients
 relative to max(1, max|ref|), d enc_proj / d pred_proj also 1e-4 absolute); f16 costs 1e-4 against the rounding-aware AND the
 unrounded oracle, gradients 1e-3 max(1, max|ref|).
-On the trained-like f32-grade cases the backward must have visited less than 30 % of the lattice rows (the few-items-per-workgroup
-branch of joint_rowplan_kernel), and RNNT_VISIT_ALL must give the same numbers to 1e-6."""
+On the trained-like cases the backward must have visited less than 30 % of the lattice rows (f32-grade: the few-items-per-workgroup
+branch of joint_rowplan_kernel; f16, groups of four rows: 35 %), and RNNT_VISIT_ALL must give the same numbers to 1e-6."""
 import numpy as np
 import pytest
 import torch
@@ -63,15 +63,15 @@ def test_mid_vocabulary_joint_at_headline_lattice(dtype, V, kind):
     f16 = dtype == "f16"
     check_against_oracle(case, dtype, PICKS, scale, costs, grads, grads_masked, gtol=1e-3 if f16 else 1e-4, also_exact=f16)
     check_properties(case, costs, grads, lambda: _run(case, scale, dtype))
-    if not f16:
-        assert rows is not None and rows[1] > 0, rows
-        frac = rows[0] / rows[1]
-        if kind == "trained":
-            assert frac < 0.3, frac  # the alignment band: most rows carry no mass
-        # no occupancy floor: the same numbers (a skipped row adds less than 2^-44 |cost_scale| to anything)
-        costs_all, grads_all = _run(case, scale, dtype, visit_all=True)
-        rows_all = joint_mod.last_backward_rows()
-        assert rows_all[0] == rows_all[1] == rows[1], (rows_all, rows)
-        assert torch.equal(costs, costs_all)
-        for a, b in zip(grads, grads_all):
-            assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+    # the backward's row pruning (both engines since round 6): how many rows it visited, and that switching it off changes nothing
+    assert rows is not None and rows[1] > 0, rows
+    frac = rows[0] / rows[1]
+    if kind == "trained":
+        assert frac < (0.35 if f16 else 0.3), frac  # the alignment band: most rows carry no mass (f16: groups of four rows)
+    # no occupancy floor: the same numbers (a skipped row adds less than 2^-44 |cost_scale| to anything)
+    costs_all, grads_all = _run(case, scale, dtype, visit_all=True)
+    rows_all = joint_mod.last_backward_rows()
+    assert rows_all[0] == rows_all[1] == rows[1], (rows_all, rows)
+    assert torch.equal(costs, costs_all)
+    for a, b in zip(grads, grads_all):
+        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
