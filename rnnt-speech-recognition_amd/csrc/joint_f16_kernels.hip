@@ -134,6 +134,7 @@ struct JhParams {
                       // four rows of an aligned group share their bit: K3 works in iterations of four rows)
     int *rowcnt;      // [0] = (rows x u-tiles) the backward visits, [1] = those inside the utterances, [2] = shape stamp
     int *order;       // [B n_ut n_ts] K3's strips, the ones with the most visited rows first (jh_order_kernel)
+    int *uorder;      // [n_units] K4's work units sorted by visited rows (descending, ties by index: deterministic); null-equivalent: identity
     int visit_all;    // RNNT_VISIT_ALL: no occupancy floor
     int J, n_ut, n_tt, n_ts, TS, n_tq, n_units, n_ranges;
     int b2_lds_off;  // K1/K2: byte offset of the bias table in LDS, -1 = read it from global memory (does not fit)
@@ -683,14 +684,79 @@ __global__ __launch_bounds__(1024) void jh_order_kernel(const JhParams jp, const
         }
         return min((w + 3) >> 2, 256);  // groups of four rows
     };
-    for (int i = tid; i < n_strips; i += 1024) atomicAdd(&hist[weight(i)], 1);
+    constexpr int kMaxStrips = 8192;
+    __shared__ short sw[kMaxStrips];  // (a strip's weight is a dozen dependent loads: computed once)
+    for (int i = tid; i < n_strips; i += 1024) {
+        const int w = weight(i);
+        if (i < kMaxStrips) sw[i] = (short)w;
+        atomicAdd(&hist[w], 1);
+    }
     __syncthreads();
     if (tid == 0) {
         int pos = 0;
         for (int w = 256; w >= 0; --w) cursor[w] = pos, pos += hist[w];
     }
     __syncthreads();
-    for (int i = tid; i < n_strips; i += 1024) jp.order[atomicAdd(&cursor[weight(i)], 1)] = i;
+    for (int i = tid; i < n_strips; i += 1024) jp.order[atomicAdd(&cursor[i < kMaxStrips ? (int)sw[i] : weight(i)], 1)] = i;
+    // K4's work units (utterance, u-tile, kTQ rows) by visited rows, descending, ties by index.  K4's workgroups keep their dW2
+    // accumulators over all of their units, so the units are DEALT (range r takes sorted positions r, 2R-1-r, 2R+r, ...: a snake), and
+    // the deal must not depend on timing: a stable counting sort (a unit's visited rows: 0 .. kTQ).
+    constexpr int kMaxUnits = 6144;
+    __shared__ short uw[kMaxUnits];
+    const int nu = jp.n_units;
+    if (nu > kMaxUnits) {  // (identity: K4 then deals the units in lattice order)
+        for (int i = tid; i < nu; i += 1024) jp.uorder[i] = i;
+        return;
+    }
+    for (int i = tid; i < nu; i += 1024) {
+        int q = i;
+        const int tq = q % jp.n_tq;
+        q /= jp.n_tq;
+        const int ut = q % jp.n_ut, b = p.b0 + q / jp.n_ut;
+        const int Tb = length_T(p, b), Ub = length_U(p, b);
+        const int t0 = tq * kTQ, t1 = min(min(t0 + kTQ, p.T), Tb);
+        int w = 0;
+        if (t0 < t1 && ut * 32 < Ub) {
+            const uint32_t *bits = (const uint32_t *)(jp.live8 + ((size_t)b * jp.n_ut + ut) * (size_t)(4 * ((p.T + 31) >> 5)));
+            for (int t = t0; t < t1;) {
+                const int e = min(t1, (t | 31) + 1);
+                uint32_t m = bits[t >> 5] >> (t & 31);
+                if (e - t < 32) m &= (1u << (e - t)) - 1u;
+                w += __popc(m);
+                t = e;
+            }
+        }
+        uw[i] = (short)w;
+    }
+    __syncthreads();
+    // stable counting sort, weight descending (a unit's visited rows: 0 .. kTQ): wave v takes the weights v, v + 16, ...; for each it
+    // walks the list 64 units at a time (ballot + prefix count), first to count, then to place
+    __shared__ int ustart[kTQ + 2];
+    const int lane = tid & 63, wv = tid >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int w = wv; w <= kTQ; w += 16) {
+        int c = 0;
+        for (int j0 = 0; j0 < nu; j0 += 64) c += __builtin_popcountll(__ballot(j0 + lane < nu && uw[j0 + lane] == w));
+        if (lane == 0) ustart[w] = c;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int pos = 0;
+        for (int w = kTQ; w >= 0; --w) {
+            const int c = ustart[w];
+            ustart[w] = pos, pos += c;
+        }
+    }
+    __syncthreads();
+    for (int w = wv; w <= kTQ; w += 16) {
+        int pos = ustart[w];
+        for (int j0 = 0; j0 < nu; j0 += 64) {
+            const bool mine = j0 + lane < nu && uw[j0 + lane] == w;
+            const unsigned long long m = __ballot(mine);
+            if (mine) jp.uorder[pos + __builtin_popcountll(m & lt)] = j0 + lane;
+            pos += __builtin_popcountll(m);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1247,7 +1313,14 @@ __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(
 #endif
     int *const rowlist = (int *)(ebuf + 4 * 512);  // [kTQ] the visited rows of the current unit, as offsets from its first row
     int *const rowcount = rowlist + kTQ;
-    for (int unit = range; unit < jp.n_units; unit += jp.n_ranges) {
+    for (int k = 0;; ++k) {
+        // round 6: the units are dealt by WORK -- sorted by visited rows (jh_order_kernel), range r takes sorted positions r, 2R-1-r,
+        // 2R+r, ... -- with the backward's row pruning a unit's work follows the alignment band (dealt in lattice order, a range's
+        // consecutive units were busy or idle together: K4 9.3 instead of 5.3 ms at config 5; dealt every R-th in lattice order, a
+        // range could draw only the short last units of the columns: 5.5 instead of 4.4 ms at V = 4096)
+        const int pos = k * jp.n_ranges + ((k & 1) ? jp.n_ranges - 1 - range : range);
+        if (pos >= jp.n_units) break;
+        const int unit = jp.uorder[pos];
         int q = unit;
         const int tq = q % jp.n_tq;
         q /= jp.n_tq;
@@ -1455,7 +1528,7 @@ __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(
 // ---------------------------------------------------------------------------------------------
 struct JhLayout {
     WsLayout w;
-    size_t W2Tp, W2c, dCacc, dl, pref, xbl, scal, expE, expP, b2l, dApart, dCpart, zrow, rowcnt, live8, order, dWpart, dbpart, total;
+    size_t W2Tp, W2c, dCacc, dl, pref, xbl, scal, expE, expP, b2l, dApart, dCpart, zrow, rowcnt, live8, order, uorder, dWpart, dbpart, total;
     int n_ut, n_tt, n_ts, TS, n_tq, n_units, n_ranges;
 };
 
@@ -1515,6 +1588,7 @@ static JhLayout make_jh_layout(int T, int U, int B, int J, int V) {
     L.rowcnt = take(256);  // (inside the region the backward zero-fills in front of its kernels: dCpart .. dWpart)
     L.live8 = take((size_t)B * L.n_ut * 4 * ((T + 31) / 32));
     L.order = take((size_t)B * L.n_ut * L.n_ts * sizeof(int));
+    L.uorder = take((size_t)L.n_units * sizeof(int));
     L.dWpart = take((size_t)L.n_ranges * J * V * sizeof(float));
     L.dbpart = take((size_t)L.n_ranges * V * sizeof(float));
     L.total = off;
@@ -1620,7 +1694,7 @@ static hipError_t jh_fill_params(JhParams &jp, const JhLayout &L, const float *e
     jp.dWpart = (float *)(ws + L.dWpart), jp.dbpart = (float *)(ws + L.dbpart);
     jp.zrow = (const f16 *)(ws + L.zrow);
     jp.live8 = (uint8_t *)(ws + L.live8), jp.rowcnt = (int *)(ws + L.rowcnt), jp.visit_all = 0;
-    jp.order = (int *)(ws + L.order);
+    jp.order = (int *)(ws + L.order), jp.uorder = (int *)(ws + L.uorder);
     jp.J = J, jp.n_ut = L.n_ut, jp.n_tt = L.n_tt, jp.n_ts = L.n_ts, jp.TS = L.TS, jp.n_tq = L.n_tq;
     jp.n_units = L.n_units, jp.n_ranges = L.n_ranges;
     jp.logits_out = nullptr, jp.logits_only = 0;
