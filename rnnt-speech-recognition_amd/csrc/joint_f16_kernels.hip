@@ -1044,6 +1044,37 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
             for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        // What a row tile of a 32-unit tile reads -- the enc-side factors of the 4 rows (per unit tile), the pred-side factors of
+        // this lane's 4 columns, the running column sums -- is loaded one tile AHEAD of its arithmetic (loaded where it was used,
+        // every tile paid a full memory latency three times: 6.9 of the kernel's 18.7 ms at config 5); the row sums are handed from
+        // column half 1 to half 0 per unit tile (two 2 KB buffers, one barrier each), so that 4, not 4 NT, of them are alive.
+        struct EpiT {
+            float pr[4];
+            float4 cs;
+        };
+        // (lane offsets from a laundered copy of the thread index, beside scalar bases: hoisted out of the row loop as 64-bit lane
+        // addresses they were spilled, and every reload -- a wait for vmcnt(0) -- drained the tile loads prefetched just before)
+        auto load_ej = [&](float (&ej)[4], const int ni) {
+            const int n3 = launder(tid) & 31;
+            const int jw = wn * JW + ni * 32;  // uniform; this lane's unit: jw + n
+#pragma unroll
+            for (int rw = 0; rw < 4; ++rw) ej[rw] = (Etab + ((size_t)b * p.T + min(t_it + rw, t_end - 1)) * J + jw)[(uint32_t)n3];
+        };
+        auto load_tile = [&](EpiT &in, const int ni, const int mi) {
+            const int ln3 = launder(tid) & 63, n3 = ln3 & 31, half3 = ln3 >> 5;
+            const int jw = wn * JW + ni * 32, ubw = u0 + 16 * wm + 8 * mi;  // uniform; this lane's columns: ubw + 4 half + 0..3
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq)
+                in.pr[cq] = (Ptab + (size_t)b * p.U * J + jw)[(uint32_t)min(ubw + 4 * half3 + cq, p.U - 1) * (uint32_t)J + (uint32_t)n3];
+            // (read even in the first iteration, where nothing has been written yet: the value is dropped below)
+            in.cs = ((const float4 *)jp.dCacc + ((((size_t)wg * 8 + wave) * 2 + mi) * NT + ni) * 64)[(uint32_t)ln3];
+        };
+        float ejp[2][4];
+        EpiT tin[3];
+        auto load_idx = [&](const int idx) {  // the loads of row tile idx & 1 of unit tile idx >> 1 (idx: compile-time constant)
+            if ((idx & 1) == 0) load_ej(ejp[(idx >> 1) & 1], idx >> 1);
+            load_tile(tin[idx % 3], idx >> 1, idx & 1);
+        };
         for (int kg = 0; kg < NK; kg += 4) {
             const bool last_group = kg + 4 >= NK;  // uniform
 #pragma unroll
@@ -1063,6 +1094,10 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
                 asm volatile("" ::: "memory");
                 DT(2);
                 const int sb1 = (sb == 2) ? 0 : sb + 1, sb2 = (sb1 == 2) ? 0 : sb1 + 1;
+                // the epilogue's first tile of inputs: a whole step ahead of their use (issued at the epilogue's start, their memory
+                // latency sat in front of the first tile; measured: no difference in the kernel's time, kept because the allocation it
+                // leads to has no spilled register)
+                if (last_group && q == 3) load_idx(0);
                 // what this step prepares: the converted A piece of chunk +1, W2 chunk +2, the raw A piece of chunk +3
                 const bool x1 = last_group && q + 1 >= 4, x2 = last_group && q + 2 >= 4, x3 = last_group && q + 3 >= 4;  // ... lies in the next iteration
                 const bool e1 = !x1 || has_next, e2 = !x2 || has_next, e3 = !x3 || has_next;                            // ... exists
@@ -1128,30 +1163,6 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
         }
         // ---- epilogue: acc[mi][ni][r] = S dh[row t_it + (r >> 2)][column u0 + 16 wm + 8 mi + 4 half + (r & 3)][unit JW wn + 32 ni + n]
         const bool last = !has_next;
-        // What a row tile of a 32-unit tile reads -- the enc-side factors of the 4 rows (per unit tile), the pred-side factors of
-        // this lane's 4 columns, the running column sums -- is loaded one tile AHEAD of its arithmetic (loaded where it was used,
-        // every tile paid a full memory latency three times: 6.9 of the kernel's 18.7 ms at config 5); the row sums are handed from
-        // column half 1 to half 0 per unit tile (two 2 KB buffers, one barrier each), so that 4, not 4 NT, of them are alive.
-        struct EpiT {
-            float pr[4];
-            float4 cs;
-        };
-        // (lane offsets from a laundered copy of the thread index, beside scalar bases: hoisted out of the row loop as 64-bit lane
-        // addresses they were spilled, and every reload -- a wait for vmcnt(0) -- drained the tile loads prefetched just before)
-        const int ln3 = launder(tid) & 63, n3 = ln3 & 31, half3 = ln3 >> 5;
-        auto load_ej = [&](float (&ej)[4], const int ni) {
-            const int jw = wn * JW + ni * 32;  // uniform; this lane's unit: jw + n
-#pragma unroll
-            for (int rw = 0; rw < 4; ++rw) ej[rw] = (Etab + ((size_t)b * p.T + min(t_it + rw, t_end - 1)) * J + jw)[(uint32_t)n3];
-        };
-        auto load_tile = [&](EpiT &in, const int ni, const int mi) {
-            const int jw = wn * JW + ni * 32, ubw = u0 + 16 * wm + 8 * mi;  // uniform; this lane's columns: ubw + 4 half + 0..3
-#pragma unroll
-            for (int cq = 0; cq < 4; ++cq)
-                in.pr[cq] = (Ptab + (size_t)b * p.U * J + jw)[(uint32_t)min(ubw + 4 * half3 + cq, p.U - 1) * (uint32_t)J + (uint32_t)n3];
-            // (read even in the first iteration, where nothing has been written yet: the value is dropped below)
-            in.cs = ((const float4 *)jp.dCacc + ((((size_t)wg * 8 + wave) * 2 + mi) * NT + ni) * 64)[(uint32_t)ln3];
-        };
 #ifdef JH_TRACE
 #define ET(k)                                                                                                   \
     do {                                                                                                        \
@@ -1161,14 +1172,8 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
 #define ET(k) do { } while (0)
 #endif
         ET(0);
-        float ejp[2][4];
-        EpiT tin[3];
-        auto load_idx = [&](const int idx) {  // the loads of row tile idx & 1 of unit tile idx >> 1 (idx: compile-time constant)
-            if ((idx & 1) == 0) load_ej(ejp[(idx >> 1) & 1], idx >> 1);
-            load_tile(tin[idx % 3], idx >> 1, idx & 1);
-        };
-        load_idx(0);
-        load_idx(1);
+        const int ln3 = launder(tid) & 63, n3 = ln3 & 31, half3 = ln3 >> 5;
+        load_idx(1);  // (tile 0: at the top of the iteration's last step)
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
             const int jw = wn * JW + ni * 32;

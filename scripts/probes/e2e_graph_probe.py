@@ -1,8 +1,14 @@
 """Dev probe: the configs[2] train step (bench.py bench_e2e) launched eagerly vs replayed from ONE HIP graph
 (forward + backward + SGD update captured with static input buffers)."""
-import sys, time, torch
+import os, sys, time, torch
 sys.path.insert(0, ".")
 import rnnt_speech_recognition_amd as pkg
+
+# BLAS=cublas|cublaslt|default: which library torch's GEMMs (the LSTM's) go to -- on ROCm "cublas" = rocBLAS, "cublaslt" = hipBLASLt
+blas = os.environ.get("BLAS", "default")
+if blas != "default":
+    torch.backends.cuda.preferred_blas_library(blas)
+print("preferred_blas_library:", torch.backends.cuda.preferred_blas_library())
 
 dev = torch.device("cuda:0")
 hp = pkg.HParams(vocab_size=28, embedding_size=320, encoder_layers=2, encoder_size=320, projection_size=320,

@@ -122,7 +122,7 @@ def test_hot_kernels_do_not_spill(kernels):
     # registers in its per-iteration EPILOGUE are tolerated, none in the main loop -- a scratch reload there waits for every LDS-DMA
     # piece in flight (test_dhx_main_loop_has_no_scratch_and_counted_waits)
     for k in _find(meta, "jh_dhx_kernel"):
-        assert int(meta[k]["private_segment_fixed_size"]) <= 160, (k, meta[k]["private_segment_fixed_size"])
+        assert int(meta[k]["private_segment_fixed_size"]) <= 64, (k, meta[k]["private_segment_fixed_size"])  # (0 in the tree as committed)
     # the logits kernels with a [cells][V] epilogue (park / recompute) at J = 640 are allowed a handful of spilled registers
     for k in _find(meta, "jh_logits_kernel", "Li40ELi1") + _find(meta, "jh_logits_kernel", "Li40ELi2"):
         assert int(meta[k]["private_segment_fixed_size"]) <= 64, meta[k]["private_segment_fixed_size"]
