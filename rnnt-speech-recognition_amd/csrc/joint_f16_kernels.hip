@@ -1316,16 +1316,28 @@ __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(
     long long *tr = (blockIdx.x == 100) ? jp.trace + (size_t)(kTraceBlocks * 8 + wave) * kTraceSlots : nullptr;
     int tstep = 0;
 #endif
-    int *const rowlist = (int *)(ebuf + 4 * 512);  // [kTQ] the visited rows of the current unit, as offsets from its first row
-    int *const rowcount = rowlist + kTQ;
+    // the visited rows of the current unit, as byte offsets from its first row: [kTQ] bytes + a count, kept in the 64 padding bytes behind the
+    // LAST dl row of the three stages (no DMA piece or h^T store touches them) -- NOT in extra LDS: the 256-column instantiation runs two
+    // workgroups per CU at exactly 2 x 81,920 B, and 1 KB more per workgroup halved its occupancy (V = 256: 2.08 instead of 1.55 ms)
+    static_assert(kTQ == 128, "the row list fills the padding of two stages, its count sits in the third's");
+    auto rowlist = [&](const int k) -> unsigned char * { return (unsigned char *)(smem + (k >> 6) * kStage + 31 * kRow + 2 * VT + (k & 63)); };
+    int *const rowcount = (int *)(smem + 2 * kStage + 31 * kRow + 2 * VT);
     for (int k = 0;; ++k) {
         // round 6: the units are dealt by WORK -- sorted by visited rows (jh_order_kernel), range r takes sorted positions r, 2R-1-r,
         // 2R+r, ... -- with the backward's row pruning a unit's work follows the alignment band (dealt in lattice order, a range's
         // consecutive units were busy or idle together: K4 9.3 instead of 5.3 ms at config 5; dealt every R-th in lattice order, a
         // range could draw only the short last units of the columns: 5.5 instead of 4.4 ms at V = 4096)
-        const int pos = k * jp.n_ranges + ((k & 1) ? jp.n_ranges - 1 - range : range);
-        if (pos >= jp.n_units) break;
-        const int unit = jp.uorder[pos];
+        int unit;
+        if (jp.visit_all) {  // every row visited: the units weigh the same -- contiguous ranges, in lattice order (consecutive units are
+                             // consecutive memory; PMC: the sorted deal fetched dl 2.0x instead of 1.3x, +0.7 ms at config 5)
+            const int lo = (int)((long long)jp.n_units * range / jp.n_ranges), hi = (int)((long long)jp.n_units * (range + 1) / jp.n_ranges);
+            if (lo + k >= hi) break;
+            unit = lo + k;
+        } else {
+            const int pos = k * jp.n_ranges + ((k & 1) ? jp.n_ranges - 1 - range : range);
+            if (pos >= jp.n_units) break;
+            unit = jp.uorder[pos];
+        }
         int q = unit;
         const int tq = q % jp.n_tq;
         q /= jp.n_tq;
@@ -1346,8 +1358,8 @@ __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(
             const unsigned long long m0 = __ballot(a0), m1 = __ballot(a1);
             const unsigned long long lt = (1ull << lane) - 1ull;
             const int n0 = __builtin_popcountll(m0);
-            if (a0) rowlist[__builtin_popcountll(m0 & lt)] = lane;
-            if (a1) rowlist[n0 + __builtin_popcountll(m1 & lt)] = 64 + lane;
+            if (a0) *rowlist(__builtin_popcountll(m0 & lt)) = (unsigned char)lane;
+            if (a1) *rowlist(n0 + __builtin_popcountll(m1 & lt)) = (unsigned char)(64 + lane);
             if (lane == 0) rowcount[0] = n0 + __builtin_popcountll(m1);
         }
         wait_lgkm();
@@ -1355,7 +1367,11 @@ __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(
         const int nsteps = rowcount[0];
         if (nsteps == 0) continue;  // workgroup-uniform
         // lattice row of step st (scalar: one LDS look per step in the main loop, not one per DMA piece)
-        auto row_of = [&](const int st) -> int { return t_begin + __builtin_amdgcn_readfirstlane(rowlist[min(st, nsteps - 1)]); };
+        // (every row visited: the list is the identity -- plain arithmetic, no LDS round trip at the top of a step)
+        auto row_of = [&](const int st) -> int {
+            const int k = min(st, nsteps - 1);
+            return t_begin + (jp.visit_all ? k : __builtin_amdgcn_readfirstlane((int)*rowlist(k)));
+        };
         float pv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e)
@@ -1412,6 +1428,7 @@ __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(
             dma_d(row_of(1), smem + kStage);
             build_h(1, smem + kStage);
         }
+        int c_s2 = row_of(2), c_s3 = row_of(3);
         for (int s = 0; s < nsteps; ++s) {
 #ifdef JH_TRACE
             const bool tron = tr && tstep < 39;
@@ -1430,7 +1447,7 @@ __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(
             // written to LDS at the end.  (Done up front, as a block, they cost 1100-1500 cycles per 32-cell step with
             // the matrix pipe idle: all eight waves are in the same phase after every barrier.)
             const bool pf = s + 2 < nsteps;
-            const int t_s2 = row_of(s + 2), t_s3 = row_of(s + 3);  // (the rows whose pieces this step issues)
+            const int t_s2 = c_s2, t_s3 = c_s3;  // (the rows whose pieces this step issues: looked up one step ago)
             char *stn = smem + ((s + 2) % 3) * kStage;
             float ejn = 0.f, hh[8];
             if (pf) ejn = ((const float *)(ebuf + ((s + 2) & 3) * 512))[jl];
@@ -1506,6 +1523,7 @@ __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(
                 for (int e = 0; e < 8; ++e) hv[e] = (u0 + 8 * cg + e < Ub) ? (f16)hh[e] : (f16)0.f;  // beyond U_b: no gradient
                 *(h8 *)(stn + kDBytes + ((((cg >> 1) * 4 + (jl >> 5)) * 2 + (cg & 1)) * 32 + (jl & 31)) * 16) = hv;
             }
+            c_s2 = c_s3, c_s3 = row_of(s + 4);  // (behind the step's MFMAs: the look-up's LDS latency is not in front of the next step)
         }
     }
     const float invS = jp.scal[1];
@@ -1822,7 +1840,7 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     if ((e = set_state(2)) != hipSuccess) return e;
     {
         const int vt = k4_vt(V);
-        const size_t shm = 3 * (size_t)(32 * (2 * vt + 64) + 2 * 4 * 32 * 32) + 4 * 512 + 1024;  // stages, enc row slices, the unit's row list
+        const size_t shm = 3 * (size_t)(32 * (2 * vt + 64) + 2 * 4 * 32 * 32) + 4 * 512;  // stages (the unit's row list in their padding), enc row slices
         const unsigned grid = (unsigned)L.n_ranges * (J / 128) * ((V + vt - 1) / vt);
         auto go = [&](auto kernel) -> hipError_t {
             hipError_t e2 = set_lds_f16(kernel, shm);

@@ -46,3 +46,50 @@ fi
 if has bench; then
   timeout 900 python bench.py > $OUT/bench.json 2>$OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json
 fi
+# ---- the profiles the round commits (profiles/r06_*), one pass: scripts/gpu_r06.sh r06final "final"
+if has final; then
+  timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $OUT/smoke.log
+  echo "== bench (default line)"; timeout 900 python bench.py > $OUT/bench_n1.json 2> $OUT/bench.err; echo "bench rc=$?"
+  echo "== kernel trace of the op-level bench (full-length launches only)"
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fused --no-ragged --no-e2e --no-config5 > $R/$OUT/rocprof.log 2>&1); echo "rocprof rc=$?"
+  python scripts/summarize_trace.py stats $OUT/prof $OUT/kernel_stats.json $OUT/kernel_stats.csv; cp $OUT/kernel_stats.json $OUT/kernel_stats_latest.json
+  echo "== PMC, op-level path"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/pmc/$c -o pmc -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fused --no-ragged --no-e2e --no-config5 > $R/$OUT/pmc_$c.log 2>&1); echo "pmc $c rc=$?"
+  done
+  python scripts/summarize_trace.py pmc $OUT/pmc $OUT/pmc_op.json; python scripts/summarize_trace.py latest $OUT/pmc_op.json $OUT/pmc_latest.json 645120000
+  echo "== kernel trace of the bench WITH the fused legs"
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/proff -o f -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-ragged --no-e2e --no-config5 > $R/$OUT/rocproff.log 2>&1); echo "rocprof rc=$?"
+  python scripts/summarize_trace.py stats $OUT/proff $OUT/fused_kernel_stats.json $OUT/fused_kernel_stats.csv
+  echo "== PMC, fused f32-grade joint at C2 (VALU / MFMA instruction counts)"
+  for c in "SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_INSTS_VALU_TRANS SQ_INSTS_LDS" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
+    n=$(echo $c | tr ' ' '_')
+    (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/pmcv/$n -o pmc -- python $R/bench.py --fused-only 32,600,150,28 --fused-leg n01_all_rows --steps 3 > $R/$OUT/pmcv_$n.log 2>&1); echo "pmcv $n rc=$?"
+  done
+  python scripts/summarize_trace.py pmc $OUT/pmcv $OUT/pmc_fused_valu.json > /dev/null
+  echo "== config 5: kernel traces of the three legs, counters of the all-rows leg"
+  for leg in n01_all_rows n01 trained; do
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/profc5_$leg -o c5 -- python $R/bench.py --fused-only 16,1500,300,1024 --fused-leg $leg --steps 3 > $R/$OUT/rocprofc5_$leg.log 2>&1); echo "rocprof c5 $leg rc=$?"
+    python scripts/summarize_trace.py stats $OUT/profc5_$leg $OUT/c5_${leg}_kernel_stats.json $OUT/c5_${leg}_kernel_stats.csv
+  done
+  (cd /tmp; for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "TCC_HIT_sum TCC_MISS_sum"; do
+    n=$(echo $c | tr ' ' '_')
+    timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/c5pmc/pmc_$n -o pmc -- python $R/bench.py --fused-only 16,1500,300,1024 --fused-leg n01_all_rows --steps 2 > $R/$OUT/c5pmc_$n.log 2>&1; echo "c5 pmc $c rc=$?"
+  done)
+  python - $OUT/c5pmc > $OUT/c5_pmc.txt <<'PY'
+import csv,glob,collections,sys
+for f in sorted(glob.glob(sys.argv[1]+'/pmc_*/*counter_collection.csv')):
+    agg=collections.defaultdict(lambda: [0,0.0])
+    for r in csv.DictReader(open(f)):
+        k=(r['Kernel_Name'][:48], r['Counter_Name'])
+        agg[k][0]+=1; agg[k][1]+=float(r['Counter_Value'])
+    for k,v in sorted(agg.items()):
+        if 'jh_' in k[0]: print(k[0], k[1], 'launches',v[0],'avg %.4g' % (v[1]/v[0]))
+PY
+  cat $OUT/c5_pmc.txt | head -60
+  echo "== PMC of the op at configs[4]'s shape (default call and RNNT_VISIT_ALL)"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/pmcop5/$c -o pmc -- python $R/scripts/probes/op_c5_probe.py > $R/$OUT/pmcop5_$c.log 2>&1); echo "pmc op5 $c rc=$?"
+  done
+  python scripts/summarize_trace.py pmc $OUT/pmcop5 $OUT/pmc_op_config5.json > /dev/null
+fi
