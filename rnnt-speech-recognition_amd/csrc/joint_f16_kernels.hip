@@ -828,6 +828,9 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
     int *const labtab = (int *)(smem + kLoff);  // [32 columns]: the label that leaves the column's cells (clamped), -1 where there is none
     if (tid < 32) labtab[tid] = (u0 + tid < Ub - 1) ? clamp_label(p.labels[(size_t)b * (p.U - 1) + u0 + tid], V) : -1;
     __syncthreads();
+    // (the main loop's copy, in a register: read from LDS in a_store -- between a step's fragment reads and its first MFMA -- the value was
+    // consumed by the store's patch tests, and the wait for it, lgkmcnt(0), was a wait for EVERY fragment read of the step in front of the first MFMA)
+    const int mylab = labtab[geo_of(tid).ccol];
     const double ll2 = p.ll[2 * b];
     const float cscale = (p.cost_scale ? p.cost_scale[b] : 1.0f) * jp.scal[0];
     // wave-uniform bases (scalar registers); everything per lane is a 32-bit offset from one of them
@@ -933,7 +936,7 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
         const Geo g = geo_of(t2);
         r.v = *(const h8 *)(smem + kAoff + sa * 8192 + t2 * 16);
         r.rf = *(const short *)(smem + kRoff + sa * 256 + (g.crow * 32 + g.ccol) * 2);
-        r.lab = labtab[g.ccol];
+        r.lab = mylab;
     };
     auto a_finish = [&](const ARaw &r, const CellSt &c, const int kc, const int sa) -> h8 {
         const int t2 = launder(tid);
@@ -970,7 +973,7 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
             __builtin_nontemporal_store(o, (h8 *)(base + off));
             if (c.flags & 2) {  // the blank / label column over it (the same lane's stores to one address stay in order)
                 const Geo g = geo_of(launder(tid));
-                const int lab = labtab[g.ccol];
+                const int lab = mylab;
                 const int vb = 32 * kc + 8 * g.lc, ib = p.blank - vb, il = ((lab >= 0 && lab != p.blank) ? lab : -1) - vb;
                 if ((unsigned)ib < 8u) ((f16 *)(base + off))[ib] = (f16)c.eb;
                 if ((unsigned)il < 8u) ((f16 *)(base + off))[il] = (f16)c.el;
