@@ -92,4 +92,7 @@ PY
     (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/pmcop5/$c -o pmc -- python $R/scripts/probes/op_c5_probe.py > $R/$OUT/pmcop5_$c.log 2>&1); echo "pmc op5 $c rc=$?"
   done
   python scripts/summarize_trace.py pmc $OUT/pmcop5 $OUT/pmc_op_config5.json > /dev/null
+  echo "== randomised parity sweep of every path through the C ABI (tests/tools/fuzz_parity.py), on the tree the profiles above are of"
+  timeout 1200 python tests/tools/fuzz_parity.py 606 160 > $OUT/fuzz.txt 2>&1; echo "fuzz rc=$?"; tail -8 $OUT/fuzz.txt
+  timeout 900 python tests/tools/fuzz_parity.py 616 60 joint16 > $OUT/fuzz_joint16.txt 2>&1; echo "fuzz joint16 rc=$?"; tail -6 $OUT/fuzz_joint16.txt
 fi
