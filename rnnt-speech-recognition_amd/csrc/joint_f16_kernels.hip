@@ -1351,23 +1351,27 @@ __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(
         const int t_begin = tq * kTQ, t_end = min(min(t_begin + kTQ, p.T), Tb);
         if (t_begin >= t_end || u0 >= Ub) continue;  // workgroup-uniform
         // the rows of the unit the backward visits (jh_rowbits_kernel), in order: wave 0 compacts the unit's 128 row bits
-        wait_lgkm();
-        __builtin_amdgcn_s_barrier();  // (the previous unit's last step has read its row list)
-        if (wave == 0) {
-            const uint32_t *bits = (const uint32_t *)(jp.live8 + ((size_t)b * jp.n_ut + ut) * (size_t)(4 * ((p.T + 31) >> 5))) + (t_begin >> 5);
-            static_assert(kTQ == 128, "two ballots cover a unit");
-            const bool a0 = t_begin + lane < t_end && ((bits[lane >> 5] >> (lane & 31)) & 1u);
-            const bool a1 = t_begin + 64 + lane < t_end && ((bits[2 + (lane >> 5)] >> (lane & 31)) & 1u);
-            const unsigned long long m0 = __ballot(a0), m1 = __ballot(a1);
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            const int n0 = __builtin_popcountll(m0);
-            if (a0) *rowlist(__builtin_popcountll(m0 & lt)) = (unsigned char)lane;
-            if (a1) *rowlist(n0 + __builtin_popcountll(m1 & lt)) = (unsigned char)(64 + lane);
-            if (lane == 0) rowcount[0] = n0 + __builtin_popcountll(m1);
+        // (every row visited: the list is the identity and is not built -- no bit fetch, no barriers in front of the unit)
+        int nsteps = t_end - t_begin;
+        if (!jp.visit_all) {
+            wait_lgkm();
+            __builtin_amdgcn_s_barrier();  // (the previous unit's last step has read its row list)
+            if (wave == 0) {
+                const uint32_t *bits = (const uint32_t *)(jp.live8 + ((size_t)b * jp.n_ut + ut) * (size_t)(4 * ((p.T + 31) >> 5))) + (t_begin >> 5);
+                static_assert(kTQ == 128, "two ballots cover a unit");
+                const bool a0 = t_begin + lane < t_end && ((bits[lane >> 5] >> (lane & 31)) & 1u);
+                const bool a1 = t_begin + 64 + lane < t_end && ((bits[2 + (lane >> 5)] >> (lane & 31)) & 1u);
+                const unsigned long long m0 = __ballot(a0), m1 = __ballot(a1);
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const int n0 = __builtin_popcountll(m0);
+                if (a0) *rowlist(__builtin_popcountll(m0 & lt)) = (unsigned char)lane;
+                if (a1) *rowlist(n0 + __builtin_popcountll(m1 & lt)) = (unsigned char)(64 + lane);
+                if (lane == 0) rowcount[0] = n0 + __builtin_popcountll(m1);
+            }
+            wait_lgkm();
+            __builtin_amdgcn_s_barrier();
+            nsteps = __builtin_amdgcn_readfirstlane(rowcount[0]);
         }
-        wait_lgkm();
-        __builtin_amdgcn_s_barrier();
-        const int nsteps = rowcount[0];
         if (nsteps == 0) continue;  // workgroup-uniform
         // lattice row of step st (scalar: one LDS look per step in the main loop, not one per DMA piece)
         // (every row visited: the list is the identity -- plain arithmetic, no LDS round trip at the top of a step)
