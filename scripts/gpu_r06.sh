@@ -93,6 +93,6 @@ PY
   done
   python scripts/summarize_trace.py pmc $OUT/pmcop5 $OUT/pmc_op_config5.json > /dev/null
   echo "== randomised parity sweep of every path through the C ABI (tests/tools/fuzz_parity.py), on the tree the profiles above are of"
-  timeout 1200 python tests/tools/fuzz_parity.py 606 160 > $OUT/fuzz.txt 2>&1; echo "fuzz rc=$?"; tail -8 $OUT/fuzz.txt
-  timeout 900 python tests/tools/fuzz_parity.py 616 60 joint16 > $OUT/fuzz_joint16.txt 2>&1; echo "fuzz joint16 rc=$?"; tail -6 $OUT/fuzz_joint16.txt
+  timeout 1200 python tests/tools/fuzz_parity.py 606 2400 > $OUT/fuzz.txt 2>&1; echo "fuzz rc=$?"; tail -8 $OUT/fuzz.txt
+  timeout 900 python tests/tools/fuzz_parity.py 616 600 joint16 > $OUT/fuzz_joint16.txt 2>&1; echo "fuzz joint16 rc=$?"; tail -6 $OUT/fuzz_joint16.txt
 fi
