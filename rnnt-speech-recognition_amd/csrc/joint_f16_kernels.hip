@@ -2,8 +2,8 @@
 // (gfx950, v_mfma_f32_32x32x16_f16).  BASELINE config 5 ("fp16 joint MFMA, fp32 lattice"): V = 1024, J = 640.
 //
 // Same path as joint_kernels.hip (model.py:158-166 + autodiff through it),
-// but the [cells x V] logits no longer fit a per-cell register tile, so the work is three GEMM-shaped kernels and one
-// streaming pass around the unchanged alpha/beta sweeps.  Nothing of size [cells x J] is ever stored; the only [cells x V]
+// but the [cells x V] logits no longer fit a per-cell register tile, so the work is three GEMM-shaped kernels around the
+// unchanged alpha/beta sweeps.  Nothing of size [cells x J] is ever stored; the only [cells x V]
 // array is binary16 (2 B per logit instead of the 4+4 B of the unfused path): the softmax numerators the forward pass parks,
 // turned in place into the loss gradient w.r.t. the logits by the backward pass.
 //
@@ -26,6 +26,9 @@
 //             second backward call over one forward.)
 //   K4 dW2    (jh_dw_kernel)  dW2 = h^T . dl, split over ranges of cells; h^T is generated in A-fragment layout,
 //             dl rows are DMA'd row-major and read TRANSPOSED with ds_read_b64_tr_b16; db2 rides along (v_dot2).
+//   rows      (jh_rowbits_kernel, jh_order_kernel, round 6)  which lattice rows the backward visits at all (a row whose cells all
+//             have an occupancy alpha beta / L below 2^-50 contributes nothing a binary32 sum can see; RNNT_VISIT_ALL: every row),
+//             and the order K3's strips / K4's units are dealt in (by visited rows: a function of the data, not of timing).
 //
 // MFMA fragment layouts used (checked on hardware by scripts/probes/probe_f16.hip):
 //   A: lane l holds A[i = l&31][k = 8*(l>>5) + 0..7];  B: lane l holds B[k = 8*(l>>5) + 0..7][n = l&31];
@@ -922,7 +925,6 @@ __global__ __launch_bounds__(512) void jh_dhx_kernel(const JhParams jp) {
         const char *src = (const char *)(jp.W2c + (size_t)kc * (J * 32)) + k * 8192;  // uniform
         lds_dma16_s(src, boff, smem0 + sb * kBS + (wave + 8 * k) * 1024);
     };
-    // the A piece in stage sa: parked values -> dlogits (K2's arithmetic), in place in LDS and, for K4, in dl
     // the A piece in stage sa: parked values -> dlogits (K2's arithmetic), in place in LDS and, for K4, in dl.  In two halves: what it
     // reads from LDS (the raw piece, the cell's chunk reference, the column's label) is fetched with the step's fragment reads; the
     // arithmetic and the LDS writes sit among the MFMAs of the step's second k-step.
@@ -1295,8 +1297,7 @@ __global__ __launch_bounds__(512, VT == 512 ? 1 : JH_K4_W256) void jh_dw_kernel(
     const int vw = PARTIAL ? min(VT, V - v0) : VT;     // columns of this V tile (a multiple of 128)
     const bool wv_live = !PARTIAL || wv * WCOL < vw;   // wave-uniform: this wave's columns exist
     constexpr bool kAllLanes = !PARTIAL && VT == 512;  // a dl row piece fills all 64 lanes of its LDS-DMA instruction
-    // (round 6: a range takes every n_ranges-th unit -- with the backward's row pruning the units' work follows the alignment band,
-    // and consecutive units, one utterance's neighbouring tiles, are busy or idle together)
+    // (round 6: how a range's units are picked -- see the unit loop below)
 
     f32x16 acc[2][VB];
 #pragma unroll
