@@ -803,6 +803,48 @@ def main():
                   "valid_fraction": valid / float(B * T * U),
                   "lengths": "T_b ~ U{T/2..T}, L_b ~ U{(U-1)/2..U-1}, one full-length utterance (SURVEY.md 8d)"}
 
+    # ---- the same op on TRAINED-LIKE logits (one dominant symbol per cell along a monotone alignment, bonus 10 nats -- the posteriors
+    # tests/test_peaky_gpu.py checks against the oracle): the headline's N(0,1) logits are the one distribution where neither a narrow
+    # alignment band nor the hand-back to the log-domain kernels can show.  Same shape, same call; reported beside the headline.
+    op_trained = None
+    if rank == 0 and not a.no_ragged and B * T * U * V <= (1 << 28):
+        gt = torch.Generator(device=dev).manual_seed(77)
+        xt = torch.randn(B, T, U, V, generator=gt, dtype=torch.float32, device=dev)
+        emit = torch.empty(B, U - 1, device=dev)
+        for b in range(B):
+            lo = int(0.6 * T) if b % 2 else 0  # odd utterances: every label is emitted late
+            emit[b] = torch.sort(torch.randint(lo, T, (U - 1,), generator=gt, device=dev)).values.float()
+        tt = torch.arange(T, device=dev, dtype=torch.float32)[None, :, None]
+        due = torch.cat([emit, torch.full((B, 1), float(T), device=dev)], 1)[:, None, :]  # [B,1,U]: frame at which column u's label is due
+        before = tt < due                                                                    # [B,T,U]
+        xt[..., 0] += 10.0 * before
+        lab_idx = torch.cat([labels.long(), torch.zeros(B, 1, dtype=torch.long, device=dev)], 1)[:, None, :, None].expand(B, T, U, 1)
+        bonus = (10.0 * (~before)).unsqueeze(-1)
+        bonus[:, :, U - 1] = 0.0  # the last column has no label
+        xt.scatter_add_(3, lab_idx, bonus)
+        del bonus, lab_idx, before
+
+        def step_t(i):
+            _lib.check(lib.compute_rnnt_loss_ex(xt.data_ptr(), grads.data_ptr(), labels.data_ptr(), ll.data_ptr(),
+                                                il.data_ptr(), scale.data_ptr(), V, B, costs.data_ptr(), ws.data_ptr(),
+                                                opts), "compute_rnnt_loss_ex")
+
+        for i in range(3):
+            step_t(i)
+        torch.cuda.synchronize()
+        t0t = time.perf_counter()
+        nt_ = max(5, min(a.steps, 20))
+        for i in range(nt_):
+            step_t(i)
+        torch.cuda.synchronize()
+        dtt = (time.perf_counter() - t0t) / nt_
+        ct = costs.float().cpu()
+        op_trained = {"ms_per_step": dtt * 1e3, "cells_per_s": B * T * U / dtt, "costs_finite": bool(torch.isfinite(ct).all()),
+                      "mean_cost_nats": float(ct.mean()),
+                      "input": "N(0,1) logits + 10 nats on blank before a cell's label is due and on the label afterwards; odd "
+                               "utterances emit every label in the last 40 % of the frames (tests/test_peaky_gpu.py 'trained'); ONE buffer"}
+        del xt
+
     # ---- fused joint + loss (SURVEY.md 8d "P2"): reported beside the headline, not as `value` ----
     fused = fused_full = fused_c5 = fused_mid = fused_ref = fused_v64 = op_c5 = fused_dp = None
     headline_shape = (B, T, U, V) == (32, 600, 150, 28)
@@ -883,7 +925,7 @@ def main():
             "warm_ms_per_step": dt_warm / a.steps * 1e3,
             "warm_value": world * cells * a.steps / dt_warm,
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
-            "roofline": roof, "cpu_baseline": cpu, "ragged_batch": ragged, "fused_joint": fused,
+            "roofline": roof, "cpu_baseline": cpu, "ragged_batch": ragged, "op_trained_like": op_trained, "fused_joint": fused,
             "fused_joint_full": fused_full, "fused_joint_config5": fused_c5, "fused_joint_v128": fused_mid, "fused_joint_v64": fused_v64, "fused_joint_refdefault": fused_ref,
             "op_config5": op_c5,
             "fused_dp_step": fused_dp, "e2e_train_step": e2e,
