@@ -87,12 +87,16 @@ for case in range(n_cases):
             # a one-column lattice with a near-certain blank produces)
             cg = costs.detach().cpu().numpy()
             dc = float((np.abs(cg - ref["costs"]) / np.maximum(1.0, np.abs(ref["costs"]))).max())
-            rel = 0.0
+            rel, per_key = 0.0, {}
             for p_, key in zip(params, ("d_enc", "d_pred", "dW1", "db1", "dW2", "db2")):
-                rel = max(rel, float(np.abs(p_.grad.cpu().numpy() - ref[key]).max() / max(1.0, np.abs(ref[key]).max())))
+                per_key[key] = float(np.abs(p_.grad.cpu().numpy() - ref[key]).max() / max(1.0, np.abs(ref[key]).max()))
+                rel = max(rel, per_key[key])
             worst["joint16_grad" if f16 else "joint_grad"] = max(worst["joint16_grad" if f16 else "joint_grad"], rel)
             if not (dc <= 1e-4 and rel <= (1e-3 if f16 else 1e-4)):
                 fails.append((kind, B, T, U, H, J, V, dc, rel))
+                # (detail for a replay: which gradient, which lengths, how peaked)
+                print("FAIL case", case, kind, dict(B=B, T=T, U=U, H=H, J=J, V=V), "il", il.tolist(), "ll", ll.tolist(), "per-gradient", per_key,
+                      "costs", cg.tolist(), "|W2|max", float(np.abs(W2).max()), flush=True)
     except Exception as e:  # noqa
         fails.append((kind, "EXC", repr(e)[:200]))
 print(f"{n_cases} cases in {time.time() - t_start:.1f} s; worst deviations {worst}")
