@@ -1,40 +1,27 @@
-"""Dev probe: the op-level step (compute_rnnt_loss_ex, B32 T600 U150 V28, logits rotating through 3 buffers) launched directly
-vs replayed from HIP graphs (one per buffer)."""
-import sys, time, torch
-sys.path.insert(0, ".")
+"""Probe: the headline op and the fused joint step, direct launches against HIP-graph replay (launch gaps between the step's kernels)."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import rnnt_speech_recognition_amd as pkg
-from rnnt_speech_recognition_amd import _lib
-pkg.build(); lib = _lib.load(); dev = torch.device("cuda:0")
+pkg.build(); dev = torch.device("cuda:0")
 B, T, U, V = 32, 600, 150, 28
-g = torch.Generator(device=dev).manual_seed(1)
-xs = [torch.randn(B, T, U, V, generator=g, device=dev) for _ in range(3)]
+g = torch.Generator(device=dev).manual_seed(3)
 labels = torch.randint(1, V, (B, U - 1), generator=g, device=dev, dtype=torch.int32)
 il = torch.full((B,), T, dtype=torch.int32, device=dev); ll = torch.full((B,), U - 1, dtype=torch.int32, device=dev)
-scale = torch.full((B,), 1.0 / B, device=dev); costs = torch.empty(B, device=dev); grads = torch.empty_like(xs[0])
-ws = torch.empty(_lib.workspace_bytes(T, U, B), dtype=torch.uint8, device=dev)
-
-def call(x, stream):
-    o = _lib.make_options(stream.cuda_stream, 0, T, U)
-    _lib.check(lib.compute_rnnt_loss_ex(x.data_ptr(), grads.data_ptr(), labels.data_ptr(), ll.data_ptr(), il.data_ptr(), scale.data_ptr(),
-                                        V, B, costs.data_ptr(), ws.data_ptr(), o), "ex")
-
-def timeit(fn, n=300):
-    for i in range(20): fn(i)
+xs = [torch.randn(B, T, U, V, generator=g, device=dev) for _ in range(3)]
+def step(i): return pkg.rnnt_loss_and_grad(xs[i % 3], labels, il, ll)
+def timeit(fn, n):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(n): fn(i)
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-
-s = torch.cuda.current_stream()
-print("direct  ms/step", timeit(lambda i: call(xs[i % 3], torch.cuda.current_stream())))
-graphs = []
-for x in xs:
+for i in range(6): step(i)
+print("op direct        %.4f ms/step" % timeit(step, 60))
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    for i in range(3): step(i)
+    torch.cuda.synchronize()
     gr = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gr):
-        call(x, torch.cuda.current_stream())
-    graphs.append(gr)
-print("graphs  ms/step", timeit(lambda i: graphs[i % 3].replay()))
-one = torch.cuda.CUDAGraph()
-with torch.cuda.graph(one):
-    for x in xs: call(x, torch.cuda.current_stream())
-print("3-step graph ms/step", timeit(lambda i: one.replay(), 100) / 3)
-print("direct  ms/step", timeit(lambda i: call(xs[i % 3], torch.cuda.current_stream())))
+    with torch.cuda.graph(gr, stream=s):
+        outs = [step(i) for i in range(3)]
+torch.cuda.synchronize()
+for _ in range(3): gr.replay()
+print("op graph replay  %.4f ms/step" % (timeit(lambda i: gr.replay(), 20) / 3))
