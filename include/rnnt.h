@@ -222,8 +222,9 @@ RNNT_API rnntStatus_t compute_rnnt_loss_flags(const float *acts, float *grads, c
  *                                    (round-to-nearest-even) before the products, accumulation is f32; the loss gradient
  *                                    w.r.t. the logits is scaled by 2^(14 - ceil(log2 max|cost_scale|)) and rounded to
  *                                    binary16 before dh = dl.W2^T and dW2 = h^T.dl (the backward skips lattice rows without mass,
- *                                    as joint_dtype 0 does -- groups of four rows of a 32-column tile here; RNNT_VISIT_ALL
- *                                    switches that off).  The lattice (log-softmax, alpha,
+ *                                    as joint_dtype 0 does -- groups of four rows of a 32-column tile here, below an occupancy of
+ *                                    2^-40: every binary16 dlogits value of such a row is an exact zero already, the scaled
+ *                                    gradient being below 2^-26 there; RNNT_VISIT_ALL switches that off).  The lattice (log-softmax, alpha,
  *                                    beta, costs) stays f32.  A forward pass that knows a backward pass follows (the
  *                                    one-call entry with gradients, or _fwd) PARKS the softmax numerators in the workspace:
  *                                    per (cell, 32-symbol chunk) 2^(x log2 e - R) rounded to binary16, R = the integer at or
@@ -333,7 +334,7 @@ RNNT_API rnntStatus_t compute_rnnt_joint_logits(const float *enc_proj, const flo
 
 /* Diagnostics of the fused joints' backward (joint_dtype 0 at joint_size <= 640; joint_dtype 1 since round 6): how many lattice rows x 32-column tiles the
  * LAST backward on this workspace visited (rows[0]) out of those inside the utterances (rows[1]).  The backward skips a row of a
- * tile when none of its 32 cells has an occupancy alpha.beta/L above 2^-50: every dlogits value of a cell is bounded by
+ * tile when none of its 32 cells has an occupancy alpha.beta/L above 2^-50 (joint_dtype 1: 2^-40, where its binary16 dlogits are exact zeros): every dlogits value of a cell is bounded by
  * 2 |cost_scale| x that occupancy, so such a row adds less than 2^-44 |cost_scale| to anything -- its cells get exactly zero where
  * the reference leaves 1e-15's.  How many rows that is depends on the data (unstructured N(0,1) logits on a 600 x 150 lattice: about
  * half; a trained model: most).  Synchronises options.stream.  rows = {-1, -1} where nothing is skipped (the wide joint, 640 < joint_size)
