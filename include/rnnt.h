@@ -173,8 +173,9 @@ RNNT_API rnntStatus_t compute_rnnt_loss_ex(const float *acts, float *grads, cons
 /* Build-only flag (no upstream counterpart): RNNT_VISIT_ALL switches the occupancy floor OFF -- the gradient kernels then visit
  * every lattice cell / row, as the reference's op and TensorFlow's autodiff do (run_rnnt.py:284), whatever the data.  Where the
  * floor applies (vocabularies above 60 symbols here; the backward of the fused joints below) a cell, or a lattice row of a
- * 32-column tile, whose occupancy alpha.beta/L is at most 2^-50 gets exact zeros without its logits being read: results differ
- * from the all-visited ones by less than 2^-44 |cost_scale| per element and run times follow the width of the alignment band.
+ * 32-column tile, whose occupancy alpha.beta/L is at most 2^-50 (the op) / 2^-40 (the fused joints: see get_rnnt_joint_backward_rows)
+ * gets exact zeros without its logits being read: results differ from the all-visited ones by less than 2^-44 |cost_scale| per
+ * element (the op; the fused joints skip only what is an exact zero already) and run times follow the width of the alignment band.
  * The floor hides no NaN: the forward pass reads every cell, a NaN logit makes the utterance's lattice, cost and occupancies NaN,
  * and a NaN occupancy counts as occupied (tests/test_loss_gpu.py::test_occupancy_floor_and_its_opt_out).  The flag is there for
  * parity debugging and for timing that does not depend on the data (bench.py reports both).
@@ -214,8 +215,8 @@ RNNT_API rnntStatus_t compute_rnnt_loss_flags(const float *acts, float *grads, c
  *                                    tiles of 32 symbols, one pass of the kernels per tile; <= 32 is the reference's character
  *                                    set), alphabet_size <= 32 for joint_size 704.
  *                                    The backward (joint_size <= 640) does not visit lattice rows, in tiles of 32 columns, whose
- *                                    cells all have an occupancy alpha.beta/L below 2^-50: those cells get exactly zero where the
- *                                    reference leaves ~1e-15 (get_rnnt_joint_backward_rows below: the bound, and how many rows a
+ *                                    cells all have an occupancy alpha.beta/L below 2^-40: those cells get exactly zero where the
+ *                                    reference leaves ~1e-12 (get_rnnt_joint_backward_rows below: the bound, and how many rows a
  *                                    call visited); its run time follows the width of the alignment band.
  *                                1 = f16 MFMA, larger vocabularies: alphabet_size a multiple of 128 (128 ... 8192),
  *                                    joint_size a multiple of 128 (128 ... 640).  h = tanh(.) and W2 are rounded to binary16
@@ -334,9 +335,10 @@ RNNT_API rnntStatus_t compute_rnnt_joint_logits(const float *enc_proj, const flo
 
 /* Diagnostics of the fused joints' backward (joint_dtype 0 at joint_size <= 640; joint_dtype 1 since round 6): how many lattice rows x 32-column tiles the
  * LAST backward on this workspace visited (rows[0]) out of those inside the utterances (rows[1]).  The backward skips a row of a
- * tile when none of its 32 cells has an occupancy alpha.beta/L above 2^-50 (joint_dtype 1: 2^-40, where its binary16 dlogits are exact zeros): every dlogits value of a cell is bounded by
- * 2 |cost_scale| x that occupancy, so such a row adds less than 2^-44 |cost_scale| to anything -- its cells get exactly zero where
- * the reference leaves 1e-15's.  How many rows that is depends on the data (unstructured N(0,1) logits on a 600 x 150 lattice: about
+ * tile when none of its 32 cells has an occupancy alpha.beta/L above 2^-40: every dlogits value of a cell is bounded by
+ * 2 |cost_scale| x that occupancy, and both joints hand dlogits to their products as binary16 parts of (power of two <= 2^13 / |cost_scale|) x
+ * dlogits -- below 2^-26 in such a row, i.e. exact zeros already: the row adds nothing, its cells get exactly zero where
+ * the reference leaves 1e-12's.  How many rows that is depends on the data (unstructured N(0,1) logits on a 600 x 150 lattice: about
  * half; a trained model: most).  Synchronises options.stream.  rows = {-1, -1} where nothing is skipped (the wide joint, 640 < joint_size)
  * and where the workspace does not hold the counts of a backward of THIS shape (fresh, or used by another shape since: the row plan stamps them).
  * The work of a backward call is divided among the workgroups by these counts, deterministically. */

@@ -211,8 +211,8 @@ def rnnt_joint_loss(enc, pred, W1, b1, W2, b2, labels, input_lengths, label_leng
     of 32).  "torch": torch.matmul + autograd around compute_rnnt_joint_loss_*.  "auto": the engine whenever it takes the shape.
 
     visit_all: RNNT_VISIT_ALL of include/rnnt.h -- the backward visits every lattice row instead of skipping the rows (x 32-column
-    tiles) whose cells all have an occupancy below 2^-50 (results differ by < 2^-44 |cost_scale| per element; timing then does not
-    depend on the data)."""
+    tiles) whose cells all have an occupancy below 2^-40 (their binary16 dlogits parts are exact zeros already: same results up to the
+    order of a few f32 sums; timing then does not depend on the data)."""
     dtype_word = lambda name: JOINT_DTYPES[name] | (_lib.RNNT_VISIT_ALL if visit_all else 0)  # noqa: E731
     if joint_dtype == "auto":
         joint_dtype = _auto_joint_dtype(W2.shape[0], W2.shape[1])
