@@ -136,7 +136,7 @@ def test_f32_joint_backward_can_be_repeated(J, w2_gain):
 
 
 def test_backward_says_how_many_lattice_rows_it_visited():
-    """joint_bwd_kernel skips the rows (x 32-column tiles) none of whose cells has an occupancy above 2^-50 and divides the rest among
+    """joint_bwd_kernel skips the rows (x 32-column tiles) none of whose cells has an occupancy above 2^-40 (round 5: 2^-50) and divides the rest among
     its workgroups by weight (include/rnnt.h get_rnnt_joint_backward_rows).  Through the C ABI: on a long lattice with unstructured
     logits a good part of the rows goes, on a tiny one nothing does; the count and every gradient are the same from call to call
     (the division of the work depends on the data, not on timing).  Parity of what is left: every other test of the fused joint."""
