@@ -14,7 +14,8 @@ cost_scale is zero for every other utterance (tests/test_baseline_sizes_gpu.py).
 relative to max(1, max|ref|), d enc_proj / d pred_proj also 1e-4 absolute); f16 costs 1e-4 against the rounding-aware AND the
 unrounded oracle, gradients 1e-3 max(1, max|ref|).
 On the trained-like cases the backward must have visited less than 30 % of the lattice rows (f32-grade: the few-items-per-workgroup
-branch of joint_rowplan_kernel; f16, groups of four rows: 35 %), and RNNT_VISIT_ALL must give the same numbers to 1e-6."""
+branch of joint_rowplan_kernel; f16, groups of four rows: 35 %), and RNNT_VISIT_ALL must give the same numbers to 1e-6.
+The f16 engine again at V = 640 / 1024 on trained-like posteriors (test_large_vocabulary_...): several chunks per K4 tile, most rows skipped."""
 import numpy as np
 import pytest
 import torch
@@ -31,10 +32,10 @@ B, T, U, J = 8, 600, 150, 640
 PICKS = [0, 3, 6]  # 0: full length; 3: an odd (late-emitting) utterance; 6: even
 
 
-def _case(kind, V, seed):
-    case = list(make_proj_case(B, T, U, J, V, seed=seed))
+def _case(kind, V, seed, nb=B):
+    case = list(make_proj_case(nb, T, U, J, V, seed=seed))
     if kind == "trained":
-        ep, pp, W2, b2, labels = pkg.synthetic_trained_like_joint(B, T, U, V, J, seed=seed, input_lengths=case[5], label_lengths=case[6])
+        ep, pp, W2, b2, labels = pkg.synthetic_trained_like_joint(nb, T, U, V, J, seed=seed, input_lengths=case[5], label_lengths=case[6])
         case[0], case[1], case[2], case[3], case[4] = ep, pp, W2, b2, labels
     return tuple(case)
 
@@ -68,10 +69,32 @@ def test_mid_vocabulary_joint_at_headline_lattice(dtype, V, kind):
     frac = rows[0] / rows[1]
     if kind == "trained":
         assert frac < (0.35 if f16 else 0.3), frac  # the alignment band: most rows carry no mass (f16: groups of four rows)
-    # no occupancy floor: the same numbers (a skipped row adds less than 2^-44 |cost_scale| to anything)
+    # no occupancy floor: the same numbers (what the skipped rows would have added are exact zeros; a few f32 sums run in another order)
     costs_all, grads_all = _run(case, scale, dtype, visit_all=True)
     rows_all = joint_mod.last_backward_rows()
     assert rows_all[0] == rows_all[1] == rows[1], (rows_all, rows)
+    assert torch.equal(costs, costs_all)
+    for a, b in zip(grads, grads_all):
+        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("V", [640, 1024])
+def test_large_vocabulary_f16_joint_on_trained_like_posteriors(V):
+    """The f16 engine's row pruning where a vocabulary spans several 32-symbol chunks per K4 tile and most rows are skipped: V = 1024 (two full
+    512-column tiles of K4, 32 chunks per K3 iteration) and V = 640 (the partly filled last tile), trained-like posteriors, ragged, B = 4 at the
+    headline lattice.  (The random sweep's lattices are too small for any row to fall below the floor; BASELINE configs[4]'s at-size test runs
+    N(0,1) projections, a third of whose rows are visited.)  Same checks as above on two utterances."""
+    nb, picks = 4, [0, 3]
+    case = _case("trained", V, seed=900 + V, nb=nb)
+    scale = torch.linspace(1.5, 0.5, nb) / nb
+    costs, grads = _run(case, scale, "f16")
+    rows = joint_mod.last_backward_rows()
+    mask = torch.zeros(nb)
+    mask[picks] = 1.0
+    _, grads_masked = _run(case, scale * mask, "f16")
+    check_against_oracle(case, "f16", picks, scale, costs, grads, grads_masked, gtol=1e-3, also_exact=True)
+    assert rows is not None and rows[1] > 0 and rows[0] / rows[1] < 0.35, rows
+    costs_all, grads_all = _run(case, scale, "f16", visit_all=True)
     assert torch.equal(costs, costs_all)
     for a, b in zip(grads, grads_all):
         assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
