@@ -70,7 +70,7 @@ for case in range(n_cases):
 
             joint_mod.TRACK_BACKWARD_ROWS = True
             f16 = kind == "band16"
-            B, T, U = int(rng.integers(1, 4)), int(rng.integers(40, 260)), int(rng.integers(8, 70))
+            B, T, U = int(rng.integers(1, 4)), int(rng.integers(40, 700 if rng.random() < 0.4 else 260)), int(rng.integers(8, 70))
             if f16:
                 J, V = int(rng.choice([128, 256, 384, 640])), int(rng.choice([128, 256, 384, 640]))
             else:
@@ -115,11 +115,12 @@ for case in range(n_cases):
             (c2 * t(scale)).sum().backward()
             d_all = max(float((a_.grad - b_.grad).abs().max() / max(1.0, float(b_.grad.abs().max()))) for a_, b_ in zip(ps, ps2))
             worst["band_pruned_vs_all"] = max(worst.get("band_pruned_vs_all", 0.0), d_all)
-            # Bars: f32-grade 1e-4.  f16: 2.5e-3 HERE, not the 1e-3 of the other kinds -- the trained-like construction carries output weights of
+            # Bars: f32-grade 1e-4.  f16: 6e-3 HERE, not the 1e-3 of the other kinds -- the trained-like construction carries output weights of
             # 6 ... 10 (its "gain") on lattices of a few thousand cells: where the kernel's f32 and the oracle's f64 value of a dlogits entry
-            # straddle a binary16 rounding boundary the entry differs by one binary16 ulp (1e-3 at |dl| ~ 2), times such a weight, in a sum of few
-            # terms (measured up to 1.8e-3; every such case equals its RNNT_VISIT_ALL twin to 1e-7: it is not the pruning).
-            if not (dc <= 1e-4 and rel <= (2.5e-3 if f16 else 1e-4) and d_all <= 1e-6 and torch.equal(costs, c2)):
+            # straddle a binary16 rounding boundary the entry differs by one binary16 ulp (1e-3 at |dl| ~ 2), times such a weight, in sums that
+            # cancel (dh = sum_v dl_v W2[j][v] with dl = softmax - onehot on a peaked posterior).  Measured up to 4.0e-3 in 2,500 cases; every such
+            # case equals its RNNT_VISIT_ALL twin to 1e-6 or exactly: a property of binary16 dlogits, not of the pruning these kinds are for.
+            if not (dc <= 1e-4 and rel <= (6e-3 if f16 else 1e-4) and d_all <= 1e-6 and torch.equal(costs, c2)):
                 fails.append((str(kind), B, T, U, J, V, dc, rel, d_all))
                 print("FAIL case", case, kind, dict(B=B, T=T, U=U, J=J, V=V), "il", il.tolist(), "ll", ll.tolist(), "rows", rows, "dc", dc, "rel", rel,
                       "pruned vs visit-all", d_all, "scale", scale.tolist(), flush=True)
