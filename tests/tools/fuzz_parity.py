@@ -60,6 +60,43 @@ for case in range(n_cases):
             bar = 1e-4
             if not (dc <= 1e-4 and dg <= bar):
                 fails.append((str(kind), B, T, U, V, blank, sc, dc, dg))
+        elif kind == "loss_band":
+            # the op on trained-like logits at vocabularies where cells below the occupancy floor are skipped (V > 60) and below (V <= 60):
+            # a monotone alignment with a 10-nat bonus (tests/test_peaky_gpu.py), medium lattices, ragged; against the oracle and, above 60
+            # symbols, against the same call with RNNT_VISIT_ALL
+            B, T, U = int(rng.integers(1, 4)), int(rng.integers(30, 300)), int(rng.integers(6, 60))
+            V = int(rng.choice([8, 28, 60, 61, 64, 100, 128, 257, 400]))
+            while B * T * U * V > 6e6:
+                T = max(30, T * 3 // 4)
+                if T == 30:
+                    break
+            blank = int(rng.integers(0, V)) if rng.random() < 0.3 else 0
+            pool = [v for v in range(V) if v != blank]
+            labels = rng.choice(pool, size=(B, U - 1)).astype(np.int32)
+            il, ll = lengths(B, T, U)
+            acts = rng.normal(size=(B, T, U, V)).astype(np.float32)
+            bonus = np.float32(rng.choice([6.0, 10.0]))
+            for b in range(B):
+                Tb, Lb = int(il[b]), int(ll[b])
+                lo = int(0.6 * Tb) if rng.random() < 0.5 else 0
+                emit = np.sort(rng.integers(lo, max(Tb, lo + 1), size=Lb))
+                for u in range(Lb + 1):
+                    te = emit[u] if u < Lb else Tb
+                    acts[b, :te, u, blank] += bonus
+                    if u < Lb:
+                        acts[b, te:, u, labels[b, u]] += bonus
+            c, g = pkg.rnnt_loss_and_grad(t(acts), t(labels), t(il), t(ll), blank_label=blank)
+            cr, gr = orc.rnnt_loss_and_grad(acts, labels, il, ll, blank=blank)
+            dc = float(np.abs(c.cpu().numpy() - cr).max() / max(1.0, np.abs(cr).max()))
+            dg = float(np.abs(g.cpu().numpy() - gr).max())
+            c2, g2 = pkg.rnnt_loss_and_grad(t(acts), t(labels), t(il), t(ll), blank_label=blank, visit_all=True)
+            d_all = float((g - g2).abs().max())
+            zero_frac = float((g == 0).float().mean())
+            worst["loss_cost"], worst["loss_grad"] = max(worst["loss_cost"], dc), max(worst["loss_grad"], dg)
+            worst["loss_band_vs_all"] = max(worst.get("loss_band_vs_all", 0.0), d_all)
+            worst["loss_band_zero_frac"] = max(worst.get("loss_band_zero_frac", 0.0), zero_frac)
+            if not (dc <= 1e-4 and dg <= 1e-4 and d_all <= 1e-12 and torch.equal(c, c2)):
+                fails.append((str(kind), B, T, U, V, blank, float(bonus), dc, dg, d_all))
         elif kind in ("band16", "band32"):
             # Round 6: the backward's ROW PRUNING under random shapes.  The lattices of the kinds above are too small for any row to fall
             # below the occupancy floor; here: trained-like posteriors (pkg.synthetic_trained_like_joint: a narrow alignment band, every second
