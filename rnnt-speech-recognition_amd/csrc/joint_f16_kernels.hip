@@ -1640,6 +1640,9 @@ bool fill_loss_params(LossParams &p, const float *acts, float *grads, const int 
                       const int *input_lengths, const float *cost_scale, int V, int B, float *costs, void *workspace,
                       int maxT, int maxU, int blank);
 hipError_t launch_reduce_partials(float *out, const float *in, int nparts, size_t n, hipStream_t s, unsigned *blockmax);
+hipError_t launch_reduce_f16_backward(float *d_enc, const float *dApart, int n_ut, const LossParams &lp, int J, unsigned *bm_enc, const uint8_t *live8,
+                                      float *d_pred, const float *dCpart, int nC, unsigned *bm_pred, float *dW2, const float *dWpart, float *db2,
+                                      const float *dbpart, int nR, int V, hipStream_t s);
 hipError_t launch_reduce_enc(float *out, const float *in, int n_ut, const LossParams &lp, int J, hipStream_t s, unsigned *blockmax,
                              const uint8_t *live8);
 
@@ -1793,12 +1796,12 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     const bool want_bwd = (phases & 2) && d_enc_proj;
     const bool park = (phases & 1) && (want_bwd || (phases & 4));
     // the binary16 weight copies and the scale are rebuilt by whichever phase runs (cheap; W2 or cost_scale may differ)
-    if (launch_fill(jp.scal, 0, 32, s) != hipSuccess) return hipErrorUnknown;
+    // (a forward phase also clears the state word behind the prep words -- dl is about to be overwritten --: one fill, not a launch of its own)
+    if (launch_fill(jp.scal, 0, (phases & 1) ? 64 : 32, s) != hipSuccess) return hipErrorUnknown;
     hipLaunchKernelGGL(jh_prep_kernel, dim3(1024), dim3(256), 0, s, jp);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (phases & 1) {
         if (launch_fill(jp.lp.W, kFillByte, L.w.A - L.w.W, s) != hipSuccess) return hipErrorUnknown;
-        if ((e = set_state(0)) != hipSuccess) return e;  // dl is about to be overwritten
         if ((e = logits(park ? 1 : 0)) != hipSuccess) return e;
         if (park && (e = set_state(1)) != hipSuccess) return e;
 #ifdef JH_TRACE
@@ -1822,7 +1825,8 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
     // are enqueued; the one whose precondition does not hold returns at once.
     // (Cutting the batch into utterance ranges and converting range q + 1 on a second stream beside the dh kernel of range q
     // was measured at config 5: the two kernels do overlap, and slow each other down by as much as the overlap hides.)
-    if ((e = logits(2)) != hipSuccess) return e;
+    // (a call that parked in its own forward phase knows the answer: the recompute kernel would read the state word and return)
+    if (!((phases & 1) && park) && (e = logits(2)) != hipSuccess) return e;
     // dC partials + the zero row + the row counters (the dA partials need no zero-fill: launch_reduce_enc reads only the rows K3 writes)
     if (launch_fill(jp.dCpart, 0, L.live8 - L.dCpart, s) != hipSuccess) return hipErrorUnknown;
     // which lattice rows (x 32-column tiles) the backward visits: K3, K4 and the d enc_proj reduction follow these bits
@@ -1866,10 +1870,9 @@ hipError_t launch_joint_loss_f16(const float *enc_proj, const float *pred_proj, 
         if (e != hipSuccess) return e;
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if ((e = launch_reduce_enc(d_enc_proj, jp.dApart, L.n_ut, jp.lp, J, s, hooks ? hooks->dmax_enc : nullptr, jp.live8)) != hipSuccess) return e;
-    if ((e = launch_reduce_partials(d_pred_proj, jp.dCpart, L.n_ts, (size_t)B * U * J, s, hooks ? hooks->dmax_pred : nullptr)) != hipSuccess) return e;
-    if ((e = launch_reduce_partials(dW2, jp.dWpart, L.n_ranges, (size_t)J * V, s, nullptr)) != hipSuccess) return e;
-    e = launch_reduce_partials(db2, jp.dbpart, L.n_ranges, (size_t)V, s, nullptr);
+    // d enc_proj, d pred_proj, dW2, db2 from their partials: one launch (joint_kernels.hip)
+    e = launch_reduce_f16_backward(d_enc_proj, jp.dApart, L.n_ut, jp.lp, J, hooks ? hooks->dmax_enc : nullptr, jp.live8, d_pred_proj, jp.dCpart, L.n_ts,
+                                   hooks ? hooks->dmax_pred : nullptr, dW2, jp.dWpart, db2, jp.dbpart, L.n_ranges, V, s);
 #ifdef JH_TRACE
     {
         hipStreamSynchronize(s);

@@ -2263,6 +2263,32 @@ hipError_t launch_reduce_enc(float *out, const float *in, int n_ut, const LossPa
     return hipGetLastError();
 }
 
+// The four reductions behind the f16 joint's backward in ONE launch (round 6; four launches before, 23 us + a launch gap apiece at
+// the small end): blocks [0, kHookBlocks) d enc_proj from its u-tile partial rows, [kHookBlocks, 2 kHookBlocks) d pred_proj from its
+// row-strip slabs, then gW blocks of dW2 and gB blocks of db2 from K4's range partials.  The same bodies, the same association per
+// element as the single launches: bit-identical results.
+__global__ __launch_bounds__(256) void reduce_f16_backward_kernel(float *d_enc, const float *dApart, const int n_ut, const LossParams p, const int J,
+                                                                  unsigned *bm_enc, const uint8_t *live8, float *d_pred, const float *dCpart,
+                                                                  const int nC, unsigned *bm_pred, float *dW2, const float *dWpart, float *db2,
+                                                                  const float *dbpart, const int nR, const int V, const unsigned gW, const unsigned gB) {
+    const unsigned blk = blockIdx.x, H = (unsigned)kHookBlocks;
+    if (blk < H) reduce_enc_body(d_enc, dApart, n_ut, p, J, blk, H, bm_enc ? bm_enc + blk : nullptr, 0.f, live8);
+    else if (blk < 2u * H) reduce_partials_body(d_pred, dCpart, nC, (size_t)p.B * p.U * J, blk - H, H, bm_pred ? bm_pred + (blk - H) : nullptr, 0.f);
+    else if (blk < 2u * H + gW) reduce_partials_body(dW2, dWpart, nR, (size_t)J * V, blk - 2u * H, gW, nullptr, 0.f);
+    else reduce_partials_body(db2, dbpart, nR, (size_t)V, blk - 2u * H - gW, gB, nullptr, 0.f);
+}
+
+hipError_t launch_reduce_f16_backward(float *d_enc, const float *dApart, int n_ut, const LossParams &lp, int J, unsigned *bm_enc, const uint8_t *live8,
+                                      float *d_pred, const float *dCpart, int nC, unsigned *bm_pred, float *dW2, const float *dWpart, float *db2,
+                                      const float *dbpart, int nR, int V, hipStream_t s) {
+    if ((unsigned long long)lp.B * lp.T * J >= (1ull << 32)) return hipErrorInvalidValue;  // 32-bit element indices in reduce_enc_body
+    const size_t nW = ((size_t)J * V + 255) / 256, nB = ((size_t)V + 255) / 256;
+    const unsigned gW = (unsigned)(nW < 1024 ? nW : 1024), gB = (unsigned)(nB < 1024 ? nB : 1024);
+    hipLaunchKernelGGL(reduce_f16_backward_kernel, dim3(2u * kHookBlocks + gW + gB), dim3(256), 0, s, d_enc, dApart, n_ut, lp, J, bm_enc, live8, d_pred,
+                       dCpart, nC, bm_pred, dW2, dWpart, db2, dbpart, nR, V, gW, gB);
+    return hipGetLastError();
+}
+
 hipError_t launch_reduce_partials(float *out, const float *in, int nparts, size_t n, hipStream_t s, unsigned *blockmax) {
     // (a consumer of `blockmax` reads kHookBlocks entries: the grid is then exactly that, whatever n is)
     const unsigned grid = blockmax ? (unsigned)kHookBlocks : (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
